@@ -1,0 +1,127 @@
+"""Host-side glue mirroring the reference's `panst3r/utils.py` interface (same names, argument meaning, errors).
+
+  batched_map            reference utils.py:90-196   chunk along a flattened dim, call fn, concatenate, unflatten
+  transpose_to_landscape reference utils.py:8-61     run a head per orientation, swap portrait results back
+  unstack_tensors        reference utils.py:198-204
+  get_dtype              reference utils.py:206-215
+
+Pure data movement on torch tensors (plumbing); pinned by tests/golden/{batched_map,transpose_to_landscape,unstack}.npz.
+"""
+import torch
+
+
+def _map_nested(val, fn):
+    if isinstance(val, dict):
+        return {k: _map_nested(v, fn) for k, v in val.items()}
+    if isinstance(val, list):
+        return [_map_nested(v, fn) for v in val]
+    if isinstance(val, tuple):
+        return tuple(_map_nested(v, fn) for v in val)
+    return fn(val)
+
+
+def transposed(val, dims=(1, 2)):
+    return _map_nested(val, lambda t: t.swapaxes(*dims))
+
+
+def _compose(land_res, port_res, is_land):
+    if isinstance(land_res, dict):
+        return {k: _compose(land_res[k], port_res[k], is_land) for k in land_res}
+    if isinstance(land_res, (list, tuple)):
+        return type(land_res)(_compose(a, b, is_land) for a, b in zip(land_res, port_res))
+    full = land_res.new_empty(land_res.shape[0] + port_res.shape[0], *land_res.shape[1:])
+    full[is_land] = land_res
+    full[~is_land] = port_res
+    return full
+
+
+def transpose_to_landscape(head, activate=True, dims=(1, 2)):
+    """Wrap `head(decout, (H, W))` so every view is predicted in its own aspect ratio and portrait results are
+    swapped back on `dims` so the batch is landscape-shaped again."""
+
+    def passthrough(decout, true_shape):
+        assert true_shape[0:1].allclose(true_shape), 'true_shape must be all identical'
+        H, W = true_shape[0].cpu().tolist()
+        return head(decout, (H, W))
+
+    def per_orientation(decout, true_shape):
+        short, long_ = int(true_shape.min()), int(true_shape.max())
+        heights, widths = true_shape.T
+        is_land = widths >= heights
+        if bool(is_land.all()):
+            return head(decout, (short, long_))
+        if bool((~is_land).all()):
+            return transposed(head(decout, (long_, short)), dims)
+        land_res = head([d[is_land] for d in decout], (short, long_))
+        port_res = transposed(head([d[~is_land] for d in decout], (long_, short)), dims)
+        return _compose(land_res, port_res, is_land)
+
+    return per_orientation if activate else passthrough
+
+
+def batched_map(fn, tensors, batch_size=None, flatten_dims=None, split_dim=0, multi_ar=False, verbose=False, desc=None):
+    """Apply `fn` to aligned mini-batches of `tensors` (optionally flattening dims first) and concatenate.
+
+    multi_ar=True: every entry of `tensors` is a list with one tensor per aspect-ratio group; results come back
+    as lists in the same group order.  `fn` may return a tensor or a tuple of tensors.
+    """
+    if isinstance(tensors, torch.Tensor):
+        tensors = (tensors,)
+    elif multi_ar and isinstance(tensors[0], torch.Tensor):
+        tensors = (tensors,)
+    groups = [list(t) for t in tensors] if multi_ar else [[t] for t in tensors]
+    n_groups = len(groups[0])
+    assert all(len(g) == n_groups for g in groups), 'All tensors must have the same number of multi-ar slices.'
+
+    results = None
+    for gi in range(n_groups):
+        args = [g[gi] for g in groups]
+        lead = None
+        if flatten_dims is not None:
+            a, b = flatten_dims
+            shapes = [t.shape[a:b + 1] for t in args]
+            assert all(s == shapes[0] for s in shapes[1:]), 'All tensors must have the same shape along flatten dimensions.'
+            lead = shapes[0]
+            args = [t.flatten(a, b) for t in args]
+        n = args[0].shape[split_dim]
+        assert all(t.shape[split_dim] == n for t in args[1:]), 'All tensors must have the same size along split_dim.'
+        step = n if batch_size is None else batch_size
+        pieces = [fn(*(t.narrow(split_dim, s, min(step, n - s)) for t in args)) for s in range(0, n, step)]
+
+        def restore(x):
+            return x.unflatten(flatten_dims[0], lead) if flatten_dims is not None else x
+
+        if isinstance(pieces[0], torch.Tensor):
+            merged = (restore(torch.cat(pieces, dim=split_dim)),)
+        elif isinstance(pieces[0], tuple):
+            merged = tuple(restore(torch.cat([p[i] for p in pieces], dim=split_dim)) for i in range(len(pieces[0])))
+        else:
+            raise ValueError('Unsupported output type from fn: {}'.format(type(pieces[0])))
+        if results is None:
+            results = [[m] for m in merged]
+        else:
+            for slot, m in zip(results, merged):
+                slot.append(m)
+
+    if not multi_ar:
+        results = [slot[0] for slot in results]
+    return results[0] if len(results) == 1 else results
+
+
+def unstack_tensors(index_stacks, stacks):
+    """Scatter stacked per-view tensors back to a flat per-view list (reference utils.py:198-204)."""
+    count = max(max(ix) for ix in index_stacks) + 1
+    flat = [None] * count
+    for stack, ix in zip(stacks, index_stacks):
+        for j in range(stack.shape[0]):
+            flat[ix[j]] = stack[j]
+    return flat
+
+
+def get_dtype(amp):
+    if amp == 'fp16':
+        return torch.float16
+    if amp == 'bf16':
+        return torch.bfloat16
+    assert not amp
+    return torch.float32

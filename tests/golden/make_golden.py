@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""Generate golden vectors by importing the REFERENCE's own modules (build container only).
+
+Run:  python tests/golden/make_golden.py          (needs /root/reference; never runs on the GPU box)
+
+Recipe: `import panst3r` fails because must3r/croco/dust3r are not installed, so the
+reference-owned files are imported through bare package stubs, and the five croco/must3r symbols they need
+(`Mlp, DropPath, CrossAttention, Block`, `get_pos_embed`) plus `torchvision.transforms.Normalize` are provided by
+stand-ins (the restated blocks in oracle/blocks.py).  Therefore these vectors pin the REFERENCE-OWNED logic
+(reshape / pixel-shuffle order, MinMaxScaler, ImplicitFeaturizer, GN/conv stack, the whole MaskTransformer,
+sine PE, batched_map, transpose_to_landscape, DINO wrapper around the installed HF Dinov2Model); they do not pin
+the croco primitives themselves.
+
+Only data is written: inputs + expected outputs as .npz.  Weights are not stored: both sides regenerate them
+with panst3r_amd.synthetic.fill_module_ (keyed by state-dict key).
+"""
+import os
+import sys
+import types
+import importlib
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = '/root/reference/src/panst3r'
+
+
+def import_reference():
+    import transformers  # noqa: F401  (must precede the torchvision stub)
+    from transformers import Dinov2Model, Dinov2Config  # noqa: F401
+    from oracle import blocks as ob
+
+    def pkg(name, path=None):
+        m = types.ModuleType(name)
+        m.__path__ = [path] if path else []
+        sys.modules[name] = m
+        return m
+
+    pkg('panst3r', REF)
+    pkg('panst3r.engine', REF + '/engine')
+    cb = pkg('croco'), pkg('croco.models'), pkg('croco.models.blocks')
+    for n in ('Mlp', 'DropPath', 'CrossAttention', 'Block'):
+        setattr(cb[2], n, getattr(ob, n))
+    pkg('must3r'), pkg('must3r.model'), pkg('must3r.model.blocks')
+    pe = pkg('must3r.model.blocks.pos_embed')
+    pe.get_pos_embed = ob.get_pos_embed
+    tv, tvt = pkg('torchvision'), pkg('torchvision.transforms')
+
+    class Normalize(torch.nn.Module):
+        def __init__(self, mean, std):
+            super().__init__()
+            self.mean, self.std = mean, std
+
+        def forward(self, x):
+            m = x.new_tensor(self.mean).view(1, 3, 1, 1)
+            s = x.new_tensor(self.std).view(1, 3, 1, 1)
+            return (x - m) / s
+    tvt.Normalize = Normalize
+    tv.transforms = tvt
+    mods = {}
+    for name in ('panst3r.utils', 'panst3r.model', 'panst3r.model.mask_transformer', 'panst3r.model.panoptic_decoder',
+                 'panst3r.model.dino', 'panst3r.model.input_mixer', 'panst3r.model.upscalers.pixel_shuffle',
+                 'panst3r.model.upscalers.loftup', 'panst3r.engine.postprocess'):
+        mods[name.split('.')[-1]] = importlib.import_module(name)
+    return mods
+
+
+def rnd(seed, *shape):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(g.standard_normal(shape).astype(np.float32))
+
+
+def npy(x):
+    if isinstance(x, (list, tuple)):
+        return [npy(v) for v in x]
+    return x.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, list):
+            for i, a in enumerate(v):
+                flat['%s.%d' % (k, i)] = a
+        else:
+            flat[k] = v
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **flat)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
+@torch.no_grad()
+def main():
+    from panst3r_amd.synthetic import fill_module_
+    R = import_reference()
+    torch.manual_seed(0)
+
+    # ---------------- G4: sine PE, batched_map, transpose_to_landscape, unstack_tensors
+    MT = R['mask_transformer']
+    pe = MT.PositionEmbeddingSine(16, normalize=True)
+    save('sine_pe', land=npy(pe(torch.zeros(2, 32, 3, 5))), port=npy(pe(torch.zeros(2, 32, 5, 3))))
+    U = R['utils']
+    a, b = rnd(1, 2, 3, 4), rnd(2, 2, 3, 5)
+    f = lambda x, y: (x * 2 + y.sum(-1, keepdim=True), y[..., :2] - 1)
+    o1 = U.batched_map(f, (a, b), batch_size=2, flatten_dims=(0, 1))
+    o2 = U.batched_map(lambda x: x.flip(-1), a, batch_size=1, flatten_dims=(0, 1))
+    o3 = U.batched_map(f, ([a, a[:1]], [b, b[:1]]), batch_size=1, flatten_dims=(0, 1), multi_ar=True)
+    save('batched_map', a=npy(a), b=npy(b), o1_0=npy(o1[0]), o1_1=npy(o1[1]), o2=npy(o2),
+         o3_0=npy(o3[0]), o3_1=npy(o3[1]))
+    head = lambda dec, shape: {'m': dec[0].reshape(dec[0].shape[0], 2, shape[0], shape[1]) * (1 + dec[1])}
+    wrapped = U.transpose_to_landscape(head, activate=True, dims=(2, 3))
+    d0, d1 = rnd(3, 3, 2 * 4 * 6), rnd(4, 3, 1, 1, 1)
+    ts = torch.tensor([[4, 6], [6, 4], [4, 6]])
+    save('transpose_to_landscape', d0=npy(d0), d1=npy(d1), ts=npy(ts), out=npy(wrapped((d0, d1), ts)['m']))
+    stacks = [rnd(5, 2, 3), rnd(6, 1, 3)]
+    un = U.unstack_tensors([[2, 0], [1]], stacks)
+    save('unstack', s0=npy(stacks[0]), s1=npy(stacks[1]), out=npy(torch.stack(un)))
+
+    # ---------------- G7: keyframe schedules (panst3r.py:186) and mem batches (:65-70)
+    kf = {('%d_%d' % (V, K)): np.linspace(0, V - 1, K, dtype=int) for V, K in [(50, 16), (200, 32), (8, 8), (9, 4), (2, 2)]}
+    save('keyframes', **kf)
+
+    # ---------------- G1: MaskTransformer tiny (single-AR landscape, multi-AR mixed orientation, heads-only)
+    def mt_make():
+        m = MT.MaskTransformer([64], 64, 128, 32, 16, 4, 2, lang_dim=48, num_feature_levels=1, landscape_only=True).eval()
+        return fill_module_(m, seed=11)
+    m = mt_make()
+    fpn = rnd(20, 1, 2, 64, 4, 6)
+    mf = rnd(21, 1, 2, 32, 32, 48)
+    ts = torch.tensor([[[64, 96], [64, 96]]])
+    cls = torch.nn.functional.normalize(rnd(22, 5, 48), dim=-1)
+    out = m([fpn], mf, ts, cls)
+    heads = m.forward_prediction_heads(out['out_queries'], mf, cls)
+    save('mask_transformer_tiny', fpn=npy(fpn), mf=npy(mf), ts=npy(ts), cls=npy(cls),
+         pred_logits=npy(out['pred_logits']), pred_masks=npy(out['pred_masks']), out_queries=npy(out['out_queries']),
+         aux0_masks=npy(out['aux_outputs'][0]['pred_masks']), aux1_logits=npy(out['aux_outputs'][1]['pred_logits']),
+         heads_logits=npy(heads[0]), heads_masks=npy(heads[1]))
+    # multi-AR: group 0 = one landscape view, group 1 = two portrait views (stored landscape-shaped, as the wrapper emits)
+    fpn_g = [rnd(23, 1, 1, 64, 4, 6), rnd(24, 1, 2, 64, 4, 6)]
+    mf_g = [rnd(25, 1, 1, 32, 32, 48), rnd(26, 1, 2, 32, 32, 48)]
+    ts_g = [torch.tensor([[[64, 96]]]), torch.tensor([[[96, 64], [96, 64]]])]
+    out = m([fpn_g], mf_g, ts_g, cls, outdevice='cpu', multi_ar=True, max_bs=1)
+    save('mask_transformer_tiny_multiar', fpn=npy(fpn_g), mf=npy(mf_g), ts=npy(ts_g), cls=npy(cls),
+         pred_logits=npy(out['pred_logits']), pred_masks=npy(out['pred_masks']), out_queries=npy(out['out_queries']))
+
+    # ---------------- G3: PanopticDecoder v1 / v2 tiny
+    PD = R['panoptic_decoder'].PanopticDecoder
+    PS = R['pixel_shuffle'].PixelShuffleUpscaler
+    LU = R['loftup'].LoftUpUpscaler
+    IM = R['input_mixer'].InputMixer
+    names = ['c%d' % i for i in range(5)]
+    cemb = rnd(30, 5, 768)
+
+    def feats(seed, n, T):
+        return (rnd(seed, 1, n, T, 16), rnd(seed + 1, 1, n, T, 8), rnd(seed + 2, 1, n, T, 16))
+
+    def grid_pos(h, w, n):
+        ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+        return torch.stack([ys, xs], -1).reshape(1, 1, -1, 2).expand(1, n, -1, -1).contiguous()
+
+    def run_pd(tag, dec, seed):
+        dec.text_encoder.class_embeddings = {n: e for n, e in zip(names, cemb)}
+        # (a) two landscape views 64x96, per-view chunks (max_bs=1: the demo convention, pins MinMaxScaler per view)
+        f = feats(seed, 2, 24)
+        imgs = rnd(seed + 3, 1, 2, 3, 64, 96).clamp(-1, 1)
+        pos = grid_pos(4, 6, 2)
+        ts = torch.tensor([[[64, 96], [64, 96]]])
+        o = dec(f, imgs, pos, ts, names, max_bs=1)
+        # (b) same stack processed as ONE chunk (batch-dependent MinMaxScaler for v2)
+        ob_ = dec(f, imgs, pos, ts, names, max_bs=None)
+        # (c) heads-only path on a third view with the queries of (a)
+        f3 = feats(seed + 10, 1, 24)
+        img3 = rnd(seed + 13, 1, 1, 3, 64, 96).clamp(-1, 1)
+        o3 = dec(f3, img3, grid_pos(4, 6, 1), ts[:, :1], names, max_bs=1, memory_queries=o['out_queries'])
+        # (d) one portrait view (native orientation 96x64, demo convention) through the features+heads path
+        fp = feats(seed + 20, 1, 24)
+        imgp = rnd(seed + 23, 1, 1, 3, 96, 64).clamp(-1, 1)
+        op = dec(fp, imgp, grid_pos(6, 4, 1), torch.tensor([[[96, 64]]]), names, max_bs=1, memory_queries=o['out_queries'])
+        save('panoptic_decoder_%s_tiny' % tag, cemb=npy(cemb),
+             f0=npy(f[0]), f1=npy(f[1]), f2=npy(f[2]), imgs=npy(imgs), pos=npy(pos), ts=npy(ts),
+             pred_logits=npy(o['pred_logits']), pred_masks=npy(o['pred_masks']), out_queries=npy(o['out_queries']),
+             batched_masks=npy(ob_['pred_masks']),
+             g0=npy(f3[0]), g1=npy(f3[1]), g2=npy(f3[2]), img3=npy(img3), heads_masks=npy(o3['pred_masks']), heads_logits=npy(o3['pred_logits']),
+             p0=npy(fp[0]), p1=npy(fp[1]), p2=npy(fp[2]), imgp=npy(imgp), port_masks=npy(op['pred_masks']))
+
+    v1 = PD(input_mixer=None, upscaler=PS(input_dim=40, fp_dim=[64, 32, 16, 8]), fpn_dim=[64], hidden_dim=64, mask_dim=8,
+            ff_dim=128, num_queries=16, num_heads=4, dec_layers=2).eval()
+    run_pd('v1', fill_module_(v1, seed=12), 40)
+    v2 = PD(input_mixer=IM([96, 96], 16, 40, 48, num_heads=4, num_layers=1, ff_dim_mult=2),
+            upscaler=LU(input_dim=48, dim=32, num_heads=4), fpn_dim=[48], hidden_dim=48, mask_dim=32,
+            ff_dim=128, num_queries=16, num_heads=4, dec_layers=2).eval()
+    run_pd('v2', fill_module_(v2, seed=13), 70)
+
+    # ---------------- G5: DinoV2Encoder wrapper around a tiny HF Dinov2Model
+    from transformers import Dinov2Model, Dinov2Config
+    D = R['dino']
+    cfg = dict(hidden_size=32, num_hidden_layers=2, num_attention_heads=4, patch_size=14, image_size=70, mlp_ratio=4)
+    D.get_dinov2_model = lambda *_a, **_k: Dinov2Model(Dinov2Config(**cfg)).eval()
+    de = fill_module_(D.DinoV2Encoder().eval(), seed=14)
+    img = rnd(50, 2, 3, 64, 96).clamp(-1, 1)
+    out_l = de(img, torch.tensor([[64, 96], [64, 96]]))
+    imgsq = rnd(51, 1, 3, 80, 80).clamp(-1, 1)              # 5x5 grid == stored grid: no interpolation branch
+    out_s = de(imgsq, torch.tensor([[80, 80]]))
+    save('dino_tiny', img=npy(img), out=npy(out_l), imgsq=npy(imgsq), outsq=npy(out_s))
+
+    # ---------------- G6: panoptic_inference_v2 on fixed logits ("next" row 8(f)1)
+    PP = R['postprocess']
+    logits = rnd(60, 1, 16, 5) * 2
+    masks = [rnd(61 + i, 1, 16, 16, 24) * 3 for i in range(3)]
+    size = np.array([[32, 48]] * 3)
+    try:
+        res = PP.panoptic_inference_v2(logits, masks, size, label_mode='sigmoid', device='cpu', multi_ar=True)
+        pan = res[0]
+        save('postprocess_v2', logits=npy(logits), masks=npy(masks), size=size,
+             pan=[np.asarray(p) for p in npy(pan['pan'])], conf=[np.asarray(c) for c in npy(pan['conf'])])
+    except Exception as e:  # pragma: no cover
+        print('postprocess golden skipped:', repr(e))
+
+
+if __name__ == '__main__':
+    main()

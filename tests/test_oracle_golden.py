@@ -1,0 +1,140 @@
+"""Pin the CPU oracle (and the host glue) to golden vectors generated from the reference's own modules
+(tests/golden/make_golden.py).  fp32 vs fp32: tolerance 1e-5 relative L2 / 2e-5 abs on O(1) values."""
+import numpy as np
+import torch
+import pytest
+
+from conftest import rel_l2
+from panst3r_amd.synthetic import fill_module_
+from panst3r_amd import utils as U
+from oracle import panoptic as OP
+from oracle import dino as OD
+
+TOL = 2e-5
+
+
+def close(a, b, tol=TOL):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert rel_l2(a, b) < tol, rel_l2(a, b)
+
+
+def test_sine_pe(golden):
+    g = golden('sine_pe')
+    pe = OP.PositionEmbeddingSine(16, normalize=True)
+    close(pe(torch.zeros(2, 32, 3, 5)), g.t('land'), 1e-6)
+    close(pe(torch.zeros(2, 32, 5, 3)), g.t('port'), 1e-6)
+
+
+def test_batched_map(golden):
+    g = golden('batched_map')
+    a, b = g.t('a'), g.t('b')
+    f = lambda x, y: (x * 2 + y.sum(-1, keepdim=True), y[..., :2] - 1)
+    o1 = U.batched_map(f, (a, b), batch_size=2, flatten_dims=(0, 1))
+    assert torch.equal(o1[0], g.t('o1_0')) and torch.equal(o1[1], g.t('o1_1'))
+    assert torch.equal(U.batched_map(lambda x: x.flip(-1), a, batch_size=1, flatten_dims=(0, 1)), g.t('o2'))
+    o3 = U.batched_map(f, ([a, a[:1]], [b, b[:1]]), batch_size=1, flatten_dims=(0, 1), multi_ar=True)
+    for got, key in zip(o3, ('o3_0', 'o3_1')):
+        for x, y in zip(got, g.lst(key)):
+            assert torch.equal(x, y)
+    with pytest.raises(AssertionError):
+        U.batched_map(f, (a, b[:1]), flatten_dims=(0, 1))
+    with pytest.raises(ValueError):
+        U.batched_map(lambda x: [x], a)
+
+
+def test_transpose_to_landscape_and_unstack(golden):
+    g = golden('transpose_to_landscape')
+    head = lambda dec, shape: {'m': dec[0].reshape(dec[0].shape[0], 2, shape[0], shape[1]) * (1 + dec[1])}
+    out = U.transpose_to_landscape(head, activate=True, dims=(2, 3))((g.t('d0'), g.t('d1')), g.t('ts'))['m']
+    assert torch.equal(out, g.t('out'))
+    g = golden('unstack')
+    un = U.unstack_tensors([[2, 0], [1]], [g.t('s0'), g.t('s1')])
+    assert torch.equal(torch.stack(un), g.t('out'))
+
+
+def test_keyframe_schedule(golden):
+    from panst3r_amd.schedule import select_keyframes, mem_batches
+    g = golden('keyframes')
+    for key in g.z.files:
+        V, K = map(int, key.split('_'))
+        assert select_keyframes(V, K) == g.z[key].tolist()
+    assert select_keyframes(50, 16) == [0, 3, 6, 9, 13, 16, 19, 22, 26, 29, 32, 35, 39, 42, 45, 49]
+    assert mem_batches(2) == [2] and mem_batches(5) == [2, 1, 1, 1]
+
+
+def _mt():
+    m = OP.MaskTransformer([64], 64, 128, 32, 16, 4, 2, lang_dim=48, num_feature_levels=1, landscape_only=True).eval()
+    return fill_module_(m, seed=11)
+
+
+@torch.no_grad()
+def test_mask_transformer_tiny(golden):
+    g = golden('mask_transformer_tiny')
+    m = _mt()
+    out = m([g.t('fpn')], g.t('mf'), g.t('ts'), g.t('cls'))
+    close(out['pred_logits'], g.t('pred_logits'))
+    close(out['pred_masks'], g.t('pred_masks'))
+    close(out['out_queries'], g.t('out_queries'))
+    close(out['aux_outputs'][0]['pred_masks'], g.t('aux0_masks'))
+    close(out['aux_outputs'][1]['pred_logits'], g.t('aux1_logits'))
+    cls, masks, _ = m.forward_prediction_heads(g.t('out_queries'), g.t('mf'), g.t('cls'))
+    close(cls, g.t('heads_logits'))
+    close(masks, g.t('heads_masks'))
+
+
+@torch.no_grad()
+def test_mask_transformer_multi_ar(golden):
+    g = golden('mask_transformer_tiny_multiar')
+    m = _mt()
+    out = m([g.lst('fpn')], g.lst('mf'), g.lst('ts'), g.t('cls'), multi_ar=True, max_bs=1)
+    close(out['pred_logits'], g.t('pred_logits'))
+    close(out['out_queries'], g.t('out_queries'))
+    for a, b in zip(out['pred_masks'], g.lst('pred_masks')):
+        close(a, b)
+
+
+def _pd(tag):
+    if tag == 'v1':
+        d = OP.PanopticDecoder(input_mixer=None, upscaler=OP.PixelShuffleUpscaler(input_dim=40, fp_dim=[64, 32, 16, 8]),
+                               fpn_dim=[64], hidden_dim=64, mask_dim=8, ff_dim=128, num_queries=16, num_heads=4, dec_layers=2)
+        return fill_module_(d.eval(), seed=12)
+    d = OP.PanopticDecoder(input_mixer=OP.InputMixer([96, 96], 16, 40, 48, num_heads=4, num_layers=1, ff_dim_mult=2),
+                           upscaler=OP.LoftUpUpscaler(input_dim=48, dim=32, num_heads=4), fpn_dim=[48], hidden_dim=48,
+                           mask_dim=32, ff_dim=128, num_queries=16, num_heads=4, dec_layers=2)
+    return fill_module_(d.eval(), seed=13)
+
+
+@pytest.mark.parametrize('tag', ['v1', 'v2'])
+@torch.no_grad()
+def test_panoptic_decoder_tiny(golden, tag):
+    g = golden('panoptic_decoder_%s_tiny' % tag)
+    d = _pd(tag)
+    names = ['c%d' % i for i in range(5)]
+    d.text_encoder.class_embeddings = {n: e for n, e in zip(names, g.t('cemb'))}
+    f = (g.t('f0'), g.t('f1'), g.t('f2'))
+    o = d(f, g.t('imgs'), g.t('pos'), g.t('ts'), names, max_bs=1)
+    close(o['pred_logits'], g.t('pred_logits'))
+    close(o['pred_masks'], g.t('pred_masks'))
+    close(o['out_queries'], g.t('out_queries'))
+    ob = d(f, g.t('imgs'), g.t('pos'), g.t('ts'), names, max_bs=None)
+    close(ob['pred_masks'], g.t('batched_masks'))
+    if tag == 'v2':   # MinMaxScaler is batch dependent: the two conventions must differ
+        assert rel_l2(ob['pred_masks'], o['pred_masks']) > 1e-4
+    o3 = d((g.t('g0'), g.t('g1'), g.t('g2')), g.t('img3'), g.t('pos')[:, :1], g.t('ts')[:, :1], names, max_bs=1,
+           memory_queries=g.t('out_queries'))
+    close(o3['pred_masks'], g.t('heads_masks'))
+    close(o3['pred_logits'], g.t('heads_logits'))
+    ys, xs = torch.meshgrid(torch.arange(6), torch.arange(4), indexing='ij')
+    ppos = torch.stack([ys, xs], -1).reshape(1, 1, -1, 2)
+    op = d((g.t('p0'), g.t('p1'), g.t('p2')), g.t('imgp'), ppos, torch.tensor([[[96, 64]]]), names, max_bs=1,
+           memory_queries=g.t('out_queries'))
+    close(op['pred_masks'], g.t('port_masks'))
+
+
+@torch.no_grad()
+def test_dino_tiny(golden):
+    g = golden('dino_tiny')
+    cfg = dict(hidden_size=32, num_hidden_layers=2, num_attention_heads=4, patch_size=14, image_size=70, mlp_ratio=4)
+    de = fill_module_(OD.DinoV2Encoder(**cfg).eval(), seed=14)
+    close(de(g.t('img'), torch.tensor([[64, 96], [64, 96]])), g.t('out'))
+    close(de(g.t('imgsq'), torch.tensor([[80, 80]])), g.t('outsq'))

@@ -1,0 +1,145 @@
+/* panst3r_hip.h -- C ABI of libpanst3r_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary of the PanSt3R inference forward path.  Plain pointers, sizes and a HIP stream only: no
+ * torch types, no allocation, no host synchronisation, no global state besides the last-error string.  The caller
+ * (PyTorch-ROCm in panst3r_amd/hip.py, via ctypes) owns every buffer; kernels borrow the raw device pointers for
+ * the duration of the enqueue.  Every entry point returns 0 on success, <0 on a rejected argument (PST_EINVAL) or
+ * a HIP launch error (PST_ELAUNCH); pst_last_error() gives the text.  `stream` is a hipStream_t passed as void*.
+ *
+ * Each op states the reference (naver/panst3r v0.2.1, /root/reference) call site it replaces.  The reference has
+ * no native code of its own: its "FFI" for this path are the torch ops / optional fused extensions listed in
+ * SURVEY.md 2.1 (cuRoPE2D, xFormers memory-efficient attention, nn.MultiheadAttention, the einsum).
+ *
+ * Conventions: bf16 = raw uint16 bfloat16; activations are token-major [rows, channels] row-major with an
+ * explicit leading dimension (elements); weights are torch nn.Linear layout [N, K] (K contiguous).
+ */
+#ifndef PANST3R_HIP_H
+#define PANST3R_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PST_ABI_VERSION 1
+
+int pst_abi_version(void);
+const char* pst_last_error(void);
+
+/* ---------------------------------------------------------------- GEMM (+ fused epilogues, implicit 3x3 conv)
+ * C[m, n] = epi( sum_k A[m,k] * W[n,k] ),  bf16 MFMA 16x16x32, fp32 accumulate.
+ *   epi(x) = res + gamma[n] * act(x + bias[n])        (each part optional)
+ * Replaces: every nn.Linear / 1x1 conv / patch-embed conv / 3x3 conv on the path -- croco Mlp/Attention/
+ * CrossAttention projections (model/blocks.py:18-26, input_mixer.py:13-20, pixel_shuffle.py:17-27), LoftUp convs
+ * (loftup.py:122-130), MaskTransformer projections + FFN + MLP heads (mask_transformer.py:222-230,314,372,435-437)
+ * and the query x pixel einsum "bqc,bnchw->bnqhw" (mask_transformer.py:280) with mask_feats kept pixel-major.
+ * Requirements: K % 64 == 0, N % 4 == 0, lda/ldw multiples of 8, A/W 16-byte aligned, C rows 16-byte aligned.
+ */
+typedef struct pst_gemm_params {
+  const void* A;  int64_t lda;       /* bf16 [M, K] (or NHWC image stack in conv mode) */
+  const void* W;  int64_t ldw;       /* bf16 [N, K] */
+  void* C;        int64_t ldc;       /* bf16 or fp32 [M, N] (or its transpose, see trans_out) */
+  int32_t M, N, K;
+  const float* bias;                 /* [N] or NULL */
+  const float* gamma;                /* [N] LayerScale or NULL */
+  const float* res;  int64_t ldr;    /* fp32 residual or NULL; row = res_mod ? m % res_mod : out_row(m) */
+  int32_t res_mod;
+  int32_t act;                       /* 0 none, 1 GELU(erf), 2 ReLU */
+  int32_t out_fp32;                  /* 0: bf16 C, 1: fp32 C */
+  int32_t trans_out;                 /* 1: store C^T, i.e. C[n*ldc + m] (bf16 only; feeds attention V^T) */
+  /* output row remap: out_row(m) = grp_in ? (m/grp_in)*grp_out + grp_off + m%grp_in : m   (e.g. skip a CLS row) */
+  int32_t grp_in, grp_out, grp_off;
+  /* pixel-shuffle store (F.pixel_shuffle fused, weight rows pre-permuted to [dy][dx][c]): ps_p > 0 enables.
+     token m = (v, y, x) on a ps_h x ps_w grid; n = dy*(ps_p*ps_c) + r  ->  C[v][(ps_p*y+dy)][(ps_p*x)*ps_c + r] */
+  int32_t ps_p, ps_c, ps_h, ps_w;
+  /* implicit 3x3 conv (pad 1): conv_c > 0 enables.  A = NHWC [M = nimg*conv_h*conv_w, conv_c] bf16,
+     K = 9*conv_c (tap-major, channel-minor), conv_c % 64 == 0, `zeros` = >=128 B of zero bytes on the device */
+  int32_t conv_c, conv_h, conv_w;
+  const void* zeros;
+} pst_gemm_params;
+
+int pst_gemm_bf16(const pst_gemm_params* p, void* stream);
+
+/* ---------------------------------------------------------------- fused attention forward (flash style)
+ * O[b,h,q,:] = softmax_k( scale * Q[b,h,q,:] . K[b,h,k,:]  (+ -inf where mask[b,q,k]) ) V[b,h,k,:]
+ * bf16 in/out, fp32 softmax/accumulate, head dim 64 or 96.  V is given TRANSPOSED: Vt[b,h,d,k] (k contiguous).
+ * Replaces: xFormers memory-efficient attention / SDPA inside croco Attention & CrossAttention, HF Dinov2
+ * attention, and nn.MultiheadAttention incl. its bool attn_mask (mask_transformer.py:264-272,314,372).
+ * Strides are in elements.  mask: uint8 [B, Nq, Nk] (1 = blocked), shared by all heads, or NULL.
+ */
+typedef struct pst_attn_params {
+  const void* Q;  int64_t q_bs, q_hs, q_rs;   /* batch / head / row strides */
+  const void* K;  int64_t k_bs, k_hs, k_rs;
+  const void* Vt; int64_t v_bs, v_hs, v_ds;   /* batch / head / head-dim-row strides (key contiguous) */
+  void* O;        int64_t o_bs, o_hs, o_rs;
+  const uint8_t* mask; int64_t m_bs, m_rs;
+  int32_t B, H, Nq, Nk, hd;
+  float scale;
+  const void* zeros;                           /* >=128 B of zero bytes on the device */
+} pst_attn_params;
+
+int pst_attn_fwd_bf16(const pst_attn_params* p, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm
+ * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dim D (D % 4 == 0, D <= 4096), fp32 statistics.
+ * in_fp32/out_fp32 select element types; input row remap as in GEMM (grp_*), output leading dim ldy.
+ * Replaces nn.LayerNorm everywhere on the path (eps 1e-6 backbones, 1e-5 PanSt3R-owned modules).
+ */
+int pst_layernorm(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy, int out_fp32,
+                  const float* gamma, const float* beta, int rows, int D, float eps,
+                  int grp_in, int grp_out, int grp_off, void* stream);
+
+/* ---------------------------------------------------------------- RoPE-2D (in place on bf16 q and k)
+ * Replaces cuRoPE2D / RoPE2D 'RoPE100' (README.md:67-71, input_mixer.py:16): per head the first hd/2 channels
+ * rotate with pos y, the last hd/2 with pos x.  x: [rows, nheads*hd] slices of a row-major buffer with ld;
+ * pos int32 [rows, 2] (y, x); cs: fp32 table [npos, hd/4, 2] (cos, sin).
+ */
+int pst_rope2d_bf16(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd,
+                    void* stream);
+
+/* ---------------------------------------------------------------- image -> patch rows
+ * patchify: img fp32 [nimg, C, H, W] -> bf16 rows [nimg*(H/p)*(W/p), ld] with column (c*p + dy)*p + dx,
+ * zero padded up to ld (patch-embed conv as GEMM; Dust3r 16x16 and DINOv2 14x14).
+ * dino_preprocess: reference model/dino.py:61-66 -- [-1,1] -> ImageNet normalise -> bilinear resize
+ * (align_corners=False) to [nimg, 3, Ho, Wo] fp32.
+ */
+int pst_patchify_bf16(const float* img, void* out, int64_t ld, int nimg, int C, int H, int W, int p, void* stream);
+int pst_dino_preprocess(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, void* stream);
+
+/* ---------------------------------------------------------------- elementwise helpers
+ * add_cast: y = a + (b ? b[row % b_mod] : 0), fp32 or bf16 in, bf16 or fp32 out, [rows, D] with leading dims. */
+int pst_add_cast(const void* a, int64_t lda, int a_fp32, const void* b, int64_t ldb, int b_fp32, int b_mod,
+                 void* y, int64_t ldy, int y_fp32, int rows, int D, void* stream);
+/* l2norm_rows: y = x / (||x|| + eps) per row (fp32 in, bf16 out) -- mask_transformer.py:225 */
+int pst_l2norm_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps, void* stream);
+
+/* ---------------------------------------------------------------- panoptic query-decoder helpers
+ * mean4: Fm[v, t, :] = mean of the central 2x2 pixels of token t's 8x8 block of the pixel-major mask features
+ *   F [nimg, Hm, Wm, C] bf16  (== the 8x bilinear down-sampling of mask_transformer.py:283-287, exact).
+ * attn_mask_from_logits: mask[q,k] = logits[q,k] < 0, rows that are fully blocked are cleared
+ *   (mask_transformer.py:172,272).  logits fp32 [Q, Nk] -> uint8 [Q, Nk]. */
+int pst_mean4_bf16(const void* F, void* Fm, int nimg, int Hm, int Wm, int C, void* stream);
+int pst_attn_mask_from_logits(const float* logits, int64_t ldl, uint8_t* mask, int64_t ldm, int Q, int Nk,
+                              void* stream);
+
+/* ---------------------------------------------------------------- LoftUp guidance branch (loftup.py:9-79,117-130,154-156)
+ * guidance: img fp32 [nimg,3,H,W] -> 2x2 mean (bilinear /2) -> per-view per-channel min-max scale -> Fourier
+ *   features (5 ch x nf freqs, sin & cos, learned biases [2,5,nf] read with the reference's reshape) + rgb
+ *   -> fp32 [nimg, H/2*W/2, 10*nf+3] pixel-major, plus per-view sum / sum-of-squares (GroupNorm(1) statistics).
+ * groupnorm_apply: y = relu?((x - mean_g) * rstd_g * gamma_c + beta_c) over pixel-major [nimg, P, C] with G groups,
+ *   stats fp32 [nimg, G, 2] (sum, sumsq), bf16 output padded with zeros to ldy.
+ * groupnorm_stats: accumulate (sum, sumsq) per (view, group) of a pixel-major tensor. */
+int pst_loftup_guidance(const float* img, const float* biases, float* feats, float* stats, int nimg, int H, int W,
+                        int nf, void* stream);
+int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float* stats, int nimg, int P, int C, int G,
+                        void* stream);
+int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma,
+                        const float* beta, void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu,
+                        void* stream);
+/* lr_pe: low-res positional features of loftup.py:159-162 (ImplicitFeaturizer(color_feats=False, n_freqs=5)):
+ * writes bf16 [h*w, 20] into columns [col0, col0+20) of a row-major buffer with ld (per view identical). */
+int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int nimg, int h, int w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANST3R_HIP_H */

@@ -1,0 +1,262 @@
+// Fused attention forward (flash style) for gfx950: bf16 in/out, fp32 online softmax, head dim 64 or 96.
+//
+// One kernel serves every attention on the PanSt3R path: CroCo encoder / decoder / InputMixer self-attention
+// (after the RoPE kernel), DINOv2 self-attention (769 tokens), the MUSt3R cross-attention over the K*T-token
+// keyframe memory, the LoftUp cross-attention (49 152 queries x 768 keys, hd 96) and the panoptic query decoder's
+// masked cross-attention / self-attention (hd 96, uint8 mask shared by all heads).
+//
+// Design
+//   * block = 4 waves, wave = 32 query rows (two 16-row MFMA fragments) -> 128 queries per block; key tile = 64.
+//   * both contractions run "transposed" so nothing ever moves between lanes:
+//       S^T = K  Q^T   (A operand = K rows from LDS, B operand = Q kept in registers)
+//       O^T = V^T P^T  (A operand = V^T rows from LDS, B operand = the lane's OWN exp'd scores)
+//     With the C layout of v_mfma_f32_16x16x32_bf16 (col = lane&15, row = 4*(lane>>4)+reg) a lane owns one query
+//     column and 4 keys per fragment; the K rows are staged in a permuted order (free: LDS-DMA takes a per-lane
+//     source address) so that those keys are exactly the 8-key K-slot the lane must supply to the second MFMA.
+//   * V arrives already transposed ([hd, Nk], key contiguous; produced by the GEMM's trans_out epilogue) so both
+//     LDS tiles are filled by 16-B LDS-DMA and read back with conflict-free XOR-swizzled ds_read_b128.
+//   * K/V tiles are double buffered (DMA of tile t+1 overlaps the math of tile t; one barrier per tile).
+//   * masked / out-of-range keys get the finite sentinel -1e30 (no inf-inf NaNs; a later real key rescales the
+//     sentinel contributions to exactly 0).
+#include "common.h"
+#include "../../include/panst3r_hip.h"
+
+namespace pst {
+
+constexpr int KT = 64;          // keys per tile
+constexpr float NEG = -1e30f;
+
+template <int HD>
+struct AttnCfg {
+  static constexpr int KPITCH = (HD == 64) ? 128 : 256;      // bytes per K row in LDS
+  static constexpr int KSLOTS = KPITCH / 16;                  // 16-B chunk slots per K row
+  static constexpr int KCHUNKS = HD / 8;                      // real chunks per K row
+  static constexpr int K_BYTES = KT * KPITCH;
+  static constexpr int V_BYTES = HD * 128;                    // V^T tile: HD rows x 64 keys
+  static constexpr int BUF = K_BYTES + V_BYTES;
+  __device__ static __forceinline__ int kswz(int row) { return (HD == 64) ? ((row >> 1) & 7) : (row & 15); }
+};
+
+template <int HD, int QF>
+__global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
+  using C = AttnCfg<HD>;
+  constexpr int NKK = HD / 32;      // K-steps of the QK^T contraction
+  constexpr int NHF = HD / 16;      // output fragments along head dim
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l16 = lane & 15;
+
+  const int qblocks = (p.Nq + 64 * QF - 1) / (64 * QF);
+  const int bid = blockIdx.x;
+  const int qb = bid % qblocks, bh = bid / qblocks;
+  const int h = bh % p.H, b = bh / p.H;
+
+  const bf16_t* Qp = (const bf16_t*)p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs;
+  const bf16_t* Kp = (const bf16_t*)p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
+  const bf16_t* Vp = (const bf16_t*)p.Vt + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;
+  bf16_t* Op = (bf16_t*)p.O + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs;
+  const uint8_t* Mp = p.mask ? p.mask + (int64_t)b * p.m_bs : nullptr;
+
+  // ---- Q fragments in registers: lane (q = l16, k-slot g)
+  const int q_wave0 = qb * (64 * QF) + wave * (16 * QF);
+  bf16x8 qf[QF][NKK];
+#pragma unroll
+  for (int a = 0; a < QF; ++a) {
+    const int q = min(q_wave0 + a * 16 + l16, p.Nq - 1);
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[a][kk] = *(const bf16x8*)(Qp + (int64_t)q * p.q_rs + kk * 32 + g * 8);
+  }
+
+  // ---- staging descriptors
+  constexpr int K_PER_THR = KT * C::KSLOTS / 256;     // 2 (hd64) or 4 (hd96)
+  constexpr int V_PER_THR = HD * 8 / 256;             // 2 or 3
+  int k_key[K_PER_THR], k_chunk[K_PER_THR];
+#pragma unroll
+  for (int j = 0; j < K_PER_THR; ++j) {
+    const int c = j * 256 + tid, row = c / C::KSLOTS, pos = c % C::KSLOTS;
+    const int f = row >> 4, i = row & 15;
+    k_key[j] = (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3);   // actual key (within tile) held by LDS row
+    k_chunk[j] = pos ^ C::kswz(row);
+  }
+  int v_row[V_PER_THR], v_chunk[V_PER_THR];
+#pragma unroll
+  for (int j = 0; j < V_PER_THR; ++j) {
+    const int c = j * 256 + tid, row = c >> 3, pos = c & 7;
+    v_row[j] = row;
+    v_chunk[j] = pos ^ ((row >> 1) & 7);
+  }
+
+  auto stage = [&](int kt, int buf) {
+    const int k0 = kt * KT;
+    char* kd = smem + buf * C::BUF + wave * 1024;
+    char* vd = smem + buf * C::BUF + C::K_BYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < K_PER_THR; ++j) {
+      if (C::KSLOTS == C::KCHUNKS || k_chunk[j] < C::KCHUNKS) {
+        const int key = min(k0 + k_key[j], p.Nk - 1);
+        glds16(Kp + (int64_t)key * p.k_rs + k_chunk[j] * 8, kd + j * 4096);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V_PER_THR; ++j) {
+      const int kcol = k0 + v_chunk[j] * 8;
+      const bf16_t* s = (kcol < p.Nk) ? Vp + (int64_t)v_row[j] * p.v_ds + kcol : (const bf16_t*)p.zeros;
+      glds16(s, vd + j * 4096);
+    }
+  };
+
+  f32x4 o[NHF][QF];
+#pragma unroll
+  for (int hf = 0; hf < NHF; ++hf)
+#pragma unroll
+    for (int a = 0; a < QF; ++a) o[hf][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[QF], l_run[QF];
+#pragma unroll
+  for (int a = 0; a < QF; ++a) { m_run[a] = NEG; l_run[a] = 0.f; }
+
+  const float c_exp = p.scale * 1.4426950408889634f;
+  const int ntiles = (p.Nk + KT - 1) / KT;
+  stage(0, 0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    wait_vm0();
+    __syncthreads();
+    if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
+    const char* kb_ = smem + (kt & 1) * C::BUF;
+    const char* vb_ = kb_ + C::K_BYTES;
+    const int k0 = kt * KT;
+
+    // ---- S^T = K Q^T
+    f32x4 s[4][QF];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+      for (int a = 0; a < QF; ++a) s[f][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = f * 16 + l16;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const int kc = kk * 4 + g;
+        const bf16x8 kf = *(const bf16x8*)(kb_ + row * C::KPITCH + ((kc ^ C::kswz(row)) << 4));
+#pragma unroll
+        for (int a = 0; a < QF; ++a) s[f][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[a][kk], s[f][a], 0, 0, 0);
+      }
+    }
+
+    // ---- mask, online softmax; P stays in the lane
+    bf16x8 pb[QF][2];
+    const bool tail = (k0 + KT > p.Nk);
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+      const int q = q_wave0 + a * 16 + l16;
+      if (Mp || tail) {
+        const uint8_t* mrow = Mp ? Mp + (int64_t)min(q, p.Nq - 1) * p.m_rs : nullptr;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int key = k0 + (f >> 1) * 32 + g * 8 + (f & 1) * 4;
+          uint32_t mb = 0;
+          if (mrow && key < p.Nk) mb = *(const uint32_t*)(mrow + key);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key + r >= p.Nk || ((mb >> (8 * r)) & 0xff)) s[f][a][r] = NEG;
+        }
+      }
+      float mx = NEG;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][a][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[a], mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[a] - m_new) * c_exp);
+      const float mc = m_new * c_exp;
+      m_run[a] = m_new;
+      float ps = 0.f;
+      float pv[4][4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[f][a][r] * c_exp - mc);
+          pv[f][r] = e;
+          ps += e;
+        }
+      l_run[a] = l_run[a] * alpha + ps;
+#pragma unroll
+      for (int hf = 0; hf < NHF; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[hf][a][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+        pk.u[0] = pack2bf(pv[2 * kb][0], pv[2 * kb][1]);
+        pk.u[1] = pack2bf(pv[2 * kb][2], pv[2 * kb][3]);
+        pk.u[2] = pack2bf(pv[2 * kb + 1][0], pv[2 * kb + 1][1]);
+        pk.u[3] = pack2bf(pv[2 * kb + 1][2], pv[2 * kb + 1][3]);
+        pb[a][kb] = pk.v;
+      }
+    }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int hf = 0; hf < NHF; ++hf) {
+      const int row = hf * 16 + l16;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int vc = kb * 4 + g;
+        const bf16x8 vf = *(const bf16x8*)(vb_ + row * 128 + ((vc ^ ((row >> 1) & 7)) << 4));
+#pragma unroll
+        for (int a = 0; a < QF; ++a) o[hf][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[a][kb], o[hf][a], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane owns q = l16, head-dim rows 16*hf + 4*g + r
+#pragma unroll
+  for (int a = 0; a < QF; ++a) {
+    float l = l_run[a];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int q = q_wave0 + a * 16 + l16;
+    if (q < p.Nq) {
+      bf16_t* dst = Op + (int64_t)q * p.o_rs + 4 * g;
+#pragma unroll
+      for (int hf = 0; hf < NHF; ++hf)
+        *(uint2*)(dst + hf * 16) = make_uint2(pack2bf(o[hf][a][0] * inv, o[hf][a][1] * inv),
+                                              pack2bf(o[hf][a][2] * inv, o[hf][a][3] * inv));
+    }
+  }
+}
+
+template <int HD, int QF>
+static int launch_attn(const pst_attn_params& p, hipStream_t s) {
+  const int qblocks = (p.Nq + 64 * QF - 1) / (64 * QF);
+  const long grid = (long)qblocks * p.H * p.B;
+  hipLaunchKernelGGL((attn_kernel<HD, QF>), dim3((unsigned)grid), dim3(256), 2 * AttnCfg<HD>::BUF, s, p);
+  return check_launch("attn_fwd_bf16");
+}
+
+}  // namespace pst
+
+extern "C" int pst_attn_fwd_bf16(const pst_attn_params* pp, void* stream) {
+  using namespace pst;
+  if (!pp) { set_error("attn: null params"); return PST_EINVAL; }
+  const pst_attn_params& p = *pp;
+  if (p.hd != 64 && p.hd != 96) { set_error("attn: head dim %d unsupported (64 or 96)", p.hd); return PST_EINVAL; }
+  if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) { set_error("attn: bad shape"); return PST_EINVAL; }
+  if (!p.Q || !p.K || !p.Vt || !p.O || !p.zeros) { set_error("attn: null operand"); return PST_EINVAL; }
+  if ((p.q_rs | p.q_hs | p.q_bs | p.k_rs | p.k_hs | p.k_bs | p.v_ds | p.v_hs | p.v_bs) % 8) {
+    set_error("attn: Q/K/Vt strides must be multiples of 8 elements (16-byte rows)"); return PST_EINVAL;
+  }
+  if ((p.o_rs | p.o_hs | p.o_bs) % 4) { set_error("attn: O strides must be multiples of 4"); return PST_EINVAL; }
+  if (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.Vt) & 15 || ((uintptr_t)p.O & 7)) {
+    set_error("attn: operands must be 16-byte aligned"); return PST_EINVAL;
+  }
+  if (p.mask && ((p.m_rs | p.m_bs) % 4 || ((uintptr_t)p.mask & 3))) { set_error("attn: mask rows must be 4-byte aligned"); return PST_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  const long big = (long)((p.Nq + 127) / 128) * p.H * p.B;
+  if (p.hd == 64) return big >= 256 ? launch_attn<64, 2>(p, s) : launch_attn<64, 1>(p, s);
+  return big >= 256 ? launch_attn<96, 2>(p, s) : launch_attn<96, 1>(p, s);
+}

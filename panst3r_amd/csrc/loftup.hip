@@ -1,0 +1,202 @@
+// LoftUp guidance-branch kernels (reference model/upscalers/loftup.py:9-79,117-130,154-156) for gfx950.
+// HBM-bound streaming work: 2x2-mean down-sampling + per-view min-max scaling, Fourier features, GroupNorm.
+// Feature maps are pixel-major ([view, pixel, channel]) so they feed the implicit-GEMM 3x3 conv directly.
+#include "common.h"
+#include "../../include/panst3r_hip.h"
+
+namespace pst {
+
+int check_launch(const char* what);
+void set_error(const char* fmt, ...);
+
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max, bool is_min) {
+  // 256-thread block reduction (sum / max / min)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(v, o);
+    v = is_max ? fmaxf(v, t) : (is_min ? fminf(v, t) : v + t);
+  }
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, sh[i]) : (is_min ? fminf(r, sh[i]) : r + sh[i]);
+  return r;
+}
+
+// one block per (view, channel): 2x2 mean (== bilinear x0.5, align_corners=False) and min / max of the result
+__global__ __launch_bounds__(256) void down2_minmax_kernel(const float* img, float* img2, float* mm, int H, int W) {
+  __shared__ float sh[4];
+  const int vc = blockIdx.x, H2 = H / 2, W2 = W / 2;
+  const float* src = img + (int64_t)vc * H * W;
+  float* dst = img2 + (int64_t)vc * H2 * W2;
+  float lo = 3.4e38f, hi = -3.4e38f;
+  for (int i = threadIdx.x; i < H2 * W2; i += 256) {
+    const int y = i / W2, x = i - y * W2;
+    const float* p = src + (int64_t)(2 * y) * W + 2 * x;
+    const float v = 0.25f * (p[0] + p[1] + p[W] + p[W + 1]);
+    dst[i] = v;
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  lo = block_reduce(lo, sh, false, true);
+  hi = block_reduce(hi, sh, true, false);
+  if (threadIdx.x == 0) { mm[2 * vc] = lo; mm[2 * vc + 1] = hi; }
+}
+
+// thread = (pixel, output channel).  Channels: [0,5nf) sin, [5nf,10nf) cos with index f*5+d, then 3 scaled rgb.
+// d: 0 = y grid, 1 = x grid, 2..4 = scaled rgb.  Bias storage is [2][5][nf] read flat as [2][nf*5] (loftup.py:62-63).
+__global__ __launch_bounds__(256) void fourier_kernel(const float* img2, const float* mm, const float* biases, float* feats,
+                                                      float* stats, int H2, int W2, int nf, float f_lo, float f_step) {
+  __shared__ float sh[4];
+  const int view = blockIdx.y, P = H2 * W2, CH = 10 * nf + 3;
+  const int64_t total = (int64_t)P * CH;
+  float s = 0.f, s2 = 0.f;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int pix = (int)(i / CH), ch = (int)(i - (int64_t)pix * CH);
+    const int y = pix / W2, x = pix - y * W2;
+    int d, f = 0, kind;   // kind 0 sin, 1 cos, 2 copy
+    if (ch < 5 * nf) { kind = 0; f = ch / 5; d = ch - f * 5; }
+    else if (ch < 10 * nf) { kind = 1; f = (ch - 5 * nf) / 5; d = ch - 5 * nf - f * 5; }
+    else { kind = 2; d = 2 + ch - 10 * nf; }
+    float base;
+    if (d == 0) base = H2 > 1 ? -1.f + 2.f * y / (H2 - 1) : -1.f;
+    else if (d == 1) base = W2 > 1 ? -1.f + 2.f * x / (W2 - 1) : -1.f;
+    else {
+      const int c = d - 2;
+      const float lo = mm[2 * (view * 3 + c)], hi = mm[2 * (view * 3 + c) + 1];
+      base = (img2[((int64_t)(view * 3 + c)) * P + pix] - lo) / fmaxf(hi - lo, 1e-4f) - 0.5f;
+    }
+    float v;
+    if (kind == 2) v = base;
+    else {
+      const float ph = base * expf(f_lo + f_step * f) + biases[kind * 5 * nf + f * 5 + d];
+      v = kind == 0 ? sinf(ph) : cosf(ph);
+    }
+    feats[(int64_t)view * total + i] = v;
+    s += v;
+    s2 += v * v;
+  }
+  s = block_reduce(s, sh, false, false);
+  s2 = block_reduce(s2, sh, false, false);
+  if (threadIdx.x == 0) { atomicAdd(stats + 2 * view, s); atomicAdd(stats + 2 * view + 1, s2); }
+}
+
+// (sum, sumsq) per (view, group); thread owns one 4-channel chunk -> one group, loops over rows
+__global__ void gn_stats_kernel(const void* x, int64_t ldx, int x_fp32, float* stats, int P, int C, int G, int rows_per_block) {
+  extern __shared__ float shs[];   // [G][2]
+  const int view = blockIdx.y, c4 = C / 4;
+  const int chunk = threadIdx.x % c4, rsub = threadIdx.x / c4, rpb = blockDim.x / c4;
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) shs[i] = 0.f;
+  __syncthreads();
+  float s = 0.f, s2 = 0.f;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, P);
+  if (rsub < rpb) {
+    for (int r = r0 + rsub; r < r1; r += rpb) {
+      const int64_t idx = ((int64_t)view * P + r) * ldx + chunk * 4;
+      float v[4];
+      if (x_fp32) { const float4 t = *(const float4*)((const float*)x + idx); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+      else { const uint2 t = *(const uint2*)((const bf16_t*)x + idx);
+             v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+             v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s += v[k]; s2 += v[k] * v[k]; }
+    }
+    const int grp = (chunk * 4) / (C / G);
+    atomicAdd(&shs[2 * grp], s);
+    atomicAdd(&shs[2 * grp + 1], s2);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(stats + (int64_t)view * 2 * G + i, shs[i]);
+}
+
+// y = relu?((x - mean_g) * rstd_g * gamma_c + beta_c); bf16 output, columns [C, ldy) zero filled
+__global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
+                                bf16_t* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu) {
+  const int64_t total = (int64_t)nimg * P * ldy;
+  const float inv_n = 1.0f / ((float)P * (C / G));
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldy);
+    const int64_t row = i / ldy;
+    float o = 0.f;
+    if (c < C) {
+      const int view = (int)(row / P), grp = c / (C / G);
+      const float sm = stats[((int64_t)view * G + grp) * 2], sq = stats[((int64_t)view * G + grp) * 2 + 1];
+      const float mean = sm * inv_n;
+      const float var = fmaxf(sq * inv_n - mean * mean, 0.f);
+      const float v = x_fp32 ? ((const float*)x)[row * ldx + c] : bf2f(((const bf16_t*)x)[row * ldx + c]);
+      o = (v - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
+      if (relu) o = fmaxf(o, 0.f);
+    }
+    y[i] = f2bf(o);
+  }
+}
+
+// low-res positional features: 20 channels = sin(f*2+d) x10, cos x10 on the (h, w) token grid
+__global__ void lr_pe_kernel(const float* biases, bf16_t* out, int64_t ld, int col0, int nimg, int h, int w) {
+  const int64_t total = (int64_t)nimg * h * w * 20;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % 20);
+    const int64_t tok = i / 20;
+    const int t = (int)(tok % (h * w)), y = t / w, x = t - y * w;
+    const int kind = ch / 10, r = ch - kind * 10, f = r / 2, d = r - f * 2;
+    const float base = d == 0 ? (h > 1 ? -1.f + 2.f * y / (h - 1) : -1.f) : (w > 1 ? -1.f + 2.f * x / (w - 1) : -1.f);
+    const float ph = base * expf(-2.f + 3.f * f) + biases[kind * 10 + f * 2 + d];
+    out[tok * ld + col0 + ch] = f2bf(kind == 0 ? sinf(ph) : cosf(ph));
+  }
+}
+
+}  // namespace pst
+
+using namespace pst;
+
+extern "C" int pst_loftup_guidance(const float* img, const float* biases, float* feats, float* stats, int nimg, int H, int W,
+                                   int nf, void* stream) {
+  if (!img || !biases || !feats || !stats || nimg <= 0 || H % 2 || W % 2 || nf < 2) { set_error("loftup_guidance: bad argument"); return PST_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = H / 2, W2 = W / 2, P = H2 * W2, CH = 10 * nf + 3;
+  // scratch: the fp32 feature buffer is large enough to host img2 + min/max behind the features of the last view?  No:
+  // keep it explicit -- img2 and min/max live at the END of `feats` (caller allocates nimg*(P*CH + 3*P + 8) floats).
+  float* img2 = feats + (int64_t)nimg * P * CH;
+  float* mm = img2 + (int64_t)nimg * 3 * P;
+  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * nimg, s) != hipSuccess) { set_error("loftup_guidance: memset failed"); return PST_ELAUNCH; }
+  hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(256), 0, s, img, img2, mm, H, W);
+  const float f_lo = -2.f, f_step = 12.f / (nf - 1);
+  int gx = (int)(((int64_t)P * CH + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(fourier_kernel, dim3(gx, nimg), dim3(256), 0, s, img2, mm, biases, feats, stats, H2, W2, nf, f_lo, f_step);
+  return check_launch("loftup_guidance");
+}
+
+extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float* stats, int nimg, int P, int C, int G, void* stream) {
+  if (!x || !stats || nimg <= 0 || P <= 0 || C % 4 || G <= 0 || C % G || (C / G) % 4 || ldx % 4 || C / 4 > 1024) { set_error("groupnorm_stats: bad argument"); return PST_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * G * nimg, s) != hipSuccess) { set_error("groupnorm_stats: memset failed"); return PST_ELAUNCH; }
+  const int c4 = C / 4;
+  const int rpb = c4 >= 256 ? 1 : 256 / c4;
+  const int threads = c4 * rpb;
+  const int rows_per_block = 64 * rpb;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((P + rows_per_block - 1) / rows_per_block, nimg), dim3(threads), sizeof(float) * 2 * G, s,
+                     x, ldx, x_fp32, stats, P, C, G, rows_per_block);
+  return check_launch("groupnorm_stats");
+}
+
+extern "C" int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
+                                   void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, void* stream) {
+  if (!x || !stats || !gamma || !beta || !y || nimg <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G || ldy < C) { set_error("groupnorm_apply: bad argument"); return PST_EINVAL; }
+  const int64_t total = (int64_t)nimg * P * ldy;
+  int64_t g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu);
+  return check_launch("groupnorm_apply");
+}
+
+extern "C" int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int nimg, int h, int w, void* stream) {
+  if (!biases || !out || nimg <= 0 || h <= 0 || w <= 0 || col0 < 0 || col0 + 20 > ld) { set_error("loftup_lr_pe: bad argument"); return PST_EINVAL; }
+  const int64_t total = (int64_t)nimg * h * w * 20;
+  int64_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(lr_pe_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, biases, (bf16_t*)out, ld, col0, nimg, h, w);
+  return check_launch("loftup_lr_pe");
+}

@@ -1,0 +1,306 @@
+// HBM-bound helper kernels of the PanSt3R forward path (gfx950): LayerNorm, RoPE-2D, patchify, DINO preprocessing,
+// add/cast, L2 row normalisation, 2x2-centre mean of mask features, attention-mask bits.
+// All are coalesced, vectorised (8-16 B per lane) streaming kernels; none of them reshapes work into GEMMs.
+#include "common.h"
+#include "../../include/panst3r_hip.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace pst {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return PST_ELAUNCH;
+  }
+  return PST_OK;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ void load4(const void* base, int64_t idx, bool fp32, float (&v)[4]) {
+  if (fp32) {
+    const float4 t = *(const float4*)((const float*)base + idx);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    const uint2 t = *(const uint2*)((const bf16_t*)base + idx);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+}
+
+__device__ __forceinline__ void store4(void* base, int64_t idx, bool fp32, const float (&v)[4]) {
+  if (fp32) *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+  else *(uint2*)((bf16_t*)base + idx) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row, row in registers
+template <int NIT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy,
+                                                        int out_fp32, const float* gamma, const float* beta, int rows,
+                                                        int D, float eps, int grp_in, int grp_out, int grp_off) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int irow = grp_in > 0 ? (row / grp_in) * grp_out + grp_off + row % grp_in : row;
+  float v[NIT][4];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < D) {
+      load4(x, (int64_t)irow * ldx + c, in_fp32, v[it]);
+      s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+    } else {
+      v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < D) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = v[it][r] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < D) {
+      const float4 gm = *(const float4*)(gamma + c);
+      const float4 bt = *(const float4*)(beta + c);
+      float o[4] = {(v[it][0] - mean) * rstd * gm.x + bt.x, (v[it][1] - mean) * rstd * gm.y + bt.y,
+                    (v[it][2] - mean) * rstd * gm.z + bt.z, (v[it][3] - mean) * rstd * gm.w + bt.w};
+      store4(y, (int64_t)row * ldy + c, out_fp32, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RoPE-2D in place
+// thread = (row, head, half, 4 consecutive frequencies): rotates pairs (i, i + hd/4) of that half.
+__global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd) {
+  const int nf = hd / 4;                 // frequencies per half
+  const int per_row = nheads * 2 * (nf / 4);
+  const int64_t total = (int64_t)rows * per_row;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / per_row);
+    int r = (int)(i - (int64_t)row * per_row);
+    const int fq = (r % (nf / 4)) * 4; r /= (nf / 4);
+    const int half = r & 1, head = r >> 1;
+    const int pp = pos[2 * row + half];
+    bf16_t* base = x + (int64_t)row * ld + head * hd + half * (hd / 2) + fq;
+    float a[4], b[4];
+    load4(base, 0, false, a);
+    load4(base, nf, false, b);
+    const float* t = cs + ((int64_t)pp * nf + fq) * 2;
+    float oa[4], ob[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = t[2 * k], s = t[2 * k + 1];
+      oa[k] = a[k] * c - b[k] * s;
+      ob[k] = b[k] * c + a[k] * s;
+    }
+    store4(base, 0, false, oa);
+    store4(base, nf, false, ob);
+  }
+}
+
+// ------------------------------------------------------------------ patchify: thread = (token, c, dy) -> p pixels
+__global__ void patchify_kernel(const float* img, bf16_t* out, int64_t ld, int nimg, int C, int H, int W, int p) {
+  const int gh = H / p, gw = W / p;
+  const int per_tok = C * p + 1;                       // +1: the thread that zero-fills the K padding
+  const int64_t total = (int64_t)nimg * gh * gw * per_tok;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tok = i / per_tok;
+    const int r = (int)(i - tok * per_tok);
+    bf16_t* orow = out + tok * ld;
+    if (r == C * p) {
+      for (int c = C * p * p; c < ld; ++c) orow[c] = 0;
+      continue;
+    }
+    const int c = r / p, dy = r - c * p;
+    const int n = (int)(tok / (gh * gw)), t = (int)(tok - (int64_t)n * gh * gw);
+    const int ty = t / gw, tx = t - ty * gw;
+    const float* src = img + (((int64_t)n * C + c) * H + ty * p + dy) * W + tx * p;
+    bf16_t* dst = orow + (c * p + dy) * p;
+    for (int dx = 0; dx < p; ++dx) dst[dx] = f2bf(src[dx]);
+  }
+}
+
+// ------------------------------------------------------------------ DINOv2 preprocessing (normalise + bilinear resize)
+__global__ void dino_pre_kernel(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo) {
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  const float sy = (float)H / Ho, sx = (float)W / Wo;
+  const int64_t total = (int64_t)nimg * 3 * Ho * Wo;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho), c = (int)((i / ((int64_t)Wo * Ho)) % 3);
+    const int64_t n = i / ((int64_t)Wo * Ho * 3);
+    const float fy = fmaxf((oy + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    const float* pl = img + (n * 3 + c) * (int64_t)H * W;
+    auto nv = [&](int yy, int xx) { return ((pl[(int64_t)yy * W + xx] * 0.5f + 0.5f) - mean[c]) / stdv[c]; };
+    const float top = nv(y0, x0) * (1.f - lx) + nv(y0, x1) * lx;
+    const float bot = nv(y1, x0) * (1.f - lx) + nv(y1, x1) * lx;
+    out[i] = top * (1.f - ly) + bot * ly;
+  }
+}
+
+// ------------------------------------------------------------------ y = a + b[row % b_mod]
+__global__ void add_cast_kernel(const void* a, int64_t lda, int a_fp32, const void* b, int64_t ldb, int b_fp32, int b_mod,
+                                void* y, int64_t ldy, int y_fp32, int rows, int D) {
+  const int d4 = D / 4;
+  const int64_t total = (int64_t)rows * d4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / d4), c = (int)(i - (int64_t)row * d4) * 4;
+    float v[4];
+    load4(a, (int64_t)row * lda + c, a_fp32, v);
+    if (b) {
+      float w[4];
+      const int brow = b_mod > 0 ? row % b_mod : row;
+      load4(b, (int64_t)brow * ldb + c, b_fp32, w);
+      v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+    }
+    store4(y, (int64_t)row * ldy + c, y_fp32, v);
+  }
+}
+
+// ------------------------------------------------------------------ y = x / (||x|| + eps), one wave per row
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, int64_t ldx, bf16_t* y, int64_t ldy, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) { const float v = x[(int64_t)row * ldx + c]; s += v * v; }
+  const float inv = 1.0f / (sqrtf(wave_sum(s)) + eps);
+  for (int c = lane; c < D; c += 64) y[(int64_t)row * ldy + c] = f2bf(x[(int64_t)row * ldx + c] * inv);
+}
+
+// ------------------------------------------------------------------ mean of the central 2x2 pixels of every 8x8 block
+__global__ void mean4_kernel(const bf16_t* F, bf16_t* Fm, int nimg, int Hm, int Wm, int C) {
+  const int th = Hm / 8, tw = Wm / 8, c4 = C / 4;
+  const int64_t total = (int64_t)nimg * th * tw * c4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4) * 4;
+    const int64_t tok = i / c4;
+    const int tx = (int)(tok % tw), ty = (int)((tok / tw) % th);
+    const int64_t n = tok / ((int64_t)tw * th);
+    const bf16_t* base = F + ((n * Hm + ty * 8 + 3) * Wm + tx * 8 + 3) * (int64_t)C + c;
+    float a[4], b[4], d[4], e[4];
+    load4(base, 0, false, a);
+    load4(base, C, false, b);
+    load4(base, (int64_t)Wm * C, false, d);
+    load4(base, (int64_t)Wm * C + C, false, e);
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = 0.25f * (a[k] + b[k] + d[k] + e[k]);
+    store4(Fm, tok * C + c, false, o);
+  }
+}
+
+// ------------------------------------------------------------------ mask[q,k] = logit < 0, fully blocked rows cleared
+__global__ __launch_bounds__(256) void attn_mask_kernel(const float* logits, int64_t ldl, uint8_t* mask, int64_t ldm, int Nk) {
+  __shared__ int any_open;
+  const int q = blockIdx.x;
+  if (threadIdx.x == 0) any_open = 0;
+  __syncthreads();
+  const float* lr = logits + (int64_t)q * ldl;
+  int open = 0;
+  for (int k = threadIdx.x; k < Nk; k += 256) open |= !(lr[k] < 0.f);
+  if (open) any_open = 1;
+  __syncthreads();
+  const int keep = any_open;
+  uint8_t* mr = mask + (int64_t)q * ldm;
+  for (int k = threadIdx.x; k < Nk; k += 256) mr[k] = (uint8_t)(keep && (lr[k] < 0.f));
+}
+
+static inline int grid_for(int64_t total, int block = 256) {
+  int64_t g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace pst
+
+using namespace pst;
+
+extern "C" int pst_abi_version(void) { return PST_ABI_VERSION; }
+extern "C" const char* pst_last_error(void) { return g_err; }
+
+extern "C" int pst_layernorm(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy, int out_fp32, const float* gamma,
+                             const float* beta, int rows, int D, float eps, int grp_in, int grp_out, int grp_off, void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0) { set_error("layernorm: null/empty argument"); return PST_EINVAL; }
+  if (D <= 0 || D % 4 || D > 4096 || ldx % 4 || ldy % 4) { set_error("layernorm: need D%%4==0, D<=4096, ld%%4==0 (D=%d)", D); return PST_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((rows + 3) / 4), block(256);
+  const int nit = (D + 255) / 256;
+#define PST_LN(N) hipLaunchKernelGGL((layernorm_kernel<N>), grid, block, 0, s, x, ldx, in_fp32, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off)
+  if (nit <= 1) PST_LN(1); else if (nit <= 2) PST_LN(2); else if (nit <= 3) PST_LN(3); else if (nit <= 4) PST_LN(4);
+  else if (nit <= 8) PST_LN(8); else PST_LN(16);
+#undef PST_LN
+  return check_launch("layernorm");
+}
+
+extern "C" int pst_rope2d_bf16(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, void* stream) {
+  if (!x || !pos || !cs || rows <= 0 || nheads <= 0) { set_error("rope2d: null/empty argument"); return PST_EINVAL; }
+  if (hd % 16 || ld % 4) { set_error("rope2d: need hd%%16==0 and ld%%4==0 (hd=%d)", hd); return PST_EINVAL; }
+  const int64_t total = (int64_t)rows * nheads * 2 * (hd / 16);
+  hipLaunchKernelGGL(rope2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ld, pos, cs, rows, nheads, hd);
+  return check_launch("rope2d");
+}
+
+extern "C" int pst_patchify_bf16(const float* img, void* out, int64_t ld, int nimg, int C, int H, int W, int p, void* stream) {
+  if (!img || !out || nimg <= 0 || p <= 0 || H % p || W % p || ld < (int64_t)C * p * p) { set_error("patchify: bad argument"); return PST_EINVAL; }
+  const int64_t total = (int64_t)nimg * (H / p) * (W / p) * (C * p + 1);
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, ld, nimg, C, H, W, p);
+  return check_launch("patchify");
+}
+
+extern "C" int pst_dino_preprocess(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, void* stream) {
+  if (!img || !out || nimg <= 0 || Ho <= 0 || Wo <= 0) { set_error("dino_preprocess: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(dino_pre_kernel, dim3(grid_for((int64_t)nimg * 3 * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, img, out, nimg, H, W, Ho, Wo);
+  return check_launch("dino_preprocess");
+}
+
+extern "C" int pst_add_cast(const void* a, int64_t lda, int a_fp32, const void* b, int64_t ldb, int b_fp32, int b_mod, void* y,
+                            int64_t ldy, int y_fp32, int rows, int D, void* stream) {
+  if (!a || !y || rows <= 0 || D <= 0 || D % 4 || lda % 4 || ldy % 4 || (b && ldb % 4)) { set_error("add_cast: bad argument (D=%d)", D); return PST_EINVAL; }
+  hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for((int64_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream, a, lda, a_fp32, b, ldb, b_fp32, b_mod, y, ldy, y_fp32, rows, D);
+  return check_launch("add_cast");
+}
+
+extern "C" int pst_l2norm_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps, void* stream) {
+  if (!x || !y || rows <= 0 || D <= 0) { set_error("l2norm_rows: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, rows, D, eps);
+  return check_launch("l2norm_rows");
+}
+
+extern "C" int pst_mean4_bf16(const void* F, void* Fm, int nimg, int Hm, int Wm, int C, void* stream) {
+  if (!F || !Fm || nimg <= 0 || Hm % 8 || Wm % 8 || C % 4) { set_error("mean4: bad argument"); return PST_EINVAL; }
+  const int64_t total = (int64_t)nimg * (Hm / 8) * (Wm / 8) * (C / 4);
+  hipLaunchKernelGGL(mean4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)F, (bf16_t*)Fm, nimg, Hm, Wm, C);
+  return check_launch("mean4");
+}
+
+extern "C" int pst_attn_mask_from_logits(const float* logits, int64_t ldl, uint8_t* mask, int64_t ldm, int Q, int Nk, void* stream) {
+  if (!logits || !mask || Q <= 0 || Nk <= 0) { set_error("attn_mask_from_logits: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(attn_mask_kernel, dim3(Q), dim3(256), 0, (hipStream_t)stream, logits, ldl, mask, ldm, Nk);
+  return check_launch("attn_mask_from_logits");
+}

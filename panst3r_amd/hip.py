@@ -1,0 +1,263 @@
+"""ctypes binding of libpanst3r_hip.so (C ABI in include/panst3r_hip.h) for torch device tensors.
+
+PyTorch is plumbing here: it owns the HBM buffers and the HIP stream; every op below passes raw device pointers,
+sizes and `torch.cuda.current_stream().cuda_stream` across the C ABI.  There is NO fallback: if the library is
+missing or an argument is rejected the op raises (RuntimeError), it never silently computes with torch.
+"""
+import ctypes as C
+import os
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
+ABI_VERSION = 1
+_lib = None
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmParams(C.Structure):
+    _fields_ = [('A', vp), ('lda', i64), ('W', vp), ('ldw', i64), ('C', vp), ('ldc', i64),
+                ('M', i32), ('N', i32), ('K', i32),
+                ('bias', vp), ('gamma', vp), ('res', vp), ('ldr', i64), ('res_mod', i32),
+                ('act', i32), ('out_fp32', i32), ('trans_out', i32),
+                ('grp_in', i32), ('grp_out', i32), ('grp_off', i32),
+                ('ps_p', i32), ('ps_c', i32), ('ps_h', i32), ('ps_w', i32),
+                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [('Q', vp), ('q_bs', i64), ('q_hs', i64), ('q_rs', i64),
+                ('K', vp), ('k_bs', i64), ('k_hs', i64), ('k_rs', i64),
+                ('Vt', vp), ('v_bs', i64), ('v_hs', i64), ('v_ds', i64),
+                ('O', vp), ('o_bs', i64), ('o_hs', i64), ('o_rs', i64),
+                ('mask', vp), ('m_bs', i64), ('m_rs', i64),
+                ('B', i32), ('H', i32), ('Nq', i32), ('Nk', i32), ('hd', i32),
+                ('scale', f32), ('zeros', vp)]
+
+
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_layernorm', 'pst_rope2d_bf16',
+           'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16',
+           'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
+           'pst_loftup_lr_pe']
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libpanst3r_hip.so not found at %s -- run `python -m panst3r_amd.build` (hipcc, gfx950). '
+                           'The HIP path has no fallback.' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.pst_last_error.restype = C.c_char_p
+    L.pst_abi_version.restype = C.c_int
+    if L.pst_abi_version() != ABI_VERSION:
+        raise RuntimeError('libpanst3r_hip.so ABI %d != expected %d; rebuild' % (L.pst_abi_version(), ABI_VERSION))
+    for name in EXPORTS:
+        getattr(L, name)          # AttributeError if a declared symbol is missing
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, lib().pst_last_error().decode()))
+
+
+def _stream():
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return vp(t.data_ptr()) if t is not None else vp(0)
+
+
+def _dev(t, *dtypes):
+    if not t.is_cuda:
+        raise RuntimeError('panst3r_amd HIP op got a %s tensor: the HIP path runs on the GPU only (no CPU fallback)' % t.device)
+    if dtypes and t.dtype not in dtypes:
+        raise RuntimeError('unexpected dtype %s (want %s)' % (t.dtype, dtypes))
+    return t
+
+
+_ZERO = {}
+
+
+def zeros_page(device):
+    z = _ZERO.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        _ZERO[device] = z
+    return z
+
+
+def _rowmajor(t):
+    assert t.dim() == 2 and t.stride(1) == 1, 'need a row-major 2-D view, got strides %s' % (t.stride(),)
+    return t.stride(0)
+
+
+# ----------------------------------------------------------------------------------------------------------- GEMM
+ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
+
+
+def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
+         M=None):
+    """out = epi(a @ w.T).  a [M,K] bf16 (row-major view), w [N,K] bf16, out bf16/fp32 2-D view (or raw buffer for ps)."""
+    _dev(a, torch.bfloat16); _dev(w, torch.bfloat16); _dev(out, torch.bfloat16, torch.float32)
+    p = GemmParams()
+    N, K = w.shape
+    if conv is not None:
+        cc, ch, cw = conv
+        p.conv_c, p.conv_h, p.conv_w = cc, ch, cw
+        Mv = a.numel() // cc
+        p.lda = cc
+        assert K == 9 * cc
+    else:
+        Mv = a.shape[0] if M is None else M
+        assert a.shape[1] == K, (a.shape, w.shape)
+        p.lda = _rowmajor(a)
+    p.A, p.W, p.C = _ptr(a), _ptr(w), _ptr(out)
+    p.ldw = _rowmajor(w)
+    p.M, p.N, p.K = Mv, N, K
+    p.zeros = _ptr(zeros_page(a.device))
+    if ps is not None:
+        p.ps_p, p.ps_c, p.ps_h, p.ps_w = ps
+        p.ldc = 0
+    else:
+        p.ldc = _rowmajor(out)
+    if bias is not None:
+        p.bias = _ptr(_dev(bias, torch.float32))
+    if gamma is not None:
+        p.gamma = _ptr(_dev(gamma, torch.float32))
+    if res is not None:
+        p.res, p.ldr, p.res_mod = _ptr(_dev(res, torch.float32)), _rowmajor(res), res_mod
+    p.act = ACT[act]
+    p.out_fp32 = int(out.dtype == torch.float32)
+    p.trans_out = int(trans_out)
+    if grp is not None:
+        p.grp_in, p.grp_out, p.grp_off = grp
+    _check(lib().pst_gemm_bf16(C.byref(p), _stream()), 'pst_gemm_bf16')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------- attention
+def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale=None, mask=None,
+              mask_strides=(0, 0)):
+    """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row)."""
+    _dev(q, torch.bfloat16); _dev(k, torch.bfloat16); _dev(vt, torch.bfloat16); _dev(out, torch.bfloat16)
+    p = AttnParams()
+    p.Q, (p.q_bs, p.q_hs, p.q_rs) = _ptr(q), q_strides
+    p.K, (p.k_bs, p.k_hs, p.k_rs) = _ptr(k), k_strides
+    p.Vt, (p.v_bs, p.v_hs, p.v_ds) = _ptr(vt), v_strides
+    p.O, (p.o_bs, p.o_hs, p.o_rs) = _ptr(out), o_strides
+    if mask is not None:
+        _dev(mask, torch.uint8)
+        p.mask, (p.m_bs, p.m_rs) = _ptr(mask), mask_strides
+    p.B, p.H, p.Nq, p.Nk, p.hd = B, H, Nq, Nk, hd
+    p.scale = float(hd ** -0.5 if scale is None else scale)
+    p.zeros = _ptr(zeros_page(q.device))
+    _check(lib().pst_attn_fwd_bf16(C.byref(p), _stream()), 'pst_attn_fwd_bf16')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------- the rest
+def layernorm(x, gamma, beta, out, eps, rows=None, grp=None):
+    _dev(x, torch.float32, torch.bfloat16); _dev(out, torch.float32, torch.bfloat16)
+    D = gamma.numel()
+    rows = out.shape[0] if rows is None else rows
+    g = grp or (0, 0, 0)
+    _check(lib().pst_layernorm(_ptr(x), i64(_rowmajor(x)), int(x.dtype == torch.float32), _ptr(out), i64(_rowmajor(out)),
+                               int(out.dtype == torch.float32), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)),
+                               rows, D, f32(eps), g[0], g[1], g[2], _stream()), 'pst_layernorm')
+    return out
+
+
+def rope2d_(x, pos, table, nheads, hd):
+    """In-place RoPE-2D on the first nheads*hd columns of the row-major bf16 view x; pos int32 [rows,2]."""
+    _dev(x, torch.bfloat16); _dev(pos, torch.int32); _dev(table, torch.float32)
+    _check(lib().pst_rope2d_bf16(_ptr(x), i64(_rowmajor(x)), _ptr(pos), _ptr(table), x.shape[0], nheads, hd, _stream()),
+           'pst_rope2d_bf16')
+    return x
+
+
+def rope_table(npos, hd, base=100.0, device='cuda'):
+    """fp32 [npos, hd/4, 2] (cos, sin) for RoPE-2D: per half D = hd/2 channels, inv_freq_i = base^(-2i/D)."""
+    D = hd // 2
+    inv = 1.0 / (base ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    ang = torch.outer(torch.arange(npos, dtype=torch.float32), inv)
+    return torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous().to(device)
+
+
+def patchify(img, out, p):
+    _dev(img, torch.float32); _dev(out, torch.bfloat16)
+    n, c, h, w = img.shape
+    assert img.is_contiguous()
+    _check(lib().pst_patchify_bf16(_ptr(img), _ptr(out), i64(_rowmajor(out)), n, c, h, w, p, _stream()), 'pst_patchify_bf16')
+    return out
+
+
+def dino_preprocess(img, out):
+    _dev(img, torch.float32); _dev(out, torch.float32)
+    n, _, h, w = img.shape
+    assert img.is_contiguous() and out.is_contiguous()
+    _check(lib().pst_dino_preprocess(_ptr(img), _ptr(out), n, h, w, out.shape[-2], out.shape[-1], _stream()), 'pst_dino_preprocess')
+    return out
+
+
+def add_cast(a, out, b=None, b_mod=0):
+    _dev(a); _dev(out)
+    rows, D = out.shape
+    fp = lambda t: int(t.dtype == torch.float32)
+    _check(lib().pst_add_cast(_ptr(a), i64(_rowmajor(a)), fp(a), _ptr(b), i64(_rowmajor(b) if b is not None else 0),
+                              fp(b) if b is not None else 0, b_mod, _ptr(out), i64(_rowmajor(out)), fp(out), rows, D, _stream()),
+           'pst_add_cast')
+    return out
+
+
+def l2norm_rows(x, out, eps):
+    _dev(x, torch.float32); _dev(out, torch.bfloat16)
+    _check(lib().pst_l2norm_rows(_ptr(x), i64(_rowmajor(x)), _ptr(out), i64(_rowmajor(out)), x.shape[0], x.shape[1], f32(eps),
+                                 _stream()), 'pst_l2norm_rows')
+    return out
+
+
+def mean4(F, Fm, nimg, Hm, Wm, Cc):
+    _dev(F, torch.bfloat16); _dev(Fm, torch.bfloat16)
+    _check(lib().pst_mean4_bf16(_ptr(F), _ptr(Fm), nimg, Hm, Wm, Cc, _stream()), 'pst_mean4_bf16')
+    return Fm
+
+
+def attn_mask_from_logits(logits, mask):
+    _dev(logits, torch.float32); _dev(mask, torch.uint8)
+    Q, Nk = logits.shape
+    _check(lib().pst_attn_mask_from_logits(_ptr(logits), i64(_rowmajor(logits)), _ptr(mask), i64(_rowmajor(mask)), Q, Nk, _stream()),
+           'pst_attn_mask_from_logits')
+    return mask
+
+
+def loftup_guidance(img, biases, feats, stats, nf):
+    _dev(img, torch.float32); _dev(biases, torch.float32); _dev(feats, torch.float32); _dev(stats, torch.float32)
+    n, _, h, w = img.shape
+    assert img.is_contiguous()
+    _check(lib().pst_loftup_guidance(_ptr(img), _ptr(biases), _ptr(feats), _ptr(stats), n, h, w, nf, _stream()), 'pst_loftup_guidance')
+
+
+def groupnorm_stats(x, stats, nimg, P, Cc, G):
+    _dev(x); _dev(stats, torch.float32)
+    _check(lib().pst_groupnorm_stats(_ptr(x), i64(_rowmajor(x)), int(x.dtype == torch.float32), _ptr(stats), nimg, P, Cc, G, _stream()),
+           'pst_groupnorm_stats')
+
+
+def groupnorm_apply(x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu):
+    _dev(x); _dev(out, torch.bfloat16)
+    _check(lib().pst_groupnorm_apply(_ptr(x), i64(_rowmajor(x)), int(x.dtype == torch.float32), _ptr(stats), _ptr(gamma), _ptr(beta),
+                                     _ptr(out), i64(_rowmajor(out)), nimg, P, Cc, G, f32(eps), int(relu), _stream()), 'pst_groupnorm_apply')
+    return out
+
+
+def loftup_lr_pe(biases, out, col0, nimg, h, w):
+    _dev(biases, torch.float32); _dev(out, torch.bfloat16)
+    _check(lib().pst_loftup_lr_pe(_ptr(biases), _ptr(out), i64(_rowmajor(out)), col0, nimg, h, w, _stream()), 'pst_loftup_lr_pe')
+    return out

@@ -1,0 +1,314 @@
+"""Per-op parity of the HIP kernels (through the C ABI) against plain fp32 torch restatements of the same op.
+
+bf16 MFMA with fp32 accumulate vs fp32 reference on bf16-rounded inputs: tolerance rel-L2 <= 1e-2 (GEMM/attention
+outputs rounded to bf16), <= 1e-5 when the output is fp32 and the op is elementwise.
+"""
+import math
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rn(seed, *shape, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 256, 384), (768, 1024, 1024), (1000, 136, 192), (4096, 512, 256), (33, 100, 64)])
+@pytest.mark.parametrize('act', [None, 'gelu', 'relu'])
+def test_gemm_basic(M, N, K, act):
+    from panst3r_amd import hip
+    a, w, b = bf(rn(1, M, K)), bf(rn(2, N, K, scale=K ** -0.5)), rn(3, N, scale=0.1)
+    ref = a.float() @ w.float().T + b
+    ref = F.gelu(ref) if act == 'gelu' else (F.relu(ref) if act == 'relu' else ref)
+    for out_dtype in (torch.bfloat16, torch.float32):
+        out = torch.full((M, N), float('nan'), dtype=out_dtype, device=dev())
+        hip.gemm(a.to(dev()), w.to(dev()), out, bias=b.to(dev()), act=act)
+        torch.cuda.synchronize()
+        assert rel_l2(out.float().cpu(), ref) < (1e-2 if out_dtype == torch.bfloat16 else 2e-3)
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric W catches a transposed / permuted C write (guide: always A=I-check)."""
+    from panst3r_amd import hip
+    K = 128
+    a = torch.eye(K)
+    w = torch.arange(256 * K, dtype=torch.float32).reshape(256, K) % 251 - 125     # exactly representable in bf16
+    out = torch.zeros(K, 256, dtype=torch.float32, device=dev())
+    hip.gemm(bf(a).to(dev()), bf(w).to(dev()), out)
+    assert torch.equal(out.cpu(), w.T.contiguous())
+
+
+def test_gemm_residual_gamma_remap():
+    from panst3r_amd import hip
+    M, N, K = 2 * 96, 64, 128
+    a, w = bf(rn(4, M, K)), bf(rn(5, N, K, scale=K ** -0.5))
+    bias, gamma = rn(6, N), rn(7, N)
+    # residual in place on a remapped output (rows 1..96 of each 104-row group), like the DINO patch-embed
+    buf = rn(8, 2 * 104, N)
+    ref = buf.clone()
+    core = (a.float() @ w.float().T + bias) * gamma
+    for v in range(2):
+        ref[v * 104 + 1: v * 104 + 97] += core[v * 96:(v + 1) * 96]
+    d = buf.to(dev())
+    hip.gemm(a.to(dev()), w.to(dev()), d, bias=bias.to(dev()), gamma=gamma.to(dev()), res=d, grp=(96, 104, 1))
+    assert rel_l2(d.cpu(), ref) < 2e-3
+    # broadcast residual (row % res_mod), like the learned position embedding
+    pe = rn(9, 96, N)
+    out = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    hip.gemm(a.to(dev()), w.to(dev()), out, bias=bias.to(dev()), res=pe.to(dev()), res_mod=96)
+    assert rel_l2(out.cpu(), a.float() @ w.float().T + bias + pe.repeat(2, 1)) < 2e-3
+
+
+def test_gemm_trans_out():
+    from panst3r_amd import hip
+    M, N, K = 2 * 769, 128, 64
+    a, w, b = bf(rn(10, M, K)), bf(rn(11, N, K, scale=K ** -0.5)), rn(12, N)
+    ldc = 1544
+    out = torch.zeros(N, ldc, dtype=torch.bfloat16, device=dev())
+    hip.gemm(a.to(dev()), w.to(dev()), out, bias=b.to(dev()), trans_out=True)
+    ref = (a.float() @ w.float().T + b).T
+    assert rel_l2(out[:, :M].float().cpu(), ref) < 1e-2
+    assert float(out[:, M:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('p,c,h,w', [(2, 8, 3, 5), (16, 7, 2, 3), (2, 512, 4, 6)])
+def test_gemm_pixel_shuffle_store(p, c, h, w):
+    """fc2 + F.pixel_shuffle fused: weight rows permuted to [dy][dx][c], output pixel-major [v, p*h, p*w, c]."""
+    from panst3r_amd import hip
+    V, K = 2, 64
+    N = c * p * p
+    Npad = (N + 3) // 4 * 4
+    a, wt, b = bf(rn(13, V * h * w, K)), bf(rn(14, N, K, scale=K ** -0.5)), rn(15, N)
+    y = (a.float() @ wt.float().T + b).reshape(V, h, w, N).permute(0, 3, 1, 2)          # [V, c*p*p, h, w] channel-major
+    ref = F.pixel_shuffle(y, p).permute(0, 2, 3, 1).contiguous()                          # [V, p*h, p*w, c]
+    perm = torch.arange(N).reshape(c, p, p).permute(1, 2, 0).reshape(-1)                  # new row (dy,dx,c) <- old row c*p*p+dy*p+dx
+    assert Npad == N
+    out = torch.zeros(V, p * h, p * w, c, dtype=torch.float32, device=dev())
+    hip.gemm(a.to(dev()), wt[perm].contiguous().to(dev()), out, bias=b[perm].contiguous().to(dev()), ps=(p, c, h, w))
+    assert rel_l2(out.cpu(), ref) < 2e-3
+
+
+@pytest.mark.parametrize('Cin,Cout,H,W', [(64, 128, 12, 20), (128, 64, 9, 7)])
+def test_gemm_implicit_conv3x3(Cin, Cout, H, W):
+    from panst3r_amd import hip
+    V = 2
+    x = bf(rn(16, V, H, W, Cin))                                  # NHWC
+    wt = bf(rn(17, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5))
+    b = rn(18, Cout)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), b, padding=1).permute(0, 2, 3, 1).reshape(V * H * W, Cout)
+    wk = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()   # [N, tap, c]
+    out = torch.zeros(V * H * W, Cout, dtype=torch.float32, device=dev())
+    hip.gemm(x.to(dev()), wk.to(dev()), out, bias=b.to(dev()), conv=(Cin, H, W))
+    assert rel_l2(out.cpu(), ref) < 2e-3
+
+
+def _attn_ref(q, k, v, mask=None):
+    s = (q @ k.transpose(-1, -2)) * q.shape[-1] ** -0.5
+    if mask is not None:
+        s = s.masked_fill(mask[:, None], float('-inf'))
+    return s.softmax(-1) @ v
+
+
+@pytest.mark.parametrize('B,H,Nq,Nk,hd', [(1, 2, 64, 64, 64), (2, 3, 200, 333, 64), (1, 16, 769, 769, 64), (1, 4, 768, 1536, 96),
+                                          (3, 2, 50, 70, 96), (1, 12, 2304, 768, 64)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_attention(B, H, Nq, Nk, hd, masked):
+    from panst3r_amd import hip
+    q, k, v = bf(rn(20, B, H, Nq, hd)), bf(rn(21, B, H, Nk, hd)), bf(rn(22, B, H, Nk, hd))
+    mask = None
+    if masked:
+        g = np.random.Generator(np.random.PCG64(5))
+        mask = torch.from_numpy(g.uniform(size=(B, Nq, Nk)) < 0.6)
+        mask[:, :, 0] = False                                    # every row keeps at least one key
+        mask[:, 0, 64:] = True                                   # a row whose later tiles are fully blocked
+        mask[:, 1, :Nk - 1] = True                               # a row whose only open key is the last one
+        mask[:, 1, Nk - 1] = False
+    ref = _attn_ref(q.float(), k.float(), v.float(), mask)
+    # device layouts: q/k/o token-major [B, N, H*hd]; V transposed [H*hd, B*Nkp] (key contiguous, views side by side)
+    Nkp = (Nk + 7) // 8 * 8
+    qd = q.permute(0, 2, 1, 3).reshape(B, Nq, H * hd).contiguous().to(dev())
+    kd = k.permute(0, 2, 1, 3).reshape(B, Nk, H * hd).contiguous().to(dev())
+    vt = torch.zeros(H * hd, B * Nkp + 8, dtype=torch.bfloat16)
+    for b in range(B):
+        vt[:, b * Nkp: b * Nkp + Nk] = v[b].permute(0, 2, 1).reshape(H * hd, Nk)
+    vt = vt.to(dev())
+    od = torch.full((B, Nq, H * hd), float('nan'), dtype=torch.bfloat16, device=dev())
+    md = None
+    ms = (0, 0)
+    if masked:
+        Nkm = (Nk + 3) // 4 * 4
+        mm = torch.zeros(B, Nq, Nkm, dtype=torch.uint8)
+        mm[:, :, :Nk] = mask.to(torch.uint8)
+        md, ms = mm.to(dev()), (Nq * Nkm, Nkm)
+    hip.attention(qd, kd, vt, od, B, H, Nq, Nk, hd,
+                  q_strides=(Nq * H * hd, hd, H * hd), k_strides=(Nk * H * hd, hd, H * hd),
+                  v_strides=(Nkp, hd * vt.stride(0), vt.stride(0)), o_strides=(Nq * H * hd, hd, H * hd),
+                  mask=md, mask_strides=ms)
+    got = od.float().cpu().reshape(B, Nq, H, hd).permute(0, 2, 1, 3)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) < 1.2e-2
+
+
+def test_attention_softmax_rescale_spike():
+    """Force the online-softmax rescale branch: one key in a late tile dominates one query row (guide rule 26)."""
+    from panst3r_amd import hip
+    H, Nq, Nk, hd = 1, 32, 256, 64
+    q, k, v = bf(rn(30, 1, H, Nq, hd)), bf(rn(31, 1, H, Nk, hd)), bf(rn(32, 1, H, Nk, hd))
+    k[0, 0, 200] = q[0, 0, 5] * 6.0
+    ref = _attn_ref(q.double(), k.double(), v.double()).float()
+    qd, kd = q[0, 0].contiguous().to(dev()), k[0, 0].contiguous().to(dev())
+    vt = torch.zeros(hd, Nk + 8, dtype=torch.bfloat16)
+    vt[:, :Nk] = v[0, 0].T
+    vt = vt.to(dev())
+    od = torch.zeros(Nq, hd, dtype=torch.bfloat16, device=dev())
+    hip.attention(qd, kd, vt, od, 1, 1, Nq, Nk, hd, (0, 0, hd), (0, 0, hd), (0, 0, vt.stride(0)), (0, 0, hd))
+    assert rel_l2(od.float().cpu(), ref[0, 0]) < 1.2e-2
+
+
+@pytest.mark.parametrize('D,eps', [(1024, 1e-6), (768, 1e-6), (384, 1e-5), (48, 1e-5), (2816, 1e-5)])
+def test_layernorm(D, eps):
+    from panst3r_amd import hip
+    rows = 2 * 37
+    x, g, b = rn(40, rows, D) * 3 + 1, 1 + 0.1 * rn(41, D), 0.1 * rn(42, D)
+    ref = F.layer_norm(x, (D,), g, b, eps)
+    out = torch.zeros(rows, D, dtype=torch.float32, device=dev())
+    hip.layernorm(x.to(dev()), g.to(dev()), b.to(dev()), out, eps)
+    assert rel_l2(out.cpu(), ref) < 1e-5
+    outb = torch.zeros(rows, D + 8, dtype=torch.bfloat16, device=dev())
+    hip.layernorm(bf(x).to(dev()), g.to(dev()), b.to(dev()), outb[:, :D], eps)
+    assert rel_l2(outb[:, :D].float().cpu(), F.layer_norm(bf(x).float(), (D,), g, b, eps)) < 5e-3
+    # input row remap: skip a leading CLS row per 38-row group
+    xs = rn(43, 2 * 38, D)
+    out2 = torch.zeros(rows, D, dtype=torch.float32, device=dev())
+    hip.layernorm(xs.to(dev()), g.to(dev()), b.to(dev()), out2, eps, grp=(37, 38, 1))
+    ref2 = F.layer_norm(xs.reshape(2, 38, D)[:, 1:].reshape(rows, D), (D,), g, b, eps)
+    assert rel_l2(out2.cpu(), ref2) < 1e-5
+
+
+@pytest.mark.parametrize('hd,H', [(64, 16), (64, 12), (96, 4), (16, 2)])
+def test_rope2d(hd, H):
+    from panst3r_amd import hip
+    from oracle.blocks import RoPE2D
+    gh, gw = 5, 7
+    T = gh * gw
+    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing='ij')
+    pos = torch.stack([ys, xs], -1).reshape(1, T, 2)
+    x = bf(rn(50, 1, T, 3, H, hd))
+    rope = RoPE2D(100.0)
+    qk = x.float().permute(2, 0, 3, 1, 4)                      # [3, B, H, T, hd]
+    ref_q, ref_k = rope(qk[0], pos), rope(qk[1], pos)
+    d = x.reshape(T, 3 * H * hd).clone().to(dev())
+    table = hip.rope_table(max(gh, gw), hd, 100.0, dev())
+    hip.rope2d_(d, pos[0].to(torch.int32).to(dev()), table, 2 * H, hd)
+    got = d.float().cpu().reshape(T, 3, H, hd)
+    assert rel_l2(got[:, 0].permute(1, 0, 2), ref_q[0]) < 5e-3
+    assert rel_l2(got[:, 1].permute(1, 0, 2), ref_k[0]) < 5e-3
+    assert torch.equal(got[:, 2], x.float().reshape(T, 3, H, hd)[:, 2])      # v untouched
+
+
+def test_patchify_and_dino_preprocess():
+    from panst3r_amd import hip
+    img = rn(60, 2, 3, 32, 48).clamp(-1, 1)
+    for p, ld in ((16, 768), (14, 640)):
+        im = img if p == 16 else img[:, :, :28, :42].contiguous()
+        n, c, h, w = im.shape
+        out = torch.full((n * (h // p) * (w // p), ld), 7.0, dtype=torch.bfloat16, device=dev())
+        hip.patchify(im.to(dev()), out, p)
+        ref = F.unfold(im, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, c * p * p)
+        assert torch.equal(out[:, :c * p * p].float().cpu(), bf(ref).float())
+        assert float(out[:, c * p * p:].abs().max()) == 0.0
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    ref = F.interpolate(((img * 0.5 + 0.5) - mean) / std, size=(28, 42), mode='bilinear', align_corners=False)
+    out = torch.zeros(2, 3, 28, 42, device=dev())
+    hip.dino_preprocess(img.to(dev()), out)
+    assert rel_l2(out.cpu(), ref) < 1e-5
+
+
+def test_small_elementwise():
+    from panst3r_amd import hip
+    a, b = rn(70, 10, 64), rn(71, 5, 64)
+    out = torch.zeros(10, 64, dtype=torch.bfloat16, device=dev())
+    hip.add_cast(a.to(dev()), out, b=b.to(dev()), b_mod=5)
+    assert torch.equal(out.float().cpu(), bf(a + b.repeat(2, 1)).float())
+    x = rn(72, 7, 48)
+    o = torch.zeros(7, 48, dtype=torch.bfloat16, device=dev())
+    hip.l2norm_rows(x.to(dev()), o, 1e-7)
+    assert rel_l2(o.float().cpu(), x / (x.norm(dim=-1, keepdim=True) + 1e-7)) < 5e-3
+    # mean4 == 8x bilinear down-sampling (align_corners=False)
+    Fm = bf(rn(73, 2, 16, 24, 8))
+    o4 = torch.zeros(2 * 2 * 3, 8, dtype=torch.bfloat16, device=dev())
+    hip.mean4(Fm.to(dev()), o4, 2, 16, 24, 8)
+    ref = F.interpolate(Fm.float().permute(0, 3, 1, 2), size=(2, 3), mode='bilinear', align_corners=False).permute(0, 2, 3, 1)
+    assert rel_l2(o4.float().cpu().reshape(2, 2, 3, 8), ref) < 5e-3
+    lg = rn(74, 6, 100)
+    lg[2] = -lg[2].abs() - 0.1            # fully blocked row -> must be cleared
+    m = torch.zeros(6, 100, dtype=torch.uint8, device=dev())
+    hip.attn_mask_from_logits(lg.to(dev()), m)
+    refm = lg < 0
+    refm[refm.all(-1)] = False
+    assert torch.equal(m.cpu().bool(), refm)
+
+
+def test_loftup_guidance_and_groupnorm():
+    from panst3r_amd import hip
+    from oracle.panoptic import MinMaxScaler, ImplicitFeaturizer
+    nf, H, W = 20, 16, 24
+    img = rn(80, 2, 3, H, W).clamp(-1, 1)
+    feat = ImplicitFeaturizer(True, n_freqs=nf, learn_bias=True)
+    with torch.no_grad():
+        feat.biases.copy_(rn(81, 2, 5, nf))
+    small = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+    with torch.no_grad():
+        ref = torch.stack([feat(MinMaxScaler()(small[i:i + 1]))[0] for i in range(2)])      # per-view scaling
+    P, CH = (H // 2) * (W // 2), 10 * nf + 3
+    buf = torch.zeros(2 * P * CH + 2 * 3 * P + 16, device=dev())
+    stats = torch.zeros(2, 2, device=dev())
+    hip.loftup_guidance(img.to(dev()), feat.biases.detach().to(dev()), buf, stats, nf)
+    got = buf[:2 * P * CH].reshape(2, P, CH).cpu()
+    refp = ref.permute(0, 2, 3, 1).reshape(2, P, CH)
+    # the highest frequencies (e^10 rad per unit) amplify 1-ulp input differences: compare with an absolute bound
+    assert float((got - refp).abs().max()) < 2e-2
+    assert rel_l2(got[..., :50], refp[..., :50]) < 1e-4
+    assert rel_l2(stats[:, 0].cpu(), refp.sum((1, 2))) < 1e-3
+    # GroupNorm(1 group) apply with zero padding to 256 columns
+    gamma, beta = 1 + 0.1 * rn(82, CH), 0.1 * rn(83, CH)
+    out = torch.full((2 * P, 256), 7.0, dtype=torch.bfloat16, device=dev())
+    st = torch.stack([got.sum((1, 2)), (got ** 2).sum((1, 2))], -1).to(dev())
+    hip.groupnorm_apply(buf[:2 * P * CH].reshape(2 * P, CH), st, gamma.to(dev()), beta.to(dev()), out, 2, P, CH, 1, 1e-5, False)
+    refn = F.group_norm(got.permute(0, 2, 1).reshape(2, CH, H // 2, W // 2), 1, gamma, beta, 1e-5).permute(0, 2, 3, 1).reshape(2 * P, CH)
+    assert rel_l2(out[:, :CH].float().cpu(), refn) < 5e-3
+    assert float(out[:, CH:].abs().max()) == 0.0
+    # GroupNorm(8) statistics + apply + ReLU on a conv-like map
+    Cc = 64
+    x = rn(84, 2 * P, Cc) * 2 + 0.3
+    st8 = torch.zeros(2, 8, 2, device=dev())
+    hip.groupnorm_stats(x.to(dev()), st8, 2, P, Cc, 8)
+    g8, b8 = 1 + 0.1 * rn(85, Cc), 0.1 * rn(86, Cc)
+    o8 = torch.zeros(2 * P, Cc, dtype=torch.bfloat16, device=dev())
+    hip.groupnorm_apply(x.to(dev()), st8, g8.to(dev()), b8.to(dev()), o8, 2, P, Cc, 8, 1e-5, True)
+    ref8 = F.relu(F.group_norm(x.reshape(2, P, Cc).permute(0, 2, 1).reshape(2, Cc, H // 2, W // 2), 8, g8, b8, 1e-5))
+    assert rel_l2(o8.float().cpu().reshape(2, P, Cc), ref8.permute(0, 2, 3, 1).reshape(2, P, Cc)) < 5e-3
+    # low-res positional features
+    lr = ImplicitFeaturizer(False, n_freqs=5, learn_bias=True)
+    with torch.no_grad():
+        lr.biases.copy_(rn(87, 2, 2, 5))
+        refl = lr(torch.zeros(1, 4, 3, 5))[0].permute(1, 2, 0).reshape(15, 20)
+    o = torch.zeros(2 * 15, 32, dtype=torch.bfloat16, device=dev())
+    hip.loftup_lr_pe(lr.biases.detach().to(dev()), o, 8, 2, 3, 5)
+    assert float((o[:15, 8:28].float().cpu() - refl).abs().max()) < 2e-2
+    assert torch.equal(o[:15], o[15:])

@@ -1,0 +1,86 @@
+"""Oracle restatement of the PanSt3R scene orchestration (TEST INFRASTRUCTURE; CPU, fp32, plain torch).
+
+Follows reference panst3r.py:169-296 with the demo's conventions (max_bs=1 => every stack holds one view, MinMaxScaler
+per view; amp=False => fp32 everywhere).  The must3r engine helpers it calls (encoder_multi_ar, inference_multi_ar,
+stack_views) are restated in oracle/must3r.py ([3P-recalled], parity unpinned).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .must3r import Dust3rEncoder, MUSt3R, encoder_multi_ar, build_memory, mem_batches_for
+from .dino import DinoV2Encoder
+from .panoptic import PanopticDecoder, PixelShuffleUpscaler, LoftUpUpscaler, InputMixer
+
+
+class PanSt3R(nn.Module):
+    def __init__(self, must3r_encoder, must3r_decoder, dino_encoder, panoptic_decoder, **kw):
+        super().__init__()
+        self.must3r_encoder, self.must3r_decoder = must3r_encoder, must3r_decoder
+        self.dino_encoder, self.panoptic_decoder = dino_encoder, panoptic_decoder
+
+    @torch.no_grad()
+    def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=1,
+                                   outdevice=None, amp=False):
+        assert not use_retrieval and not amp
+        N = len(imgs)
+        x_enc, pos = encoder_multi_ar(self.must3r_encoder, imgs, true_shape)                       # :174-175
+        if num_keyframes is None or num_keyframes > N:                                             # :183-186
+            keyframes = list(range(N))
+        else:
+            keyframes = np.linspace(0, N - 1, num_keyframes, dtype=int).tolist()
+        rest = sorted(set(range(N)) - set(keyframes))
+        order = keyframes + rest                                                                   # :191-196
+        K = len(keyframes)
+        imgs = [imgs[i] for i in order]
+        shapes = [true_shape[i].tolist() for i in order]
+        x_enc = [x_enc[i] for i in order]
+        pos = [pos[i] for i in order]
+        mem = build_memory(self.must3r_decoder, x_enc[:K], pos[:K], shapes[:K], mem_batches_for(K))  # :205-210
+
+        def render(i):                                                                             # :221-234 / :127-167
+            _, pm, out = self.must3r_decoder.forward_list([x_enc[i][None]], [pos[i][None]], [shapes[i]], mem, render=True)
+            ts = torch.tensor([shapes[i]])
+            x_dino = self.dino_encoder(imgs[i][None], ts)
+            return pm[0], out[0], x_dino
+        pd = self.panoptic_decoder
+        pointmaps, feats = [], []
+        for i in range(N):
+            pm, y, xd = render(i)
+            pointmaps.append(pm)
+            cat = torch.cat([x_enc[i][None], y, xd], dim=-1)[None]                                  # [1,1,T,2816]
+            ts = torch.tensor([[shapes[i]]])
+            fpn, mf = pd.features(cat, imgs[i][None, None], pos[i][None, None], ts, max_bs=1)
+            feats.append((fpn, mf, ts))
+        cls_emb = pd.text_encoder(classes)
+        mt = pd.mask_transformer
+        out = mt([[f[0] for f in feats[:K]]], [f[1] for f in feats[:K]], [f[2] for f in feats[:K]], cls_emb, multi_ar=True)  # :244
+        masks = [m[:, 0] for m in out['pred_masks']]
+        for i in range(K, N):                                                                      # :254-277 (heads only)
+            _, m, _ = mt.forward_prediction_heads(out['out_queries'], feats[i][1], cls_emb)
+            masks.append(m[:, 0])
+        inv = np.argsort(order)
+        panout = {'pred_logits': out['pred_logits'], 'pred_masks': [masks[i] for i in inv], 'out_queries': out['out_queries']}
+        return [pointmaps[i] for i in inv], panout
+
+    @torch.no_grad()
+    def forward(self, imgs, true_shape, classes, max_bs=1, outdevice=None):
+        """panst3r.py:286-296 for one scene: all n views are memory views and all are rendered."""
+        n = imgs.shape[1]
+        pms, panout = self.forward_inference_multi_ar(list(imgs[0]), true_shape[0], classes, num_keyframes=n)
+        panout = dict(panout)
+        panout['pred_masks'] = torch.stack([m[0] for m in panout['pred_masks']])[None]
+        return panout, torch.stack([p[0] for p in pms])[None]
+
+
+def build(variant='v1', **over):
+    """Full-size oracle model of the released configurations (configs/base.yaml / base_v2.yaml)."""
+    enc = Dust3rEncoder(img_size=[512, 512], patch_embed='PatchEmbedDust3R')
+    dec = MUSt3R(img_size=[512, 512], feedback_type='single_mlp', memory_mode='norm_y')
+    dino = DinoV2Encoder()
+    if variant == 'v1':
+        pan = PanopticDecoder(input_mixer=None, upscaler=PixelShuffleUpscaler(input_dim=2816))
+    else:
+        pan = PanopticDecoder(input_mixer=InputMixer([512, 512], 16, 2816, 768, 12, 3, 4),
+                              upscaler=LoftUpUpscaler(input_dim=768, dim=384, output_stride=2, patch_size=16), mask_dim=384)
+    return PanSt3R(enc, dec, dino, pan).eval()

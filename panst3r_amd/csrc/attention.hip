@@ -170,7 +170,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run[a], mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run[a] - m_new) * c_exp);
-      const float mc = m_new * c_exp;
       m_run[a] = m_new;
       float ps = 0.f;
       float pv[4][4];
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[f][a][r] * c_exp - mc);
+          const float e = __builtin_amdgcn_exp2f((s[f][a][r] - m_new) * c_exp);   // subtract first: sentinel - sentinel == 0 exactly
           pv[f][r] = e;
           ps += e;
         }

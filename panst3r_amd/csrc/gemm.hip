@@ -244,7 +244,9 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) { set_error("gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K); return PST_EINVAL; }
   if (p.K % 64 || p.N % 4) { set_error("gemm: need K%%64==0 and N%%4==0 (K=%d N=%d)", p.K, p.N); return PST_EINVAL; }
   if (!p.A || !p.W || !p.C) { set_error("gemm: null operand"); return PST_EINVAL; }
-  if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.C) & 15) { set_error("gemm: operands must be 16-byte aligned"); return PST_EINVAL; }
+  if ((((uintptr_t)p.A | (uintptr_t)p.W) & 15) || ((uintptr_t)p.C & (p.out_fp32 ? 15 : 7))) {
+    set_error("gemm: A/W must be 16-byte aligned, C 8-byte (bf16) / 16-byte (fp32) aligned"); return PST_EINVAL;
+  }
   if ((p.ldw % 8) || (p.conv_c == 0 && (p.lda % 8))) { set_error("gemm: lda/ldw must be multiples of 8"); return PST_EINVAL; }
   if (p.conv_c > 0 && (p.conv_c % 64 || p.K != 9 * p.conv_c || !p.zeros || p.M % (p.conv_h * p.conv_w))) {
     set_error("gemm: bad conv mode (conv_c=%d K=%d)", p.conv_c, p.K); return PST_EINVAL;

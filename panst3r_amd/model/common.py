@@ -1,0 +1,164 @@
+"""Shared plumbing of the HIP modules: weight packing, token layouts, the transformer-block driver.
+
+Modules keep their parameters as fp32 `nn.Parameter`s under the reference's state-dict keys (so reference
+checkpoints load unchanged, panst3r.py:301-325) and pack bf16 / fused / padded copies for the kernels lazily.
+All compute goes through panst3r_amd.hip (C ABI); torch only allocates buffers and takes views.
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip
+
+BF16 = torch.bfloat16
+
+
+def ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+class Packed:
+    """bf16 weight [N, Kpad] (K zero-padded to a multiple of 64) + fp32 bias."""
+    __slots__ = ('w', 'b', 'n', 'k')
+
+    def __init__(self, weight, bias=None, device=None, row_perm=None):
+        w = weight.detach().reshape(weight.shape[0], -1).float()
+        b = None if bias is None else bias.detach().float()
+        if row_perm is not None:
+            w = w[row_perm]
+            b = None if b is None else b[row_perm]
+        n, k = w.shape
+        kp = ceil_to(k, 64)
+        wp = torch.zeros(n, kp, dtype=BF16, device=device)
+        wp[:, :k] = w.to(device=device, dtype=BF16)
+        self.w, self.n, self.k = wp, n, kp
+        self.b = None if b is None else b.to(device).contiguous()
+
+    def rows(self, a, b):
+        out = Packed.__new__(Packed)
+        out.w, out.n, out.k = self.w[a:b], b - a, self.k
+        out.b = None if self.b is None else self.b[a:b]
+        return out
+
+
+def f32(t, device):
+    return t.detach().float().to(device).contiguous()
+
+
+class HipModule(nn.Module):
+    """nn.Module whose forward runs on the HIP library; `self.pk` caches packed weights per device."""
+
+    def __init__(self):
+        super().__init__()
+        self._pk = None
+        self._pk_device = None
+
+    def _pack(self, device):      # override
+        raise NotImplementedError
+
+    def packed(self, device):
+        if self._pk is None or self._pk_device != device:
+            if device.type != 'cuda':
+                raise RuntimeError('%s runs on the GPU only (HIP path, no CPU fallback); got device %s'
+                                   % (type(self).__name__, device))
+            hip.lib()
+            self._pk = self._pack(device)
+            self._pk_device = device
+        return self._pk
+
+    def invalidate(self):
+        self._pk = None
+        for m in self.children():
+            if isinstance(m, HipModule):
+                m.invalidate()
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pk = None
+        return super()._load_from_state_dict(*a, **k)
+
+
+class Layout:
+    """Token buffer layout for V views: each view owns `Tp` rows (multiple of 8) of which rows [off, off+T) are real."""
+
+    def __init__(self, V, T, extra=0):
+        self.V, self.T, self.extra = V, T, extra
+        self.Tp = ceil_to(T + extra, 8)
+        self.rows = V * self.Tp
+        self.N = T + extra            # real tokens per view (attention length)
+
+    @property
+    def grp(self):                    # GEMM/LN remap for the T payload rows of each view
+        return None if (self.Tp == self.T and self.extra == 0) else (self.T, self.Tp, self.extra)
+
+
+def empty(rows, cols, dtype, device):
+    return torch.empty(rows, cols, dtype=dtype, device=device)
+
+
+def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None):
+    """q,k projection (+RoPE) / transposed v projection / flash attention on a [lay.rows, D] bf16 buffer."""
+    dev = xn.device
+    D = H * hd
+    qk = empty(lay.rows, 2 * D, BF16, dev)
+    hip.gemm(xn, w_qk.w, qk, bias=w_qk.b)
+    if rope is not None:
+        hip.rope2d_(qk, pos, rope, 2 * H, hd)
+    vt = torch.empty(D, lay.rows + 8, dtype=BF16, device=dev)
+    hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True)
+    o = empty(lay.rows, D, BF16, dev)
+    if lay.Tp != lay.N:
+        o.zero_()                     # pad rows stay finite
+    ldq, ldv = qk.stride(0), vt.stride(0)
+    hip.attention(qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd,
+                  q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq),
+                  v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D))
+    return o
+
+
+class BlockW:
+    """Packed weights of one pre-LN ViT block (croco Block / HF Dinov2 layer)."""
+
+    def __init__(self, norm1, qk, v, proj, norm2, fc1, fc2, ls1=None, ls2=None):
+        self.norm1, self.qk, self.v, self.proj, self.norm2, self.fc1, self.fc2, self.ls1, self.ls2 = \
+            norm1, qk, v, proj, norm2, fc1, fc2, ls1, ls2
+
+
+def pack_norm(ln, device):
+    return (f32(ln.weight, device), f32(ln.bias, device), float(ln.eps))
+
+
+def pack_croco_block(blk, device):
+    D = blk.attn.qkv.weight.shape[1]
+    qkv = Packed(blk.attn.qkv.weight, blk.attn.qkv.bias, device)
+    return BlockW(pack_norm(blk.norm1, device), qkv.rows(0, 2 * D), qkv.rows(2 * D, 3 * D),
+                  Packed(blk.attn.proj.weight, blk.attn.proj.bias, device), pack_norm(blk.norm2, device),
+                  Packed(blk.mlp.fc1.weight, blk.mlp.fc1.bias, device), Packed(blk.mlp.fc2.weight, blk.mlp.fc2.bias, device))
+
+
+def vit_block(x, bw, lay, H, hd, pos=None, rope=None):
+    """x fp32 [lay.rows, D] residual stream, updated in place."""
+    dev = x.device
+    D = H * hd
+    xn = empty(lay.rows, D, BF16, dev)
+    hip.layernorm(x, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
+    o = self_attention(xn, lay, H, hd, bw.qk, bw.v, pos, rope)
+    hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, gamma=bw.ls1, res=x)
+    hip.layernorm(x, bw.norm2[0], bw.norm2[1], xn, bw.norm2[2])
+    h = empty(lay.rows, bw.fc1.n, BF16, dev)
+    hip.gemm(xn, bw.fc1.w, h, bias=bw.fc1.b, act='gelu')
+    hip.gemm(h, bw.fc2.w, x, bias=bw.fc2.b, gamma=bw.ls2, res=x)
+    return x
+
+
+class ParamLinear(nn.Linear):
+    """Parameter container (reference key names); never called -- compute goes through hip.gemm."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError('parameter container; use the HIP path')
+
+
+def grid_pos(V, h, w, Tp, off, device):
+    """int32 [V*Tp, 2] (y, x) positions of a row-major h x w token grid, zero for pad rows."""
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    p = torch.zeros(Tp, 2, dtype=torch.int32)
+    p[off:off + h * w] = torch.stack([ys, xs], -1).reshape(-1, 2).to(torch.int32)
+    return p.repeat(V, 1).to(device)

@@ -1,0 +1,69 @@
+"""Dust3rEncoder on the HIP path: CroCo ViT-L/16 with 2-D RoPE ([3P-recalled] -- see oracle/must3r.py).
+
+Interface kept from the reference call sites: `encoder(img [b,3,H,W], true_shape [b,2]) -> (x [b,T,1024], pos [b,T,2])`
+(engine/must3r.py:17-19), attribute `patch_size` (tools/demo_panst3r.py:207), ctor kwargs of configs/base.yaml:7-10.
+All views of a call are batched through every GEMM (M = b*T rows); attention is per view.
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip
+from .common import (HipModule, Packed, Layout, BF16, empty, vit_block, pack_croco_block, pack_norm, grid_pos)
+from .params import BlockP
+
+
+class _PatchEmbedP(nn.Module):
+    def __init__(self, patch_size, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class Dust3rEncoder(HipModule):
+    def __init__(self, img_size=(224, 224), patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4.0,
+                 patch_embed='PatchEmbedDust3R', pos_embed='RoPE100', **kw):
+        super().__init__()
+        assert patch_embed == 'PatchEmbedDust3R' and pos_embed.startswith('RoPE')
+        self.patch_size, self.embed_dim, self.num_heads = patch_size, embed_dim, num_heads
+        self.rope_base = float(pos_embed[4:])
+        self.patch_embed = _PatchEmbedP(patch_size, embed_dim)
+        self.blocks_enc = nn.ModuleList([BlockP(embed_dim, mlp_ratio, True, 1e-6) for _ in range(depth)])
+        self.norm_enc = nn.LayerNorm(embed_dim, eps=1e-6)
+
+    def _pack(self, device):
+        return dict(patch=Packed(self.patch_embed.proj.weight, self.patch_embed.proj.bias, device),
+                    blocks=[pack_croco_block(b, device) for b in self.blocks_enc],
+                    norm=pack_norm(self.norm_enc, device), rope={})
+
+    def rope_table(self, pk, n, hd, device):
+        if pk['rope'].get('n', 0) < n:
+            pk['rope'] = dict(n=n, t=hip.rope_table(n, hd, self.rope_base, device))
+        return pk['rope']['t']
+
+    @torch.no_grad()
+    def encode_tokens(self, img, out=None):
+        """img fp32 [V,3,H,W] (one shape) -> bf16 tokens [V*T, out_ld] written into `out[:, :D]` (or a new buffer),
+        plus int32 positions [V*T, 2]."""
+        dev = img.device
+        pk = self.packed(dev)
+        V, _, H, W = img.shape
+        p, D, Hh = self.patch_size, self.embed_dim, self.num_heads
+        gh, gw = H // p, W // p
+        lay = Layout(V, gh * gw)
+        patches = empty(V * lay.T, pk['patch'].k, BF16, dev)
+        hip.patchify(img.contiguous(), patches, p)
+        x = torch.zeros(lay.rows, D, dtype=torch.float32, device=dev)
+        hip.gemm(patches, pk['patch'].w, x, bias=pk['patch'].b, grp=lay.grp)
+        pos = grid_pos(V, gh, gw, lay.Tp, 0, dev)
+        rope = self.rope_table(pk, max(gh, gw), D // Hh, dev)
+        for bw in pk['blocks']:
+            vit_block(x, bw, lay, Hh, D // Hh, pos, rope)
+        if out is None:
+            out = empty(V * lay.T, D, BF16, dev)
+        hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, :D] if out.shape[1] != D else out, pk['norm'][2],
+                      rows=V * lay.T, grp=lay.grp)
+        return out, grid_pos(V, gh, gw, lay.T, 0, dev)
+
+    def forward(self, img, true_shape=None):
+        V = img.shape[0]
+        tok, pos = self.encode_tokens(img.float())
+        return tok.float().reshape(V, -1, self.embed_dim), pos.reshape(V, -1, 2).long()

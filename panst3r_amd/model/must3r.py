@@ -1,0 +1,277 @@
+"""MUSt3R cross-view decoder with its growing keyframe memory bank, on the HIP path.
+
+[3P-recalled: the upstream module is absent from /root/reference; the restated spec is in oracle/must3r.py and
+DESIGN.md.]  Interface from the reference call sites (engine/must3r.py:45-46,76-80,93-94):
+    decoder(x [B,n,T,1024], pos, true_shape, mem|None, render=, return_feats=True) -> (mem, pointmaps [B,n,H,W,7], feats)
+
+MI355X-first choices
+  * the memory is kept as per-layer *projected* K [Nmem,768] and V^T [768,Nmem] bf16 caches (norm_y + projk/projv
+    applied once, when a keyframe enters the memory) instead of raw tokens that every rendered chunk re-projects
+    (reference engine/must3r.py:104-108): identical math, 21.7 GFLOP per keyframe paid once per scene;
+  * rendering batches ALL views of a call through every GEMM (M = n*T) and through one cross-attention launch
+    (the memory is shared by every query row), so the 12 288..24 576-key K/V tiles stay L2/MALL resident;
+  * the pointmap head stores through the fused pixel-shuffle epilogue straight into [n,H,W,7] fp32.
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip
+from .common import (HipModule, Packed, Layout, BF16, BlockW, empty, pack_norm, pack_croco_block, self_attention, f32,
+                     ParamLinear, grid_pos)
+from .params import BlockP, CrossAttnP, MlpP, AttnP
+
+
+class _DecBlockP(nn.Module):
+    def __init__(self, dim, mlp_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = AttnP(dim, True)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.cross_attn = CrossAttnP(dim, qkv_bias=True)
+        self.norm3 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = MlpP(dim, int(dim * mlp_ratio))
+        self.norm_y = nn.LayerNorm(dim, eps=1e-6)
+
+
+class _HeadP(nn.Module):
+    def __init__(self, dim, p, ch):
+        super().__init__()
+        self.proj = ParamLinear(dim, ch * p * p)
+
+
+class MemoryBank:
+    """Per-layer projected memory: K[l] bf16 [cap, D], Vt[l] bf16 [D, cap+8]; `n` tokens are valid."""
+
+    def __init__(self, L, D, cap, device):
+        self.L, self.D, self.cap, self.n = L, D, cap, 0
+        self.K = [torch.zeros(cap, D, dtype=BF16, device=device) for _ in range(L)]
+        self.Vt = [torch.zeros(D, cap + 8, dtype=BF16, device=device) for _ in range(L)]
+        self.labels = []          # image id of every T-token slot
+        self.nimgs = 0
+
+    def reserve(self, n_tokens):
+        if n_tokens <= self.cap:
+            return
+        cap = max(n_tokens, 2 * self.cap)
+        for l in range(self.L):
+            K = torch.zeros(cap, self.D, dtype=BF16, device=self.K[l].device)
+            K[:self.n] = self.K[l][:self.n]
+            Vt = torch.zeros(self.D, cap + 8, dtype=BF16, device=K.device)
+            Vt[:, :self.n] = self.Vt[l][:, :self.n]
+            self.K[l], self.Vt[l] = K, Vt
+        self.cap = cap
+
+    # list-like face expected by the reference glue (engine/must3r.py:76-80 reads mem_vals[-1].shape)
+    def __len__(self):
+        return self.L
+
+    def __getitem__(self, l):
+        return self.K[l][:self.n].unsqueeze(0)
+
+
+class MUSt3R(HipModule):
+    def __init__(self, img_size=(224, 224), patch_size=16, enc_embed_dim=1024, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4.0, pos_embed='RoPE100', feedback_type='single_mlp', memory_mode='norm_y', pointmap_channels=7, **kw):
+        super().__init__()
+        assert feedback_type in ('single_mlp', None) and memory_mode == 'norm_y'
+        self.patch_size, self.embed_dim, self.depth, self.num_heads = patch_size, embed_dim, depth, num_heads
+        self.feedback_type, self.pointmap_channels = feedback_type, pointmap_channels
+        self.rope_base = float(pos_embed[4:])
+        self.feat_embed_enc_to_dec = ParamLinear(enc_embed_dim, embed_dim)
+        self.image2_embed = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.blocks_dec = nn.ModuleList([_DecBlockP(embed_dim, mlp_ratio) for _ in range(depth)])
+        self.norm_dec = nn.LayerNorm(embed_dim, eps=1e-6)
+        if feedback_type == 'single_mlp':
+            self.feedback_norm = nn.LayerNorm(embed_dim, eps=1e-6)
+            self.feedback_layer = MlpP(embed_dim, int(mlp_ratio * embed_dim), embed_dim)
+        self.head_dec = _HeadP(embed_dim, patch_size, pointmap_channels)
+
+    def _pack(self, device):
+        D, p, ch = self.embed_dim, self.patch_size, self.pointmap_channels
+        e2d = Packed(self.feat_embed_enc_to_dec.weight, self.feat_embed_enc_to_dec.bias, device)
+        blocks = []
+        for b in self.blocks_dec:
+            bw = pack_croco_block(b, device)
+            c = b.cross_attn
+            bw.cross = dict(norm=pack_norm(b.norm2, device), q=Packed(c.projq.weight, c.projq.bias, device),
+                            k=Packed(c.projk.weight, c.projk.bias, device), v=Packed(c.projv.weight, c.projv.bias, device),
+                            proj=Packed(c.proj.weight, c.proj.bias, device), norm_y=pack_norm(b.norm_y, device))
+            bw.norm2 = pack_norm(b.norm3, device)           # the MLP's pre-norm in a decoder block is norm3
+            blocks.append(bw)
+        perm = torch.arange(ch * p * p).reshape(ch, p, p).permute(1, 2, 0).reshape(-1)
+        pk = dict(e2d=e2d, bias_ref=e2d.b, bias_other=(e2d.b + f32(self.image2_embed, device).reshape(-1)).contiguous(),
+                  blocks=blocks, norm=pack_norm(self.norm_dec, device),
+                  head=Packed(self.head_dec.proj.weight, self.head_dec.proj.bias, device, row_perm=perm), rope={})
+        if self.feedback_type:
+            pk['fb_norm'] = pack_norm(self.feedback_norm, device)
+            pk['fb1'] = Packed(self.feedback_layer.fc1.weight, self.feedback_layer.fc1.bias, device)
+            pk['fb2'] = Packed(self.feedback_layer.fc2.weight, self.feedback_layer.fc2.bias, device)
+        return pk
+
+    def _rope(self, pk, n, device):
+        if pk['rope'].get('n', 0) < n:
+            pk['rope'] = dict(n=n, t=hip.rope_table(n, self.embed_dim // self.num_heads, self.rope_base, device))
+        return pk['rope']['t']
+
+    def new_bank(self, device, cap_tokens):
+        return MemoryBank(self.depth, self.embed_dim, cap_tokens, device)
+
+    # ------------------------------------------------------------------ core
+    def _embed(self, pk, x_enc, lay, first_is_ref):
+        dev = x_enc.device
+        x = torch.zeros(lay.rows, self.embed_dim, dtype=torch.float32, device=dev)
+        hip.gemm(x_enc, pk['e2d'].w, x, bias=pk['bias_other'], grp=lay.grp)
+        if first_is_ref:       # scene image 0 carries no image2_embed
+            hip.gemm(x_enc[:lay.T], pk['e2d'].w, x[:lay.Tp], bias=pk['bias_ref'])
+        return x
+
+    def _self_and_mlp_pre(self, x, bw, lay, pos, rope):
+        H, hd, dev = self.num_heads, self.embed_dim // self.num_heads, x.device
+        xn = empty(lay.rows, self.embed_dim, BF16, dev)
+        hip.layernorm(x, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
+        o = self_attention(xn, lay, H, hd, bw.qk, bw.v, pos, rope)
+        hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, res=x)
+        return xn
+
+    def _cross_q(self, x, bw, xn):
+        c = bw.cross
+        hip.layernorm(x, c['norm'][0], c['norm'][1], xn, c['norm'][2])
+        q = empty(xn.shape[0], self.embed_dim, BF16, x.device)
+        hip.gemm(xn, c['q'].w, q, bias=c['q'].b)
+        return q
+
+    def _mlp(self, x, bw, xn):
+        hip.layernorm(x, bw.norm2[0], bw.norm2[1], xn, bw.norm2[2])
+        h = empty(xn.shape[0], bw.fc1.n, BF16, x.device)
+        hip.gemm(xn, bw.fc1.w, h, bias=bw.fc1.b, act='gelu')
+        hip.gemm(h, bw.fc2.w, x, bias=bw.fc2.b, res=x)
+
+    def _head(self, pk, feat, V, h, w):
+        """feat bf16 [V*T, D] (row-major view) -> pointmaps fp32 [V, H, W, 7] through the fused pixel-shuffle store."""
+        p, ch = self.patch_size, self.pointmap_channels
+        pm = torch.empty(V, h * p, w * p, ch, dtype=torch.float32, device=feat.device)
+        hip.gemm(feat, pk['head'].w, pm, bias=pk['head'].b, ps=(p, ch, h, w))
+        return pm
+
+    @torch.no_grad()
+    def render_tokens(self, x_enc, V, h, w, bank, feat_out=None, pointmaps=True):
+        """Render V same-shape views against the frozen memory.  x_enc: bf16 [V*T, >=1024] row-major view."""
+        dev = x_enc.device
+        pk = self.packed(dev)
+        D, H = self.embed_dim, self.num_heads
+        hd = D // H
+        lay = Layout(V, h * w)
+        x = self._embed(pk, x_enc, lay, first_is_ref=False)
+        pos = grid_pos(V, h, w, lay.Tp, 0, dev)
+        rope = self._rope(pk, max(h, w), dev)
+        for l, bw in enumerate(pk['blocks']):
+            xn = self._self_and_mlp_pre(x, bw, lay, pos, rope)
+            q = self._cross_q(x, bw, xn)
+            o = empty(lay.rows, D, BF16, dev)
+            ldv = bank.Vt[l].stride(0)
+            hip.attention(q, bank.K[l], bank.Vt[l], o, 1, H, lay.rows, bank.n, hd,
+                          q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
+            hip.gemm(o, bw.cross['proj'].w, x, bias=bw.cross['proj'].b, res=x)
+            self._mlp(x, bw, xn)
+        if feat_out is None:
+            feat_out = empty(V * lay.T, D, BF16, dev)
+        hip.layernorm(x, pk['norm'][0], pk['norm'][1], feat_out, pk['norm'][2], rows=V * lay.T, grp=lay.grp)
+        pm = self._head(pk, feat_out, V, h, w) if pointmaps else None
+        return pm, feat_out
+
+    @torch.no_grad()
+    def update_tokens(self, x_enc, n, h, w, bank, want_outputs=False):
+        """Memory-update call for n new same-shape images (n == 2 on an empty bank, else n == 1): the reference
+        schedule [2,1,1,...] (panst3r.py:65-70).  Appends the images' projected entries to `bank`."""
+        dev = x_enc.device
+        pk = self.packed(dev)
+        D, H, L = self.embed_dim, self.num_heads, self.depth
+        hd = D // H
+        T = h * w
+        if T % 4:
+            raise NotImplementedError('HIP memory bank needs T %% 4 == 0 tokens per view (got %d)' % T)
+        if not ((n == 2 and bank.n == 0) or (n == 1 and bank.n > 0)):
+            raise NotImplementedError('memory batches other than [2,1,1,...] are not on the HIP path')
+        lay = Layout(n, T)
+        x = self._embed(pk, x_enc, lay, first_is_ref=(bank.nimgs == 0))
+        pos = grid_pos(n, h, w, lay.Tp, 0, dev)
+        rope = self._rope(pk, max(h, w), dev)
+        hs = []
+        for l, bw in enumerate(pk['blocks']):
+            hs.append(x.clone())
+            xn = self._self_and_mlp_pre(x, bw, lay, pos, rope)
+            c = bw.cross
+            o = empty(lay.rows, D, BF16, dev)
+            if n == 2:
+                # each image attends to the other image's layer input (norm_y + projk / projv on the fly)
+                y = empty(lay.rows, D, BF16, dev)
+                hip.layernorm(hs[l], c['norm_y'][0], c['norm_y'][1], y, c['norm_y'][2])
+                kk = empty(lay.rows, D, BF16, dev)
+                hip.gemm(y, c['k'].w, kk, bias=c['k'].b)
+                vt = torch.zeros(D, lay.rows + 8, dtype=BF16, device=dev)
+                hip.gemm(y, c['v'].w, vt, bias=c['v'].b, trans_out=True)
+                q = self._cross_q(x, bw, xn)
+                ldv = vt.stride(0)
+                hip.attention(q, kk[lay.Tp:], vt[:, lay.Tp:], o, 2, H, T, T, hd,
+                              q_strides=(lay.Tp * D, hd, D), k_strides=(-lay.Tp * D, hd, D),
+                              v_strides=(-lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D))
+                if lay.Tp != T:
+                    o.view(2, lay.Tp, D)[:, T:] = 0
+            else:
+                q = self._cross_q(x, bw, xn)
+                ldv = bank.Vt[l].stride(0)
+                hip.attention(q, bank.K[l], bank.Vt[l], o, 1, H, lay.rows, bank.n, hd,
+                              q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
+            hip.gemm(o, c['proj'].w, x, bias=c['proj'].b, res=x)
+            self._mlp(x, bw, xn)
+        # feedback ('single_mlp'): fb = Mlp(LN(norm_dec(x))) added to every layer's entry of these images
+        out = empty(lay.rows, D, torch.float32, dev)
+        hip.layernorm(x, pk['norm'][0], pk['norm'][1], out, pk['norm'][2])
+        fb = None
+        if self.feedback_type:
+            fbn = empty(lay.rows, D, BF16, dev)
+            hip.layernorm(out, pk['fb_norm'][0], pk['fb_norm'][1], fbn, pk['fb_norm'][2])
+            hh = empty(lay.rows, pk['fb1'].n, BF16, dev)
+            hip.gemm(fbn, pk['fb1'].w, hh, bias=pk['fb1'].b, act='gelu')
+            fb = empty(lay.rows, D, torch.float32, dev)
+            hip.gemm(hh, pk['fb2'].w, fb, bias=pk['fb2'].b)
+        bank.reserve(bank.n + n * T)
+        e = empty(lay.rows, D, torch.float32, dev)
+        y = empty(n * T, D, BF16, dev)
+        for l, bw in enumerate(pk['blocks']):
+            c = bw.cross
+            src = hs[l]
+            if fb is not None:
+                hip.add_cast(hs[l], e, b=fb)
+                src = e
+            hip.layernorm(src, c['norm_y'][0], c['norm_y'][1], y, c['norm_y'][2], rows=n * T, grp=lay.grp)
+            hip.gemm(y, c['k'].w, bank.K[l][bank.n: bank.n + n * T], bias=c['k'].b)
+            hip.gemm(y, c['v'].w, bank.Vt[l][:, bank.n:], bias=c['v'].b, trans_out=True)
+        bank.n += n * T
+        bank.labels += list(range(bank.nimgs, bank.nimgs + n))
+        bank.nimgs += n
+        if not want_outputs:
+            return bank
+        feat = empty(n * T, D, BF16, dev)       # first-pass outputs of the update call (engine/must3r.py:45-46)
+        hip.add_cast(out.view(n, lay.Tp, D)[:, :T].reshape(n * T, D) if lay.Tp == T else
+                     out.view(n, lay.Tp, D)[:, :T].contiguous().view(n * T, D), feat)
+        return bank, self._head(pk, feat, n, h, w), feat
+
+    # ------------------------------------------------------------------ reference-signature wrapper
+    def forward(self, x, pos, true_shape, mem=None, render=False, return_feats=False):
+        B, n, T, _ = x.shape
+        if B != 1:
+            raise NotImplementedError('HIP MUSt3R handles one scene per call (B == 1)')
+        H, W = [int(v) for v in true_shape[0, 0].tolist()]
+        h, w = H // self.patch_size, W // self.patch_size
+        dev = x.device
+        xe = x.reshape(n * T, -1).to(BF16).contiguous()
+        bank = mem[0] if mem is not None else self.new_bank(dev, max(n, 8) * T)
+        if render:
+            pm, feat = self.render_tokens(xe, n, h, w, bank)
+        else:
+            _, pm, feat = self.update_tokens(xe, n, h, w, bank, want_outputs=True)
+        mem_out = (bank, bank.labels, bank.nimgs, 0, 0)
+        pm = pm.reshape(1, n, H, W, -1)
+        feats = [feat.float().reshape(1, n, T, -1)]
+        return (mem_out, pm, feats) if return_feats else (mem_out, pm)

@@ -1,0 +1,604 @@
+"""PanSt3R-owned panoptic half on the HIP path.
+
+Same class names, ctor kwargs and state-dict keys as the reference modules:
+  InputMixer            model/input_mixer.py:9-29
+  PixelShuffleUpscaler  model/upscalers/pixel_shuffle.py:9-59
+  LoftUpUpscaler        model/upscalers/loftup.py:82-190
+  MaskTransformer       model/mask_transformer.py:12-288
+  TextEncoder           model/text_encoder.py:33-103 (fixed-vocabulary branch)
+  PanopticDecoder       model/panoptic_decoder.py:16-77
+
+MI355X-first data layout: every feature map is pixel/token-major ([view, pixel, channel], channel contiguous, bf16), so
+  * F.pixel_shuffle is a store permutation in the producing GEMM (weight rows re-ordered once to [dy][dx][c]),
+  * the 3x3 convs are implicit GEMMs over NHWC,
+  * the query x pixel einsum "bqc,bnchw->bnqhw" (mask_transformer.py:280) is a plain NT GEMM
+    mask_embed[Q,C] x mask_feats[P,C]^T whose fp32 [Q,P] output IS pred_masks[view],
+  * the attention mask of the 6 intermediate decoder layers needs only the mean of the central 2x2 pixels of each 8x8
+    block (== the 8x bilinear resize, mask_transformer.py:283-287): E . mean4(F) is one tiny GEMM per layer instead of
+    a full-resolution einsum + resize; the never-consumed aux_outputs are not produced.
+"""
+import math
+import torch
+import torch.nn as nn
+
+from .. import hip
+from .common import (HipModule, Packed, Layout, BF16, empty, vit_block, pack_croco_block, pack_norm, f32, ParamLinear,
+                     grid_pos, ceil_to)
+from .params import BlockP, MlpP, CrossAttnP, MHAP
+
+VIEW_CHUNK = 8      # views per upscaler pass (bounds the [rows, 22528] / [P, 384] workspaces)
+
+
+# =========================================================================================== InputMixer
+class InputMixer(HipModule):
+    def __init__(self, img_size, patch_size, in_dim, hidden_dim, num_heads=12, num_layers=3, ff_dim_mult=4):
+        super().__init__()
+        self.hidden_dim, self.num_heads = hidden_dim, num_heads
+        self.in_proj = ParamLinear(in_dim, hidden_dim)
+        self.mixer_blk = nn.ModuleList([BlockP(hidden_dim, ff_dim_mult, True, 1e-5) for _ in range(num_layers)])
+        self.mixer_norm = nn.LayerNorm(hidden_dim)
+
+    def _pack(self, device):
+        return dict(inp=Packed(self.in_proj.weight, self.in_proj.bias, device),
+                    blocks=[pack_croco_block(b, device) for b in self.mixer_blk], norm=pack_norm(self.mixer_norm, device), rope={})
+
+    @torch.no_grad()
+    def mix_tokens(self, cat, V, h, w, out):
+        """cat bf16 [V*T, in_dim] -> LN'd mixer tokens written to out[:, :hidden] (bf16, row-major view)."""
+        dev = cat.device
+        pk = self.packed(dev)
+        D, H = self.hidden_dim, self.num_heads
+        lay = Layout(V, h * w)
+        x = torch.zeros(lay.rows, D, dtype=torch.float32, device=dev)
+        hip.gemm(cat, pk['inp'].w, x, bias=pk['inp'].b, grp=lay.grp)
+        pos = grid_pos(V, h, w, lay.Tp, 0, dev)
+        if pk['rope'].get('n', 0) < max(h, w):
+            pk['rope'] = dict(n=max(h, w), t=hip.rope_table(max(h, w), D // H, 100.0, dev))
+        for bw in pk['blocks']:
+            vit_block(x, bw, lay, H, D // H, pos, pk['rope']['t'])
+        hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, :D], pk['norm'][2], rows=V * lay.T, grp=lay.grp)
+        return out
+
+    def forward(self, x, pos):
+        V, T, _ = x.shape
+        h = int(pos[0, :, 0].max()) + 1
+        out = torch.empty(V * T, self.hidden_dim, dtype=BF16, device=x.device)
+        self.mix_tokens(x.reshape(V * T, -1).to(BF16).contiguous(), V, h, T // h, out)
+        return out.float().reshape(V, T, -1)
+
+
+# =========================================================================================== PixelShuffle upscaler (v1)
+def _ps_perm(c, p=2):
+    """row permutation that turns F.pixel_shuffle's channel order c*p*p + dy*p + dx into [dy][dx][c]."""
+    return torch.arange(c * p * p).reshape(c, p, p).permute(1, 2, 0).reshape(-1)
+
+
+class PixelShuffleUpscaler(HipModule):
+    def __init__(self, input_dim, patch_size=16, hidden_dim_factor=4, fp_dim=(768, 512, 384, 256), fp_activation=nn.GELU, **kw):
+        super().__init__()
+        assert fp_activation is nn.GELU
+        self.patch_size, self.fp_dim, self.input_dim = patch_size, list(fp_dim), input_dim
+        f = hidden_dim_factor
+        self.proj_8 = MlpP(input_dim, int(f * input_dim), fp_dim[1] * 4)
+        self.proj_4 = MlpP(fp_dim[1], int(f * fp_dim[1]), fp_dim[2] * 4)
+        self.proj_2 = MlpP(fp_dim[2], int(f * fp_dim[2]), fp_dim[3] * 4)
+        self.proj_16 = MlpP(input_dim, int(f * input_dim), fp_dim[0])
+        self.mask_dim = fp_dim[3]
+        self.fpn_dim = fp_dim[0]
+
+    def _pack(self, device):
+        P = lambda lin, perm=None: Packed(lin.weight, lin.bias, device, row_perm=perm)
+        fc1 = Packed(torch.cat([self.proj_16.fc1.weight, self.proj_8.fc1.weight]),
+                     torch.cat([self.proj_16.fc1.bias, self.proj_8.fc1.bias]), device)     # one GEMM, N = 2*hidden
+        return dict(fc1=fc1, hid=self.proj_16.fc1.weight.shape[0], p16=P(self.proj_16.fc2),
+                    p8=P(self.proj_8.fc2, _ps_perm(self.fp_dim[1])),
+                    p4a=P(self.proj_4.fc1), p4b=P(self.proj_4.fc2, _ps_perm(self.fp_dim[2])),
+                    p2a=P(self.proj_2.fc1), p2b=P(self.proj_2.fc2, _ps_perm(self.fp_dim[3])))
+
+    @torch.no_grad()
+    def upscale_tokens(self, cat, imgs, V, h, w, fpn_out, mask_out):
+        """cat bf16 [V*T, input_dim] -> fpn_out bf16 [V*T, 768], mask_out bf16 [V, 8h, 8w, 256] (pixel-major)."""
+        dev = cat.device
+        pk = self.packed(dev)
+        T = h * w
+        d1, d2, d3 = self.fp_dim[1], self.fp_dim[2], self.fp_dim[3]
+        for v0 in range(0, V, VIEW_CHUNK):
+            n = min(VIEW_CHUNK, V - v0)
+            a = cat[v0 * T:(v0 + n) * T]
+            hid = empty(n * T, pk['fc1'].n, BF16, dev)
+            hip.gemm(a, pk['fc1'].w, hid, bias=pk['fc1'].b, act='gelu')
+            hip.gemm(hid[:, :pk['hid']], pk['p16'].w, fpn_out[v0 * T:(v0 + n) * T], bias=pk['p16'].b)
+            f8 = empty(n * 4 * T, d1, BF16, dev)
+            hip.gemm(hid[:, pk['hid']:], pk['p8'].w, f8, bias=pk['p8'].b, ps=(2, d1, h, w))
+            del hid
+            h4 = empty(n * 4 * T, pk['p4a'].n, BF16, dev)
+            hip.gemm(f8, pk['p4a'].w, h4, bias=pk['p4a'].b, act='gelu')
+            f4 = empty(n * 16 * T, d2, BF16, dev)
+            hip.gemm(h4, pk['p4b'].w, f4, bias=pk['p4b'].b, ps=(2, d2, 2 * h, 2 * w))
+            del h4, f8
+            h2 = empty(n * 16 * T, pk['p2a'].n, BF16, dev)
+            hip.gemm(f4, pk['p2a'].w, h2, bias=pk['p2a'].b, act='gelu')
+            hip.gemm(h2, pk['p2b'].w, mask_out[v0:v0 + n], bias=pk['p2b'].b, ps=(2, d3, 4 * h, 4 * w))
+            del h2, f4
+        return fpn_out, mask_out
+
+    def forward(self, feats, img_shape):
+        """Reference signature: feats=(tokens [b,T,C], ...), img_shape (H,W) -> ([f16 [b,768,h,w]], mask_feats [b,256,H/2,W/2])."""
+        x = feats[0]
+        V, T, _ = x.shape
+        H, W = img_shape
+        h, w = H // self.patch_size, W // self.patch_size
+        fpn = torch.empty(V * T, self.fpn_dim, dtype=BF16, device=x.device)
+        mf = torch.empty(V, 8 * h, 8 * w, self.mask_dim, dtype=BF16, device=x.device)
+        self.upscale_tokens(x.reshape(V * T, -1).to(BF16).contiguous(), None, V, h, w, fpn, mf)
+        return [fpn.float().reshape(V, h, w, -1).permute(0, 3, 1, 2)], mf.float().permute(0, 3, 1, 2)
+
+
+# =========================================================================================== LoftUp upscaler (v2)
+class _Featurizer(nn.Module):
+    def __init__(self, dm, nf):
+        super().__init__()
+        self.biases = nn.Parameter(torch.randn(2, dm, nf))
+
+
+class _CrossOnlyP(nn.Module):
+    """CrossonlyDecoderBlock parameters (model/blocks.py:9-35): cross_attn (no qkv bias), norm2, norm3, mlp, norm_y."""
+
+    def __init__(self, dim, mlp_ratio):
+        super().__init__()
+        self.cross_attn = CrossAttnP(dim, qkv_bias=False)
+        self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.mlp = MlpP(dim, int(dim * mlp_ratio))
+        self.norm_y = nn.LayerNorm(dim)
+
+
+class LoftUpUpscaler(HipModule):
+    def __init__(self, input_dim, dim, output_stride=2, patch_size=16, color_feats=True, n_freqs=20, num_heads=4, num_layers=2,
+                 lr_pe_type='sine'):
+        super().__init__()
+        assert lr_pe_type == 'sine' and color_feats and output_stride == 2, 'released LoftUp configuration only'
+        self.input_dim, self.dim, self.patch_size, self.n_freqs, self.num_heads = input_dim, dim, patch_size, n_freqs, num_heads
+        self.patch_embed = nn.Conv2d(input_dim, input_dim, kernel_size=1)
+        start = 5 * n_freqs * 2 + 3
+        self.start_dim = start
+        self.lr_pe = _Featurizer(2, 5)
+        self.lr_input_proj = nn.Sequential(ParamLinear(input_dim + 20, dim), nn.LayerNorm(dim))
+        self.fourier_feat = nn.Sequential(nn.Identity(), _Featurizer(5, n_freqs))
+        self.first_conv = nn.Sequential(nn.GroupNorm(1, start), nn.Conv2d(start, dim, 3, padding=1), nn.GroupNorm(8, dim), nn.ReLU(),
+                                        nn.Conv2d(dim, dim, 3, padding=1), nn.GroupNorm(8, dim), nn.ReLU())
+        self.ca_transformer_blocks = nn.ModuleList([_CrossOnlyP(dim, 1) for _ in range(num_layers)])
+        self.ca_transformer_norm = nn.LayerNorm(dim)
+        self.mask_dim, self.fpn_dim = dim, input_dim
+
+    def _pack(self, device):
+        def conv_w(conv, cpad):      # [Cout, Cin, 3, 3] -> [Cout, 9, cpad] tap-major / channel-minor, zero padded
+            wt = conv.weight.detach().float().permute(0, 2, 3, 1)
+            out = torch.zeros(wt.shape[0], 3, 3, cpad)
+            out[..., :wt.shape[-1]] = wt
+            return Packed(out.reshape(wt.shape[0], -1), conv.bias, device)
+        c0 = ceil_to(self.start_dim, 64)
+        fc = self.first_conv
+        blocks = []
+        for b in self.ca_transformer_blocks:
+            c = b.cross_attn
+            blocks.append(dict(norm2=pack_norm(b.norm2, device), norm3=pack_norm(b.norm3, device), norm_y=pack_norm(b.norm_y, device),
+                               q=Packed(c.projq.weight, c.projq.bias, device), k=Packed(c.projk.weight, c.projk.bias, device),
+                               v=Packed(c.projv.weight, c.projv.bias, device), proj=Packed(c.proj.weight, c.proj.bias, device),
+                               fc1=Packed(b.mlp.fc1.weight, b.mlp.fc1.bias, device), fc2=Packed(b.mlp.fc2.weight, b.mlp.fc2.bias, device)))
+        gn = lambda g: (f32(g.weight, device), f32(g.bias, device), float(g.eps))
+        return dict(pe=Packed(self.patch_embed.weight, self.patch_embed.bias, device), c0=c0,
+                    lr_bias=f32(self.lr_pe.biases, device), ff_bias=f32(self.fourier_feat[1].biases, device),
+                    lr_proj=Packed(self.lr_input_proj[0].weight, self.lr_input_proj[0].bias, device),
+                    lr_norm=pack_norm(self.lr_input_proj[1], device),
+                    gn0=gn(fc[0]), conv1=conv_w(fc[1], c0), gn1=gn(fc[2]), conv2=conv_w(fc[4], self.dim), gn2=gn(fc[5]),
+                    blocks=blocks, norm=pack_norm(self.ca_transformer_norm, device))
+
+    def lr_width(self):
+        return ceil_to(self.input_dim + 20, 64)
+
+    @torch.no_grad()
+    def upscale_tokens(self, lr, imgs, V, h, w, fpn_out, mask_out):
+        """lr bf16 [V*T, lr_width()] with the mixer tokens in columns [0, input_dim) (the rest is filled here);
+        imgs fp32 [V,3,H,W] landscape -> fpn_out bf16 [V*T, input_dim], mask_out bf16 [V, H/2, W/2, dim]."""
+        dev = lr.device
+        pk = self.packed(dev)
+        T, D, C, Hh = h * w, self.input_dim, self.dim, self.num_heads
+        hd = C // Hh
+        H2, W2 = imgs.shape[2] // 2, imgs.shape[3] // 2
+        P, CH = H2 * W2, self.start_dim
+        hip.gemm(lr[:, :D], pk['pe'].w, fpn_out, bias=pk['pe'].b)
+        lr[:, D:].zero_()
+        hip.loftup_lr_pe(pk['lr_bias'], lr, D, V, h, w)
+        lay = Layout(V, T)
+        kv = torch.zeros(lay.rows, C, dtype=torch.float32, device=dev)
+        hip.gemm(lr, pk['lr_proj'].w, kv, bias=pk['lr_proj'].b, grp=lay.grp)
+        kvn = empty(lay.rows, C, torch.float32, dev)
+        hip.layernorm(kv, pk['lr_norm'][0], pk['lr_norm'][1], kvn, pk['lr_norm'][2])
+        for v0 in range(0, V, VIEW_CHUNK):
+            n = min(VIEW_CHUNK, V - v0)
+            # ---- guidance branch: Fourier features -> GN(1) -> conv3x3 -> GN(8)+ReLU -> conv3x3 -> GN(8)+ReLU
+            scratch = torch.empty(n * (P * CH + 3 * P) + 8 * n + 16, dtype=torch.float32, device=dev)
+            st0 = torch.empty(n, 2, dtype=torch.float32, device=dev)
+            hip.loftup_guidance(imgs[v0:v0 + n].contiguous(), pk['ff_bias'], scratch, st0, self.n_freqs)
+            g0 = empty(n * P, pk['c0'], BF16, dev)
+            hip.groupnorm_apply(scratch[:n * P * CH].view(n * P, CH), st0, pk['gn0'][0], pk['gn0'][1], g0, n, P, CH, 1, pk['gn0'][2], False)
+            del scratch
+            c1 = empty(n * P, C, BF16, dev)
+            hip.gemm(g0, pk['conv1'].w, c1, bias=pk['conv1'].b, conv=(pk['c0'], H2, W2))
+            st = torch.empty(n, 8, 2, dtype=torch.float32, device=dev)
+            hip.groupnorm_stats(c1, st, n, P, C, 8)
+            g1 = empty(n * P, C, BF16, dev)
+            hip.groupnorm_apply(c1, st, pk['gn1'][0], pk['gn1'][1], g1, n, P, C, 8, pk['gn1'][2], True)
+            hip.gemm(g1, pk['conv2'].w, c1, bias=pk['conv2'].b, conv=(C, H2, W2))
+            hip.groupnorm_stats(c1, st, n, P, C, 8)
+            hip.groupnorm_apply(c1, st, pk['gn2'][0], pk['gn2'][1], g1, n, P, C, 8, pk['gn2'][2], True)
+            x = empty(n * P, C, torch.float32, dev)
+            hip.add_cast(g1, x)
+            del g0, c1
+            # ---- 2 x cross-only blocks: 49k queries per view attend to the view's T low-res tokens (hd 96)
+            xn, q, o = g1, empty(n * P, C, BF16, dev), empty(n * P, C, BF16, dev)
+            rows0, rows1 = v0 * lay.Tp, (v0 + n) * lay.Tp
+            for bw in pk['blocks']:
+                y = empty(rows1 - rows0, C, BF16, dev)
+                hip.layernorm(kvn[rows0:rows1], bw['norm_y'][0], bw['norm_y'][1], y, bw['norm_y'][2])
+                kk = empty(rows1 - rows0, C, BF16, dev)
+                hip.gemm(y, bw['k'].w, kk, bias=bw['k'].b)
+                vt = torch.zeros(C, rows1 - rows0 + 8, dtype=BF16, device=dev)
+                hip.gemm(y, bw['v'].w, vt, bias=bw['v'].b, trans_out=True)
+                hip.layernorm(x, bw['norm2'][0], bw['norm2'][1], xn, bw['norm2'][2])
+                hip.gemm(xn, bw['q'].w, q, bias=bw['q'].b)
+                ldv = vt.stride(0)
+                hip.attention(q, kk, vt, o, n, Hh, P, T, hd, q_strides=(P * C, hd, C), k_strides=(lay.Tp * C, hd, C),
+                              v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(P * C, hd, C))
+                hip.gemm(o, bw['proj'].w, x, bias=bw['proj'].b, res=x)
+                hip.layernorm(x, bw['norm3'][0], bw['norm3'][1], xn, bw['norm3'][2])
+                hip.gemm(xn, bw['fc1'].w, q, bias=bw['fc1'].b, act='gelu')
+                hip.gemm(q, bw['fc2'].w, x, bias=bw['fc2'].b, res=x)
+            hip.layernorm(x, pk['norm'][0], pk['norm'][1], mask_out[v0:v0 + n].view(n * P, C), pk['norm'][2])
+            del x, xn, q, o, g1
+        return fpn_out, mask_out
+
+    def forward(self, inputs, img_shape):
+        tok, img = inputs
+        V, T, _ = tok.shape
+        H, W = img_shape
+        if H > W:
+            raise NotImplementedError('portrait guidance on the HIP LoftUp path: feed landscape views (round-1 scope)')
+        h, w = H // self.patch_size, W // self.patch_size
+        lr = torch.zeros(V * T, self.lr_width(), dtype=BF16, device=tok.device)
+        lr[:, :self.input_dim] = tok.reshape(V * T, -1).to(BF16)
+        fpn = torch.empty(V * T, self.fpn_dim, dtype=BF16, device=tok.device)
+        mf = torch.empty(V, H // 2, W // 2, self.dim, dtype=BF16, device=tok.device)
+        self.upscale_tokens(lr, img.float(), V, h, w, fpn, mf)
+        return [fpn.float().reshape(V, h, w, -1).permute(0, 3, 1, 2)], mf.float().permute(0, 3, 1, 2)
+
+
+# =========================================================================================== MaskTransformer
+def sine_pe(h, w, dim, temperature=10000.0):
+    """PositionEmbeddingSine(dim/2, normalize=True) of an h x w grid as [h*w, dim] (mask_transformer.py:488-527):
+    channels [0, dim/2) encode y, [dim/2, dim) encode x; 1-based cumulative index / (size + 1e-6) * 2*pi."""
+    npf = dim // 2
+    ye = torch.arange(1, h + 1, dtype=torch.float32).view(h, 1).expand(h, w) / (h + 1e-6) * (2 * math.pi)
+    xe = torch.arange(1, w + 1, dtype=torch.float32).view(1, w).expand(h, w) / (w + 1e-6) * (2 * math.pi)
+    i = torch.arange(npf, dtype=torch.float32)
+    div = temperature ** (2 * torch.div(i, 2, rounding_mode='floor') / npf)
+
+    def enc(e):
+        p = e[..., None] / div
+        return torch.stack([p[..., 0::2].sin(), p[..., 1::2].cos()], dim=3).flatten(2)
+    return torch.cat([enc(ye), enc(xe)], dim=2).reshape(h * w, dim)
+
+
+class _SelfLayerP(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.self_attn, self.norm = MHAP(d), nn.LayerNorm(d)
+
+
+class _CrossLayerP(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.multihead_attn, self.norm = MHAP(d), nn.LayerNorm(d)
+
+
+class _FFNP(nn.Module):
+    def __init__(self, d, ff):
+        super().__init__()
+        self.linear1, self.linear2, self.norm = ParamLinear(d, ff), ParamLinear(ff, d), nn.LayerNorm(d)
+
+
+class _MLP3P(nn.Module):
+    def __init__(self, i, h, o, n):
+        super().__init__()
+        dims = [i] + [h] * (n - 1) + [o]
+        self.layers = nn.ModuleList(ParamLinear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+
+class HeadState:
+    """Per-scene products of the frozen queries: class logits and the mask embedding (reused by every rendered view)."""
+    __slots__ = ('logits', 'embed')
+
+
+class MaskTransformer(HipModule):
+    def __init__(self, in_dim, hidden_dim, ff_dim, mask_dim, num_queries, num_heads, dec_layers, lang_dim=768,
+                 num_feature_levels=1, landscape_only=False, **kw):
+        super().__init__()
+        in_dim = [in_dim] if isinstance(in_dim, int) else list(in_dim)
+        assert num_feature_levels == 1 and in_dim[0] == hidden_dim and not kw.get('two_stage', False)
+        if mask_dim % 64 or (hidden_dim // num_heads) not in (64, 96):
+            raise NotImplementedError('HIP MaskTransformer: mask_dim %% 64 == 0 and head dim 64/96 (got %d, %d)'
+                                      % (mask_dim, hidden_dim // num_heads))
+        self.hidden_dim, self.mask_dim, self.num_heads, self.num_layers = hidden_dim, mask_dim, num_heads, dec_layers
+        self.num_queries, self.landscape_only = num_queries, landscape_only
+        self.self_attn_layers = nn.ModuleList(_SelfLayerP(hidden_dim) for _ in range(dec_layers))
+        self.cross_attn_layers = nn.ModuleList(_CrossLayerP(hidden_dim) for _ in range(dec_layers))
+        self.ffn_layers = nn.ModuleList(_FFNP(hidden_dim, ff_dim) for _ in range(dec_layers))
+        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.query_feat = nn.Embedding(num_queries, hidden_dim)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.level_embed = nn.Embedding(1, hidden_dim)
+        self.input_proj = nn.ModuleList([nn.Sequential()])
+        self.lang_embed = ParamLinear(hidden_dim, lang_dim)
+        self.cls_logit_scale = nn.Parameter(torch.ones([]))
+        self.mask_embed = _MLP3P(hidden_dim, hidden_dim, mask_dim, 3)
+
+    def _pack(self, device):
+        d = self.hidden_dim
+
+        def mha(m):
+            w = Packed(m.in_proj_weight, m.in_proj_bias, device)
+            return dict(q=w.rows(0, d), k=w.rows(d, 2 * d), v=w.rows(2 * d, 3 * d), qk=w.rows(0, 2 * d),
+                        o=Packed(m.out_proj.weight, m.out_proj.bias, device))
+        layers = []
+        for i in range(self.num_layers):
+            ca, sa, ff = self.cross_attn_layers[i], self.self_attn_layers[i], self.ffn_layers[i]
+            layers.append(dict(ca=mha(ca.multihead_attn), ca_norm=pack_norm(ca.norm, device), sa=mha(sa.self_attn),
+                               sa_norm=pack_norm(sa.norm, device), l1=Packed(ff.linear1.weight, ff.linear1.bias, device),
+                               l2=Packed(ff.linear2.weight, ff.linear2.bias, device), ff_norm=pack_norm(ff.norm, device)))
+        return dict(layers=layers, dn=pack_norm(self.decoder_norm, device), qf=f32(self.query_feat.weight, device),
+                    qe=f32(self.query_embed.weight, device), lvl=f32(self.level_embed.weight, device),
+                    lang=Packed(self.lang_embed.weight, self.lang_embed.bias, device),
+                    me=[Packed(l.weight, l.bias, device) for l in self.mask_embed.layers],
+                    scale=float(self.cls_logit_scale.detach().exp()), pe={})
+
+    def _pe(self, pk, h, w, portrait, device):
+        key = (h, w, bool(portrait))
+        if key not in pk['pe']:
+            # portrait views use the PE of the transposed grid, flattened in ITS raster order (mask_transformer.py:106-119)
+            pe = sine_pe(w, h, self.hidden_dim) if portrait else sine_pe(h, w, self.hidden_dim)
+            pk['pe'][key] = pe.to(device).contiguous()
+        return pk['pe'][key]
+
+    # ---- prediction heads
+    def _embed(self, pk, out):
+        dev = out.device
+        Q, d = out.shape
+        dn = empty(Q, d, BF16, dev)
+        hip.layernorm(out, pk['dn'][0], pk['dn'][1], dn, pk['dn'][2])
+        a = dn
+        for j, l in enumerate(pk['me']):
+            b = empty(Q, l.n, BF16, dev)
+            hip.gemm(a, l.w, b, bias=l.b, act=None if j == len(pk['me']) - 1 else 'relu')
+            a = b
+        return dn, a
+
+    def _class_logits(self, pk, dn, cls_bf16):
+        dev = dn.device
+        Q = dn.shape[0]
+        lang = empty(Q, pk['lang'].n, torch.float32, dev)
+        hip.gemm(dn, pk['lang'].w, lang, bias=pk['lang'].b)
+        ln = torch.zeros(Q, cls_bf16.shape[1], dtype=BF16, device=dev)
+        hip.l2norm_rows(lang, ln[:, :lang.shape[1]], 1e-7)
+        logits = empty(Q, cls_bf16.shape[0], torch.float32, dev)
+        gam = torch.full((cls_bf16.shape[0],), pk['scale'], dtype=torch.float32, device=dev)
+        hip.gemm(ln, cls_bf16, logits, gamma=gam)
+        return logits
+
+    @torch.no_grad()
+    def head_state(self, out_queries, cls_bf16):
+        """decoder_norm -> class logits + mask embedding for a fixed set of queries (mask_transformer.py:222-230);
+        computed once per scene, the reference recomputes it per rendered chunk (panoptic_decoder.py:71)."""
+        pk = self.packed(out_queries.device)
+        hs = HeadState()
+        dn, hs.embed = self._embed(pk, out_queries)
+        hs.logits = self._class_logits(pk, dn, cls_bf16)
+        return hs
+
+    @torch.no_grad()
+    def masks_for(self, embed, mask_feats, out=None):
+        """pred_masks of one view: embed bf16 [Q,C] x mask_feats bf16 [Hm,Wm,C] -> fp32 [Q,Hm,Wm]."""
+        Hm, Wm, C = mask_feats.shape
+        if out is None:
+            out = torch.empty(embed.shape[0], Hm, Wm, dtype=torch.float32, device=embed.device)
+        hip.gemm(embed, mask_feats.view(Hm * Wm, C), out.view(embed.shape[0], Hm * Wm))
+        return out
+
+    @torch.no_grad()
+    def decode_tokens(self, fpn, mask_feats, grids, cls_bf16, portrait=None):
+        """Query decoding on the keyframes.
+        fpn: list (per keyframe) of bf16 [T_v, d];  mask_feats: list of bf16 [Hm_v, Wm_v, C];  grids: list of (h, w)
+        Returns out_queries fp32 [Q,d], HeadState (final logits / embedding)."""
+        dev = fpn[0].device
+        pk = self.packed(dev)
+        d, H, Q, C = self.hidden_dim, self.num_heads, self.num_queries, self.mask_dim
+        hd = d // H
+        portrait = portrait or [False] * len(fpn)
+        Ts = [f.shape[0] for f in fpn]
+        NK = sum(Ts)
+        src = empty(NK, d, BF16, dev)           # value input: fpn + level_embed
+        srcpos = empty(NK, d, BF16, dev)        # key input:   ... + sine PE of the view's grid
+        fm = empty(NK, C, BF16, dev)            # mean4(mask_feats): attention-mask features
+        o0 = 0
+        for f, mfv, (h, w), pt in zip(fpn, mask_feats, grids, portrait):
+            T = f.shape[0]
+            hip.add_cast(f, src[o0:o0 + T], b=pk['lvl'], b_mod=1)
+            hip.add_cast(src[o0:o0 + T], srcpos[o0:o0 + T], b=self._pe(pk, h, w, pt, dev))
+            hip.mean4(mfv, fm[o0:o0 + T], 1, mfv.shape[0], mfv.shape[1], C)
+            o0 += T
+        out = pk['qf'].clone()
+        qpos = pk['qe']
+        NKm = ceil_to(NK, 4)
+        mask = torch.zeros(Q, NKm, dtype=torch.uint8, device=dev)
+        logits_attn = empty(Q, NK, torch.float32, dev)
+
+        def next_mask(o):
+            dn, emb = self._embed(pk, o)
+            hip.gemm(emb, fm, logits_attn)
+            hip.attn_mask_from_logits(logits_attn, mask[:, :NK] if NKm == NK else mask)
+            return dn, emb
+        if NKm != NK:
+            raise NotImplementedError('total keyframe tokens must be a multiple of 4')
+        next_mask(out)
+        qin, ob = empty(Q, d, BF16, dev), empty(Q, d, BF16, dev)
+        t32 = empty(Q, d, torch.float32, dev)
+        dn = emb = None
+        for i, L in enumerate(pk['layers']):
+            # masked cross-attention (post-LN): K from src+pos, V from src
+            kc = empty(NK, d, BF16, dev)
+            hip.gemm(srcpos, L['ca']['k'].w, kc, bias=L['ca']['k'].b)
+            vt = torch.zeros(d, NK + 8, dtype=BF16, device=dev)
+            hip.gemm(src, L['ca']['v'].w, vt, bias=L['ca']['v'].b, trans_out=True)
+            hip.add_cast(out, qin, b=qpos)
+            q = empty(Q, d, BF16, dev)
+            hip.gemm(qin, L['ca']['q'].w, q, bias=L['ca']['q'].b)
+            ldv = vt.stride(0)
+            hip.attention(q, kc, vt, ob, 1, H, Q, NK, hd, (0, hd, d), (0, hd, d), (0, hd * ldv, ldv), (0, hd, d),
+                          mask=mask, mask_strides=(0, NKm))
+            hip.gemm(ob, L['ca']['o'].w, t32, bias=L['ca']['o'].b, res=out)
+            hip.layernorm(t32, L['ca_norm'][0], L['ca_norm'][1], out, L['ca_norm'][2])
+            # self-attention: q = k = out + query_pos, v = out
+            hip.add_cast(out, qin, b=qpos)
+            qk = empty(Q, 2 * d, BF16, dev)
+            hip.gemm(qin, L['sa']['qk'].w, qk, bias=L['sa']['qk'].b)
+            hip.add_cast(out, ob)
+            vts = torch.zeros(d, ceil_to(Q, 8) + 8, dtype=BF16, device=dev)
+            hip.gemm(ob, L['sa']['v'].w, vts, bias=L['sa']['v'].b, trans_out=True)
+            o2 = empty(Q, d, BF16, dev)
+            lds = vts.stride(0)
+            hip.attention(qk, qk[:, d:], vts, o2, 1, H, Q, Q, hd, (0, hd, 2 * d), (0, hd, 2 * d), (0, hd * lds, lds), (0, hd, d))
+            hip.gemm(o2, L['sa']['o'].w, t32, bias=L['sa']['o'].b, res=out)
+            hip.layernorm(t32, L['sa_norm'][0], L['sa_norm'][1], out, L['sa_norm'][2])
+            # FFN
+            hip.add_cast(out, ob)
+            hmid = empty(Q, L['l1'].n, BF16, dev)
+            hip.gemm(ob, L['l1'].w, hmid, bias=L['l1'].b, act='relu')
+            hip.gemm(hmid, L['l2'].w, t32, bias=L['l2'].b, res=out)
+            hip.layernorm(t32, L['ff_norm'][0], L['ff_norm'][1], out, L['ff_norm'][2])
+            dn, emb = next_mask(out) if i + 1 < self.num_layers else self._embed(pk, out)
+        hs = HeadState()
+        hs.embed = emb
+        hs.logits = self._class_logits(pk, dn, cls_bf16)
+        return out, hs
+
+
+# =========================================================================================== text + PanopticDecoder
+class TextEncoder(nn.Module):
+    """Fixed-vocabulary text encoder (text_encoder.py:44-47,94-101): cached class embeddings -> unit-norm rows.
+    Live SigLIP inference (fixed_vocab=False) needs HF weights that cannot be fetched offline: set `class_embeddings`."""
+
+    def __init__(self, model_name='siglip', out_dim=768, fixed_vocab=True):
+        super().__init__()
+        self.model_name = model_name
+        self.embed_dim = {'siglip': 768, 'siglip2': 768, 'clip': 512}[model_name]
+        self.fixed_vocab = True
+        self.class_embeddings = {}
+
+    def change_mode(self, fixed_vocab):
+        if not fixed_vocab:
+            raise NotImplementedError('live text-encoder inference is outside the hot path; inject class_embeddings')
+
+    def set_vocab(self, classes, embeddings=None, device=None):
+        if embeddings is None:
+            raise NotImplementedError('offline build: pass the pooled SigLIP embeddings explicitly')
+        self.class_embeddings = {c: e for c, e in zip(classes, embeddings)}
+
+    def forward(self, classes):
+        assert all(c in self.class_embeddings for c in classes), \
+            "Missing classes in vocabulary. 'set_vocab' must be called if using fixed vocabulary"
+        e = torch.stack([self.class_embeddings[c] for c in classes])
+        return e / e.norm(dim=-1, keepdim=True)
+
+    def normalized_bf16(self, classes, device):
+        """unit-norm class embeddings as the bf16 [Ncls, 768] W operand of the class-logit GEMM (normalised on device)."""
+        assert all(c in self.class_embeddings for c in classes), \
+            "Missing classes in vocabulary. 'set_vocab' must be called if using fixed vocabulary"
+        raw = torch.stack([self.class_embeddings[c] for c in classes]).float().to(device).contiguous()
+        out = torch.zeros(raw.shape[0], ceil_to(raw.shape[1], 64), dtype=BF16, device=device)
+        hip.l2norm_rows(raw, out[:, :raw.shape[1]], 0.0)
+        return out
+
+
+class PanopticDecoder(HipModule):
+    def __init__(self, input_mixer=None, upscaler=None, fpn_dim=(768,), hidden_dim=768, mask_dim=256, ff_dim=2048, num_queries=200,
+                 num_heads=8, dec_layers=6, text_encoder='siglip', fixed_vocab=True, label_mode='sigmoid', two_stage=False,
+                 landscape_only=True, deep_supervision=True):
+        super().__init__()
+        assert upscaler is not None, 'Upscaler module must be provided'
+        if label_mode != 'sigmoid' or two_stage:
+            raise NotImplementedError('released configs use label_mode=sigmoid, two_stage=False')
+        self.input_mixer, self.upscaler = input_mixer, upscaler
+        self.text_encoder = TextEncoder(text_encoder, out_dim=hidden_dim, fixed_vocab=fixed_vocab)
+        self.label_mode, self.landscape_only = label_mode, landscape_only
+        self.mask_transformer = MaskTransformer(list(fpn_dim), hidden_dim, ff_dim, mask_dim, num_queries, num_heads, dec_layers,
+                                                lang_dim=self.text_encoder.embed_dim, num_feature_levels=len(fpn_dim),
+                                                landscape_only=landscape_only)
+
+    def _pack(self, device):
+        return {}
+
+    def cat_width(self):
+        return None
+
+    @torch.no_grad()
+    def features_tokens(self, cat, imgs, V, h, w):
+        """cat bf16 [V*T, 2816] (enc | dec | dino) -> (fpn bf16 [V*T, d], mask_feats bf16 [V, Hm, Wm, C])."""
+        dev = cat.device
+        up = self.upscaler
+        T = h * w
+        fpn = torch.empty(V * T, up.fpn_dim, dtype=BF16, device=dev)
+        if isinstance(up, LoftUpUpscaler):
+            lr = torch.zeros(V * T, up.lr_width(), dtype=BF16, device=dev)
+            if self.input_mixer is not None:
+                self.input_mixer.mix_tokens(cat, V, h, w, lr)
+            else:
+                lr[:, :up.input_dim] = cat
+            mf = torch.empty(V, imgs.shape[2] // 2, imgs.shape[3] // 2, up.mask_dim, dtype=BF16, device=dev)
+            up.upscale_tokens(lr, imgs, V, h, w, fpn, mf)
+        else:
+            x = cat
+            if self.input_mixer is not None:
+                x = torch.empty(V * T, self.input_mixer.hidden_dim, dtype=BF16, device=dev)
+                self.input_mixer.mix_tokens(cat, V, h, w, x)
+            mf = torch.empty(V, 8 * h, 8 * w, up.mask_dim, dtype=BF16, device=dev)
+            up.upscale_tokens(x, imgs, V, h, w, fpn, mf)
+        return fpn, mf
+
+    def forward(self, in_feats, in_imgs, pos, true_shape, classes, max_bs=None, outdevice=None, memory_queries=None, multi_ar=False):
+        """Reference signature (panoptic_decoder.py:41) for one scene of same-shape landscape views:
+        in_feats = (x_enc, y_dec, x_dino) each [1,n,T,*]; returns pred_logits [1,Q,Ncls], pred_masks [1,n,Q,H/2,W/2], out_queries [Q,1,d].
+        MinMaxScaler is applied per view (the demo's max_bs=1 convention)."""
+        if multi_ar:
+            raise NotImplementedError('use PanSt3R.forward_inference_multi_ar (token-level pipeline) for multi-AR scenes')
+        B, n, T = in_feats[0].shape[:3]
+        assert B == 1
+        H, W = [int(v) for v in true_shape[0, 0].tolist()]
+        if H > W:
+            raise NotImplementedError('portrait views: round-1 HIP path is landscape-only')
+        dev = in_feats[0].device
+        p = self.upscaler.patch_size
+        h, w = H // p, W // p
+        cat = torch.cat([f.reshape(n * T, -1) for f in in_feats], dim=-1).to(BF16).contiguous()
+        fpn, mf = self.features_tokens(cat, in_imgs[0].float().contiguous(), n, h, w)
+        cls = self.text_encoder.normalized_bf16(classes, dev)
+        mt = self.mask_transformer
+        if memory_queries is None:
+            outq, hs = mt.decode_tokens([fpn[i * T:(i + 1) * T] for i in range(n)], [mf[i] for i in range(n)], [(h, w)] * n, cls)
+        else:
+            outq = memory_queries.reshape(-1, mt.hidden_dim).float().to(dev).contiguous()
+            hs = mt.head_state(outq, cls)
+        masks = torch.stack([mt.masks_for(hs.embed, mf[i]) for i in range(n)])[None]
+        res = {'pred_logits': hs.logits[None], 'pred_masks': masks if outdevice is None else masks.to(outdevice)}
+        if memory_queries is None:
+            res['out_queries'] = outq[:, None].clone()
+            res['aux_outputs'] = []
+        return res

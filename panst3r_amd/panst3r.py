@@ -1,0 +1,174 @@
+"""PanSt3R orchestrator on the HIP path -- drop-in for the reference's `panst3r.panst3r.PanSt3R` on the inference path.
+
+Mirrors reference src/panst3r/panst3r.py:
+  __init__ (:20-45), forward_inference_multi_ar (:169-284), forward (:286-296), set_vocab (:298-299),
+  from_checkpoint (:301-325; checkpoint layout of engine/io.py:16-22,51-55).
+Same call signatures and output structure; what changed is HOW the scene is executed (MI355X-first):
+  * all views of a shape group are batched through the encoder / DINOv2 / decoder-render / upscaler GEMMs
+    (the reference walks them one by one at max_bs=1: utils.py:154-165), their features land directly in one
+    [views*T, 2816] bf16 buffer (no torch.cat), and nothing leaves the GPU unless `outdevice` says so;
+  * the keyframe memory is built once as projected K / V^T caches (model/must3r.py);
+  * decoder_norm -> class logits -> mask_embed of the frozen queries is computed once per scene, each view then costs
+    one [Q,C]x[C,P] GEMM (the reference recomputes the heads per chunk, panoptic_decoder.py:71);
+  * MinMaxScaler is per view (the demo's max_bs=1 convention), see SURVEY quirk 5.
+`amp` is accepted for signature compatibility: the HIP kernels always compute in bf16 MFMA with fp32 accumulation,
+fp32 residual streams / softmax / normalisation statistics.
+"""
+from argparse import Namespace
+import numpy as np
+import torch
+from torch import nn
+
+from . import hip
+from .model import *            # noqa: F401,F403  (ctor-expression namespace of from_checkpoint, reference panst3r.py:9,14)
+from .model.common import BF16
+from .schedule import select_keyframes, view_order, mem_batches
+
+ENC_CHUNK = 16        # views per encoder / DINOv2 / render pass
+
+
+class PanSt3R(nn.Module):
+    def __init__(self, must3r_encoder, must3r_decoder, dino_encoder, panoptic_decoder, retrieval=None, preserve_gpu_mem=False,
+                 postprocess_default='standard_v2', qubo_enabled=True, must3r_encoder_requires_grad=False,
+                 must3r_decoder_requires_grad=False, verbose=False):
+        super().__init__()
+        self.must3r_encoder, self.must3r_decoder = must3r_encoder, must3r_decoder
+        self.dino_encoder, self.panoptic_decoder = dino_encoder, panoptic_decoder
+        self.retrieval, self.preserve_gpu_mem, self.verbose = retrieval, preserve_gpu_mem, verbose
+        self.must3r_params = dict(init_num_views=2, batch_num_views=1, render_iterations=1)
+        self.postprocess_default, self.qubo_enabled = postprocess_default, qubo_enabled
+
+    def get_must3r_mem_batches(self, n_imgs):
+        return mem_batches(n_imgs, self.must3r_params['init_num_views'], self.must3r_params['batch_num_views'])
+
+    def set_vocab(self, class_names, embeddings=None, device=None):
+        self.panoptic_decoder.text_encoder.set_vocab(class_names, embeddings, device=device)
+
+    # ------------------------------------------------------------------ scene stages (token level)
+    def _cat_width(self):
+        return self.must3r_encoder.embed_dim + self.must3r_decoder.embed_dim + self.dino_encoder.embed_dim
+
+    @torch.no_grad()
+    def encode_views(self, imgs, cat):
+        """imgs fp32 [V,3,H,W]; writes encoder tokens to cat[:, :De] and DINOv2 tokens to cat[:, De+Dd:]."""
+        V, _, H, W = imgs.shape
+        p = self.must3r_encoder.patch_size
+        T = (H // p) * (W // p)
+        De, Dd = self.must3r_encoder.embed_dim, self.must3r_decoder.embed_dim
+        for v0 in range(0, V, ENC_CHUNK):
+            sl = slice(v0 * T, min(V, v0 + ENC_CHUNK) * T)
+            im = imgs[v0:v0 + ENC_CHUNK]
+            self.must3r_encoder.encode_tokens(im, out=cat[sl])
+            self.dino_encoder.encode_tokens(im, cat[sl], col0=De + Dd)
+
+    @torch.no_grad()
+    def build_memory(self, cat_kf, K, h, w):
+        """Sequential keyframe memory build, batches [2,1,1,...] (panst3r.py:65-70,205-210)."""
+        T = h * w
+        bank = self.must3r_decoder.new_bank(cat_kf.device, K * T)
+        De = self.must3r_encoder.embed_dim
+        start = 0
+        for nb in self.get_must3r_mem_batches(K):
+            self.must3r_decoder.update_tokens(cat_kf[start * T:(start + nb) * T, :De], nb, h, w, bank)
+            start += nb
+        return bank
+
+    @torch.no_grad()
+    def render_views(self, cat, V, h, w, bank):
+        """Render V views against the memory: decoder features -> cat[:, De:De+Dd]; returns pointmaps fp32 [V,H,W,7]."""
+        T = h * w
+        De, Dd = self.must3r_encoder.embed_dim, self.must3r_decoder.embed_dim
+        pms = []
+        for v0 in range(0, V, ENC_CHUNK):
+            n = min(ENC_CHUNK, V - v0)
+            rows = cat[v0 * T:(v0 + n) * T]
+            pm, _ = self.must3r_decoder.render_tokens(rows[:, :De], n, h, w, bank, feat_out=rows[:, De:De + Dd])
+            pms.append(pm)
+        return torch.cat(pms) if len(pms) > 1 else pms[0]
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=None,
+                                   outdevice=None, amp=False):
+        """imgs: list[V] of [3,H,W] in [-1,1]; true_shape [V,2]; returns (pointmaps list[V] of [1,H,W,7],
+        {'pred_logits' [1,Q,Ncls], 'pred_masks' list[V] of [1,Q,H/2,W/2], 'out_queries' [Q,1,768]})."""
+        if use_retrieval:
+            raise NotImplementedError('retrieval keyframes need asmk/faiss (outside the hot path, SURVEY 8(f)3)')
+        V = len(imgs)
+        dev = imgs[0].device
+        shapes = {tuple(int(s) for s in im.shape[-2:]) for im in imgs}
+        if len(shapes) != 1:
+            raise NotImplementedError('round-1 HIP pipeline runs one aspect ratio per scene (got %s)' % sorted(shapes))
+        H, W = shapes.pop()
+        if H > W:
+            raise NotImplementedError('portrait scenes: round-1 HIP pipeline is landscape-only')
+        K = V if (num_keyframes is None or num_keyframes > V) else max(int(num_keyframes), 2)
+        keyframes = select_keyframes(V, K)
+        order, inv = view_order(V, keyframes)
+        p = self.must3r_encoder.patch_size
+        h, w = H // p, W // p
+        T = h * w
+        x = torch.stack([imgs[i] for i in order]).float().contiguous()
+        cat = torch.empty(V * T, self._cat_width(), dtype=BF16, device=dev)
+        self.encode_views(x, cat)
+        bank = self.build_memory(cat[:K * T], K, h, w)
+        pointmaps = self.render_views(cat, V, h, w, bank)
+        pd = self.panoptic_decoder
+        fpn, mf = pd.features_tokens(cat, x, V, h, w)
+        cls = pd.text_encoder.normalized_bf16(classes, dev)
+        mt = pd.mask_transformer
+        outq, hs = mt.decode_tokens([fpn[i * T:(i + 1) * T] for i in range(K)], [mf[i] for i in range(K)], [(h, w)] * K, cls)
+        masks = []
+        for i in range(V):
+            m = mt.masks_for(hs.embed, mf[i])[None]
+            masks.append(m if outdevice is None else m.to(outdevice))
+        pms = [pointmaps[i][None] if outdevice is None else pointmaps[i][None].to(outdevice) for i in range(V)]
+        panout = {'pred_logits': hs.logits[None] if outdevice is None else hs.logits[None].to(outdevice),
+                  'pred_masks': [masks[i] for i in inv], 'out_queries': outq[:, None]}
+        return [pms[i] for i in inv], panout
+
+    @torch.no_grad()
+    def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):
+        """Same-shape batch variant (panst3r.py:286-296): imgs [1,n,3,H,W] -> (panout, pointmaps [1,n,H,W,7]);
+        every view is a memory view (mem batches [2,1,...]) and every view is rendered."""
+        B, n = imgs.shape[:2]
+        if B != 1:
+            raise NotImplementedError('one scene per call on the HIP path')
+        pms, panout = self.forward_inference_multi_ar(list(imgs[0]), true_shape[0], classes, num_keyframes=n, outdevice=outdevice)
+        panout = dict(panout)
+        panout['pred_masks'] = torch.stack([m[0] for m in panout['pred_masks']])[None]
+        return panout, torch.stack([p[0] for p in pms])[None]
+
+    @classmethod
+    def from_checkpoint(cls, checkpoint_path, retrieval_path=None):
+        """Reference checkpoint layout {'args': Namespace(ctor strings), 'weights': state_dict, ...} (engine/io.py:51-55)."""
+        ckpt = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
+        assert 'args' in ckpt, "Checkpoint must contain 'args' with model parameters."
+        a = ckpt['args']
+        must3r_encoder = eval(a.must3r_encoder)
+        must3r_decoder = eval(a.must3r_decoder)
+        dino_encoder = eval(a.dino_encoder)
+        panoptic_decoder = eval(a.panoptic_decoder)
+        model = cls(must3r_encoder=must3r_encoder, must3r_decoder=must3r_decoder, dino_encoder=dino_encoder,
+                    panoptic_decoder=panoptic_decoder, retrieval=ckpt.get('retrieval'),
+                    postprocess_default=getattr(a, 'postprocess_default', 'standard_v2'), qubo_enabled=getattr(a, 'qubo_enabled', True))
+        model.load_state_dict(ckpt['weights'], strict=False)
+        return model
+
+
+# ---------------------------------------------------------------------- released configurations (configs/base.yaml, base_v2.yaml)
+CONFIG_V1 = dict(
+    must3r_encoder="Dust3rEncoder(img_size=[512, 512], patch_embed='PatchEmbedDust3R')",
+    must3r_decoder="MUSt3R(img_size=[512, 512], feedback_type='single_mlp', memory_mode='norm_y')",
+    dino_encoder="DinoV2Encoder()",
+    panoptic_decoder="PanopticDecoder(input_mixer=None, upscaler=PixelShuffleUpscaler(input_dim=2816), label_mode='sigmoid', text_encoder='siglip')")
+CONFIG_V2 = dict(CONFIG_V1, panoptic_decoder=(
+    "PanopticDecoder(input_mixer=InputMixer(img_size=[512, 512], patch_size=16, in_dim=2816, hidden_dim=768, num_heads=12, "
+    "num_layers=3, ff_dim_mult=4), upscaler=LoftUpUpscaler(input_dim=768, dim=384, output_stride=2, patch_size=16), "
+    "mask_dim=384, label_mode='sigmoid', text_encoder='siglip')"))
+
+
+def build_from_config(cfg):
+    """Instantiate a PanSt3R from ctor-expression strings exactly like from_checkpoint does (random init)."""
+    return PanSt3R(must3r_encoder=eval(cfg['must3r_encoder']), must3r_decoder=eval(cfg['must3r_decoder']),
+                   dino_encoder=eval(cfg['dino_encoder']), panoptic_decoder=eval(cfg['panoptic_decoder']))

@@ -1,0 +1,112 @@
+"""Module-level and end-to-end parity of the HIP path against the fp32 CPU oracle (same seeded weights and inputs).
+
+Tolerances (bf16 MFMA / fp32 accumulate vs fp32 oracle): rel-L2 <= 2e-2 on tokens / pointmaps / queries,
+<= 3e-2 on mask logits with >= 99 % sign agreement, class logits abs <= 0.05.
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+import tiny
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module', params=['v1', 'v2'])
+def pair(request):
+    o = tiny.build(tiny.OracleNS, request.param)
+    h = tiny.build(tiny.hip_ns(), request.param).to(DEV)
+    return request.param, o, h
+
+
+def grid_pos(h, w):
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    return torch.stack([ys, xs], -1).reshape(1, -1, 2)
+
+
+@pytest.mark.parametrize('H,W', [(64, 96), (128, 192), (112, 112)])
+def test_encoder_and_dino(pair, H, W):
+    _, o, h = pair
+    img = torch.stack(tiny.images(3, H, W))
+    ts = torch.tensor([[H, W]] * 3)
+    with torch.no_grad():
+        xo, po = o.must3r_encoder(img, ts)
+        xh, ph = h.must3r_encoder(img.to(DEV), ts)
+        do = o.dino_encoder(img, ts)
+        dh = h.dino_encoder(img.to(DEV), ts)
+    assert torch.equal(po, ph.cpu())
+    assert rel_l2(xh.cpu(), xo) < 2e-2
+    assert rel_l2(dh.cpu(), do) < 2e-2
+
+
+def test_decoder_memory_and_render(pair):
+    _, o, h = pair
+    H, W, n = 64, 96, 4
+    img = torch.stack(tiny.images(n, H, W))
+    ts = torch.tensor([[H, W]] * n)
+    with torch.no_grad():
+        x, pos = o.must3r_encoder(img, ts)
+        x, pos, tsb = x[None], pos[None], ts[None]
+        mem_o, mem_h = None, None
+        for a, b in ((0, 2), (2, 3), (3, 4)):
+            mem_o, pm_o, f_o = o.must3r_decoder(x[:, a:b], pos[:, a:b], tsb[:, a:b], mem_o, render=False, return_feats=True)
+            mem_h, pm_h, f_h = h.must3r_decoder(x[:, a:b].to(DEV), pos[:, a:b].to(DEV), tsb[:, a:b], mem_h, render=False, return_feats=True)
+            assert rel_l2(pm_h.cpu(), pm_o) < 2e-2, (a, b)
+            assert rel_l2(f_h[-1].cpu(), f_o[-1]) < 2e-2
+        _, pm_o, f_o = o.must3r_decoder(x, pos, tsb, mem_o, render=True, return_feats=True)
+        _, pm_h, f_h = h.must3r_decoder(x.to(DEV), pos.to(DEV), tsb, mem_h, render=True, return_feats=True)
+    assert mem_h[0].n == 4 * 24 and mem_h[2] == 4
+    assert rel_l2(pm_h.cpu(), pm_o) < 2e-2
+    assert rel_l2(f_h[-1].cpu(), f_o[-1]) < 2e-2
+
+
+def test_panoptic_decoder(pair):
+    variant, o, h = pair
+    H, W, n, T = 64, 96, 3, 24
+    g = torch.Generator().manual_seed(3)
+    feats = tuple(torch.randn(1, n, T, 128, generator=g) for _ in range(3))
+    imgs = torch.stack(tiny.images(n, H, W))[None]
+    pos = grid_pos(4, 6)[None].expand(1, n, -1, -1).contiguous()
+    ts = torch.tensor([[[H, W]] * n])
+    with torch.no_grad():
+        ro = o.panoptic_decoder(feats, imgs, pos, ts, tiny.NAMES, max_bs=1)
+        rh = h.panoptic_decoder(tuple(f.to(DEV) for f in feats), imgs.to(DEV), pos.to(DEV), ts, tiny.NAMES, max_bs=1)
+        # per-module: features (mixer + upscaler) in the reference layouts
+        cat = torch.cat(feats, -1)
+        fo, mo = o.panoptic_decoder.features(cat, imgs, pos, ts, max_bs=1)
+        fh, mh = h.panoptic_decoder.features_tokens(cat.reshape(n * T, -1).to(torch.bfloat16).to(DEV), imgs[0].to(DEV), n, 4, 6)
+    assert rel_l2(fh.float().cpu().reshape(n, 4, 6, -1).permute(0, 3, 1, 2), fo[0]) < 2e-2
+    assert rel_l2(mh.float().cpu().permute(0, 3, 1, 2), mo[0]) < 2.5e-2
+    assert rel_l2(rh['out_queries'].cpu(), ro['out_queries']) < 3e-2
+    assert float((rh['pred_logits'].cpu() - ro['pred_logits']).abs().max()) < 0.05
+    mk_h, mk_o = rh['pred_masks'].cpu(), ro['pred_masks']
+    assert rel_l2(mk_h, mk_o) < 4e-2
+    assert float(((mk_h > 0) == (mk_o > 0)).float().mean()) > 0.99
+    # heads-only path with the oracle's queries
+    with torch.no_grad():
+        r2o = o.panoptic_decoder(feats, imgs, pos, ts, tiny.NAMES, max_bs=1, memory_queries=ro['out_queries'])
+        r2h = h.panoptic_decoder(tuple(f.to(DEV) for f in feats), imgs.to(DEV), pos.to(DEV), ts, tiny.NAMES, max_bs=1,
+                                 memory_queries=ro['out_queries'].to(DEV))
+    assert rel_l2(r2h['pred_masks'].cpu(), r2o['pred_masks']) < 3e-2
+
+
+@pytest.mark.parametrize('V,K', [(5, 3), (2, 2)])
+def test_scene_end_to_end(pair, V, K):
+    variant, o, h = pair
+    H, W = 64, 96
+    imgs = tiny.images(V, H, W)
+    ts = torch.tensor([[H, W]] * V)
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K)
+    pm_h, pan_h = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K)
+    assert len(pm_h) == V and pm_h[0].shape == (1, H, W, 7)
+    assert pan_h['pred_masks'][0].shape == (1, 24, H // 2, W // 2)
+    for a, b in zip(pm_h, pm_o):
+        assert rel_l2(a.cpu(), b) < 2e-2
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 4e-2
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.08
+    agree = []
+    for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
+        assert rel_l2(a.cpu(), b) < 6e-2
+        agree.append(float(((a.cpu() > 0) == (b > 0)).float().mean()))
+    assert min(agree) > 0.985

@@ -230,7 +230,8 @@ def test_patchify_and_dino_preprocess():
         hip.patchify(im.to(dev()), out, p)
         ref = F.unfold(im, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, c * p * p)
         assert torch.equal(out[:, :c * p * p].float().cpu(), bf(ref).float())
-        assert float(out[:, c * p * p:].abs().max()) == 0.0
+        if ld > c * p * p:
+            assert float(out[:, c * p * p:].abs().max()) == 0.0
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
     ref = F.interpolate(((img * 0.5 + 0.5) - mean) / std, size=(28, 42), mode='bilinear', align_corners=False)

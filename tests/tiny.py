@@ -1,0 +1,52 @@
+"""Tiny model configurations shared by the CPU (gloo) and GPU parity tests: same ctor kwargs for oracle and HIP classes."""
+import torch
+from panst3r_amd.synthetic import fill_module_, synth_image
+
+ENC = dict(img_size=[96, 96], patch_size=16, embed_dim=128, depth=2, num_heads=2)
+DEC = dict(img_size=[96, 96], patch_size=16, enc_embed_dim=128, embed_dim=128, depth=2, num_heads=2)
+DINO = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, patch_size=14, image_size=70)
+CAT = 128 + 128 + 128
+NAMES = ['c%d' % i for i in range(8)]
+
+
+def build(ns, variant, seed=21, sharp=1.0):
+    """ns: module namespace providing the reference class names (oracle.* or panst3r_amd.model)."""
+    enc = ns.Dust3rEncoder(**ENC)
+    dec = ns.MUSt3R(**DEC)
+    dino = ns.DinoV2Encoder(**DINO)
+    if variant == 'v1':
+        pan = ns.PanopticDecoder(input_mixer=None, upscaler=ns.PixelShuffleUpscaler(input_dim=CAT, fp_dim=[192, 128, 64, 64]),
+                                 fpn_dim=[192], hidden_dim=192, mask_dim=64, ff_dim=256, num_queries=24, num_heads=2, dec_layers=2)
+    else:
+        pan = ns.PanopticDecoder(input_mixer=ns.InputMixer([96, 96], 16, CAT, 128, num_heads=2, num_layers=1, ff_dim_mult=2),
+                                 upscaler=ns.LoftUpUpscaler(input_dim=128, dim=192, num_heads=2), fpn_dim=[128], hidden_dim=128,
+                                 mask_dim=192, ff_dim=256, num_queries=24, num_heads=2, dec_layers=2)
+    model = ns.PanSt3R(enc, dec, dino, pan).eval()
+    fill_module_(model, seed=seed, sharp=sharp)
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(len(NAMES), 768, generator=g)
+    model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(NAMES, emb)}
+    return model
+
+
+class OracleNS:
+    from oracle.must3r import Dust3rEncoder, MUSt3R
+    from oracle.dino import DinoV2Encoder
+    from oracle.panoptic import PanopticDecoder, PixelShuffleUpscaler, LoftUpUpscaler, InputMixer
+    from oracle.pipeline import PanSt3R
+
+
+def hip_ns():
+    import panst3r_amd.model as m
+    from panst3r_amd.panst3r import PanSt3R
+
+    class NS:
+        pass
+    for k in ('Dust3rEncoder', 'MUSt3R', 'DinoV2Encoder', 'PanopticDecoder', 'PixelShuffleUpscaler', 'LoftUpUpscaler', 'InputMixer'):
+        setattr(NS, k, getattr(m, k))
+    NS.PanSt3R = PanSt3R
+    return NS
+
+
+def images(V, H, W, seed_base=7):
+    return [synth_image(i, H, W, seed_base) for i in range(V)]

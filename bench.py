@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py -- frames/s of N-view 512-px PanSt3R panoptic inference on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--variant v2] [--views 50] [--keyframes 16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full scene forward (encoder + DINOv2 on every view, sequential keyframe-memory build, render of every
+view, upscaler, panoptic query decoder, query x pixel masks of every view) on synthetic images already resident in
+HBM, random-init full-size weights.  Default workload = BASELINE.json configs[3] (v2 / LoftUp, 50 views, 16
+keyframes, 384x512), which fits one GPU; with --gpus N the SAME scene is view-sharded over N ranks (RCCL all-gathers
+of keyframe tokens, panst3r_amd/scene.py), i.e. strong scaling.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak per MI355X (MI355X_MICROARCH.md chip table)
+
+
+def cpu_baseline(variant, H, W, state, names, emb, threads):
+    """Oracle (fp32 torch restatement, the "port" kind) timed on the host cores on a bounded sample:
+    one 2-view / 2-keyframe scene of the same model at the same resolution."""
+    from oracle.pipeline import build
+    from panst3r_amd.synthetic import synth_image
+    torch.set_num_threads(threads)
+    model = build(variant)
+    model.load_state_dict(state, strict=True)
+    model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
+    imgs = [synth_image(i, H, W) for i in range(2)]
+    ts = torch.tensor([[H, W]] * 2)
+    t0 = time.perf_counter()
+    model.forward_inference_multi_ar(imgs, ts, names, num_keyframes=2)
+    dt = time.perf_counter() - t0
+    return {'value': round(2 / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': '1 scene of 2 views / 2 keyframes at %dx%d, same %s model and weights, fp32 torch on %d host threads (%.1f s)'
+                      % (H, W, variant, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--variant', default='v2', choices=['v1', 'v2'])
+    ap.add_argument('--views', type=int, default=50)
+    ap.add_argument('--keyframes', type=int, default=16)
+    ap.add_argument('--height', type=int, default=384)
+    ap.add_argument('--width', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from panst3r_amd import hip
+    from panst3r_amd.panst3r import CONFIG_V1, CONFIG_V2, build_from_config
+    from panst3r_amd.synthetic import fill_module_, synth_image, synth_class_embeddings
+    from panst3r_amd import flops as F
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    hip.lib()      # fail loudly if the HIP library is missing
+
+    V, K, H, W = args.views, args.keyframes, args.height, args.width
+    model = build_from_config(CONFIG_V2 if args.variant == 'v2' else CONFIG_V1).eval()
+    fill_module_(model, seed=1)
+    names, emb = synth_class_embeddings(100)
+    state = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
+    model.to(dev)
+
+    from panst3r_amd.scene import assign_views
+    _, order, owner = assign_views(V, K, world)
+    mine = {order[i] for i in range(V) if owner[i] == rank}
+    images = {i: synth_image(i, H, W).to(dev) for i in sorted(mine)}        # inputs resident in HBM before timing
+
+    def step():
+        return model.forward_inference_sharded(lambda i: images[i], V, H, W, names, num_keyframes=K)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = None
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        if s == args.steps - 1 and not args.no_kernel_timing:
+            timer = hip.KernelTimer()        # the LAST timed step also records HIP events around every MFMA-kernel launch
+            hip.TIMER = timer
+        step()
+    hip.TIMER = None
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        fps = V * args.steps / elapsed
+        scene_flops = F.scene_flops(H, W, V, K, args.variant)
+        out = {
+            'metric': 'frames/sec (whole node), N-view 512px panoptic inference', 'value': round(fps, 3), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'PanSt3R_%s_512 scene: %d views, %d keyframes, %dx%d, 100 classes, random-init full-size weights'
+                                   % (args.variant, V, K, H, W),
+                       'variant': args.variant, 'views': V, 'keyframes': K, 'resolution': [H, W],
+                       'parallelism': 'views sharded over %d rank(s)' % world,
+                       'scene_algorithmic_tflop': round(scene_flops / 1e12, 2),
+                       'scene_mfma_frac': round(scene_flops / (elapsed / args.steps) / world / (PEAK_BF16_TFLOPS * 1e12), 4)},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dom = max(summ, key=lambda k: summ[k]['ms'])
+            d = summ[dom]
+            ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None, 'launches': d['launches'],
+                               'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
+                               'avg_launch_gflop': round(d['flops'] / d['launches'] / 1e9, 3)}
+            out['kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 2),
+                                  'tflops': round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1)} for k, v in sorted(summ.items())}
+        if state is not None:
+            out['cpu_baseline'] = cpu_baseline(args.variant, H, W, state, names, emb, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

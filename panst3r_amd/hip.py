@@ -82,6 +82,31 @@ def _dev(t, *dtypes):
     return t
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the two MFMA kernels (bench.py roofline leg).  Events are recorded on
+    torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = []          # (kernel name, flops, start event, end event)
+
+    def bracket(self, name, flops):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((name, flops, a, b))
+        return a, b
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, a, b in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+            d['launches'] += 1
+            d['ms'] += a.elapsed_time(b)
+            d['flops'] += flops
+        return out
+
+
+TIMER = None      # set to a KernelTimer to time launches
+
 _ZERO = {}
 
 
@@ -138,6 +163,13 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
     p.trans_out = int(trans_out)
     if grp is not None:
         p.grp_in, p.grp_out, p.grp_off = grp
+    if TIMER is not None:
+        big = ((Mv + 127) // 128) * ((N + 127) // 128) >= 384
+        ev = TIMER.bracket(('gemm_kernel<4,4,%s>' if big else 'gemm_kernel<2,2,%s>') % ('true' if trans_out else 'false'), 2.0 * Mv * N * K)
+        ev[0].record()
+        _check(lib().pst_gemm_bf16(C.byref(p), _stream()), 'pst_gemm_bf16')
+        ev[1].record()
+        return out
     _check(lib().pst_gemm_bf16(C.byref(p), _stream()), 'pst_gemm_bf16')
     return out
 
@@ -158,6 +190,13 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
     p.B, p.H, p.Nq, p.Nk, p.hd = B, H, Nq, Nk, hd
     p.scale = float(hd ** -0.5 if scale is None else scale)
     p.zeros = _ptr(zeros_page(q.device))
+    if TIMER is not None:
+        big = ((Nq + 127) // 128) * H * B >= 256
+        ev = TIMER.bracket('attn_kernel<%d,%d>' % (hd, 2 if big else 1), 4.0 * B * H * Nq * Nk * hd)
+        ev[0].record()
+        _check(lib().pst_attn_fwd_bf16(C.byref(p), _stream()), 'pst_attn_fwd_bf16')
+        ev[1].record()
+        return out
     _check(lib().pst_attn_fwd_bf16(C.byref(p), _stream()), 'pst_attn_fwd_bf16')
     return out
 

@@ -414,27 +414,37 @@ class MaskTransformer(HipModule):
         return out
 
     @torch.no_grad()
-    def decode_tokens(self, fpn, mask_feats, grids, cls_bf16, portrait=None):
+    def attn_feats(self, mask_feats):
+        """mean of the central 2x2 pixels of each 8x8 block: bf16 [n, Hm, Wm, C] -> [n*T, C] (the only part of the
+        full-resolution masks the 6 intermediate decoder layers look at, mask_transformer.py:283-287)."""
+        n, Hm, Wm, C = mask_feats.shape
+        fm = torch.empty(n * (Hm // 8) * (Wm // 8), C, dtype=BF16, device=mask_feats.device)
+        hip.mean4(mask_feats, fm, n, Hm, Wm, C)
+        return fm
+
+    @torch.no_grad()
+    def decode_tokens(self, fpn, fm, grids, cls_bf16, portrait=None):
         """Query decoding on the keyframes.
-        fpn: list (per keyframe) of bf16 [T_v, d];  mask_feats: list of bf16 [Hm_v, Wm_v, C];  grids: list of (h, w)
-        Returns out_queries fp32 [Q,d], HeadState (final logits / embedding)."""
-        dev = fpn[0].device
+        fpn bf16 [NK, d] (keyframe FPN tokens, concatenated);  fm bf16 [NK, C] = attn_feats of their mask features;
+        grids: list (per keyframe) of (h, w).  Returns out_queries fp32 [Q,d] and the HeadState (logits, mask embedding)."""
+        dev = fpn.device
         pk = self.packed(dev)
         d, H, Q, C = self.hidden_dim, self.num_heads, self.num_queries, self.mask_dim
         hd = d // H
-        portrait = portrait or [False] * len(fpn)
-        Ts = [f.shape[0] for f in fpn]
-        NK = sum(Ts)
+        portrait = portrait or [False] * len(grids)
+        NK = fpn.shape[0]
+        assert NK == sum(h * w for h, w in grids) and fm.shape[0] == NK
         src = empty(NK, d, BF16, dev)           # value input: fpn + level_embed
         srcpos = empty(NK, d, BF16, dev)        # key input:   ... + sine PE of the view's grid
-        fm = empty(NK, C, BF16, dev)            # mean4(mask_feats): attention-mask features
-        o0 = 0
-        for f, mfv, (h, w), pt in zip(fpn, mask_feats, grids, portrait):
-            T = f.shape[0]
-            hip.add_cast(f, src[o0:o0 + T], b=pk['lvl'], b_mod=1)
-            hip.add_cast(src[o0:o0 + T], srcpos[o0:o0 + T], b=self._pe(pk, h, w, pt, dev))
-            hip.mean4(mfv, fm[o0:o0 + T], 1, mfv.shape[0], mfv.shape[1], C)
-            o0 += T
+        hip.add_cast(fpn, src, b=pk['lvl'], b_mod=1)
+        if len(set(zip(grids, portrait))) == 1:
+            h, w = grids[0]
+            hip.add_cast(src, srcpos, b=self._pe(pk, h, w, portrait[0], dev), b_mod=h * w)
+        else:
+            o0 = 0
+            for (h, w), pt in zip(grids, portrait):
+                hip.add_cast(src[o0:o0 + h * w], srcpos[o0:o0 + h * w], b=self._pe(pk, h, w, pt, dev))
+                o0 += h * w
         out = pk['qf'].clone()
         qpos = pk['qe']
         NKm = ceil_to(NK, 4)
@@ -592,7 +602,7 @@ class PanopticDecoder(HipModule):
         cls = self.text_encoder.normalized_bf16(classes, dev)
         mt = self.mask_transformer
         if memory_queries is None:
-            outq, hs = mt.decode_tokens([fpn[i * T:(i + 1) * T] for i in range(n)], [mf[i] for i in range(n)], [(h, w)] * n, cls)
+            outq, hs = mt.decode_tokens(fpn, mt.attn_feats(mf), [(h, w)] * n, cls)
         else:
             outq = memory_queries.reshape(-1, mt.hidden_dim).float().to(dev).contiguous()
             hs = mt.head_state(outq, cls)

@@ -22,7 +22,7 @@ from torch import nn
 from . import hip
 from .model import *            # noqa: F401,F403  (ctor-expression namespace of from_checkpoint, reference panst3r.py:9,14)
 from .model.common import BF16
-from .schedule import select_keyframes, view_order, mem_batches
+from .schedule import mem_batches
 
 ENC_CHUNK = 16        # views per encoder / DINOv2 / render pass
 
@@ -102,30 +102,20 @@ class PanSt3R(nn.Module):
         H, W = shapes.pop()
         if H > W:
             raise NotImplementedError('portrait scenes: round-1 HIP pipeline is landscape-only')
-        K = V if (num_keyframes is None or num_keyframes > V) else max(int(num_keyframes), 2)
-        keyframes = select_keyframes(V, K)
-        order, inv = view_order(V, keyframes)
-        p = self.must3r_encoder.patch_size
-        h, w = H // p, W // p
-        T = h * w
-        x = torch.stack([imgs[i] for i in order]).float().contiguous()
-        cat = torch.empty(V * T, self._cat_width(), dtype=BF16, device=dev)
-        self.encode_views(x, cat)
-        bank = self.build_memory(cat[:K * T], K, h, w)
-        pointmaps = self.render_views(cat, V, h, w, bank)
-        pd = self.panoptic_decoder
-        fpn, mf = pd.features_tokens(cat, x, V, h, w)
-        cls = pd.text_encoder.normalized_bf16(classes, dev)
-        mt = pd.mask_transformer
-        outq, hs = mt.decode_tokens([fpn[i * T:(i + 1) * T] for i in range(K)], [mf[i] for i in range(K)], [(h, w)] * K, cls)
-        masks = []
-        for i in range(V):
-            m = mt.masks_for(hs.embed, mf[i])[None]
-            masks.append(m if outdevice is None else m.to(outdevice))
-        pms = [pointmaps[i][None] if outdevice is None else pointmaps[i][None].to(outdevice) for i in range(V)]
-        panout = {'pred_logits': hs.logits[None] if outdevice is None else hs.logits[None].to(outdevice),
-                  'pred_masks': [masks[i] for i in inv], 'out_queries': outq[:, None]}
-        return [pms[i] for i in inv], panout
+        from .scene import run_scene, HipBackend
+        res, scene = run_scene(HipBackend(self), lambda i: imgs[i], V, H, W, num_keyframes, classes, outdevice=outdevice)
+        panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
+                  'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
+        return [res[i][0] for i in range(V)], panout
+
+    @torch.no_grad()
+    def forward_inference_sharded(self, get_image, V, H, W, classes, num_keyframes=None, outdevice=None, group=None):
+        """View-sharded scene over the ranks of `group` (one process per GPU, RCCL): returns this rank's
+        {view_id: (pointmap, masks)} and the scene-level dict.  See panst3r_amd/scene.py for the plan."""
+        import torch.distributed as dist
+        from .scene import run_scene, HipBackend
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice)
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):

@@ -1,0 +1,136 @@
+"""One PanSt3R scene, view-sharded over the ranks of a torch.distributed group (option 1).
+
+Plan (one process per GPU; RCCL over xGMI when the backend is "nccl", gloo in the CPU tests):
+  A. each rank encodes ITS views (CroCo encoder + DINOv2), keyframes dealt round-robin first     -- no collective
+  B. all_gather of the keyframes' encoder tokens ([K,T,1024] bf16 = 1.5 MiB x K); every rank then replays the
+     sequential memory build redundantly -> identical memory bank everywhere (bit-exact, no broadcast of 13.5 MiB x K)
+  C. each rank renders + upscales its views against the memory                                   -- no collective
+  D. all_gather of the keyframes' FPN tokens and 2x2-centre mask features ([K,T,768+C] bf16); every rank runs the
+     (tiny) panoptic query decoder redundantly -> identical frozen queries everywhere
+  E. each rank computes the query x pixel masks of its views                                       -- no collective
+The math per view is independent of the sharding, so results equal the 1-GPU run of the same build.
+
+`run_scene` is written against a small stage backend so that the same orchestration is exercised on the GPU
+(HipBackend: the HIP kernels) and in the world_size-2 gloo tests on CPU (tests/ provide an oracle-driven backend).
+"""
+import torch
+import torch.distributed as dist
+
+from .schedule import select_keyframes, view_order
+
+
+def assign_views(V, K, world):
+    """keyframes (in schedule order) dealt round-robin to ranks, then the remaining views continue the deal.
+    Returns (keyframes, order, owner) with owner[i] = rank of order[i]."""
+    keyframes = select_keyframes(V, K)
+    order, _ = view_order(V, keyframes)
+    owner = [i % world for i in range(V)]
+    return keyframes, order, owner
+
+
+def _all_gather_rows(t, counts, world, group):
+    """all_gather of row blocks with uneven row counts (padded to the maximum); returns the list of per-rank blocks."""
+    if world == 1:
+        return [t]
+    mx = max(counts)
+    pad = torch.zeros(mx, t.shape[1], dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    raw = pad.view(torch.uint8)          # bit-preserving byte view: every backend (RCCL, gloo) moves uint8
+    outs = [torch.empty_like(raw) for _ in range(world)]
+    dist.all_gather(outs, raw.contiguous(), group=group)
+    return [o.view(t.dtype)[:c] for o, c in zip(outs, counts)]
+
+
+def gather_keyframe_rows(local_rows, K, T, rank, world, group):
+    """local_rows: [k_local*T, C] for this rank's keyframes (in deal order) -> [K*T, C] in keyframe-schedule order."""
+    counts = [len(range(r, K, world)) * T for r in range(world)]
+    blocks = _all_gather_rows(local_rows, counts, world, group)
+    out = torch.empty(K * T, local_rows.shape[1], dtype=local_rows.dtype, device=local_rows.device)
+    for r, blk in enumerate(blocks):
+        for j, kf in enumerate(range(r, K, world)):
+            out[kf * T:(kf + 1) * T] = blk[j * T:(j + 1) * T]
+    return out
+
+
+@torch.no_grad()
+def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None):
+    """Run one scene.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
+    Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
+    {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank)."""
+    K = V if (K is None or K > V) else max(int(K), 2)
+    keyframes, order, owner = assign_views(V, K, world)
+    mine = [i for i in range(V) if owner[i] == rank]            # positions in `order`; keyframe positions come first
+    n_local = len(mine)
+    k_local = sum(1 for i in mine if i < K)
+    p = backend.patch_size
+    h, w = H // p, W // p
+    T = h * w
+    imgs = torch.stack([get_image(order[i]) for i in mine]).float().contiguous() if n_local else None
+    # A. encode own views
+    cat = backend.encode(imgs, n_local, h, w)
+    # B. all-gather keyframe encoder tokens, replay the memory build everywhere
+    enc_kf = gather_keyframe_rows(backend.enc_rows(cat, k_local * T), K, T, rank, world, group)
+    bank = backend.build_memory(enc_kf, K, h, w)
+    # C. render + upscale own views
+    pointmaps = backend.render(cat, n_local, h, w, bank)
+    fpn, mf = backend.features(cat, imgs, n_local, h, w)
+    # D. all-gather keyframe FPN tokens + attention-mask features, decode the queries everywhere
+    fm = backend.attn_feats(mf, k_local)
+    both = torch.cat([fpn[:k_local * T], fm], dim=1) if k_local else fpn.new_zeros(0, fpn.shape[1] + backend.mask_dim)
+    both = gather_keyframe_rows(both.contiguous(), K, T, rank, world, group)
+    d = fpn.shape[1]
+    outq, head = backend.decode(both[:, :d].contiguous(), both[:, d:].contiguous(), K, h, w, classes)
+    # E. masks of own views
+    res = {}
+    for j, i in enumerate(mine):
+        m = backend.masks(head, mf, j)[None]
+        pm = pointmaps[j][None]
+        if outdevice is not None:
+            m, pm = m.to(outdevice), pm.to(outdevice)
+        res[order[i]] = (pm, m)
+    return res, {'pred_logits': backend.logits(head)[None], 'out_queries': outq[:, None]}
+
+
+class HipBackend:
+    """Stage backend on the HIP kernels (wraps a panst3r_amd.PanSt3R)."""
+
+    def __init__(self, model):
+        self.m = model
+        self.patch_size = model.must3r_encoder.patch_size
+        self.mask_dim = model.panoptic_decoder.mask_transformer.mask_dim
+        self.De = model.must3r_encoder.embed_dim
+
+    def encode(self, imgs, n, h, w):
+        dev = imgs.device
+        cat = torch.empty(n * h * w, self.m._cat_width(), dtype=torch.bfloat16, device=dev)
+        self.m.encode_views(imgs, cat)
+        return cat
+
+    def enc_rows(self, cat, rows):
+        return cat[:rows, :self.De].contiguous()
+
+    def build_memory(self, enc_kf, K, h, w):
+        return self.m.build_memory(enc_kf, K, h, w)
+
+    def render(self, cat, n, h, w, bank):
+        return self.m.render_views(cat, n, h, w, bank)
+
+    def features(self, cat, imgs, n, h, w):
+        return self.m.panoptic_decoder.features_tokens(cat, imgs, n, h, w)
+
+    def attn_feats(self, mf, k_local):
+        mt = self.m.panoptic_decoder.mask_transformer
+        if k_local == 0:
+            return torch.zeros(0, mt.mask_dim, dtype=torch.bfloat16, device=mf.device)
+        return mt.attn_feats(mf[:k_local])
+
+    def decode(self, fpn_kf, fm_kf, K, h, w, classes):
+        pd = self.m.panoptic_decoder
+        cls = pd.text_encoder.normalized_bf16(classes, fpn_kf.device)
+        return pd.mask_transformer.decode_tokens(fpn_kf, fm_kf, [(h, w)] * K, cls)
+
+    def masks(self, head, mf, j):
+        return self.m.panoptic_decoder.mask_transformer.masks_for(head.embed, mf[j])
+
+    def logits(self, head):
+        return head.logits

@@ -1,0 +1,97 @@
+"""Stage backend for panst3r_amd.scene.run_scene driven by the CPU oracle (TEST INFRASTRUCTURE).
+
+Lets the world_size-2 gloo tests exercise the real sharding / collective plan without a GPU.  `decode` restates the
+oracle's MaskTransformer loop with the attention-mask logits computed as mask_embed . mean4(mask_feats) -- the
+algebraically identical (bilinear resize is linear) formulation the HIP path uses; test_scene_sharding checks it
+against the reference formulation (full-resolution einsum, then resize).
+"""
+import torch
+import torch.nn.functional as F
+
+
+class OracleBackend:
+    def __init__(self, model):
+        self.m = model
+        self.patch_size = model.must3r_encoder.patch_size
+        self.mask_dim = model.panoptic_decoder.mask_transformer.mask_embed.layers[-1].out_features
+        self.De = model.must3r_encoder.embed_dim
+        self.Dd = model.must3r_decoder.embed_dim
+
+    def _pos(self, h, w):
+        ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+        return torch.stack([ys, xs], -1).reshape(1, -1, 2)
+
+    def encode(self, imgs, n, h, w):
+        ts = torch.tensor([[h * self.patch_size, w * self.patch_size]] * n)
+        x, _ = self.m.must3r_encoder(imgs, ts)
+        d = self.m.dino_encoder(imgs, ts)
+        cat = torch.zeros(n * h * w, self.De + self.Dd + d.shape[-1])
+        cat[:, :self.De] = x.reshape(n * h * w, -1)
+        cat[:, self.De + self.Dd:] = d.reshape(n * h * w, -1)
+        return cat
+
+    def enc_rows(self, cat, rows):
+        return cat[:rows, :self.De].contiguous()
+
+    def build_memory(self, enc_kf, K, h, w):
+        from oracle.must3r import build_memory, mem_batches_for
+        T, p = h * w, self.patch_size
+        xs = [enc_kf[i * T:(i + 1) * T] for i in range(K)]
+        return build_memory(self.m.must3r_decoder, xs, [self._pos(h, w)[0]] * K, [[h * p, w * p]] * K, mem_batches_for(K))
+
+    def render(self, cat, n, h, w, bank):
+        T, p = h * w, self.patch_size
+        pms = []
+        for i in range(n):
+            _, pm, out = self.m.must3r_decoder.forward_list([cat[i * T:(i + 1) * T, :self.De][None]], [self._pos(h, w)],
+                                                            [[h * p, w * p]], bank, render=True)
+            cat[i * T:(i + 1) * T, self.De:self.De + self.Dd] = out[0][0]
+            pms.append(pm[0][0])
+        return torch.stack(pms)
+
+    def features(self, cat, imgs, n, h, w):
+        T, p = h * w, self.patch_size
+        ts = torch.tensor([[[h * p, w * p]] * n])
+        pos = self._pos(h, w)[None].expand(1, n, -1, -1)
+        fpn, mf = self.m.panoptic_decoder.features(cat.reshape(1, n, T, -1), imgs[None], pos, ts, max_bs=1)
+        return fpn[0].flatten(2).transpose(1, 2).reshape(n * T, -1).contiguous(), mf[0]          # tokens, [n,C,Hm,Wm]
+
+    def attn_feats(self, mf, k_local):
+        if k_local == 0:
+            return torch.zeros(0, self.mask_dim)
+        Hm, Wm = mf.shape[-2:]
+        a = F.interpolate(mf[:k_local], size=(Hm // 8, Wm // 8), mode='bilinear', align_corners=False)
+        return a.flatten(2).transpose(1, 2).reshape(-1, mf.shape[1]).contiguous()
+
+    def decode(self, fpn_kf, fm_kf, K, h, w, classes):
+        pd = self.m.panoptic_decoder
+        mt = pd.mask_transformer
+        cls = pd.text_encoder(classes)
+        p = self.patch_size
+        src = fpn_kf[:, None] + mt.level_embed.weight[0][None, None]
+        pos = mt._pos(torch.zeros(1, fpn_kf.shape[1], h, w), torch.tensor([[h * p, w * p]])).repeat(K, 1, 1)
+        qpos = mt.query_embed.weight[:, None]
+        out = mt.query_feat.weight[:, None]
+
+        def amask(o):
+            _, memb = mt.class_and_embed(o)
+            lg = memb[0] @ fm_kf.T
+            return (lg.sigmoid() < 0.5)[None].repeat(mt.num_heads, 1, 1)
+        am = amask(out)
+        for i in range(mt.num_layers):
+            am = am.clone()
+            am[am.all(-1)] = False
+            out = mt.cross_attn_layers[i](out, src, am, pos, qpos)
+            out = mt.self_attn_layers[i](out, qpos)
+            out = mt.ffn_layers[i](out)
+            if i + 1 < mt.num_layers:
+                am = amask(out)
+        lang, memb = mt.class_and_embed(out)
+        logits = mt.cls_logit_scale.exp() * lang @ cls[None].transpose(1, 2)
+        return out[:, 0], (logits[0], memb[0])
+
+    def masks(self, head, mf, j):
+        return torch.einsum('qc,chw->qhw', head[1], mf[j])
+
+    def logits(self, head):
+        return head[0]

@@ -1,0 +1,88 @@
+"""N>1 path on CPU: the view-sharded scene plan (panst3r_amd/scene.py) over a world_size-2 gloo group, driven by the
+oracle backend.  Checks (1) the plan's algebra (mean4-then-dot attention masks, heads once per scene) against the
+reference formulation, (2) sharded == unsharded, (3) the collective plumbing for uneven keyframe counts."""
+import os
+import socket
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import rel_l2
+import tiny
+from oracle_backend import OracleBackend
+from panst3r_amd.scene import run_scene, assign_views, gather_keyframe_rows
+
+H, W = 64, 96
+
+
+def _scene(variant, V, K, rank=0, world=1, group=None):
+    torch.set_num_threads(2)
+    model = tiny.build(tiny.OracleNS, variant)
+    imgs = tiny.images(V, H, W)
+    with torch.no_grad():
+        return run_scene(OracleBackend(model), lambda i: imgs[i], V, H, W, K, tiny.NAMES, rank, world, group)
+
+
+def test_assign_views():
+    kf, order, owner = assign_views(50, 16, 8)
+    assert kf == [0, 3, 6, 9, 13, 16, 19, 22, 26, 29, 32, 35, 39, 42, 45, 49]
+    assert sorted(order) == list(range(50)) and order[:16] == kf
+    assert max(owner.count(r) for r in range(8)) - min(owner.count(r) for r in range(8)) <= 1
+    assert [owner[i] for i in range(16)] == [i % 8 for i in range(16)]
+
+
+@pytest.mark.parametrize('variant', ['v1', 'v2'])
+def test_plan_matches_reference_formulation(variant):
+    """run_scene(world=1) with the oracle backend == the oracle pipeline that follows reference panst3r.py:169-284."""
+    V, K = 4, 3
+    model = tiny.build(tiny.OracleNS, variant)
+    imgs = tiny.images(V, H, W)
+    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor([[H, W]] * V), tiny.NAMES, num_keyframes=K)
+    res, scene = _scene(variant, V, K)
+    assert rel_l2(scene['out_queries'], pan_ref['out_queries']) < 1e-4
+    assert rel_l2(scene['pred_logits'], pan_ref['pred_logits']) < 1e-4
+    for i in range(V):
+        assert rel_l2(res[i][0], pm_ref[i]) < 1e-5
+        assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
+
+
+def _worker(rank, world, port, variant, V, K, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        res, scene = _scene(variant, V, K, rank, world, None)
+        t = torch.arange(6, dtype=torch.bfloat16).reshape(3, 2) + 10 * rank if rank == 0 else torch.arange(4, dtype=torch.bfloat16).reshape(2, 2) + 10
+        g = gather_keyframe_rows(t, 5, 1, rank, world, None)                # K=5 dealt 3/2 over two ranks, bf16 payload
+        q.put((rank, {k: (v[0].clone(), v[1].clone()) for k, v in res.items()}, scene['out_queries'].clone(), g.float()))
+    except Exception as e:      # fail fast instead of letting the parent wait for the queue timeout
+        q.put((rank, repr(e), None, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('variant,V,K', [('v1', 5, 3), ('v2', 4, 2)])
+def test_two_rank_gloo_equals_single(variant, V, K):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, variant, V, K, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    assert all(not isinstance(g[1], str) for g in got), got
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, ref_scene = _scene(variant, V, K)
+    merged = {}
+    for rank, res, outq, g in got:
+        assert torch.equal(outq, ref_scene['out_queries'])                  # identical frozen queries on every rank
+        assert torch.equal(g, torch.tensor([[0., 1.], [10., 11.], [2., 3.], [12., 13.], [4., 5.]]))
+        merged.update(res)
+    assert sorted(merged) == list(range(V))
+    for i in range(V):
+        assert torch.equal(merged[i][0], ref[i][0]) and torch.equal(merged[i][1], ref[i][1])

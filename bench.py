@@ -24,6 +24,26 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak per MI355X (MI355X_MICROARCH.md chip table)
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a 256-thread torch pool
+    on a 16-core quota oversubscribes by 16x and runs ~50x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(variant, H, W, state, names, emb, threads):
     """Oracle (fp32 torch restatement, the "port" kind) timed on the host cores on a bounded sample:
     one 2-view / 2-keyframe scene of the same model at the same resolution."""
@@ -140,7 +160,7 @@ def main():
             out['kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 2),
                                   'tflops': round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1)} for k, v in sorted(summ.items())}
         if state is not None:
-            out['cpu_baseline'] = cpu_baseline(args.variant, H, W, state, names, emb, os.cpu_count() or 1)
+            out['cpu_baseline'] = cpu_baseline(args.variant, H, W, state, names, emb, usable_cores())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

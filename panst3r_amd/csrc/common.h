@@ -28,7 +28,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
-__device__ __forceinline__ uint32_t pack2bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+// two fp32 -> packed bf16x2 in ONE v_cvt_pk_bf16_f32 (round-to-nearest-even in hardware)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+  const bf16x2_t r = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+  return *(const uint32_t*)&r;
+}
 
 // LDS-DMA: every lane copies 16 B from its own global address to (wave-uniform LDS base + lane*16).
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -38,7 +44,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-GELU 0.5 x (1 + erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 output
+// resolution): one v_exp_f32 + one v_rcp_f32 + 7 FMAs instead of libm erff's ~25-instruction polynomial.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erf(|x|/sqrt2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
 
 // Bijective XCD-aware remap: hardware places block b on XCD b%8; give each XCD a contiguous chunk of tiles.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

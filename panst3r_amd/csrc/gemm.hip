@@ -12,7 +12,8 @@
 //   * MFMA operands are swapped (D = W_frag x A_frag) so a lane ends up with 4 CONSECUTIVE n for one m: epilogue
 //     loads (bias/gamma/residual) and stores are 8-16 B vectors.  trans_out uses the plain order instead, giving 4
 //     consecutive m for one n, i.e. vector stores into C^T (used to emit V^T for the attention kernel).
-//   * 1-D grid, XCD-aware + grouped tile order (8 row panels x all column tiles per group) for L2 reuse.
+//   * 1-D grid, XCD-aware + grouped tile order (8 row panels x all column tiles per group) for L2 reuse; the epilogue stages the
+//     C tile through LDS and stores whole rows (16 B/lane) - direct accumulator-layout stores are issue-bound.
 //   * implicit 3x3 conv: the A-side DMA source address is computed per (pixel, tap); out-of-image taps read a zero page.
 #include "common.h"
 #include "../../include/panst3r_hip.h"
@@ -22,8 +23,19 @@ namespace pst {
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
+// Output-run permutation.  The MFMA C layout gives a lane the fragment rows 4g..4g+3 of every fragment f of its wave
+// tile.  LDS row (16f + 4g + r) of a wave's F-fragment sub-tile is therefore filled with the ACTUAL row
+// g*(4F) + 4f + r (free: LDS-DMA takes a per-lane source address), so that a lane ends up owning 4F CONTIGUOUS output
+// columns: 16-B LDS writes in the epilogue, 32/64-B runs in the transposed store.
+template <int F>
+__device__ __forceinline__ int perm_row(int row) {
+  const int sub = row / (16 * F), rho = row - sub * (16 * F);
+  const int f = rho >> 4, g = (rho >> 2) & 3, r = rho & 3;
+  return sub * (16 * F) + g * (4 * F) + 4 * f + r;
+}
+
 template <int FM, int FN, bool TRANS>
-__global__ __launch_bounds__(256) void gemm_kernel(const pst_gemm_params p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                          // [2][BM][128 B]
@@ -34,46 +46,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(const pst_gemm_params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int g = lane >> 4, l16 = lane & 15;
-
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int grp = t / (GROUP_M * tiles_n);
-  const int first_m = grp * GROUP_M;
-  const int gm = min(GROUP_M, tiles_m - first_m);
-  const int tl = t - grp * GROUP_M * tiles_n;
-  const int m0 = (first_m + tl % gm) * BM;
-  const int n0 = (tl / gm) * BN;
-
-  // ---- per-thread staging descriptors (fixed across K steps)
-  const bf16_t* a_src[FM];   // row base (plain mode)
-  int a_y[FM], a_x[FM];      // conv mode: pixel coordinates;  a_src = image base
-  int a_sw[FM];              // swizzled chunk -> element offset within the 64-wide K slab
-  const bf16_t* b_src[FN];
-  int b_sw[FN];
   const bf16_t* Ap = (const bf16_t*)p.A;
   const bf16_t* Wp = (const bf16_t*)p.W;
+
+  // ---- tile of this block: XCD-aware + grouped order
+  int m0, n0;
+  {
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int grp = t / (GROUP_M * tiles_n);
+    const int first_m = grp * GROUP_M;
+    const int gm = min(GROUP_M, tiles_m - first_m);
+    const int tl = t - grp * GROUP_M * tiles_n;
+    m0 = (first_m + tl % gm) * BM;
+    n0 = (tl / gm) * BN;
+  }
+
+  // ---- per-thread staging descriptors (fixed across K steps)
+  const bf16_t* a_src[FM];   // row base (plain mode) / image base (conv mode)
+  int a_yx[FM];              // conv mode: (y << 16) | x of the staged pixel
+  const bf16_t* b_src[FN];
+  int a_sw[FM], b_sw[FN];    // swizzled chunk -> element offset within the 64-wide K slab
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
-    const int c = j * 256 + tid, row = c >> 3, pos = c & 7;
+    const int c = j * 256 + tid, lrow = c >> 3, pos = c & 7;
+    a_sw[j] = ((pos ^ ((lrow >> 1) & 7)) << 3);
+    const int row = TRANS ? perm_row<FM>(lrow) : lrow;
     const int m = min(m0 + row, p.M - 1);
-    a_sw[j] = ((pos ^ ((row >> 1) & 7)) << 3);
     if (p.conv_c > 0) {
       const int hw = p.conv_h * p.conv_w;
       const int img = m / hw, r = m - img * hw;
-      a_y[j] = r / p.conv_w;
-      a_x[j] = r - a_y[j] * p.conv_w;
+      const int y = r / p.conv_w;
+      a_yx[j] = (y << 16) | (r - y * p.conv_w);
       a_src[j] = Ap + (int64_t)img * hw * p.conv_c;
     } else {
-      a_y[j] = a_x[j] = 0;
+      a_yx[j] = 0;
       a_src[j] = Ap + (int64_t)m * p.lda;
     }
   }
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const int c = j * 256 + tid, row = c >> 3, pos = c & 7;
-    const int n = min(n0 + row, p.N - 1);
-    b_sw[j] = ((pos ^ ((row >> 1) & 7)) << 3);
-    b_src[j] = Wp + (int64_t)n * p.ldw;
+    const int c = j * 256 + tid, lrow = c >> 3, pos = c & 7;
+    b_sw[j] = ((pos ^ ((lrow >> 1) & 7)) << 3);
+    const int row = TRANS ? lrow : perm_row<FN>(lrow);
+    b_src[j] = Wp + (int64_t)min(n0 + row, p.N - 1) * p.ldw;
   }
 
   auto stage = [&](int kt, int buf) {
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const pst_gemm_params p) {
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
-        const int yy = a_y[j] + dy, xx = a_x[j] + dx;
+        const int yy = (a_yx[j] >> 16) + dy, xx = (a_yx[j] & 0xffff) + dx;
         const bool ok = (yy >= 0) & (yy < p.conv_h) & (xx >= 0) & (xx < p.conv_w);
         const bf16_t* s = ok ? a_src[j] + ((int64_t)yy * p.conv_w + xx) * p.conv_c + c0 + a_sw[j]
                              : (const bf16_t*)p.zeros + a_sw[j];
@@ -105,10 +120,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const pst_gemm_params p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // LDS read offsets: fragment i of a wave lives 16 rows further (same swizzle key), K-half kk flips chunk bit 2
+  const int a_row = wr * (16 * FM) + l16, b_row = wc * (16 * FN) + l16;
+  const int a_off = a_row * 128 + ((g ^ ((a_row >> 1) & 7)) << 4);
+  const int b_off = b_row * 128 + ((g ^ ((b_row >> 1) & 7)) << 4);
+
   const int nk = p.K / BK;
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    wait_vm0();            // tile kt has landed (issued one iteration ago)
+    wait_vm0();            // the slab of this step has landed (issued one step ago)
     __syncthreads();       // ... for every wave, and everybody is done reading the other buffer
     if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
     const char* a_buf = As + (kt & 1) * (BM * 128);
@@ -116,17 +136,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const pst_gemm_params p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[FM], bfv[FN];
-      const int kc = kk * 4 + g;
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int row = wr * (16 * FM) + i * 16 + l16;
-        af[i] = *(const bf16x8*)(a_buf + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-      }
+      for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(a_buf + ((a_off ^ (kk << 6)) + i * 2048));
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int row = wc * (16 * FN) + j * 16 + l16;
-        bfv[j] = *(const bf16x8*)(b_buf + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-      }
+      for (int j = 0; j < FN; ++j) bfv[j] = *(const bf16x8*)(b_buf + ((b_off ^ (kk << 6)) + j * 2048));
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -139,99 +152,166 @@ __global__ __launch_bounds__(256) void gemm_kernel(const pst_gemm_params p) {
 
   // ---------------------------------------------------------------- epilogue
   if (TRANS) {
-    // lane: n = .. + l16 ; m = .. + 4g + r  -> C^T[n][m..m+3]
+    // lane: n = .. + l16 ; owns the 4*FM contiguous rows m = .. + g*4FM + 4i + r  ->  C^T[n][m..]
     bf16_t* Ct = (bf16_t*)p.C;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + wc * (16 * FN) + j * 16 + l16;
       if (n >= p.N) continue;
       const float b = p.bias ? p.bias[n] : 0.f;
+      const int mb = m0 + wr * (16 * FM) + g * (4 * FM);
+      bf16_t* dst = Ct + (int64_t)n * p.ldc + mb;
+      float v[4 * FM];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wr * (16 * FM) + i * 16 + 4 * g;
-        if (m >= p.M) continue;
-        float v[4];
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float x = acc[i][j][r] + b;
           if (p.act == 1) x = gelu_erf(x); else if (p.act == 2) x = fmaxf(x, 0.f);
-          v[r] = x;
+          v[4 * i + r] = x;
         }
-        bf16_t* dst = Ct + (int64_t)n * p.ldc + m;
-        if (m + 3 < p.M) {
-          *(uint2*)dst = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        } else {
-          for (int r = 0; r < 4 && m + r < p.M; ++r) dst[r] = f2bf(v[r]);
-        }
+      if (mb + 4 * FM <= p.M && (((uintptr_t)dst) & 15) == 0) {
+#pragma unroll
+        for (int q = 0; q < FM / 2; ++q)
+          *(uint4*)(dst + 8 * q) = make_uint4(pack2bf(v[8 * q], v[8 * q + 1]), pack2bf(v[8 * q + 2], v[8 * q + 3]),
+                                              pack2bf(v[8 * q + 4], v[8 * q + 5]), pack2bf(v[8 * q + 6], v[8 * q + 7]));
+      } else if (mb + 4 * FM <= p.M) {
+#pragma unroll
+        for (int q = 0; q < FM; ++q)
+          *(uint2*)(dst + 4 * q) = make_uint2(pack2bf(v[4 * q], v[4 * q + 1]), pack2bf(v[4 * q + 2], v[4 * q + 3]));
+      } else {
+        for (int r = 0; r < 4 * FM && mb + r < p.M; ++r) dst[r] = f2bf(v[r]);
       }
     }
     return;
   }
 
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wr * (16 * FM) + i * 16 + l16;
-    if (m >= p.M) continue;
-    int64_t row_off;       // element offset of (m, n=0) in C, plain / remapped rows
-    int orow = m;
-    int ps_v = 0, ps_y = 0, ps_x = 0;
-    if (p.ps_p > 0) {
-      const int hw = p.ps_h * p.ps_w;
-      ps_v = m / hw;
-      const int tt = m - ps_v * hw;
-      ps_y = tt / p.ps_w;
-      ps_x = tt - ps_y * p.ps_w;
-      row_off = 0;
-    } else {
-      if (p.grp_in > 0) orow = (m / p.grp_in) * p.grp_out + p.grp_off + (m % p.grp_in);
-      row_off = (int64_t)orow * p.ldc;
-    }
-    const float* res_row = nullptr;
-    if (p.res) res_row = p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr;
+  // ---- C tile -> LDS (all slab buffers are free now) -> whole-row stores.
+  // A lane owns 4*FN contiguous columns of 4 fragment rows, so writing C straight from the accumulators makes every
+  // store instruction touch 16 different rows (issue-bound, cf. guide T21).  Instead bias / activation / LayerScale are
+  // applied in the accumulator layout, the tile goes to LDS (16-B chunks XOR-swizzled by row: conflict-free both ways)
+  // and is written back row-wise: 16 B per lane, consecutive lanes = consecutive bytes of one output row.  The fp32
+  // residual is read in that coalesced phase too.
+  const bool f32o = p.out_fp32 != 0;
+  const int pitch = BN * (f32o ? 4 : 2);                    // bytes per LDS C row
+  const int nch = pitch >> 4;                               // 16-B chunks per row (8 / 16 / 32)
+  __syncthreads();                                          // every wave is done with its MFMA operand reads
+  {
+    const int cb = wc * (16 * FN) + g * (4 * FN);           // tile-local first column of the lane's run
+    float4 bias4[FN], gam4[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const int n = n0 + wc * (16 * FN) + j * 16 + 4 * g;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-        const float4 b = *(const float4*)(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (p.act == 1) {
+      const int n = min(n0 + cb + 4 * j, p.N - 4);
+      bias4[j] = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gam4[j] = p.gamma ? *(const float4*)(p.gamma + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      } else if (p.act == 2) {
+    for (int i = 0; i < FM; ++i) {
+      const int r = wr * (16 * FM) + i * 16 + l16;          // tile-local row of this lane
+      char* rowp = smem + r * pitch;
+      const int key = r & (nch - 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      for (int j = 0; j < FN; ++j) {
+        float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+        if (p.act == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        v[0] *= gam4[j].x; v[1] *= gam4[j].y; v[2] *= gam4[j].z; v[3] *= gam4[j].w;
+        const int col = cb + 4 * j;
+        if (f32o) *(float4*)(rowp + ((((col >> 2) ^ key)) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+        else *(uint2*)(rowp + ((((col >> 3) ^ key)) << 4) + ((col & 4) << 1)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
       }
-      if (p.gamma) {
-        const float4 s = *(const float4*)(p.gamma + n);
-        v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
-      }
-      if (res_row) {
-        const float4 q = *(const float4*)(res_row + n);
-        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-      }
-      int64_t off;
-      if (p.ps_p > 0) {
-        const int seg = p.ps_p * p.ps_c;
-        const int dy = n / seg, r = n - dy * seg;
-        off = ((int64_t)(ps_v * p.ps_p * p.ps_h + p.ps_p * ps_y + dy) * p.ps_w + ps_x) * seg + r;
-      } else {
-        off = row_off + n;
-      }
-      if (p.out_fp32) *(float4*)((float*)p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
-      else *(uint2*)((bf16_t*)p.C + off) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
     }
   }
+  __syncthreads();
+  {
+    const int c = tid % nch;                                // 16-B chunk of the row
+    const int epc = f32o ? 4 : 8;                           // elements per chunk
+    const int n = n0 + c * epc;
+    const int seg = p.ps_p * p.ps_c;
+    for (int r = tid / nch; r < BM; r += 256 / nch) {
+      const int m = m0 + r;
+      if (m >= p.M || n >= p.N) continue;
+      uint4 val = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
+      int orow = m;
+      int64_t off;
+      int ps_v = 0, ps_y = 0, ps_x = 0;
+      if (p.ps_p > 0) {
+        const int hw = p.ps_h * p.ps_w;
+        ps_v = m / hw;
+        const int tt = m - ps_v * hw;
+        ps_y = tt / p.ps_w;
+        ps_x = tt - ps_y * p.ps_w;
+        const int dy = n / seg, rem = n - dy * seg;
+        off = ((int64_t)(ps_v * p.ps_p * p.ps_h + p.ps_p * ps_y + dy) * p.ps_w + ps_x) * seg + rem;
+      } else {
+        if (p.grp_in > 0) orow = (m / p.grp_in) * p.grp_out + p.grp_off + (m % p.grp_in);
+        off = (int64_t)orow * p.ldc + n;
+      }
+      const float* rp = p.res ? p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + n : nullptr;
+      if (f32o) {
+        if (rp) {
+          const float4 q = *(const float4*)rp;
+          float4 f = *(float4*)&val;
+          f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
+          *(float4*)((float*)p.C + off) = f;
+        } else {
+          *(uint4*)((float*)p.C + off) = val;
+        }
+        continue;
+      }
+      if (rp) {              // bf16 output with an fp32 residual: add in fp32, round once more
+        uint32_t* w32 = (uint32_t*)&val;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(w32[q] << 16) + ((n + 2 * q < p.N) ? rp[2 * q] : 0.f);
+          const float hi = __uint_as_float(w32[q] & 0xffff0000u) + ((n + 2 * q + 1 < p.N) ? rp[2 * q + 1] : 0.f);
+          w32[q] = pack2bf(lo, hi);
+        }
+      }
+      bf16_t* dst = (bf16_t*)p.C + off;
+      // a chunk is 8 columns; N % 4 == 0, so the last chunk of a row may hold only 4 valid columns, and a pixel-shuffle
+      // segment (a multiple of 4 columns) may end in the middle of a chunk: split into two 8-byte stores then.
+      const bool full = (n + 8 <= p.N) && (p.ps_p == 0 || ((n % seg) + 8 <= seg));
+      if (full && ((((uintptr_t)dst) & 15) == 0)) {
+        *(uint4*)dst = val;
+      } else {
+        *(uint2*)dst = make_uint2(val.x, val.y);
+        if (n + 8 <= p.N) {
+          int64_t off2 = off + 4;
+          if (p.ps_p > 0) {
+            const int n2 = n + 4, dy = n2 / seg, rem = n2 - dy * seg;
+            off2 = ((int64_t)(ps_v * p.ps_p * p.ps_h + p.ps_p * ps_y + dy) * p.ps_w + ps_x) * seg + rem;
+          }
+          *(uint2*)((bf16_t*)p.C + off2) = make_uint2(val.z, val.w);
+        }
+      }
+    }
+  }
+}
+
+static int num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
 }
 
 template <int FM, int FN, bool TRANS>
 static int launch(const pst_gemm_params& p, hipStream_t s) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_m * tiles_n;
   const size_t lds = 2 * (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS>), dim3(tiles), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS>), dim3(tiles), dim3(256), lds, s, p, tiles, tiles_m, tiles_n);
   return check_launch("gemm_bf16");
 }
 

@@ -111,25 +111,42 @@ __global__ void gn_stats_kernel(const void* x, int64_t ldx, int x_fp32, float* s
   for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(stats + (int64_t)view * 2 * G + i, shs[i]);
 }
 
-// y = relu?((x - mean_g) * rstd_g * gamma_c + beta_c); bf16 output, columns [C, ldy) zero filled
+// y = relu?((x - mean_g) * rstd_g * gamma_c + beta_c); bf16 output, columns [C, ldy) zero filled.
+// VEC=4: one thread = 4 consecutive channels (8-16 B loads, 8 B stores); VEC=1 is the generic path (C = 203).
+template <int VEC>
 __global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
                                 bf16_t* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu) {
-  const int64_t total = (int64_t)nimg * P * ldy;
+  const int64_t cols = ldy / VEC;
+  const int64_t total = (int64_t)nimg * P * cols;
   const float inv_n = 1.0f / ((float)P * (C / G));
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % ldy);
-    const int64_t row = i / ldy;
-    float o = 0.f;
+    const int c = (int)(i % cols) * VEC;
+    const int64_t row = i / cols;
+    float o[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = 0.f;
     if (c < C) {
       const int view = (int)(row / P), grp = c / (C / G);
       const float sm = stats[((int64_t)view * G + grp) * 2], sq = stats[((int64_t)view * G + grp) * 2 + 1];
       const float mean = sm * inv_n;
-      const float var = fmaxf(sq * inv_n - mean * mean, 0.f);
-      const float v = x_fp32 ? ((const float*)x)[row * ldx + c] : bf2f(((const bf16_t*)x)[row * ldx + c]);
-      o = (v - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
-      if (relu) o = fmaxf(o, 0.f);
+      const float rstd = rsqrtf(fmaxf(sq * inv_n - mean * mean, 0.f) + eps);
+      float v[VEC];
+      if (VEC == 4) {
+        if (x_fp32) { const float4 t = *(const float4*)((const float*)x + row * ldx + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else { const uint2 t = *(const uint2*)((const bf16_t*)x + row * ldx + c);
+               v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+               v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+      } else {
+        v[0] = x_fp32 ? ((const float*)x)[row * ldx + c] : bf2f(((const bf16_t*)x)[row * ldx + c]);
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        o[k] = (v[k] - mean) * rstd * gamma[c + k] + beta[c + k];
+        if (relu) o[k] = fmaxf(o[k], 0.f);
+      }
     }
-    y[i] = f2bf(o);
+    if (VEC == 4) *(uint2*)(y + row * ldy + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+    else y[row * ldy + c] = f2bf(o[0]);
   }
 }
 
@@ -185,10 +202,12 @@ extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float
 extern "C" int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
                                    void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, void* stream) {
   if (!x || !stats || !gamma || !beta || !y || nimg <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G || ldy < C) { set_error("groupnorm_apply: bad argument"); return PST_EINVAL; }
-  const int64_t total = (int64_t)nimg * P * ldy;
+  const bool vec = (C % 4 == 0) && ((C / G) % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0);
+  const int64_t total = (int64_t)nimg * P * (vec ? ldy / 4 : ldy);
   int64_t g = (total + 255) / 256;
   if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu);
+  if (vec) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu);
+  else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu);
   return check_launch("groupnorm_apply");
 }
 

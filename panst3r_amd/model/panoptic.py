@@ -26,7 +26,7 @@ from .common import (HipModule, Packed, Layout, BF16, empty, vit_block, pack_cro
                      grid_pos, ceil_to)
 from .params import BlockP, MlpP, CrossAttnP, MHAP
 
-VIEW_CHUNK = 8      # views per upscaler pass (bounds the [rows, 22528] / [P, 384] workspaces)
+VIEW_CHUNK = 16     # views per upscaler pass (bounds the [rows, 22528] / [P, 384] workspaces)
 
 
 # =========================================================================================== InputMixer

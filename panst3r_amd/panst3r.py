@@ -24,7 +24,7 @@ from .model import *            # noqa: F401,F403  (ctor-expression namespace of
 from .model.common import BF16
 from .schedule import mem_batches
 
-ENC_CHUNK = 16        # views per encoder / DINOv2 / render pass
+ENC_CHUNK = 64        # views per encoder / DINOv2 / render pass (M = views*T rows through every GEMM)
 
 
 class PanSt3R(nn.Module):

@@ -66,7 +66,7 @@ def cpu_baseline(variant, H, W, state, names, emb, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--variant', default='v2', choices=['v1', 'v2'])
     ap.add_argument('--views', type=int, default=50)
@@ -75,6 +75,7 @@ def main():
     ap.add_argument('--width', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying HIP graphs')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -108,24 +109,29 @@ def main():
     mine = {order[i] for i in range(V) if owner[i] == rank}
     images = {i: synth_image(i, H, W).to(dev) for i in sorted(mine)}        # inputs resident in HBM before timing
 
-    def step():
-        return model.forward_inference_sharded(lambda i: images[i], V, H, W, names, num_keyframes=K)
+    runner = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager)
+
+    def step(eager=False):
+        return runner.run(eager=eager)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):      # the first run also captures the three HIP graphs of the scene
         step()
     timer = None
     fence()
     t0 = time.perf_counter()
     for s in range(args.steps):
         if s == args.steps - 1 and not args.no_kernel_timing:
-            timer = hip.KernelTimer()        # the LAST timed step also records HIP events around every MFMA-kernel launch
+            # the LAST timed step runs eagerly (not as a graph replay) with HIP events around every MFMA-kernel launch
+            timer = hip.KernelTimer()
             hip.TIMER = timer
-        step()
+            step(eager=True)
+        else:
+            step()
     hip.TIMER = None
     fence()
     elapsed = time.perf_counter() - t0
@@ -145,6 +151,7 @@ def main():
                                    % (args.variant, V, K, H, W),
                        'variant': args.variant, 'views': V, 'keyframes': K, 'resolution': [H, W],
                        'parallelism': 'views sharded over %d rank(s)' % world,
+                       'launch': 'eager' if args.eager else 'HIP-graph replay (3 graphs per scene; last timed step eager + HIP-event instrumented)',
                        'scene_algorithmic_tflop': round(scene_flops / 1e12, 2),
                        'scene_mfma_frac': round(scene_flops / (elapsed / args.steps) / world / (PEAK_BF16_TFLOPS * 1e12), 4)},
         }

@@ -156,8 +156,19 @@ class ParamLinear(nn.Linear):
         raise RuntimeError('parameter container; use the HIP path')
 
 
+_GRID_POS = {}
+
+
 def grid_pos(V, h, w, Tp, off, device):
-    """int32 [V*Tp, 2] (y, x) positions of a row-major h x w token grid, zero for pad rows."""
+    """int32 [V*Tp, 2] (y, x) positions of a row-major h x w token grid, zero for pad rows (cached per shape: it is a
+    constant, and a host->device copy per call would also break HIP-graph capture)."""
+    key = (V, h, w, Tp, off, str(device))
+    if key not in _GRID_POS:
+        _GRID_POS[key] = _grid_pos(V, h, w, Tp, off, device)
+    return _GRID_POS[key]
+
+
+def _grid_pos(V, h, w, Tp, off, device):
     ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
     p = torch.zeros(Tp, 2, dtype=torch.int32)
     p[off:off + h * w] = torch.stack([ys, xs], -1).reshape(-1, 2).to(torch.int32)

@@ -390,7 +390,9 @@ class MaskTransformer(HipModule):
         ln = torch.zeros(Q, cls_bf16.shape[1], dtype=BF16, device=dev)
         hip.l2norm_rows(lang, ln[:, :lang.shape[1]], 1e-7)
         logits = empty(Q, cls_bf16.shape[0], torch.float32, dev)
-        gam = torch.full((cls_bf16.shape[0],), pk['scale'], dtype=torch.float32, device=dev)
+        if pk.get('gam_n') != cls_bf16.shape[0]:
+            pk['gam'], pk['gam_n'] = torch.full((cls_bf16.shape[0],), pk['scale'], dtype=torch.float32, device=dev), cls_bf16.shape[0]
+        gam = pk['gam']
         hip.gemm(ln, cls_bf16, logits, gamma=gam)
         return logits
 
@@ -521,6 +523,7 @@ class TextEncoder(nn.Module):
         if embeddings is None:
             raise NotImplementedError('offline build: pass the pooled SigLIP embeddings explicitly')
         self.class_embeddings = {c: e for c, e in zip(classes, embeddings)}
+        self._cls_cache = (None, None)
 
     def forward(self, classes):
         assert all(c in self.class_embeddings for c in classes), \
@@ -532,10 +535,13 @@ class TextEncoder(nn.Module):
         """unit-norm class embeddings as the bf16 [Ncls, 768] W operand of the class-logit GEMM (normalised on device)."""
         assert all(c in self.class_embeddings for c in classes), \
             "Missing classes in vocabulary. 'set_vocab' must be called if using fixed vocabulary"
-        raw = torch.stack([self.class_embeddings[c] for c in classes]).float().to(device).contiguous()
-        out = torch.zeros(raw.shape[0], ceil_to(raw.shape[1], 64), dtype=BF16, device=device)
-        hip.l2norm_rows(raw, out[:, :raw.shape[1]], 0.0)
-        return out
+        key = (tuple(classes), str(device))
+        if getattr(self, '_cls_cache', (None, None))[0] != key:
+            raw = torch.stack([self.class_embeddings[c] for c in classes]).float().to(device).contiguous()
+            out = torch.zeros(raw.shape[0], ceil_to(raw.shape[1], 64), dtype=BF16, device=device)
+            hip.l2norm_rows(raw, out[:, :raw.shape[1]], 0.0)
+            self._cls_cache = (key, out)
+        return self._cls_cache[1]
 
 
 class PanopticDecoder(HipModule):

@@ -117,6 +117,14 @@ class PanSt3R(nn.Module):
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
         return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice)
 
+    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True):
+        """Static-shape scene runner (panst3r_amd/scene.py): `images` = {view_id: [3,H,W] device tensor} of the views
+        this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True."""
+        import torch.distributed as dist
+        from .scene import SceneRunner, HipBackend
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs)
+
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):
         """Same-shape batch variant (panst3r.py:286-296): imgs [1,n,3,H,W] -> (panout, pointmaps [1,n,H,W,7]);

@@ -52,43 +52,118 @@ def gather_keyframe_rows(local_rows, K, T, rank, world, group):
     return out
 
 
+class SceneRunner:
+    """One scene as three stages separated by the two all-gathers:
+         stage1  encode own views                                   -> enc_send
+         gather  keyframe encoder tokens                            -> enc_kf
+         stage2  memory build (replayed on every rank), render, upscale -> pointmaps, mask feats, both_send
+         gather  keyframe FPN tokens + attention-mask features      -> both_kf
+         stage3  query decoding (replayed on every rank) + query x pixel masks of own views
+    With `use_graphs=True` (GPU only) each stage is captured once into a HIP graph and replayed: a scene is ~4 700
+    kernel launches, most of them 5-20 us kernels of the sequential memory build, so eager launching is host-bound.
+    The collectives stay eager between the graph replays.  Shapes, keyframe schedule and class list are static."""
+
+    def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False):
+        self.b, self.V, self.H, self.W, self.classes = backend, V, H, W, classes
+        self.rank, self.world, self.group = rank, world, group
+        self.K = K = V if (K is None or K > V) else max(int(K), 2)
+        if V < world:
+            raise ValueError('need at least one view per rank (V=%d, world=%d)' % (V, world))
+        self.keyframes, self.order, owner = assign_views(V, K, world)
+        self.mine = [i for i in range(V) if owner[i] == rank]       # positions in `order`; keyframe positions first
+        self.n_local = len(self.mine)
+        self.k_local = sum(1 for i in self.mine if i < K)
+        p = backend.patch_size
+        self.h, self.w = H // p, W // p
+        self.T = self.h * self.w
+        self.imgs = torch.stack([images[self.order[i]] for i in self.mine]).float().contiguous()   # static input buffer
+        self.use_graphs = use_graphs
+        self.graphs = None
+        self.enc_kf = self.both_kf = None
+        self.out = None
+
+    # ---- stages (every tensor they leave on `self` is read by a later stage)
+    def stage1(self):
+        b, T = self.b, self.T
+        self.cat = b.encode(self.imgs, self.n_local, self.h, self.w)
+        self.enc_send = b.enc_rows(self.cat, self.k_local * T)
+
+    def gather1(self):
+        kf = gather_keyframe_rows(self.enc_send, self.K, T=self.T, rank=self.rank, world=self.world, group=self.group)
+        if self.enc_kf is None:
+            self.enc_kf = kf
+        else:
+            self.enc_kf.copy_(kf)
+
+    def stage2(self):
+        b, T, kl = self.b, self.T, self.k_local
+        bank = b.build_memory(self.enc_kf, self.K, self.h, self.w)
+        self.pointmaps = b.render(self.cat, self.n_local, self.h, self.w, bank)
+        fpn, self.mf = b.features(self.cat, self.imgs, self.n_local, self.h, self.w)
+        fm = b.attn_feats(self.mf, kl)
+        self.d = fpn.shape[1]
+        self.both_send = (torch.cat([fpn[:kl * T], fm], dim=1) if kl else fpn.new_zeros(0, self.d + b.mask_dim)).contiguous()
+
+    def gather2(self):
+        kf = gather_keyframe_rows(self.both_send, self.K, T=self.T, rank=self.rank, world=self.world, group=self.group)
+        if self.both_kf is None:
+            self.both_kf = kf
+        else:
+            self.both_kf.copy_(kf)
+
+    def stage3(self):
+        b = self.b
+        outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.h, self.w,
+                              self.classes)
+        masks = [b.masks(head, self.mf, j) for j in range(self.n_local)]
+        self.out = (outq, b.logits(head), masks)
+
+    def _eager(self):
+        self.stage1(); self.gather1(); self.stage2(); self.gather2(); self.stage3()
+
+    def _capture(self):
+        self._eager()                              # warm-up: packs weights, builds tables, fills allocator pools
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        self.graphs = []
+        for stage, gather in ((self.stage1, self.gather1), (self.stage2, self.gather2), (self.stage3, None)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                stage()
+            self.graphs.append(g)
+            g.replay()
+            if gather is not None:
+                gather()
+        torch.cuda.synchronize()
+
+    @torch.no_grad()
+    def run(self, outdevice=None, eager=False):
+        if self.use_graphs and not eager:
+            if self.graphs is None:
+                self._capture()
+            else:
+                self.graphs[0].replay(); self.gather1(); self.graphs[1].replay(); self.gather2(); self.graphs[2].replay()
+        else:
+            self._eager()
+        outq, logits, masks = self.out
+        res = {}
+        for j, i in enumerate(self.mine):
+            m, pm = masks[j][None], self.pointmaps[j][None]
+            if outdevice is not None:
+                m, pm = m.to(outdevice), pm.to(outdevice)
+            res[self.order[i]] = (pm, m)
+        return res, {'pred_logits': logits[None], 'out_queries': outq[:, None]}
+
+
 @torch.no_grad()
 def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None):
-    """Run one scene.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
+    """Run one scene eagerly.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
     Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
     {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank)."""
-    K = V if (K is None or K > V) else max(int(K), 2)
-    keyframes, order, owner = assign_views(V, K, world)
-    mine = [i for i in range(V) if owner[i] == rank]            # positions in `order`; keyframe positions come first
-    n_local = len(mine)
-    k_local = sum(1 for i in mine if i < K)
-    p = backend.patch_size
-    h, w = H // p, W // p
-    T = h * w
-    imgs = torch.stack([get_image(order[i]) for i in mine]).float().contiguous() if n_local else None
-    # A. encode own views
-    cat = backend.encode(imgs, n_local, h, w)
-    # B. all-gather keyframe encoder tokens, replay the memory build everywhere
-    enc_kf = gather_keyframe_rows(backend.enc_rows(cat, k_local * T), K, T, rank, world, group)
-    bank = backend.build_memory(enc_kf, K, h, w)
-    # C. render + upscale own views
-    pointmaps = backend.render(cat, n_local, h, w, bank)
-    fpn, mf = backend.features(cat, imgs, n_local, h, w)
-    # D. all-gather keyframe FPN tokens + attention-mask features, decode the queries everywhere
-    fm = backend.attn_feats(mf, k_local)
-    both = torch.cat([fpn[:k_local * T], fm], dim=1) if k_local else fpn.new_zeros(0, fpn.shape[1] + backend.mask_dim)
-    both = gather_keyframe_rows(both.contiguous(), K, T, rank, world, group)
-    d = fpn.shape[1]
-    outq, head = backend.decode(both[:, :d].contiguous(), both[:, d:].contiguous(), K, h, w, classes)
-    # E. masks of own views
-    res = {}
-    for j, i in enumerate(mine):
-        m = backend.masks(head, mf, j)[None]
-        pm = pointmaps[j][None]
-        if outdevice is not None:
-            m, pm = m.to(outdevice), pm.to(outdevice)
-        res[order[i]] = (pm, m)
-    return res, {'pred_logits': backend.logits(head)[None], 'out_queries': outq[:, None]}
+    Kc = V if (K is None or K > V) else max(int(K), 2)
+    _, order, owner = assign_views(V, Kc, world)
+    images = {order[i]: get_image(order[i]) for i in range(V) if owner[i] == rank}
+    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False).run(outdevice)
 
 
 class HipBackend:

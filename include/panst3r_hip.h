@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 1
+#define PST_ABI_VERSION 2
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -75,7 +75,13 @@ typedef struct pst_attn_params {
   int32_t B, H, Nq, Nk, hd;
   float scale;
   const void* zeros;                           /* >=128 B of zero bytes on the device */
+  /* split-K ("flash-decoding") for few queries x many keys: nsplit > 1 splits the key range over nsplit blocks per
+     query block; partial (O, max, sum) go to `ws` (fp32, >= pst_attn_workspace_bytes) and a combine kernel merges. */
+  int32_t nsplit;
+  void* ws; int64_t ws_bytes;
 } pst_attn_params;
+
+int64_t pst_attn_workspace_bytes(int B, int H, int Nq, int hd, int nsplit);
 
 int pst_attn_fwd_bf16(const pst_attn_params* p, void* stream);
 

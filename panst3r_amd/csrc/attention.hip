@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   const int g = lane >> 4, l16 = lane & 15;
 
   const int qblocks = (p.Nq + 64 * QF - 1) / (64 * QF);
-  const int bid = blockIdx.x;
+  const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+  const int split = blockIdx.x % nsplit;          // key-range split (flash-decoding): consecutive blocks share the queries
+  const int bid = blockIdx.x / nsplit;
   const int qb = bid % qblocks, bh = bid / qblocks;
   const int h = bh % p.H, b = bh / p.H;
 
@@ -117,13 +119,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   for (int a = 0; a < QF; ++a) { m_run[a] = NEG; l_run[a] = 0.f; }
 
   const float c_exp = p.scale * 1.4426950408889634f;
-  const int ntiles = (p.Nk + KT - 1) / KT;
-  stage(0, 0);
-  for (int kt = 0; kt < ntiles; ++kt) {
+  const int tiles_all = (p.Nk + KT - 1) / KT;
+  const int tps = (tiles_all + nsplit - 1) / nsplit;
+  const int kt_begin = split * tps;
+  const int ntiles = min(tiles_all, kt_begin + tps);
+  if (kt_begin < ntiles) stage(kt_begin, 0);
+  for (int kt = kt_begin; kt < ntiles; ++kt) {
     wait_vm0();
     __syncthreads();
-    if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
-    const char* kb_ = smem + (kt & 1) * C::BUF;
+    if (kt + 1 < ntiles) stage(kt + 1, (kt + 1 - kt_begin) & 1);
+    const char* kb_ = smem + ((kt - kt_begin) & 1) * C::BUF;
     const char* vb_ = kb_ + C::K_BYTES;
     const int k0 = kt * KT;
 
@@ -211,6 +216,28 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
     }
   }
 
+  // ---- split-K: unnormalised partial O plus (running max, sum) go to the fp32 workspace; attn_combine_kernel merges
+  if (nsplit > 1) {
+    float* ws_o = (float*)p.ws;
+    const int64_t rows = (int64_t)p.B * p.H * p.Nq;
+    float* ws_ml = ws_o + (int64_t)nsplit * rows * HD;
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+      float l = l_run[a];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const int q = q_wave0 + a * 16 + l16;
+      if (q < p.Nq) {
+        const int64_t row = ((int64_t)b * p.H + h) * p.Nq + q;
+        float* dst = ws_o + ((int64_t)split * rows + row) * HD + 4 * g;
+#pragma unroll
+        for (int hf = 0; hf < NHF; ++hf) *(float4*)(dst + hf * 16) = make_float4(o[hf][a][0], o[hf][a][1], o[hf][a][2], o[hf][a][3]);
+        if (g == 0) *(float2*)(ws_ml + ((int64_t)split * rows + row) * 2) = make_float2(m_run[a], l);
+      }
+    }
+    return;
+  }
+
   // ---- normalise and store: lane owns q = l16, head-dim rows 16*hf + 4*g + r
 #pragma unroll
   for (int a = 0; a < QF; ++a) {
@@ -229,11 +256,47 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   }
 }
 
+// merge the nsplit partial results of one (b, h, q) row: O = sum_s O_s 2^((m_s-m)c) / sum_s l_s 2^((m_s-m)c)
+__global__ void attn_combine_kernel(const pst_attn_params p, int hd) {
+  const int64_t rows = (int64_t)p.B * p.H * p.Nq;
+  const int per_row = hd / 4;
+  const int64_t total = rows * per_row;
+  const float c_exp = p.scale * 1.4426950408889634f;
+  const float* ws_o = (const float*)p.ws;
+  const float* ws_ml = ws_o + (int64_t)p.nsplit * rows * hd;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / per_row;
+    const int d = (int)(i - row * per_row) * 4;
+    float m = NEG;
+    for (int s = 0; s < p.nsplit; ++s) m = fmaxf(m, ws_ml[((int64_t)s * rows + row) * 2]);
+    float l = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.nsplit; ++s) {
+      const float2 ml = *(const float2*)(ws_ml + ((int64_t)s * rows + row) * 2);
+      const float wgt = __builtin_amdgcn_exp2f((ml.x - m) * c_exp);
+      const float4 v = *(const float4*)(ws_o + ((int64_t)s * rows + row) * hd + d);
+      l += ml.y * wgt;
+      acc[0] += v.x * wgt; acc[1] += v.y * wgt; acc[2] += v.z * wgt; acc[3] += v.w * wgt;
+    }
+    const float inv = 1.0f / l;
+    const int q = (int)(row % p.Nq);
+    const int bh = (int)(row / p.Nq), h = bh % p.H, b = bh / p.H;
+    bf16_t* dst = (bf16_t*)p.O + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)q * p.o_rs + d;
+    *(uint2*)dst = make_uint2(pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv));
+  }
+}
+
 template <int HD, int QF>
 static int launch_attn(const pst_attn_params& p, hipStream_t s) {
   const int qblocks = (p.Nq + 64 * QF - 1) / (64 * QF);
-  const long grid = (long)qblocks * p.H * p.B;
+  const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+  const long grid = (long)qblocks * p.H * p.B * nsplit;
   hipLaunchKernelGGL((attn_kernel<HD, QF>), dim3((unsigned)grid), dim3(256), 2 * AttnCfg<HD>::BUF, s, p);
+  if (nsplit > 1) {
+    const int64_t total = (int64_t)p.B * p.H * p.Nq * (HD / 4);
+    int64_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)g), dim3(256), 0, s, p, HD);
+  }
   return check_launch("attn_fwd_bf16");
 }
 
@@ -254,8 +317,17 @@ extern "C" int pst_attn_fwd_bf16(const pst_attn_params* pp, void* stream) {
     set_error("attn: operands must be 16-byte aligned"); return PST_EINVAL;
   }
   if (p.mask && ((p.m_rs | p.m_bs) % 4 || ((uintptr_t)p.mask & 3))) { set_error("attn: mask rows must be 4-byte aligned"); return PST_EINVAL; }
+  if (p.nsplit > 1) {
+    const int64_t need = (int64_t)p.nsplit * p.B * p.H * p.Nq * (p.hd + 2) * 4;
+    if (!p.ws || p.ws_bytes < need || ((uintptr_t)p.ws & 15)) { set_error("attn: split-K needs a 16-byte aligned workspace of %lld bytes", (long long)need); return PST_EINVAL; }
+    if (p.nsplit > 64) { set_error("attn: nsplit <= 64"); return PST_EINVAL; }
+  }
   hipStream_t s = (hipStream_t)stream;
-  const long big = (long)((p.Nq + 127) / 128) * p.H * p.B;
+  const long big = p.nsplit > 1 ? 0 : (long)((p.Nq + 127) / 128) * p.H * p.B;     // split-K always uses 64-query blocks
   if (p.hd == 64) return big >= 256 ? launch_attn<64, 2>(p, s) : launch_attn<64, 1>(p, s);
   return big >= 256 ? launch_attn<96, 2>(p, s) : launch_attn<96, 1>(p, s);
+}
+
+extern "C" int64_t pst_attn_workspace_bytes(int B, int H, int Nq, int hd, int nsplit) {
+  return nsplit > 1 ? (int64_t)nsplit * B * H * Nq * (hd + 2) * 4 : 0;
 }

@@ -25,6 +25,11 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max, b
   return r;
 }
 
+// statistics accumulators are cleared by a kernel (not hipMemsetAsync) so the clear is an ordinary node of a captured graph
+__global__ void zero_kernel(float* p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 // one block per (view, channel): 2x2 mean (== bilinear x0.5, align_corners=False) and min / max of the result
 __global__ __launch_bounds__(256) void down2_minmax_kernel(const float* img, float* img2, float* mm, int H, int W) {
   __shared__ float sh[4];
@@ -177,7 +182,7 @@ extern "C" int pst_loftup_guidance(const float* img, const float* biases, float*
   // keep it explicit -- img2 and min/max live at the END of `feats` (caller allocates nimg*(P*CH + 3*P + 8) floats).
   float* img2 = feats + (int64_t)nimg * P * CH;
   float* mm = img2 + (int64_t)nimg * 3 * P;
-  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * nimg, s) != hipSuccess) { set_error("loftup_guidance: memset failed"); return PST_ELAUNCH; }
+  hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, s, stats, 2 * nimg);
   hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(256), 0, s, img, img2, mm, H, W);
   const float f_lo = -2.f, f_step = 12.f / (nf - 1);
   int gx = (int)(((int64_t)P * CH + 255) / 256);
@@ -189,7 +194,7 @@ extern "C" int pst_loftup_guidance(const float* img, const float* biases, float*
 extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float* stats, int nimg, int P, int C, int G, void* stream) {
   if (!x || !stats || nimg <= 0 || P <= 0 || C % 4 || G <= 0 || C % G || (C / G) % 4 || ldx % 4 || C / 4 > 1024) { set_error("groupnorm_stats: bad argument"); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * G * nimg, s) != hipSuccess) { set_error("groupnorm_stats: memset failed"); return PST_ELAUNCH; }
+  hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, s, stats, 2 * G * nimg);
   const int c4 = C / 4;
   const int rpb = c4 >= 256 ? 1 : 256 / c4;
   const int threads = c4 * rpb;

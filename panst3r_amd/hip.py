@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -33,10 +33,10 @@ class AttnParams(C.Structure):
                 ('O', vp), ('o_bs', i64), ('o_hs', i64), ('o_rs', i64),
                 ('mask', vp), ('m_bs', i64), ('m_rs', i64),
                 ('B', i32), ('H', i32), ('Nq', i32), ('Nk', i32), ('hd', i32),
-                ('scale', f32), ('zeros', vp)]
+                ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64)]
 
 
-EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_layernorm', 'pst_rope2d_bf16',
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_rope2d_bf16',
            'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe']
@@ -175,8 +175,16 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
 
 
 # ----------------------------------------------------------------------------------------------------------- attention
+def auto_nsplit(B, H, Nq, Nk):
+    """Key-range splits for few-query / many-key attention (memory build, query decoder): fill ~2 blocks per CU."""
+    blocks = ((Nq + 63) // 64) * H * B
+    if blocks >= 256 or Nk < 1024:
+        return 1
+    return max(1, min(512 // blocks, Nk // 512, 32))
+
+
 def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale=None, mask=None,
-              mask_strides=(0, 0)):
+              mask_strides=(0, 0), nsplit=None):
     """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row)."""
     _dev(q, torch.bfloat16); _dev(k, torch.bfloat16); _dev(vt, torch.bfloat16); _dev(out, torch.bfloat16)
     p = AttnParams()
@@ -190,8 +198,12 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
     p.B, p.H, p.Nq, p.Nk, p.hd = B, H, Nq, Nk, hd
     p.scale = float(hd ** -0.5 if scale is None else scale)
     p.zeros = _ptr(zeros_page(q.device))
+    ns = auto_nsplit(B, H, Nq, Nk) if nsplit is None else nsplit
+    if ns > 1:
+        ws = torch.empty(ns * B * H * Nq * (hd + 2), dtype=torch.float32, device=q.device)
+        p.nsplit, p.ws, p.ws_bytes = ns, _ptr(ws), ws.numel() * 4
     if TIMER is not None:
-        big = ((Nq + 127) // 128) * H * B >= 256
+        big = ns == 1 and ((Nq + 127) // 128) * H * B >= 256
         ev = TIMER.bracket('attn_kernel<%d,%d>' % (hd, 2 if big else 1), 4.0 * B * H * Nq * Nk * hd)
         ev[0].record()
         _check(lib().pst_attn_fwd_bf16(C.byref(p), _stream()), 'pst_attn_fwd_bf16')

@@ -163,6 +163,36 @@ def test_attention(B, H, Nq, Nk, hd, masked):
     assert rel_l2(got, ref) < 1.2e-2
 
 
+@pytest.mark.parametrize('H,Nq,Nk,hd,ns,masked', [(12, 768, 6144, 64, 4, False), (8, 200, 3000, 96, 7, True), (2, 70, 1100, 64, 32, False)])
+def test_attention_split_k(H, Nq, Nk, hd, ns, masked):
+    """flash-decoding split over the key range + combine == unsplit softmax (incl. empty / tail splits and masks)."""
+    from panst3r_amd import hip
+    q, k, v = bf(rn(23, 1, H, Nq, hd)), bf(rn(24, 1, H, Nk, hd)), bf(rn(25, 1, H, Nk, hd))
+    mask = None
+    if masked:
+        g = np.random.Generator(np.random.PCG64(6))
+        mask = torch.from_numpy(g.uniform(size=(1, Nq, Nk)) < 0.7)
+        mask[:, :, 5] = False
+        mask[:, 3, :2048] = True           # a row whose first splits are fully blocked
+    ref = _attn_ref(q.float(), k.float(), v.float(), mask)
+    D = H * hd
+    qd = q[0].permute(1, 0, 2).reshape(Nq, D).contiguous().to(dev())
+    kd = k[0].permute(1, 0, 2).reshape(Nk, D).contiguous().to(dev())
+    vt = torch.zeros(D, (Nk + 7) // 8 * 8 + 8, dtype=torch.bfloat16)
+    vt[:, :Nk] = v[0].permute(0, 2, 1).reshape(D, Nk)
+    vt = vt.to(dev())
+    md, ms = None, (0, 0)
+    if masked:
+        md, ms = mask[0].to(torch.uint8).contiguous().to(dev()), (0, Nk)
+    for nsplit in (ns, None):
+        od = torch.full((Nq, D), float('nan'), dtype=torch.bfloat16, device=dev())
+        hip.attention(qd, kd, vt, od, 1, H, Nq, Nk, hd, (0, hd, D), (0, hd, D), (0, hd * vt.stride(0), vt.stride(0)), (0, hd, D),
+                      mask=md, mask_strides=ms, nsplit=nsplit)
+        got = od.float().cpu().reshape(Nq, H, hd).permute(1, 0, 2)
+        assert torch.isfinite(got).all()
+        assert rel_l2(got, ref[0]) < 1.2e-2
+
+
 def test_attention_softmax_rescale_spike():
     """Force the online-softmax rescale branch: one key in a late tile dominates one query row (guide rule 26)."""
     from panst3r_amd import hip

@@ -134,6 +134,11 @@ int pst_attn_mask_from_logits(const float* logits, int64_t ldl, uint8_t* mask, i
  * groupnorm_apply: y = relu?((x - mean_g) * rstd_g * gamma_c + beta_c) over pixel-major [nimg, P, C] with G groups,
  *   stats fp32 [nimg, G, 2] (sum, sumsq), bf16 output padded with zeros to ldy.
  * groupnorm_stats: accumulate (sum, sumsq) per (view, group) of a pixel-major tensor. */
+#define PST_STATS_BLOCKS 128   /* max partial-sum blocks per view of the deterministic two-level reductions */
+/* Buffer sizes (floats): feats >= nimg*(P*(10*nf+3) + 3*P + 6) (features, then scratch);
+   guidance stats >= nimg*2*(1 + PST_STATS_BLOCKS);  groupnorm stats >= nimg*G*2*(1 + PST_STATS_BLOCKS).
+   The result occupies the first nimg*2 / nimg*G*2 floats; the rest holds per-block partial sums (no atomics: the
+   statistics are bit-reproducible). */
 int pst_loftup_guidance(const float* img, const float* biases, float* feats, float* stats, int nimg, int H, int W,
                         int nf, void* stream);
 int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float* stats, int nimg, int P, int C, int G,

@@ -25,11 +25,6 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max, b
   return r;
 }
 
-// statistics accumulators are cleared by a kernel (not hipMemsetAsync) so the clear is an ordinary node of a captured graph
-__global__ void zero_kernel(float* p, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.f;
-}
-
 // one block per (view, channel): 2x2 mean (== bilinear x0.5, align_corners=False) and min / max of the result
 __global__ __launch_bounds__(256) void down2_minmax_kernel(const float* img, float* img2, float* mm, int H, int W) {
   __shared__ float sh[4];
@@ -53,7 +48,7 @@ __global__ __launch_bounds__(256) void down2_minmax_kernel(const float* img, flo
 // thread = (pixel, output channel).  Channels: [0,5nf) sin, [5nf,10nf) cos with index f*5+d, then 3 scaled rgb.
 // d: 0 = y grid, 1 = x grid, 2..4 = scaled rgb.  Bias storage is [2][5][nf] read flat as [2][nf*5] (loftup.py:62-63).
 __global__ __launch_bounds__(256) void fourier_kernel(const float* img2, const float* mm, const float* biases, float* feats,
-                                                      float* stats, int H2, int W2, int nf, float f_lo, float f_step) {
+                                                      float* part, int H2, int W2, int nf, float f_lo, float f_step) {
   __shared__ float sh[4];
   const int view = blockIdx.y, P = H2 * W2, CH = 10 * nf + 3;
   const int64_t total = (int64_t)P * CH;
@@ -83,37 +78,51 @@ __global__ __launch_bounds__(256) void fourier_kernel(const float* img2, const f
     s += v;
     s2 += v * v;
   }
+  // deterministic: fixed per-thread element order, fixed-tree block reduction, per-block partial (no atomics)
   s = block_reduce(s, sh, false, false);
   s2 = block_reduce(s2, sh, false, false);
-  if (threadIdx.x == 0) { atomicAdd(stats + 2 * view, s); atomicAdd(stats + 2 * view + 1, s2); }
+  if (threadIdx.x == 0) { part[((int64_t)view * gridDim.x + blockIdx.x) * 2] = s; part[((int64_t)view * gridDim.x + blockIdx.x) * 2 + 1] = s2; }
 }
 
-// (sum, sumsq) per (view, group); thread owns one 4-channel chunk -> one group, loops over rows
-__global__ void gn_stats_kernel(const void* x, int64_t ldx, int x_fp32, float* stats, int P, int C, int G, int rows_per_block) {
-  extern __shared__ float shs[];   // [G][2]
+// stats[view][g] = sum over blocks (in index order) of part[view][block][g]; one thread per (view, group, component)
+__global__ void reduce_partials_kernel(const float* part, float* stats, int nimg, int nb, int per) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nimg * per) return;
+  const int view = i / per, c = i - view * per;
+  float a = 0.f;
+  for (int b = 0; b < nb; ++b) a += part[((int64_t)view * nb + b) * per + c];
+  stats[i] = a;
+}
+
+// (sum, sumsq) per (view, group): thread owns one 4-channel chunk (one group) and a fixed set of rows; threads of a
+// group are summed in index order through LDS, blocks through reduce_partials_kernel -> bit-reproducible statistics.
+__global__ void gn_stats_kernel(const void* x, int64_t ldx, int x_fp32, float* part, int P, int C, int G, int rows_per_block) {
+  extern __shared__ float shs[];   // [blockDim][2]
   const int view = blockIdx.y, c4 = C / 4;
   const int chunk = threadIdx.x % c4, rsub = threadIdx.x / c4, rpb = blockDim.x / c4;
-  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) shs[i] = 0.f;
-  __syncthreads();
   float s = 0.f, s2 = 0.f;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, P);
-  if (rsub < rpb) {
-    for (int r = r0 + rsub; r < r1; r += rpb) {
-      const int64_t idx = ((int64_t)view * P + r) * ldx + chunk * 4;
-      float v[4];
-      if (x_fp32) { const float4 t = *(const float4*)((const float*)x + idx); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-      else { const uint2 t = *(const uint2*)((const bf16_t*)x + idx);
-             v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-             v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+  for (int r = r0 + rsub; r < r1; r += rpb) {
+    const int64_t idx = ((int64_t)view * P + r) * ldx + chunk * 4;
+    float v[4];
+    if (x_fp32) { const float4 t = *(const float4*)((const float*)x + idx); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else { const uint2 t = *(const uint2*)((const bf16_t*)x + idx);
+           v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+           v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { s += v[k]; s2 += v[k] * v[k]; }
-    }
-    const int grp = (chunk * 4) / (C / G);
-    atomicAdd(&shs[2 * grp], s);
-    atomicAdd(&shs[2 * grp + 1], s2);
+    for (int k = 0; k < 4; ++k) { s += v[k]; s2 += v[k] * v[k]; }
   }
+  shs[2 * threadIdx.x] = s;
+  shs[2 * threadIdx.x + 1] = s2;
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(stats + (int64_t)view * 2 * G + i, shs[i]);
+  if (threadIdx.x < 2 * G) {
+    const int grp = threadIdx.x >> 1, comp = threadIdx.x & 1;
+    const int cpg = (C / G) / 4;                      // chunks per group
+    float a = 0.f;
+    for (int rs = 0; rs < rpb; ++rs)
+      for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) a += shs[2 * (rs * c4 + c) + comp];
+    part[(((int64_t)view * gridDim.x + blockIdx.x) * G + grp) * 2 + comp] = a;
+  }
 }
 
 // y = relu?((x - mean_g) * rstd_g * gamma_c + beta_c); bf16 output, columns [C, ldy) zero filled.
@@ -182,25 +191,29 @@ extern "C" int pst_loftup_guidance(const float* img, const float* biases, float*
   // keep it explicit -- img2 and min/max live at the END of `feats` (caller allocates nimg*(P*CH + 3*P + 8) floats).
   float* img2 = feats + (int64_t)nimg * P * CH;
   float* mm = img2 + (int64_t)nimg * 3 * P;
-  hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, s, stats, 2 * nimg);
   hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(256), 0, s, img, img2, mm, H, W);
   const float f_lo = -2.f, f_step = 12.f / (nf - 1);
   int gx = (int)(((int64_t)P * CH + 255) / 256);
-  if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(fourier_kernel, dim3(gx, nimg), dim3(256), 0, s, img2, mm, biases, feats, stats, H2, W2, nf, f_lo, f_step);
+  if (gx > PST_STATS_BLOCKS) gx = PST_STATS_BLOCKS;
+  float* part = stats + 2 * nimg;                      // [nimg][gx][2] partial sums behind the result
+  hipLaunchKernelGGL(fourier_kernel, dim3(gx, nimg), dim3(256), 0, s, img2, mm, biases, feats, part, H2, W2, nf, f_lo, f_step);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 63) / 64), dim3(64), 0, s, part, stats, nimg, gx, 2);
   return check_launch("loftup_guidance");
 }
 
 extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float* stats, int nimg, int P, int C, int G, void* stream) {
   if (!x || !stats || nimg <= 0 || P <= 0 || C % 4 || G <= 0 || C % G || (C / G) % 4 || ldx % 4 || C / 4 > 1024) { set_error("groupnorm_stats: bad argument"); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, s, stats, 2 * G * nimg);
   const int c4 = C / 4;
   const int rpb = c4 >= 256 ? 1 : 256 / c4;
   const int threads = c4 * rpb;
-  const int rows_per_block = 64 * rpb;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((P + rows_per_block - 1) / rows_per_block, nimg), dim3(threads), sizeof(float) * 2 * G, s,
-                     x, ldx, x_fp32, stats, P, C, G, rows_per_block);
+  if (2 * G > threads) { set_error("groupnorm_stats: too many groups for C=%d", C); return PST_EINVAL; }
+  int nb = (P + 64 * rpb - 1) / (64 * rpb);
+  if (nb > PST_STATS_BLOCKS) nb = PST_STATS_BLOCKS;
+  const int rows_per_block = (P + nb - 1) / nb;
+  float* part = stats + (int64_t)2 * G * nimg;         // [nimg][nb][G][2] partial sums behind the result
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nb, nimg), dim3(threads), sizeof(float) * 2 * threads, s, x, ldx, x_fp32, part, P, C, G, rows_per_block);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 * G + 63) / 64), dim3(64), 0, s, part, stats, nimg, nb, 2 * G);
   return check_launch("groupnorm_stats");
 }
 

@@ -11,6 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
 ABI_VERSION = 2
+STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -286,6 +287,11 @@ def attn_mask_from_logits(logits, mask):
     _check(lib().pst_attn_mask_from_logits(_ptr(logits), i64(_rowmajor(logits)), _ptr(mask), i64(_rowmajor(mask)), Q, Nk, _stream()),
            'pst_attn_mask_from_logits')
     return mask
+
+
+def stats_buffer(nimg, G, device):
+    """fp32 statistics buffer for loftup_guidance (G=1) / groupnorm_stats: result [nimg, G, 2] + per-block partials."""
+    return torch.empty(nimg * G * 2 * (1 + STATS_BLOCKS), dtype=torch.float32, device=device)
 
 
 def loftup_guidance(img, biases, feats, stats, nf):

@@ -218,14 +218,14 @@ class LoftUpUpscaler(HipModule):
             n = min(VIEW_CHUNK, V - v0)
             # ---- guidance branch: Fourier features -> GN(1) -> conv3x3 -> GN(8)+ReLU -> conv3x3 -> GN(8)+ReLU
             scratch = torch.empty(n * (P * CH + 3 * P) + 8 * n + 16, dtype=torch.float32, device=dev)
-            st0 = torch.empty(n, 2, dtype=torch.float32, device=dev)
+            st0 = hip.stats_buffer(n, 1, dev)
             hip.loftup_guidance(imgs[v0:v0 + n].contiguous(), pk['ff_bias'], scratch, st0, self.n_freqs)
             g0 = empty(n * P, pk['c0'], BF16, dev)
             hip.groupnorm_apply(scratch[:n * P * CH].view(n * P, CH), st0, pk['gn0'][0], pk['gn0'][1], g0, n, P, CH, 1, pk['gn0'][2], False)
             del scratch
             c1 = empty(n * P, C, BF16, dev)
             hip.gemm(g0, pk['conv1'].w, c1, bias=pk['conv1'].b, conv=(pk['c0'], H2, W2))
-            st = torch.empty(n, 8, 2, dtype=torch.float32, device=dev)
+            st = hip.stats_buffer(n, 8, dev)
             hip.groupnorm_stats(c1, st, n, P, C, 8)
             g1 = empty(n * P, C, BF16, dev)
             hip.groupnorm_apply(c1, st, pk['gn1'][0], pk['gn1'][1], g1, n, P, C, 8, pk['gn1'][2], True)

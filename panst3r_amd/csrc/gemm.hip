@@ -20,6 +20,8 @@
 
 namespace pst {
 
+int launch_gemm256(const pst_gemm_params& p, hipStream_t s);   // gemm256.hip
+
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
@@ -321,6 +323,8 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
   using namespace pst;
   if (!pp) { set_error("gemm: null params"); return PST_EINVAL; }
   const pst_gemm_params& p = *pp;
+  if (p.kernel != 0 && p.kernel != 128 && p.kernel != 256) { set_error("gemm: kernel must be 0 (auto), 128 or 256"); return PST_EINVAL; }
+  if (p.kernel == 256 && (p.conv_c > 0 || p.trans_out)) { set_error("gemm: the 256x256 kernel has no conv / trans_out mode"); return PST_EINVAL; }
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) { set_error("gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K); return PST_EINVAL; }
   if (p.K % 64 || p.N % 4) { set_error("gemm: need K%%64==0 and N%%4==0 (K=%d N=%d)", p.K, p.N); return PST_EINVAL; }
   if (!p.A || !p.W || !p.C) { set_error("gemm: null operand"); return PST_EINVAL; }
@@ -341,7 +345,14 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
   if (p.res && (p.ldr % 4)) { set_error("gemm: ldr must be a multiple of 4"); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  const bool small = big_tiles < 384;   // < 1.5 waves of the 256 CUs: prefer 64x64 tiles to fill the chip
+  const bool small = p.kernel == 0 && big_tiles < 384;   // < 1.5 waves of the 256 CUs: prefer 64x64 tiles to fill the chip
   if (p.trans_out) return small ? launch<2, 2, true>(p, s) : launch<4, 4, true>(p, s);
+  // large plain GEMMs: 256x256 tiles, 8 waves, counted-vmcnt pipeline (>= 3 full rounds of the 256 CUs, or forced)
+  const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const bool fits32 = (int64_t)p.M * p.lda < (1ll << 31) && (int64_t)p.N * p.ldw < (1ll << 31);
+  // measured on MI355X: the 256^2 kernel wins for deep K / wide N (v1 MLPs +10 %, 8192^3 +20 %), loses for K < 1024 or ragged N
+  const bool shape256 = p.N % 256 == 0 && p.K >= 1024 && (p.N >= 2048 || p.K >= 2048) && tiles256 >= 3 * 256 - 64;
+  const int want256 = p.conv_c == 0 && fits32 && (p.kernel == 256 || (p.kernel == 0 && shape256));
+  if (want256) return launch_gemm256(p, s);
   return small ? launch<2, 2, false>(p, s) : launch<4, 4, false>(p, s);
 }

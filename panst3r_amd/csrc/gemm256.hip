@@ -1,0 +1,252 @@
+// 256x256x64 bf16 MFMA GEMM for the large batched GEMMs of the PanSt3R path (encoder / DINOv2 / decoder / upscaler MLPs
+// with M = views*T rows): 8 waves (2 x 4), wave tile 128 x 64, one workgroup per CU, 128 KiB LDS, 4-phase K tiles with
+// LDS-DMA loads kept in flight ACROSS barriers by a counted s_waitcnt vmcnt (guide: "256^2 8-phase template").
+//
+// Per K tile t (LDS buffer b = t & 1; each buffer = A-lo, A-hi, B-lo, B-hi half-tiles of 128 rows x 64 K = 16 KiB):
+//   phase 0: ds_read A(m0) 8x + B(n0) 4x + B(n1) 4x | DMA A-lo(t+1) | MFMA quadrant (m0,n0)   16 MFMA per wave and phase
+//   phase 1:                                        | DMA A-hi(t+1) | MFMA (m0,n1)            then barrier (B reads done)
+//   phase 2: ds_read A(m1) 8x                       | DMA B-lo(t+2) | MFMA (m1,n1)   (B halves of buffer b are dead)
+//   phase 3:                                        | DMA B-hi(t+2) | MFMA (m1,n0)            then s_waitcnt vmcnt(4) + barrier:
+// everything but the two newest half-tiles (B(t+2)) has landed, i.e. all of tile t+1.  A(t+1) goes to buffer b^1, whose
+// last reads (tile t-1, phase 2) are two barriers old; B(t+2) goes to buffer b after its last B read (phase 1 of tile t).
+// Each output element accumulates its K products in the same order as the 128x128 kernel => bit-identical results.
+#include "common.h"
+#include "../../include/panst3r_hip.h"
+
+namespace pst {
+
+constexpr int HALF_BYTES = 128 * 128;           // 128 rows x 64 bf16
+constexpr int BUF_BYTES = 4 * HALF_BYTES;       // A-lo, A-hi, B-lo, B-hi
+constexpr int G256_GROUP_M = 4;
+
+__device__ __forceinline__ int perm_row4(int row) {      // see gemm.hip perm_row<4>: lane owns 16 contiguous columns
+  const int sub = row >> 6, rho = row & 63;
+  const int f = rho >> 4, g = (rho >> 2) & 3, r = rho & 3;
+  return (sub << 6) + g * 16 + 4 * f + r;
+}
+
+#define PST_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int g = lane >> 4, l16 = lane & 15;
+
+  int m0, n0;
+  {
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int grp = t / (G256_GROUP_M * tiles_n);
+    const int first_m = grp * G256_GROUP_M;
+    const int gm = min(G256_GROUP_M, tiles_m - first_m);
+    const int tl = t - grp * G256_GROUP_M * tiles_n;
+    m0 = (first_m + tl % gm) * 256;
+    n0 = (tl / gm) * 256;
+  }
+
+  // ---- staging descriptors: a half-tile is 1024 16-B chunks = 2 per thread
+  // (32-bit element offsets from the A / W base pointers keep the register count down: M*lda, N*ldw < 2^31 checked on the host)
+  int a_src[2][2], b_src[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = j * 512 + tid, lrow = c >> 3, pos = c & 7;
+    const int sw = ((pos ^ ((lrow >> 1) & 7)) << 3);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      a_src[h][j] = min(m0 + h * 128 + lrow, p.M - 1) * (int)p.lda + sw;
+      b_src[h][j] = min(n0 + h * 128 + perm_row4(lrow), p.N - 1) * (int)p.ldw + sw;
+    }
+  }
+  const bf16_t* Ab = (const bf16_t*)p.A;
+  const bf16_t* Wb = (const bf16_t*)p.W;
+  const int nk = p.K / 64;
+  // stage one half-tile (which: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi) of K tile kt; no-op past the end of K
+  auto stage = [&](int which, int kt) {
+    if (kt >= nk) return;
+    char* dst = smem + (kt & 1) * BUF_BYTES + which * HALF_BYTES + wave * 1024;
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16_t* s = which < 2 ? Ab + (a_src[which & 1][j] + k0) : Wb + (b_src[which & 1][j] + k0);
+      glds16(s, dst + j * 8192);
+    }
+  };
+
+  // ---- LDS read offsets (swizzle key depends on l16 only: all fragment row offsets are multiples of 16)
+  const int key = (l16 >> 1) & 7;
+  const int a_off = wm * HALF_BYTES + l16 * 128 + ((g ^ key) << 4);
+  const int b_off = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + ((wn & 1) * 64 + l16) * 128 + ((g ^ key) << 4);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 af[4][2];        // current A sub-tile: 4 row fragments x 2 K halves
+  bf16x8 bfr[2][2][2];    // both B sub-tiles: [n sub-tile][fragment][K half]
+
+  auto read_a = [&](const char* buf, int mi) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) af[i][kk] = *(const bf16x8*)(buf + ((a_off ^ (kk << 6)) + (mi * 64 + i * 16) * 128));
+  };
+  auto read_b = [&](const char* buf, int ni) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) bfr[ni][j][kk] = *(const bf16x8*)(buf + ((b_off ^ (kk << 6)) + (ni * 32 + j * 16) * 128));
+  };
+  auto mma = [&](int mi, int ni) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[mi * 4 + i][ni * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: tile 0 (4 half-tiles) + B of tile 1; wait for tile 0 only
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  stage(2, 1); stage(3, 1);
+  if (nk > 1) PST_VMCNT(4); else PST_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* buf = smem + (kt & 1) * BUF_BYTES;
+    // phase 0 / 1: quadrants (m0,n0), (m0,n1); B(n1) is fetched while (m0,n0) is multiplied
+    read_a(buf, 0);
+    read_b(buf, 0);
+    stage(0, kt + 1);
+    read_b(buf, 1);
+    mma(0, 0);
+    stage(1, kt + 1);
+    mma(0, 1);
+    __builtin_amdgcn_s_barrier();        // every wave has finished its B reads of this buffer -> B halves may be refilled
+    // phase 2 / 3: quadrants (m1,n1), (m1,n0)
+    read_a(buf, 1);
+    stage(2, kt + 2);
+    mma(1, 1);
+    stage(3, kt + 2);
+    mma(1, 0);
+    if (kt + 2 < nk) PST_VMCNT(4); else PST_VMCNT(0);     // tile kt+1 complete (only B(kt+2) may still be in flight)
+    __builtin_amdgcn_s_barrier();        // ... for every wave; also: all A reads of this buffer are done
+  }
+
+  // ---------------------------------------------------------------- epilogue: C tile -> LDS -> whole-row stores
+  const bool f32o = p.out_fp32 != 0;
+  const int pitch = 256 * (f32o ? 4 : 2);
+  const int nch = pitch >> 4;                                // 32 (bf16) / 64 (fp32) chunks per row
+  const int rows_pass = f32o ? 128 : 256;                    // 128 KiB of LDS
+  const int cb = wn * 64 + g * 16;                           // tile-local first column of the lane's 16-column run
+  const int seg = p.ps_p * p.ps_c;
+  for (int pass = 0; pass * rows_pass < 256; ++pass) {
+    __syncthreads();
+    if (!f32o || wm == pass) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nn = min(n0 + cb + 4 * j, p.N - 4);
+        const float4 bias4 = p.bias ? *(const float4*)(p.bias + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gam4 = p.gamma ? *(const float4*)(p.gamma + nn) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = wm * 128 + i * 16 + l16;             // tile-local row
+          const int rr = r - pass * rows_pass;
+          char* rowp = smem + rr * pitch;
+          const int rkey = rr & (nch - 1);
+          float v[4] = {acc[i][j][0] + bias4.x, acc[i][j][1] + bias4.y, acc[i][j][2] + bias4.z, acc[i][j][3] + bias4.w};
+          if (p.act == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          }
+          v[0] *= gam4.x; v[1] *= gam4.y; v[2] *= gam4.z; v[3] *= gam4.w;
+          const int col = cb + 4 * j;
+          if (f32o) *(float4*)(rowp + (((col >> 2) ^ rkey) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+          else *(uint2*)(rowp + (((col >> 3) ^ rkey) << 4) + ((col & 4) << 1)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
+      }
+    }
+    __syncthreads();
+    const int c = tid % nch;
+    const int epc = f32o ? 4 : 8;
+    const int n = n0 + c * epc;
+    for (int rr = tid / nch; rr < rows_pass; rr += 512 / nch) {
+      const int m = m0 + pass * rows_pass + rr;
+      if (m >= p.M || n >= p.N) continue;
+      uint4 val = *(const uint4*)(smem + rr * pitch + ((c ^ (rr & (nch - 1))) << 4));
+      int orow = m;
+      int64_t off;
+      int ps_v = 0, ps_y = 0, ps_x = 0;
+      if (p.ps_p > 0) {
+        const int hw = p.ps_h * p.ps_w;
+        ps_v = m / hw;
+        const int tt = m - ps_v * hw;
+        ps_y = tt / p.ps_w;
+        ps_x = tt - ps_y * p.ps_w;
+        const int dy = n / seg, rem = n - dy * seg;
+        off = ((int64_t)(ps_v * p.ps_p * p.ps_h + p.ps_p * ps_y + dy) * p.ps_w + ps_x) * seg + rem;
+      } else {
+        if (p.grp_in > 0) orow = (m / p.grp_in) * p.grp_out + p.grp_off + (m % p.grp_in);
+        off = (int64_t)orow * p.ldc + n;
+      }
+      const float* rp = p.res ? p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + n : nullptr;
+      if (f32o) {
+        if (rp) {
+          const float4 q = *(const float4*)rp;
+          float4 f = *(float4*)&val;
+          f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
+          *(float4*)((float*)p.C + off) = f;
+        } else {
+          *(uint4*)((float*)p.C + off) = val;
+        }
+        continue;
+      }
+      if (rp) {
+        uint32_t* w32 = (uint32_t*)&val;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(w32[q] << 16) + ((n + 2 * q < p.N) ? rp[2 * q] : 0.f);
+          const float hi = __uint_as_float(w32[q] & 0xffff0000u) + ((n + 2 * q + 1 < p.N) ? rp[2 * q + 1] : 0.f);
+          w32[q] = pack2bf(lo, hi);
+        }
+      }
+      bf16_t* dst = (bf16_t*)p.C + off;
+      const bool full = (n + 8 <= p.N) && (p.ps_p == 0 || ((n % seg) + 8 <= seg));
+      if (full && ((((uintptr_t)dst) & 15) == 0)) {
+        *(uint4*)dst = val;
+      } else {
+        *(uint2*)dst = make_uint2(val.x, val.y);
+        if (n + 8 <= p.N) {
+          int64_t off2 = off + 4;
+          if (p.ps_p > 0) {
+            const int n2 = n + 4, dy = n2 / seg, rem = n2 - dy * seg;
+            off2 = ((int64_t)(ps_v * p.ps_p * p.ps_h + p.ps_p * ps_y + dy) * p.ps_w + ps_x) * seg + rem;
+          }
+          *(uint2*)((bf16_t*)p.C + off2) = make_uint2(val.z, val.w);
+        }
+      }
+    }
+  }
+}
+
+int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const int tiles = tiles_m * tiles_n;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm256_kernel, dim3(tiles), dim3(512), 2 * BUF_BYTES, s, p, tiles, tiles_m, tiles_n);
+  return check_launch("gemm256_bf16");
+}
+
+}  // namespace pst

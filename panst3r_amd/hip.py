@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -24,7 +24,7 @@ class GemmParams(C.Structure):
                 ('act', i32), ('out_fp32', i32), ('trans_out', i32),
                 ('grp_in', i32), ('grp_out', i32), ('grp_off', i32),
                 ('ps_p', i32), ('ps_c', i32), ('ps_h', i32), ('ps_w', i32),
-                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp)]
+                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('kernel', i32)]
 
 
 class AttnParams(C.Structure):
@@ -129,7 +129,7 @@ ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 
 
 def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
-         M=None):
+         M=None, kernel=0):
     """out = epi(a @ w.T).  a [M,K] bf16 (row-major view), w [N,K] bf16, out bf16/fp32 2-D view (or raw buffer for ps)."""
     _dev(a, torch.bfloat16); _dev(w, torch.bfloat16); _dev(out, torch.bfloat16, torch.float32)
     p = GemmParams()
@@ -162,11 +162,16 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
     p.act = ACT[act]
     p.out_fp32 = int(out.dtype == torch.float32)
     p.trans_out = int(trans_out)
+    p.kernel = kernel
     if grp is not None:
         p.grp_in, p.grp_out, p.grp_off = grp
     if TIMER is not None:
         big = ((Mv + 127) // 128) * ((N + 127) // 128) >= 384
-        ev = TIMER.bracket(('gemm_kernel<4,4,%s>' if big else 'gemm_kernel<2,2,%s>') % ('true' if trans_out else 'false'), 2.0 * Mv * N * K)
+        name = ('gemm_kernel<4,4,%s>' if big else 'gemm_kernel<2,2,%s>') % ('true' if trans_out else 'false')
+        if (conv is None and not trans_out and kernel != 128 and N % 256 == 0 and K >= 1024 and (N >= 2048 or K >= 2048)
+                and ((Mv + 255) // 256) * ((N + 255) // 256) >= 3 * 256 - 64) or kernel == 256:
+            name = 'gemm256_kernel'
+        ev = TIMER.bracket(name, 2.0 * Mv * N * K)
         ev[0].record()
         _check(lib().pst_gemm_bf16(C.byref(p), _stream()), 'pst_gemm_bf16')
         ev[1].record()

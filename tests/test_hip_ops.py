@@ -52,6 +52,46 @@ def test_gemm_asymmetric_identity():
     assert torch.equal(out.cpu(), w.T.contiguous())
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 128), (1000, 520, 192), (3000, 1024, 1024), (777, 260, 2816)])
+def test_gemm256_bit_identical_to_gemm128(M, N, K):
+    """The 256x256 8-wave counted-vmcnt kernel accumulates every output element in the same order as the 128x128 kernel:
+    results must be bit-identical for every epilogue (also run 20x to screen the LDS-DMA pipeline for races)."""
+    from panst3r_amd import hip
+    a, w = bf(rn(90, M, K)).to(dev()), bf(rn(91, N, K, scale=K ** -0.5)).to(dev())
+    bias, gamma = rn(92, N).to(dev()), rn(93, N).to(dev())
+    res = rn(94, M, N).to(dev())
+    cases = [dict(bias=bias, act='gelu'), dict(bias=bias, gamma=gamma, res=res), dict(), dict(bias=bias, act='relu')]
+    for kw in cases:
+        for dtype in (torch.bfloat16, torch.float32):
+            outs = []
+            for kern in (128, 256):
+                out = torch.full((M, N), float('nan'), dtype=dtype, device=dev())
+                hip.gemm(a, w, out, kernel=kern, **kw)
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), (kw.keys(), dtype)
+    ref = None
+    for it in range(20):
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+        hip.gemm(a, w, out, bias=bias, kernel=256)
+        ref = out if ref is None else ref
+        assert torch.equal(out, ref)
+    # row remap + in-place residual, pixel-shuffle store
+    if M % 8 == 0:
+        g = M // 2
+        buf = rn(95, 2 * (g + 8), N).to(dev())
+        b1, b2 = buf.clone(), buf.clone()
+        hip.gemm(a, w, b1, bias=bias, res=b1, grp=(g, g + 8, 3), kernel=128)
+        hip.gemm(a, w, b2, bias=bias, res=b2, grp=(g, g + 8, 3), kernel=256)
+        assert torch.equal(b1, b2)
+    if N % 16 == 0 and M % 12 == 0:
+        c = N // 4
+        o1 = torch.zeros(M // 12, 6, 8, c, dtype=torch.bfloat16, device=dev())
+        o2 = torch.zeros_like(o1)
+        hip.gemm(a, w, o1, bias=bias, ps=(2, c, 3, 4), kernel=128)
+        hip.gemm(a, w, o2, bias=bias, ps=(2, c, 3, 4), kernel=256)
+        assert torch.equal(o1, o2)
+
+
 def test_gemm_residual_gamma_remap():
     from panst3r_amd import hip
     M, N, K = 2 * 96, 64, 128

@@ -21,7 +21,7 @@ def timeit(fn, n=20, w=3):
     return a.elapsed_time(b) / n * 1e-3
 
 
-def gemm_case(M, N, K, out_fp32=False, trans=False, act=None, res=False):
+def gemm_case(M, N, K, out_fp32=False, trans=False, act=None, res=False, kernel=0):
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
     b = torch.randn(N, device=dev)
@@ -29,7 +29,7 @@ def gemm_case(M, N, K, out_fp32=False, trans=False, act=None, res=False):
         out = torch.zeros(N, M + 8, dtype=torch.bfloat16, device=dev)
     else:
         out = torch.zeros(M, N, dtype=torch.float32 if (out_fp32 or res) else torch.bfloat16, device=dev)
-    t = timeit(lambda: hip.gemm(a, w, out, bias=b, act=act, trans_out=trans, res=out if res else None))
+    t = timeit(lambda: hip.gemm(a, w, out, bias=b, act=act, trans_out=trans, res=out if res else None, kernel=kernel))
     return 2.0 * M * N * K / t / 1e12, t * 1e6
 
 
@@ -57,6 +57,13 @@ if __name__ == '__main__':
                        ('build fc2', (768, 768, 3072, False, False, None, True)), ('square 4096', (4096, 4096, 4096)), ('square 8192', (8192, 8192, 8192))]:
         tf, us = gemm_case(*args)
         print('%-20s %-40s %8.1f TF %9.1f us' % (name, args[:3], tf, us))
+    print('== 128 vs 256 kernel (M=%d and M=38400)' % M)
+    for MM in (M, 38400):
+        for name, args in [('qk', (MM, 2048, 1024)), ('proj+res', (MM, 1024, 1024, False, False, None, True)), ('fc1 gelu', (MM, 4096, 1024, False, False, 'gelu')),
+                           ('fc2+res', (MM, 1024, 4096, False, False, None, True)), ('dec fc1', (MM, 3072, 768, False, False, 'gelu')), ('sq4096', (4096, 4096, 4096)), ('sq8192', (8192, 8192, 8192))]:
+            a1 = gemm_case(*args, kernel=128) if len(args) == 7 else gemm_case(*(args + (False, False, None, False)[len(args) - 3:]), kernel=128)
+            a2 = gemm_case(*args, kernel=256) if len(args) == 7 else gemm_case(*(args + (False, False, None, False)[len(args) - 3:]), kernel=256)
+            print('%-10s %-22s 128: %7.1f TF   256: %7.1f TF' % (name, args[:3], a1[0], a2[0]))
     print('== attention')
     for name, args in [('enc self', (V, 16, 768, 768, 64)), ('dino self', (V, 16, 769, 769, 64)), ('dec cross K=16', (1, 12, M, 12288, 64)),
                        ('dec cross K=32', (1, 12, M, 24576, 64)), ('build cross j=8', (1, 12, 768, 6144, 64)), ('build self', (1, 12, 768, 768, 64)),

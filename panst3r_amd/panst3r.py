@@ -49,7 +49,7 @@ class PanSt3R(nn.Module):
         return self.must3r_encoder.embed_dim + self.must3r_decoder.embed_dim + self.dino_encoder.embed_dim
 
     @torch.no_grad()
-    def encode_views(self, imgs, cat):
+    def encode_views(self, imgs, cat, enc=True, dino=True):
         """imgs fp32 [V,3,H,W]; writes encoder tokens to cat[:, :De] and DINOv2 tokens to cat[:, De+Dd:]."""
         V, _, H, W = imgs.shape
         p = self.must3r_encoder.patch_size
@@ -58,8 +58,10 @@ class PanSt3R(nn.Module):
         for v0 in range(0, V, ENC_CHUNK):
             sl = slice(v0 * T, min(V, v0 + ENC_CHUNK) * T)
             im = imgs[v0:v0 + ENC_CHUNK]
-            self.must3r_encoder.encode_tokens(im, out=cat[sl])
-            self.dino_encoder.encode_tokens(im, cat[sl], col0=De + Dd)
+            if enc:
+                self.must3r_encoder.encode_tokens(im, out=cat[sl])
+            if dino:
+                self.dino_encoder.encode_tokens(im, cat[sl], col0=De + Dd)
 
     @torch.no_grad()
     def build_memory(self, cat_kf, K, h, w):

@@ -78,15 +78,26 @@ class SceneRunner:
         self.T = self.h * self.w
         self.imgs = torch.stack([images[self.order[i]] for i in self.mine]).float().contiguous()   # static input buffer
         self.use_graphs = use_graphs
+        self.serial = False          # True: run the two branches of stage 2 back-to-back (clean per-kernel timing)
         self.graphs = None
         self.enc_kf = self.both_kf = None
         self.out = None
 
     # ---- stages (every tensor they leave on `self` is read by a later stage)
     def stage1(self):
-        b, T = self.b, self.T
-        self.cat = b.encode(self.imgs, self.n_local, self.h, self.w)
-        self.enc_send = b.enc_rows(self.cat, self.k_local * T)
+        """CroCo encoder on this rank's keyframes only: all the memory build needs."""
+        b, T, kl = self.b, self.T, self.k_local
+        self.cat = b.alloc_cat(self.n_local * T, self.imgs.device)
+        if kl:
+            b.encode_enc(self.imgs[:kl], self.cat[:kl * T])
+        self.enc_send = b.enc_rows(self.cat, kl * T)
+
+    def _encode_rest(self):
+        """Everything the build does not depend on: encoder of the non-keyframe views + DINOv2 of every view."""
+        b, T, kl, n = self.b, self.T, self.k_local, self.n_local
+        if n > kl:
+            b.encode_enc(self.imgs[kl:], self.cat[kl * T:])
+        b.encode_dino(self.imgs, self.cat)
 
     def gather1(self):
         kf = gather_keyframe_rows(self.enc_send, self.K, T=self.T, rank=self.rank, world=self.world, group=self.group)
@@ -96,8 +107,20 @@ class SceneRunner:
             self.enc_kf.copy_(kf)
 
     def stage2(self):
+        """The sequential memory build is a chain of thousands of tiny kernels that leaves most CUs idle; the independent
+        bulk work (_encode_rest) runs concurrently on a second stream (a parallel branch of the captured graph)."""
         b, T, kl = self.b, self.T, self.k_local
-        bank = b.build_memory(self.enc_kf, self.K, self.h, self.w)
+        side = None if self.serial else b.side_stream(self.imgs.device)
+        if side is None:
+            self._encode_rest()
+            bank = b.build_memory(self.enc_kf, self.K, self.h, self.w)
+        else:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._encode_rest()
+            bank = b.build_memory(self.enc_kf, self.K, self.h, self.w)
+            main.wait_stream(side)
         self.pointmaps = b.render(self.cat, self.n_local, self.h, self.w, bank)
         fpn, self.mf = b.features(self.cat, self.imgs, self.n_local, self.h, self.w)
         fm = b.attn_feats(self.mf, kl)
@@ -137,7 +160,14 @@ class SceneRunner:
         torch.cuda.synchronize()
 
     @torch.no_grad()
-    def run(self, outdevice=None, eager=False):
+    def run(self, outdevice=None, eager=False, serial=None):
+        if serial is not None:
+            assert eager or not self.use_graphs or self.graphs is None, 'overlap mode is fixed once the graphs are captured'
+            prev, self.serial = self.serial, serial
+            try:
+                return self.run(outdevice, eager)
+            finally:
+                self.serial = prev
         if self.use_graphs and not eager:
             if self.graphs is None:
                 self._capture()
@@ -175,11 +205,19 @@ class HipBackend:
         self.mask_dim = model.panoptic_decoder.mask_transformer.mask_dim
         self.De = model.must3r_encoder.embed_dim
 
-    def encode(self, imgs, n, h, w):
-        dev = imgs.device
-        cat = torch.empty(n * h * w, self.m._cat_width(), dtype=torch.bfloat16, device=dev)
-        self.m.encode_views(imgs, cat)
-        return cat
+    def alloc_cat(self, rows, device):
+        return torch.empty(rows, self.m._cat_width(), dtype=torch.bfloat16, device=device)
+
+    def encode_enc(self, imgs, cat_rows):
+        self.m.encode_views(imgs, cat_rows, dino=False)
+
+    def encode_dino(self, imgs, cat_rows):
+        self.m.encode_views(imgs, cat_rows, enc=False)
+
+    def side_stream(self, device):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def enc_rows(self, cat, rows):
         return cat[:rows, :self.De].contiguous()

@@ -21,14 +21,22 @@ class OracleBackend:
         ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
         return torch.stack([ys, xs], -1).reshape(1, -1, 2)
 
-    def encode(self, imgs, n, h, w):
-        ts = torch.tensor([[h * self.patch_size, w * self.patch_size]] * n)
-        x, _ = self.m.must3r_encoder(imgs, ts)
-        d = self.m.dino_encoder(imgs, ts)
-        cat = torch.zeros(n * h * w, self.De + self.Dd + d.shape[-1])
-        cat[:, :self.De] = x.reshape(n * h * w, -1)
-        cat[:, self.De + self.Dd:] = d.reshape(n * h * w, -1)
-        return cat
+    def alloc_cat(self, rows, device):
+        return torch.zeros(rows, self.De + self.Dd + self.m.dino_encoder.embed_dim)
+
+    def _ts(self, imgs):
+        return torch.tensor([list(imgs.shape[-2:])] * imgs.shape[0])
+
+    def encode_enc(self, imgs, cat_rows):
+        x, _ = self.m.must3r_encoder(imgs, self._ts(imgs))
+        cat_rows[:, :self.De] = x.reshape(cat_rows.shape[0], -1)
+
+    def encode_dino(self, imgs, cat_rows):
+        d = self.m.dino_encoder(imgs, self._ts(imgs))
+        cat_rows[:, self.De + self.Dd:] = d.reshape(cat_rows.shape[0], -1)
+
+    def side_stream(self, device):
+        return None
 
     def enc_rows(self, cat, rows):
         return cat[:rows, :self.De].contiguous()

@@ -92,7 +92,8 @@ def main():
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('PST_FORCE_DIST') == '1'       # PST_FORCE_DIST=1: exercise the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     hip.lib()      # fail loudly if the HIP library is missing
@@ -120,7 +121,7 @@ def main():
         return runner.run(eager=eager, serial=True) if eager else runner.run()
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +176,7 @@ def main():
         if state is not None:
             out['cpu_baseline'] = cpu_baseline(args.variant, H, W, state, names, emb, usable_cores())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

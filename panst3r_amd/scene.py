@@ -30,7 +30,7 @@ def assign_views(V, K, world):
 
 def _all_gather_rows(t, counts, world, group):
     """all_gather of row blocks with uneven row counts (padded to the maximum); returns the list of per-rank blocks."""
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return [t]
     mx = max(counts)
     pad = torch.zeros(mx, t.shape[1], dtype=t.dtype, device=t.device)
@@ -151,7 +151,8 @@ class SceneRunner:
         self.graphs = []
         for stage, gather in ((self.stage1, self.gather1), (self.stage2, self.gather2), (self.stage3, None)):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            # thread_local: the RCCL watchdog thread of torch.distributed may query events while we capture
+            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
                 stage()
             self.graphs.append(g)
             g.replay()

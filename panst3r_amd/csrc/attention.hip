@@ -125,10 +125,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   const int ntiles = min(tiles_all, kt_begin + tps);
   if (kt_begin < ntiles) stage(kt_begin, 0);
   for (int kt = kt_begin; kt < ntiles; ++kt) {
+#ifndef PST_ABL_NOSTAGE
     wait_vm0();
     __syncthreads();
     if (kt + 1 < ntiles) stage(kt + 1, (kt + 1 - kt_begin) & 1);
     const char* kb_ = smem + ((kt - kt_begin) & 1) * C::BUF;
+#else
+    if (kt == kt_begin) { wait_vm0(); __syncthreads(); }
+    const char* kb_ = smem;
+#endif
     const char* vb_ = kb_ + C::K_BYTES;
     const int k0 = kt * KT;
 
@@ -182,7 +187,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#ifndef PST_ABL_NOEXP
           const float e = __builtin_amdgcn_exp2f((s[f][a][r] - m_new) * c_exp);   // subtract first: sentinel - sentinel == 0 exactly
+#else
+          const float e = (s[f][a][r] - m_new) * c_exp;
+#endif
           pv[f][r] = e;
           ps += e;
         }

@@ -167,8 +167,18 @@ def main():
             dom = max(summ, key=lambda k: summ[k]['ms'])
             d = summ[dom]
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r1_pmc_summary.json: FETCH_SIZE and
+            # WRITE_SIZE in separate rocprofv3 --pmc runs of this same workload, FETCH_SIZE doubled per the gfx950 note)
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_summary.json')))
+                e = pmc.get(dom.replace(',', ', '))
+                if e and args.views == 50 and args.keyframes == 16 and args.variant == 'v2':
+                    traffic = int(e['hbm_read_bytes_per_launch'] + e['hbm_write_bytes_per_launch'])
+            except Exception:
+                pass
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None, 'launches': d['launches'],
+                               'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic, 'launches': d['launches'],
                                'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
                                'avg_launch_gflop': round(d['flops'] / d['launches'] / 1e9, 3)}
             out['kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 2),

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 3
+#define PST_ABI_VERSION 4
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -55,6 +55,7 @@ typedef struct pst_gemm_params {
      K = 9*conv_c (tap-major, channel-minor), conv_c % 64 == 0, `zeros` = >=128 B of zero bytes on the device */
   int32_t conv_c, conv_h, conv_w;
   const void* zeros;
+  int32_t res_bf16;                  /* 1: `res` points to bf16 (same indexing, ldr in elements) instead of fp32 */
   int32_t kernel;                    /* 0 = auto; 128 / 256 force the 128x128 / 256x256 tile kernel (tests, benchmarks) */
 } pst_gemm_params;
 

@@ -254,17 +254,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, c
         if (p.grp_in > 0) orow = (m / p.grp_in) * p.grp_out + p.grp_off + (m % p.grp_in);
         off = (int64_t)orow * p.ldc + n;
       }
-      const float* rp = p.res ? p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + n : nullptr;
+      const int64_t roff = p.res ? (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + n : 0;
+      const float* rp = (p.res && !p.res_bf16) ? p.res + roff : nullptr;
+      const bf16_t* rpb = (p.res && p.res_bf16) ? (const bf16_t*)p.res + roff : nullptr;
       if (f32o) {
         if (rp) {
           const float4 q = *(const float4*)rp;
           float4 f = *(float4*)&val;
           f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
           *(float4*)((float*)p.C + off) = f;
+        } else if (rpb) {
+          const uint2 q = *(const uint2*)rpb;
+          float4 f = *(float4*)&val;
+          f.x += __uint_as_float(q.x << 16); f.y += __uint_as_float(q.x & 0xffff0000u);
+          f.z += __uint_as_float(q.y << 16); f.w += __uint_as_float(q.y & 0xffff0000u);
+          *(float4*)((float*)p.C + off) = f;
         } else {
           *(uint4*)((float*)p.C + off) = val;
         }
         continue;
+      }
+      if (rpb) {             // bf16 residual stream (LoftUp blocks): 16-byte load, add in fp32, one rounding
+        uint32_t* w32 = (uint32_t*)&val;
+        uint32_t rq[4] = {0u, 0u, 0u, 0u};
+        if (n + 8 <= p.N) { const uint4 t = *(const uint4*)rpb; rq[0] = t.x; rq[1] = t.y; rq[2] = t.z; rq[3] = t.w; }
+        else { const uint2 t = *(const uint2*)rpb; rq[0] = t.x; rq[1] = t.y; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          w32[q] = pack2bf(__uint_as_float(w32[q] << 16) + __uint_as_float(rq[q] << 16),
+                           __uint_as_float(w32[q] & 0xffff0000u) + __uint_as_float(rq[q] & 0xffff0000u));
       }
       if (rp) {              // bf16 output with an fp32 residual: add in fp32, round once more
         uint32_t* w32 = (uint32_t*)&val;
@@ -342,7 +360,8 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
     set_error("gemm: trans_out supports bf16 + bias/act only, ldc%%4==0"); return PST_EINVAL;
   }
   if (!p.trans_out && !p.ps_p && (p.ldc % 4)) { set_error("gemm: ldc must be a multiple of 4"); return PST_EINVAL; }
-  if (p.res && (p.ldr % 4)) { set_error("gemm: ldr must be a multiple of 4"); return PST_EINVAL; }
+  if (p.res && (p.ldr % (p.res_bf16 ? 8 : 4))) { set_error("gemm: ldr must be a multiple of 4 (fp32) / 8 (bf16)"); return PST_EINVAL; }
+  if (p.res && p.res_bf16 && ((uintptr_t)p.res & 15)) { set_error("gemm: bf16 residual must be 16-byte aligned"); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const bool small = p.kernel == 0 && big_tiles < 384;   // < 1.5 waves of the 256 CUs: prefer 64x64 tiles to fill the chip

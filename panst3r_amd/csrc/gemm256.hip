@@ -197,17 +197,35 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
         if (p.grp_in > 0) orow = (m / p.grp_in) * p.grp_out + p.grp_off + (m % p.grp_in);
         off = (int64_t)orow * p.ldc + n;
       }
-      const float* rp = p.res ? p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + n : nullptr;
+      const int64_t roff = p.res ? (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + n : 0;
+      const float* rp = (p.res && !p.res_bf16) ? p.res + roff : nullptr;
+      const bf16_t* rpb = (p.res && p.res_bf16) ? (const bf16_t*)p.res + roff : nullptr;
       if (f32o) {
         if (rp) {
           const float4 q = *(const float4*)rp;
           float4 f = *(float4*)&val;
           f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
           *(float4*)((float*)p.C + off) = f;
+        } else if (rpb) {
+          const uint2 q = *(const uint2*)rpb;
+          float4 f = *(float4*)&val;
+          f.x += __uint_as_float(q.x << 16); f.y += __uint_as_float(q.x & 0xffff0000u);
+          f.z += __uint_as_float(q.y << 16); f.w += __uint_as_float(q.y & 0xffff0000u);
+          *(float4*)((float*)p.C + off) = f;
         } else {
           *(uint4*)((float*)p.C + off) = val;
         }
         continue;
+      }
+      if (rpb) {             // bf16 residual stream (LoftUp blocks): 16-byte load, add in fp32, one rounding
+        uint32_t* w32 = (uint32_t*)&val;
+        uint32_t rq[4] = {0u, 0u, 0u, 0u};
+        if (n + 8 <= p.N) { const uint4 t = *(const uint4*)rpb; rq[0] = t.x; rq[1] = t.y; rq[2] = t.z; rq[3] = t.w; }
+        else { const uint2 t = *(const uint2*)rpb; rq[0] = t.x; rq[1] = t.y; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          w32[q] = pack2bf(__uint_as_float(w32[q] << 16) + __uint_as_float(rq[q] << 16),
+                           __uint_as_float(w32[q] & 0xffff0000u) + __uint_as_float(rq[q] & 0xffff0000u));
       }
       if (rp) {
         uint32_t* w32 = (uint32_t*)&val;

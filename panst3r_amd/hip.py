@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -24,7 +24,7 @@ class GemmParams(C.Structure):
                 ('act', i32), ('out_fp32', i32), ('trans_out', i32),
                 ('grp_in', i32), ('grp_out', i32), ('grp_off', i32),
                 ('ps_p', i32), ('ps_c', i32), ('ps_h', i32), ('ps_w', i32),
-                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('kernel', i32)]
+                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('res_bf16', i32), ('kernel', i32)]
 
 
 class AttnParams(C.Structure):
@@ -158,7 +158,8 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
     if gamma is not None:
         p.gamma = _ptr(_dev(gamma, torch.float32))
     if res is not None:
-        p.res, p.ldr, p.res_mod = _ptr(_dev(res, torch.float32)), _rowmajor(res), res_mod
+        p.res, p.ldr, p.res_mod = _ptr(_dev(res, torch.float32, torch.bfloat16)), _rowmajor(res), res_mod
+        p.res_bf16 = int(res.dtype == torch.bfloat16)
     p.act = ACT[act]
     p.out_fp32 = int(out.dtype == torch.float32)
     p.trans_out = int(trans_out)

@@ -232,11 +232,12 @@ class LoftUpUpscaler(HipModule):
             hip.gemm(g1, pk['conv2'].w, c1, bias=pk['conv2'].b, conv=(C, H2, W2))
             hip.groupnorm_stats(c1, st, n, P, C, 8)
             hip.groupnorm_apply(c1, st, pk['gn2'][0], pk['gn2'][1], g1, n, P, C, 8, pk['gn2'][2], True)
-            x = empty(n * P, C, torch.float32, dev)
-            hip.add_cast(g1, x)
+            # ---- 2 x cross-only blocks: 49k queries per view attend to the view's T low-res tokens (hd 96).
+            # The residual stream of these two blocks is kept in bf16: they are HBM-bound over P x C elements per view
+            # (fp32 would double the read-modify-write traffic of both residual GEMMs and of every LayerNorm).
+            x = g1
             del g0, c1
-            # ---- 2 x cross-only blocks: 49k queries per view attend to the view's T low-res tokens (hd 96)
-            xn, q, o = g1, empty(n * P, C, BF16, dev), empty(n * P, C, BF16, dev)
+            xn, q, o = empty(n * P, C, BF16, dev), empty(n * P, C, BF16, dev), empty(n * P, C, BF16, dev)
             rows0, rows1 = v0 * lay.Tp, (v0 + n) * lay.Tp
             for bw in pk['blocks']:
                 y = empty(rows1 - rows0, C, BF16, dev)

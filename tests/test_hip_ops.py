@@ -113,6 +113,21 @@ def test_gemm_residual_gamma_remap():
     assert rel_l2(out.cpu(), a.float() @ w.float().T + bias + pe.repeat(2, 1)) < 2e-3
 
 
+@pytest.mark.parametrize('M,N,K,kern', [(300, 384, 384, 0), (1024, 2048, 1024, 256), (200, 104, 64, 0)])
+def test_gemm_bf16_residual(M, N, K, kern):
+    """bf16 residual stream (LoftUp blocks): out = bf16(acc + bias + float(res_bf16)), in place."""
+    from panst3r_amd import hip
+    a, w, b = bf(rn(100, M, K)), bf(rn(101, N, K, scale=K ** -0.5)), rn(102, N)
+    x = bf(rn(103, M, N))
+    ref = a.float() @ w.float().T + b + x.float()
+    d = x.clone().to(dev())
+    hip.gemm(a.to(dev()), w.to(dev()), d, bias=b.to(dev()), res=d, kernel=kern)
+    assert rel_l2(d.float().cpu(), ref) < 6e-3
+    o32 = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    hip.gemm(a.to(dev()), w.to(dev()), o32, bias=b.to(dev()), res=x.to(dev()), kernel=kern)
+    assert rel_l2(o32.cpu(), ref) < 2e-3
+
+
 def test_gemm_trans_out():
     from panst3r_amd import hip
     M, N, K = 2 * 769, 128, 64

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 4
+#define PST_ABI_VERSION 5
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -55,6 +55,9 @@ typedef struct pst_gemm_params {
      K = 9*conv_c (tap-major, channel-minor), conv_c % 64 == 0, `zeros` = >=128 B of zero bytes on the device */
   int32_t conv_c, conv_h, conv_w;
   const void* zeros;
+  /* RoPE-2D fused into the store (q,k projections): rope_hd == 64 enables (bf16 output, N % 64 == 0); rope_pos int32
+     [rows, 2] (y, x) indexed by the A row m, rope_cs fp32 [npos, 16, 2] as for pst_rope2d_bf16. */
+  const int32_t* rope_pos; const float* rope_cs; int32_t rope_hd;
   int32_t res_bf16;                  /* 1: `res` points to bf16 (same indexing, ldr in elements) instead of fp32 */
   int32_t kernel;                    /* 0 = auto; 128 / 256 force the 128x128 / 256x256 tile kernel (tests, benchmarks) */
 } pst_gemm_params;

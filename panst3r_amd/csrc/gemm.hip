@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, c
       const int m = m0 + r;
       if (m >= p.M || n >= p.N) continue;
       uint4 val = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
+      if (p.rope_hd == 64 && !f32o) val = rope_chunk(p, val, *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4)), m, n);
       int orow = m;
       int64_t off;
       int ps_v = 0, ps_y = 0, ps_x = 0;
@@ -360,6 +361,9 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
     set_error("gemm: trans_out supports bf16 + bias/act only, ldc%%4==0"); return PST_EINVAL;
   }
   if (!p.trans_out && !p.ps_p && (p.ldc % 4)) { set_error("gemm: ldc must be a multiple of 4"); return PST_EINVAL; }
+  if (p.rope_hd != 0 && (p.rope_hd != 64 || p.out_fp32 || p.trans_out || p.ps_p || p.N % 64 || !p.rope_pos || !p.rope_cs || p.res)) {
+    set_error("gemm: fused RoPE needs head dim 64, bf16 plain output, N%%64==0, no residual"); return PST_EINVAL;
+  }
   if (p.res && (p.ldr % (p.res_bf16 ? 8 : 4))) { set_error("gemm: ldr must be a multiple of 4 (fp32) / 8 (bf16)"); return PST_EINVAL; }
   if (p.res && p.res_bf16 && ((uintptr_t)p.res & 15)) { set_error("gemm: bf16 residual must be 16-byte aligned"); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
       const int m = m0 + pass * rows_pass + rr;
       if (m >= p.M || n >= p.N) continue;
       uint4 val = *(const uint4*)(smem + rr * pitch + ((c ^ (rr & (nch - 1))) << 4));
+      if (p.rope_hd == 64 && !f32o) val = rope_chunk(p, val, *(const uint4*)(smem + rr * pitch + (((c ^ 2) ^ (rr & (nch - 1))) << 4)), m, n);
       int orow = m;
       int64_t off;
       int ps_v = 0, ps_y = 0, ps_x = 0;

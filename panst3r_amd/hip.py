@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -24,7 +24,7 @@ class GemmParams(C.Structure):
                 ('act', i32), ('out_fp32', i32), ('trans_out', i32),
                 ('grp_in', i32), ('grp_out', i32), ('grp_off', i32),
                 ('ps_p', i32), ('ps_c', i32), ('ps_h', i32), ('ps_w', i32),
-                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('res_bf16', i32), ('kernel', i32)]
+                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('rope_pos', vp), ('rope_cs', vp), ('rope_hd', i32), ('res_bf16', i32), ('kernel', i32)]
 
 
 class AttnParams(C.Structure):
@@ -129,7 +129,7 @@ ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 
 
 def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
-         M=None, kernel=0):
+         M=None, kernel=0, rope=None):
     """out = epi(a @ w.T).  a [M,K] bf16 (row-major view), w [N,K] bf16, out bf16/fp32 2-D view (or raw buffer for ps)."""
     _dev(a, torch.bfloat16); _dev(w, torch.bfloat16); _dev(out, torch.bfloat16, torch.float32)
     p = GemmParams()
@@ -164,6 +164,8 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
     p.out_fp32 = int(out.dtype == torch.float32)
     p.trans_out = int(trans_out)
     p.kernel = kernel
+    if rope is not None:            # (pos int32 [rows,2], table fp32 [npos,16,2]): RoPE-2D fused into the store, hd 64
+        p.rope_pos, p.rope_cs, p.rope_hd = _ptr(_dev(rope[0], torch.int32)), _ptr(_dev(rope[1], torch.float32)), 64
     if grp is not None:
         p.grp_in, p.grp_out, p.grp_off = grp
     if TIMER is not None:

@@ -99,9 +99,12 @@ def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None):
     dev = xn.device
     D = H * hd
     qk = empty(lay.rows, 2 * D, BF16, dev)
-    hip.gemm(xn, w_qk.w, qk, bias=w_qk.b)
-    if rope is not None:
-        hip.rope2d_(qk, pos, rope, 2 * H, hd)
+    if rope is not None and hd == 64:
+        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, rope=(pos, rope))      # RoPE-2D applied in the GEMM's store phase
+    else:
+        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b)
+        if rope is not None:
+            hip.rope2d_(qk, pos, rope, 2 * H, hd)
     vt = torch.empty(D, lay.rows + 8, dtype=BF16, device=dev)
     hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True)
     o = empty(lay.rows, D, BF16, dev)

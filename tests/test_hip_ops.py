@@ -305,6 +305,24 @@ def test_rope2d(hd, H):
     assert torch.equal(got[:, 2], x.float().reshape(T, 3, H, hd)[:, 2])      # v untouched
 
 
+@pytest.mark.parametrize('kern,V', [(0, 2), (128, 5), (256, 6)])
+def test_gemm_fused_rope_equals_separate_kernel(kern, V):
+    """q,k projection with RoPE fused into the GEMM store == GEMM followed by the stand-alone RoPE kernel (bit-exact)."""
+    from panst3r_amd import hip
+    gh, gw, H, hd, K = 8, 12, 4, 64, 128
+    T, D = gh * gw, H * hd
+    a, w, b = bf(rn(110, V * T, K)).to(dev()), bf(rn(111, 2 * D, K, scale=K ** -0.5)).to(dev()), rn(112, 2 * D).to(dev())
+    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing='ij')
+    pos = torch.stack([ys, xs], -1).reshape(T, 2).to(torch.int32).repeat(V, 1).to(dev())
+    table = hip.rope_table(max(gh, gw), hd, 100.0, dev())
+    ref = torch.empty(V * T, 2 * D, dtype=torch.bfloat16, device=dev())
+    hip.gemm(a, w, ref, bias=b, kernel=kern)
+    hip.rope2d_(ref, pos, table, 2 * H, hd)
+    out = torch.empty_like(ref)
+    hip.gemm(a, w, out, bias=b, kernel=kern, rope=(pos, table))
+    assert torch.equal(out, ref)
+
+
 def test_patchify_and_dino_preprocess():
     from panst3r_amd import hip
     img = rn(60, 2, 3, 32, 48).clamp(-1, 1)

@@ -128,3 +128,20 @@ def test_graph_replay_equals_eager(pair):
         for got in (r2, r3):
             assert torch.equal(got[k][0], r1[k][0]) and torch.equal(got[k][1], r1[k][1])
     assert torch.equal(s2['out_queries'], q1) and torch.equal(s3['out_queries'], q1)
+
+
+def test_scene_224_padded_token_layout(pair):
+    """BASELINE config C1 shape (2 views, 224x224): T = 196 tokens -> 200-row padded layout per view (Layout.grp remaps,
+    pad rows in every GEMM / attention launch) through the whole scene, against the oracle."""
+    variant, o, h = pair
+    H = W = 224
+    V = K = 2
+    imgs = tiny.images(V, H, W)
+    ts = torch.tensor([[H, W]] * V)
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K)
+    pan_h, pm_h = h.forward(torch.stack(imgs)[None].to(DEV), ts[None], tiny.NAMES)      # the reference's same-shape entry point
+    assert pm_h.shape == (1, V, H, W, 7) and pan_h['pred_masks'].shape == (1, V, 24, H // 2, W // 2)
+    for i in range(V):
+        assert rel_l2(pm_h[0, i].cpu(), pm_o[i][0]) < 2e-2
+        assert rel_l2(pan_h['pred_masks'][0, i].cpu(), pan_o['pred_masks'][i][0]) < 6e-2
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.08

@@ -94,8 +94,9 @@ def empty(rows, cols, dtype, device):
     return torch.empty(rows, cols, dtype=dtype, device=device)
 
 
-def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None):
-    """q,k projection (+RoPE) / transposed v projection / flash attention on a [lay.rows, D] bf16 buffer."""
+def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
+    """q,k projection (+RoPE) / transposed v projection / flash attention on a [lay.rows, D] bf16 buffer.
+    `vt`: optional caller-owned V^T scratch [D, >= lay.rows + 8] (saves an allocation per layer)."""
     dev = xn.device
     D = H * hd
     qk = empty(lay.rows, 2 * D, BF16, dev)
@@ -105,7 +106,8 @@ def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None):
         hip.gemm(xn, w_qk.w, qk, bias=w_qk.b)
         if rope is not None:
             hip.rope2d_(qk, pos, rope, 2 * H, hd)
-    vt = torch.empty(D, lay.rows + 8, dtype=BF16, device=dev)
+    if vt is None:
+        vt = torch.empty(D, lay.rows + 8, dtype=BF16, device=dev)
     hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True)
     o = empty(lay.rows, D, BF16, dev)
     if lay.Tp != lay.N:

@@ -36,12 +36,16 @@ __device__ __forceinline__ int perm_row(int row) {
   return sub * (16 * F) + g * (4 * F) + 4 * f + r;
 }
 
-template <int FM, int FN, bool TRANS>
+// NST = number of LDS slab buffers.  NST = 2: classic double buffering (128x128 tiles: 64 KiB, 2 blocks/CU).
+// NST = 4 (64x64 tiles, the 768-row GEMMs of the sequential memory build): with only 8 MFMAs per K step those GEMMs
+// are bound by the global->LDS LATENCY of a one-deep prefetch, so three slabs are kept in flight and each step waits
+// with a COUNTED s_waitcnt vmcnt (raw s_barrier: __syncthreads() would drain the LDS-DMA queue).
+template <int FM, int FN, bool TRANS, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;                          // [2][BM][128 B]
-  char* Bs = smem + 2 * BM * 128;           // [2][BN][128 B]
+  char* As = smem;                          // [NST][BM][128 B]
+  char* Bs = smem + NST * BM * 128;         // [NST][BN][128 B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -128,13 +132,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, c
   const int b_off = b_row * 128 + ((g ^ ((b_row >> 1) & 7)) << 4);
 
   const int nk = p.K / BK;
-  stage(0, 0);
+  static_assert(NST == 2 || ((NST == 3 || NST == 4) && FM + FN == 4), "counted waits below assume 4 LDS-DMA ops per slab when NST > 2");
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nk) stage(st, st);
   for (int kt = 0; kt < nk; ++kt) {
-    wait_vm0();            // the slab of this step has landed (issued one step ago)
-    __syncthreads();       // ... for every wave, and everybody is done reading the other buffer
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const char* a_buf = As + (kt & 1) * (BM * 128);
-    const char* b_buf = Bs + (kt & 1) * (BN * 128);
+    // slab kt has landed once at most `newer` younger slabs (4 LDS-DMA ops each) are still in flight
+    const int newer = min(NST - 2, nk - 1 - kt);
+    if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else wait_vm0();
+    __builtin_amdgcn_s_barrier();   // ... for every wave, and everybody is done reading the buffer that is refilled next
+    if (kt + NST - 1 < nk) stage(kt + NST - 1, (kt + NST - 1) % NST);
+    const char* a_buf = As + (kt % NST) * (BM * 128);
+    const char* b_buf = Bs + (kt % NST) * (BN * 128);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[FM], bfv[FN];
@@ -326,13 +337,13 @@ static int num_cus() {
   return cus;
 }
 
-template <int FM, int FN, bool TRANS>
+template <int FM, int FN, bool TRANS, int NST>
 static int launch(const pst_gemm_params& p, hipStream_t s) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
-  const size_t lds = 2 * (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS>), dim3(tiles), dim3(256), lds, s, p, tiles, tiles_m, tiles_n);
+  const size_t lds = NST * (BM + BN) * 128;
+  hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS, NST>), dim3(tiles), dim3(256), lds, s, p, tiles, tiles_m, tiles_n);
   return check_launch("gemm_bf16");
 }
 
@@ -369,7 +380,8 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const bool small = p.kernel == 0 && big_tiles < 384;   // < 1.5 waves of the 256 CUs: prefer 64x64 tiles to fill the chip
-  if (p.trans_out) return small ? launch<2, 2, true>(p, s) : launch<4, 4, true>(p, s);
+  // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
+  if (p.trans_out) return small ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
   // large plain GEMMs: 256x256 tiles, 8 waves, counted-vmcnt pipeline (>= 3 full rounds of the 256 CUs, or forced)
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool fits32 = (int64_t)p.M * p.lda < (1ll << 31) && (int64_t)p.N * p.ldw < (1ll << 31);
@@ -377,5 +389,5 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
   const bool shape256 = p.N % 256 == 0 && p.K >= 1024 && (p.N >= 2048 || p.K >= 2048) && tiles256 >= 3 * 256 - 64;
   const int want256 = p.conv_c == 0 && fits32 && (p.kernel == 256 || (p.kernel == 0 && shape256));
   if (want256) return launch_gemm256(p, s);
-  return small ? launch<2, 2, false>(p, s) : launch<4, 4, false>(p, s);
+  return small ? launch<2, 2, false, 4>(p, s) : launch<4, 4, false, 2>(p, s);
 }

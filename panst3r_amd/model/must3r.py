@@ -45,7 +45,7 @@ class MemoryBank:
     def __init__(self, L, D, cap, device):
         self.L, self.D, self.cap, self.n = L, D, cap, 0
         self.K = [torch.zeros(cap, D, dtype=BF16, device=device) for _ in range(L)]
-        self.Vt = [torch.zeros(D, cap + 8, dtype=BF16, device=device) for _ in range(L)]
+        self.Vt = [torch.zeros(D, (cap + 7) // 8 * 8 + 8, dtype=BF16, device=device) for _ in range(L)]   # 16-byte rows
         self.labels = []          # image id of every T-token slot
         self.nimgs = 0
 
@@ -56,7 +56,7 @@ class MemoryBank:
         for l in range(self.L):
             K = torch.zeros(cap, self.D, dtype=BF16, device=self.K[l].device)
             K[:self.n] = self.K[l][:self.n]
-            Vt = torch.zeros(self.D, cap + 8, dtype=BF16, device=K.device)
+            Vt = torch.zeros(self.D, (cap + 7) // 8 * 8 + 8, dtype=BF16, device=K.device)
             Vt[:, :self.n] = self.Vt[l][:, :self.n]
             self.K[l], self.Vt[l] = K, Vt
         self.cap = cap
@@ -234,10 +234,69 @@ class MUSt3R(HipModule):
             hip.gemm(o, c['proj'].w, x, bias=c['proj'].b, res=x)
             self._mlp(x, bw, xn)
             hs.append(x)
-        x = hs[-1]
-        # feedback ('single_mlp'): fb = Mlp(LN(norm_dec(x))) added to every layer's entry of these images
+        out = self._append(pk, bank, hs, lay, n, T)
+        if not want_outputs:
+            return bank
+        feat = empty(n * T, D, BF16, dev)       # first-pass outputs of the update call (engine/must3r.py:45-46)
+        hip.add_cast(out.view(n, lay.Tp, D)[:, :T].reshape(n * T, D) if lay.Tp == T else
+                     out.view(n, lay.Tp, D)[:, :T].contiguous().view(n * T, D), feat)
+        return bank, self._head(pk, feat, n, h, w), feat
+
+    @torch.no_grad()
+    def update_pair_tokens(self, x_enc, grids, bank):
+        """First memory-update call (two images attend to each other) for images of DIFFERENT token grids
+        (multi-aspect-ratio scenes).  x_enc: list of two bf16 [T_i, >=1024] row-major views; grids: [(h0,w0),(h1,w1)].
+        Same math as update_tokens(n=2); the two images run through each layer in lock-step."""
+        dev = x_enc[0].device
+        pk = self.packed(dev)
+        D, H = self.embed_dim, self.num_heads
+        hd = D // H
+        assert bank.n == 0 and bank.nimgs == 0
+        Ts = [h * w for h, w in grids]
+        if any(T % 4 for T in Ts):
+            raise NotImplementedError('HIP memory bank needs T %% 4 == 0 tokens per view (got %s)' % Ts)
+        lays = [Layout(1, T) for T in Ts]
+        xs = [self._embed(pk, x_enc[i], lays[i], first_is_ref=(i == 0)) for i in range(2)]
+        poss = [grid_pos(1, h, w, lay.Tp, 0, dev) for (h, w), lay in zip(grids, lays)]
+        rope = self._rope(pk, max(max(g) for g in grids), dev)
+        hs = [[xs[0]], [xs[1]]]
+        for l, bw in enumerate(pk['blocks']):
+            c = bw.cross
+            kvs = []
+            for i in range(2):          # K / V^T of each image's layer input (the other image's context)
+                lay = lays[i]
+                y = empty(lay.rows, D, BF16, dev)
+                hip.layernorm(hs[i][l], c['norm_y'][0], c['norm_y'][1], y, c['norm_y'][2])
+                kk = empty(lay.rows, D, BF16, dev)
+                hip.gemm(y, c['k'].w, kk, bias=c['k'].b)
+                vt = torch.zeros(D, lay.rows + 8, dtype=BF16, device=dev)
+                hip.gemm(y, c['v'].w, vt, bias=c['v'].b, trans_out=True)
+                kvs.append((kk, vt))
+            for i in range(2):
+                lay, x_in = lays[i], hs[i][l]
+                xn = empty(lay.rows, D, BF16, dev)
+                x = empty(lay.rows, D, torch.float32, dev)
+                hip.layernorm(x_in, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
+                o = self_attention(xn, lay, H, hd, bw.qk, bw.v, poss[i], rope)
+                hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, res=x_in)
+                q = self._cross_q(x, bw, xn)
+                kk, vt = kvs[1 - i]
+                o = torch.zeros(lay.rows, D, dtype=BF16, device=dev)
+                ldv = vt.stride(0)
+                hip.attention(q, kk, vt, o, 1, H, lay.T, Ts[1 - i], hd, q_strides=(0, hd, D), k_strides=(0, hd, D),
+                              v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
+                hip.gemm(o, c['proj'].w, x, bias=c['proj'].b, res=x)
+                self._mlp(x, bw, xn)
+                hs[i].append(x)
+        for i in range(2):
+            self._append(pk, bank, hs[i], lays[i], 1, Ts[i])
+        return bank
+
+    def _append(self, pk, bank, hs, lay, n, T):
+        """feedback + append of n same-shape images whose per-layer inputs are hs[0..L] (hs[L] = final stream)."""
+        dev, D = hs[0].device, self.embed_dim
         out = empty(lay.rows, D, torch.float32, dev)
-        hip.layernorm(x, pk['norm'][0], pk['norm'][1], out, pk['norm'][2])
+        hip.layernorm(hs[-1], pk['norm'][0], pk['norm'][1], out, pk['norm'][2])
         fb = None
         if self.feedback_type:
             fbn = empty(lay.rows, D, BF16, dev)
@@ -263,12 +322,7 @@ class MUSt3R(HipModule):
         bank.n += n * T
         bank.labels += list(range(bank.nimgs, bank.nimgs + n))
         bank.nimgs += n
-        if not want_outputs:
-            return bank
-        feat = empty(n * T, D, BF16, dev)       # first-pass outputs of the update call (engine/must3r.py:45-46)
-        hip.add_cast(out.view(n, lay.Tp, D)[:, :T].reshape(n * T, D) if lay.Tp == T else
-                     out.view(n, lay.Tp, D)[:, :T].contiguous().view(n * T, D), feat)
-        return bank, self._head(pk, feat, n, h, w), feat
+        return out
 
     # ------------------------------------------------------------------ reference-signature wrapper
     def forward(self, x, pos, true_shape, mem=None, render=False, return_feats=False):

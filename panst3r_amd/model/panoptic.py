@@ -469,7 +469,7 @@ class MaskTransformer(HipModule):
             # masked cross-attention (post-LN): K from src+pos, V from src
             kc = empty(NK, d, BF16, dev)
             hip.gemm(srcpos, L['ca']['k'].w, kc, bias=L['ca']['k'].b)
-            vt = torch.zeros(d, NK + 8, dtype=BF16, device=dev)
+            vt = torch.zeros(d, ceil_to(NK, 8) + 8, dtype=BF16, device=dev)
             hip.gemm(src, L['ca']['v'].w, vt, bias=L['ca']['v'].b, trans_out=True)
             hip.add_cast(out, qin, b=qpos)
             q = empty(Q, d, BF16, dev)

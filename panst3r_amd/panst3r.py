@@ -64,14 +64,26 @@ class PanSt3R(nn.Module):
                 self.dino_encoder.encode_tokens(im, cat[sl], col0=De + Dd)
 
     @torch.no_grad()
-    def build_memory(self, cat_kf, K, h, w):
-        """Sequential keyframe memory build, batches [2,1,1,...] (panst3r.py:65-70,205-210)."""
-        T = h * w
-        bank = self.must3r_decoder.new_bank(cat_kf.device, K * T)
+    def build_memory(self, enc_kf, K, h=None, w=None, grids=None):
+        """Sequential keyframe memory build, batches [2,1,1,...] (panst3r.py:65-70,205-210).
+        enc_kf: bf16 rows of the K keyframes' encoder tokens, concatenated in schedule order; `grids` = per-keyframe (h, w)
+        token grids for multi-aspect-ratio scenes (default: all (h, w))."""
+        grids = grids or [(h, w)] * K
+        Ts = [a * b for a, b in grids]
+        offs = [0]
+        for T in Ts:
+            offs.append(offs[-1] + T)
+        bank = self.must3r_decoder.new_bank(enc_kf.device, offs[-1])
         De = self.must3r_encoder.embed_dim
         start = 0
         for nb in self.get_must3r_mem_batches(K):
-            self.must3r_decoder.update_tokens(cat_kf[start * T:(start + nb) * T, :De], nb, h, w, bank)
+            rows = enc_kf[offs[start]:offs[start + nb], :De]
+            if nb == 1 or grids[start] == grids[start + 1]:
+                self.must3r_decoder.update_tokens(rows, nb, grids[start][0], grids[start][1], bank)
+            else:
+                assert nb == 2
+                self.must3r_decoder.update_pair_tokens([enc_kf[offs[start]:offs[start + 1], :De], enc_kf[offs[start + 1]:offs[start + 2], :De]],
+                                                       grids[start:start + 2], bank)
             start += nb
         return bank
 
@@ -98,14 +110,12 @@ class PanSt3R(nn.Module):
             raise NotImplementedError('retrieval keyframes need asmk/faiss (outside the hot path, SURVEY 8(f)3)')
         V = len(imgs)
         dev = imgs[0].device
-        shapes = {tuple(int(s) for s in im.shape[-2:]) for im in imgs}
-        if len(shapes) != 1:
-            raise NotImplementedError('round-1 HIP pipeline runs one aspect ratio per scene (got %s)' % sorted(shapes))
-        H, W = shapes.pop()
-        if H > W:
-            raise NotImplementedError('portrait scenes: round-1 HIP pipeline is landscape-only')
+        shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
+        if any(hh > ww for hh, ww in shapes):
+            raise NotImplementedError('portrait views: the round-1 HIP pipeline handles landscape shapes only')
+        H, W = shapes[0]
         from .scene import run_scene, HipBackend
-        res, scene = run_scene(HipBackend(self), lambda i: imgs[i], V, H, W, num_keyframes, classes, outdevice=outdevice)
+        res, scene = run_scene(HipBackend(self), lambda i: imgs[i], V, H, W, num_keyframes, classes, outdevice=outdevice, shapes=shapes)
         panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
                   'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
         return [res[i][0] for i in range(V)], panout
@@ -119,13 +129,13 @@ class PanSt3R(nn.Module):
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
         return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice)
 
-    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True):
+    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None):
         """Static-shape scene runner (panst3r_amd/scene.py): `images` = {view_id: [3,H,W] device tensor} of the views
         this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True."""
         import torch.distributed as dist
         from .scene import SceneRunner, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs)
+        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes)
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):

@@ -42,65 +42,117 @@ def _all_gather_rows(t, counts, world, group):
 
 
 def gather_keyframe_rows(local_rows, K, T, rank, world, group):
-    """local_rows: [k_local*T, C] for this rank's keyframes (in deal order) -> [K*T, C] in keyframe-schedule order."""
-    counts = [len(range(r, K, world)) * T for r in range(world)]
+    """local_rows: [sum of this rank's keyframe token counts, C] (keyframes in deal order) -> all K keyframes' rows in
+    keyframe-schedule order.  T: tokens per keyframe, an int or a per-keyframe list (multi-aspect-ratio scenes)."""
+    Ts = [T] * K if isinstance(T, int) else list(T)
+    counts = [sum(Ts[kf] for kf in range(r, K, world)) for r in range(world)]
     blocks = _all_gather_rows(local_rows, counts, world, group)
-    out = torch.empty(K * T, local_rows.shape[1], dtype=local_rows.dtype, device=local_rows.device)
+    offs = [0]
+    for t in Ts:
+        offs.append(offs[-1] + t)
+    out = torch.empty(offs[-1], local_rows.shape[1], dtype=local_rows.dtype, device=local_rows.device)
     for r, blk in enumerate(blocks):
-        for j, kf in enumerate(range(r, K, world)):
-            out[kf * T:(kf + 1) * T] = blk[j * T:(j + 1) * T]
+        o = 0
+        for kf in range(r, K, world):
+            out[offs[kf]:offs[kf + 1]] = blk[o:o + Ts[kf]]
+            o += Ts[kf]
     return out
+
+
+class _Group:
+    """The views of one image shape owned by this rank (keyframes first)."""
+    __slots__ = ('H', 'W', 'h', 'w', 'T', 'idx', 'k', 'imgs', 'cat', 'pointmaps', 'fpn', 'mf')
 
 
 class SceneRunner:
     """One scene as three stages separated by the two all-gathers:
-         stage1  encode own views                                   -> enc_send
+         stage1  CroCo encoder on own keyframes                     -> enc_send
          gather  keyframe encoder tokens                            -> enc_kf
-         stage2  memory build (replayed on every rank), render, upscale -> pointmaps, mask feats, both_send
+         stage2  memory build (replayed on every rank) || encoder of the other views + DINOv2; render; upscale
          gather  keyframe FPN tokens + attention-mask features      -> both_kf
          stage3  query decoding (replayed on every rank) + query x pixel masks of own views
     With `use_graphs=True` (GPU only) each stage is captured once into a HIP graph and replayed: a scene is ~4 700
     kernel launches, most of them 5-20 us kernels of the sequential memory build, so eager launching is host-bound.
-    The collectives stay eager between the graph replays.  Shapes, keyframe schedule and class list are static."""
+    The collectives stay eager between the graph replays.  Shapes, keyframe schedule and class list are static.
+    Views may have different (landscape) shapes: they are batched per shape group (multi-aspect-ratio scenes)."""
 
-    def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False):
-        self.b, self.V, self.H, self.W, self.classes = backend, V, H, W, classes
+    def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None):
+        self.b, self.V, self.classes = backend, V, classes
         self.rank, self.world, self.group = rank, world, group
         self.K = K = V if (K is None or K > V) else max(int(K), 2)
         if V < world:
             raise ValueError('need at least one view per rank (V=%d, world=%d)' % (V, world))
+        self.shapes = [tuple(sh) for sh in shapes] if shapes is not None else [(H, W)] * V      # per view id
+        for (hh, ww) in self.shapes:
+            if hh > ww:
+                raise NotImplementedError('portrait views: the round-1 HIP scene runner handles landscape shapes only')
         self.keyframes, self.order, owner = assign_views(V, K, world)
         self.mine = [i for i in range(V) if owner[i] == rank]       # positions in `order`; keyframe positions first
         self.n_local = len(self.mine)
         self.k_local = sum(1 for i in self.mine if i < K)
         p = backend.patch_size
-        self.h, self.w = H // p, W // p
-        self.T = self.h * self.w
-        self.imgs = torch.stack([images[self.order[i]] for i in self.mine]).float().contiguous()   # static input buffer
+        self.kf_grids = [(self.shapes[v][0] // p, self.shapes[v][1] // p) for v in self.keyframes]     # schedule order
+        self.kf_T = [a * c for a, c in self.kf_grids]
+        # shape groups of the local views (local index j = position in `mine`)
+        self.groups = []
+        by_shape = {}
+        for j, i in enumerate(self.mine):
+            sh = self.shapes[self.order[i]]
+            if sh not in by_shape:
+                g = _Group()
+                g.H, g.W = sh
+                g.h, g.w = sh[0] // p, sh[1] // p
+                g.T = g.h * g.w
+                g.idx, g.k = [], 0
+                by_shape[sh] = g
+                self.groups.append(g)
+            by_shape[sh].idx.append(j)
+            if i < K:
+                by_shape[sh].k += 1
+        for g in self.groups:
+            g.imgs = torch.stack([images[self.order[self.mine[j]]] for j in g.idx]).float().contiguous()   # static input buffers
+        self.where = {}                       # local index j -> (group, row within group)
+        for g in self.groups:
+            for r, j in enumerate(g.idx):
+                self.where[j] = (g, r)
         self.use_graphs = use_graphs
         self.serial = False          # True: run the two branches of stage 2 back-to-back (clean per-kernel timing)
         self.graphs = None
         self.enc_kf = self.both_kf = None
         self.out = None
 
+    def _kf_rows(self, per_group_rows):
+        """concatenate this rank's keyframe rows (one [k_g*T_g, C] tensor per group) in deal order."""
+        if len(self.groups) == 1:
+            return per_group_rows[0].contiguous()
+        parts = []
+        for j in range(self.k_local):
+            g, r = self.where[j]
+            parts.append(per_group_rows[self.groups.index(g)][r * g.T:(r + 1) * g.T])
+        return torch.cat(parts) if parts else per_group_rows[0][:0].contiguous()
+
     # ---- stages (every tensor they leave on `self` is read by a later stage)
     def stage1(self):
         """CroCo encoder on this rank's keyframes only: all the memory build needs."""
-        b, T, kl = self.b, self.T, self.k_local
-        self.cat = b.alloc_cat(self.n_local * T, self.imgs.device)
-        if kl:
-            b.encode_enc(self.imgs[:kl], self.cat[:kl * T])
-        self.enc_send = b.enc_rows(self.cat, kl * T)
+        b = self.b
+        rows = []
+        for g in self.groups:
+            g.cat = b.alloc_cat(len(g.idx) * g.T, g.imgs.device)
+            if g.k:
+                b.encode_enc(g.imgs[:g.k], g.cat[:g.k * g.T])
+            rows.append(b.enc_rows(g.cat, g.k * g.T))
+        self.enc_send = self._kf_rows(rows)
 
     def _encode_rest(self):
         """Everything the build does not depend on: encoder of the non-keyframe views + DINOv2 of every view."""
-        b, T, kl, n = self.b, self.T, self.k_local, self.n_local
-        if n > kl:
-            b.encode_enc(self.imgs[kl:], self.cat[kl * T:])
-        b.encode_dino(self.imgs, self.cat)
+        b = self.b
+        for g in self.groups:
+            if len(g.idx) > g.k:
+                b.encode_enc(g.imgs[g.k:], g.cat[g.k * g.T:])
+            b.encode_dino(g.imgs, g.cat)
 
     def gather1(self):
-        kf = gather_keyframe_rows(self.enc_send, self.K, T=self.T, rank=self.rank, world=self.world, group=self.group)
+        kf = gather_keyframe_rows(self.enc_send, self.K, self.kf_T, rank=self.rank, world=self.world, group=self.group)
         if self.enc_kf is None:
             self.enc_kf = kf
         else:
@@ -109,26 +161,31 @@ class SceneRunner:
     def stage2(self):
         """The sequential memory build is a chain of thousands of tiny kernels that leaves most CUs idle; the independent
         bulk work (_encode_rest) runs concurrently on a second stream (a parallel branch of the captured graph)."""
-        b, T, kl = self.b, self.T, self.k_local
-        side = None if self.serial else b.side_stream(self.imgs.device)
+        b = self.b
+        dev = self.groups[0].imgs.device
+        side = None if self.serial else b.side_stream(dev)
         if side is None:
             self._encode_rest()
-            bank = b.build_memory(self.enc_kf, self.K, self.h, self.w)
+            bank = b.build_memory(self.enc_kf, self.K, self.kf_grids)
         else:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._encode_rest()
-            bank = b.build_memory(self.enc_kf, self.K, self.h, self.w)
+            bank = b.build_memory(self.enc_kf, self.K, self.kf_grids)
             main.wait_stream(side)
-        self.pointmaps = b.render(self.cat, self.n_local, self.h, self.w, bank)
-        fpn, self.mf = b.features(self.cat, self.imgs, self.n_local, self.h, self.w)
-        fm = b.attn_feats(self.mf, kl)
-        self.d = fpn.shape[1]
-        self.both_send = (torch.cat([fpn[:kl * T], fm], dim=1) if kl else fpn.new_zeros(0, self.d + b.mask_dim)).contiguous()
+        rows = []
+        for g in self.groups:
+            n = len(g.idx)
+            g.pointmaps = b.render(g.cat, n, g.h, g.w, bank)
+            g.fpn, g.mf = b.features(g.cat, g.imgs, n, g.h, g.w)
+            fm = b.attn_feats(g.mf, g.k)
+            self.d = g.fpn.shape[1]
+            rows.append(torch.cat([g.fpn[:g.k * g.T], fm], dim=1) if g.k else g.fpn.new_zeros(0, self.d + b.mask_dim))
+        self.both_send = self._kf_rows(rows)
 
     def gather2(self):
-        kf = gather_keyframe_rows(self.both_send, self.K, T=self.T, rank=self.rank, world=self.world, group=self.group)
+        kf = gather_keyframe_rows(self.both_send, self.K, self.kf_T, rank=self.rank, world=self.world, group=self.group)
         if self.both_kf is None:
             self.both_kf = kf
         else:
@@ -136,9 +193,12 @@ class SceneRunner:
 
     def stage3(self):
         b = self.b
-        outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.h, self.w,
+        outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.kf_grids,
                               self.classes)
-        masks = [b.masks(head, self.mf, j) for j in range(self.n_local)]
+        masks = [None] * self.n_local
+        for g in self.groups:
+            for r, j in enumerate(g.idx):
+                masks[j] = b.masks(head, g.mf, r)
         self.out = (outq, b.logits(head), masks)
 
     def _eager(self):
@@ -179,7 +239,8 @@ class SceneRunner:
         outq, logits, masks = self.out
         res = {}
         for j, i in enumerate(self.mine):
-            m, pm = masks[j][None], self.pointmaps[j][None]
+            g, r = self.where[j]
+            m, pm = masks[j][None], g.pointmaps[r][None]
             if outdevice is not None:
                 m, pm = m.to(outdevice), pm.to(outdevice)
             res[self.order[i]] = (pm, m)
@@ -187,14 +248,14 @@ class SceneRunner:
 
 
 @torch.no_grad()
-def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None):
+def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None):
     """Run one scene eagerly.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
     Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
-    {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank)."""
+    {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W)."""
     Kc = V if (K is None or K > V) else max(int(K), 2)
     _, order, owner = assign_views(V, Kc, world)
     images = {order[i]: get_image(order[i]) for i in range(V) if owner[i] == rank}
-    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False).run(outdevice)
+    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes).run(outdevice)
 
 
 class HipBackend:
@@ -223,8 +284,8 @@ class HipBackend:
     def enc_rows(self, cat, rows):
         return cat[:rows, :self.De].contiguous()
 
-    def build_memory(self, enc_kf, K, h, w):
-        return self.m.build_memory(enc_kf, K, h, w)
+    def build_memory(self, enc_kf, K, grids):
+        return self.m.build_memory(enc_kf, K, grids=grids)
 
     def render(self, cat, n, h, w, bank):
         return self.m.render_views(cat, n, h, w, bank)
@@ -238,10 +299,10 @@ class HipBackend:
             return torch.zeros(0, mt.mask_dim, dtype=torch.bfloat16, device=mf.device)
         return mt.attn_feats(mf[:k_local])
 
-    def decode(self, fpn_kf, fm_kf, K, h, w, classes):
+    def decode(self, fpn_kf, fm_kf, K, grids, classes):
         pd = self.m.panoptic_decoder
         cls = pd.text_encoder.normalized_bf16(classes, fpn_kf.device)
-        return pd.mask_transformer.decode_tokens(fpn_kf, fm_kf, [(h, w)] * K, cls)
+        return pd.mask_transformer.decode_tokens(fpn_kf, fm_kf, list(grids), cls)
 
     def masks(self, head, mf, j):
         return self.m.panoptic_decoder.mask_transformer.masks_for(head.embed, mf[j])

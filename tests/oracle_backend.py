@@ -41,11 +41,15 @@ class OracleBackend:
     def enc_rows(self, cat, rows):
         return cat[:rows, :self.De].contiguous()
 
-    def build_memory(self, enc_kf, K, h, w):
+    def build_memory(self, enc_kf, K, grids):
         from oracle.must3r import build_memory, mem_batches_for
-        T, p = h * w, self.patch_size
-        xs = [enc_kf[i * T:(i + 1) * T] for i in range(K)]
-        return build_memory(self.m.must3r_decoder, xs, [self._pos(h, w)[0]] * K, [[h * p, w * p]] * K, mem_batches_for(K))
+        p = self.patch_size
+        xs, o = [], 0
+        for h, w in grids:
+            xs.append(enc_kf[o:o + h * w])
+            o += h * w
+        return build_memory(self.m.must3r_decoder, xs, [self._pos(h, w)[0] for h, w in grids], [[h * p, w * p] for h, w in grids],
+                            mem_batches_for(K))
 
     def render(self, cat, n, h, w, bank):
         T, p = h * w, self.patch_size
@@ -71,13 +75,13 @@ class OracleBackend:
         a = F.interpolate(mf[:k_local], size=(Hm // 8, Wm // 8), mode='bilinear', align_corners=False)
         return a.flatten(2).transpose(1, 2).reshape(-1, mf.shape[1]).contiguous()
 
-    def decode(self, fpn_kf, fm_kf, K, h, w, classes):
+    def decode(self, fpn_kf, fm_kf, K, grids, classes):
         pd = self.m.panoptic_decoder
         mt = pd.mask_transformer
         cls = pd.text_encoder(classes)
         p = self.patch_size
         src = fpn_kf[:, None] + mt.level_embed.weight[0][None, None]
-        pos = mt._pos(torch.zeros(1, fpn_kf.shape[1], h, w), torch.tensor([[h * p, w * p]])).repeat(K, 1, 1)
+        pos = torch.cat([mt._pos(torch.zeros(1, fpn_kf.shape[1], h, w), torch.tensor([[h * p, w * p]])) for h, w in grids])
         qpos = mt.query_embed.weight[:, None]
         out = mt.query_feat.weight[:, None]
 

@@ -145,3 +145,20 @@ def test_scene_224_padded_token_layout(pair):
         assert rel_l2(pm_h[0, i].cpu(), pm_o[i][0]) < 2e-2
         assert rel_l2(pan_h['pred_masks'][0, i].cpu(), pan_o['pred_masks'][i][0]) < 6e-2
     assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.08
+
+
+@pytest.mark.parametrize('K', [3, 5])
+def test_scene_multi_aspect_ratio(pair, K):
+    """forward_inference_multi_ar on views of different landscape shapes (batched per shape group on the HIP path;
+    K=5 makes the first two keyframes differ in shape -> update_pair_tokens) against the oracle."""
+    variant, o, h = pair
+    shapes = [(64, 96), (32, 96), (64, 96), (64, 64), (32, 96)]
+    imgs = [tiny.synth_image(i, a, b, 7) for i, (a, b) in enumerate(shapes)]
+    ts = torch.tensor(shapes)
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K)
+    pm_h, pan_h = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K)
+    for i, (a, b) in enumerate(shapes):
+        assert pm_h[i].shape == (1, a, b, 7) and pan_h['pred_masks'][i].shape == (1, 24, a // 2, b // 2)
+        assert rel_l2(pm_h[i].cpu(), pm_o[i]) < 2e-2
+        assert rel_l2(pan_h['pred_masks'][i].cpu(), pan_o['pred_masks'][i]) < 6e-2
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 4e-2

@@ -47,11 +47,43 @@ def test_plan_matches_reference_formulation(variant):
         assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
 
 
+MULTI_AR = [(64, 96), (32, 96), (64, 96), (64, 64), (32, 96)]
+
+
+def _multi_ar_images():
+    return [tiny.synth_image(i, h, w, 7) for i, (h, w) in enumerate(MULTI_AR)]
+
+
+@pytest.mark.parametrize('variant,K', [('v1', 3), ('v2', 5)])
+def test_multi_aspect_ratio_scene_matches_reference_formulation(variant, K):
+    """Views of different (landscape) shapes: the grouped scene plan == the oracle pipeline that walks the views one by
+    one like reference panst3r.py:169-284 (K=5: the first two keyframes already differ in shape)."""
+    V = len(MULTI_AR)
+    model = tiny.build(tiny.OracleNS, variant)
+    imgs = _multi_ar_images()
+    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor(MULTI_AR), tiny.NAMES, num_keyframes=K)
+    with torch.no_grad():
+        res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], V, None, None, K, tiny.NAMES, shapes=MULTI_AR)
+    assert rel_l2(scene['out_queries'], pan_ref['out_queries']) < 1e-4
+    for i in range(V):
+        assert res[i][0].shape == pm_ref[i].shape and res[i][1].shape == pan_ref['pred_masks'][i].shape
+        assert rel_l2(res[i][0], pm_ref[i]) < 1e-5
+        assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
+
+
 def _worker(rank, world, port, variant, V, K, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        res, scene = _scene(variant, V, K, rank, world, None)
+        if V == 'multi_ar':
+            torch.set_num_threads(2)
+            model = tiny.build(tiny.OracleNS, variant)
+            imgs = _multi_ar_images()
+            with torch.no_grad():
+                res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], len(MULTI_AR), None, None, K, tiny.NAMES, rank, world, None,
+                                       shapes=MULTI_AR)
+        else:
+            res, scene = _scene(variant, V, K, rank, world, None)
         t = torch.arange(6, dtype=torch.bfloat16).reshape(3, 2) + 10 * rank if rank == 0 else torch.arange(4, dtype=torch.bfloat16).reshape(2, 2) + 10
         g = gather_keyframe_rows(t, 5, 1, rank, world, None)                # K=5 dealt 3/2 over two ranks, bf16 payload
         q.put((rank, {k: (v[0].clone(), v[1].clone()) for k, v in res.items()}, scene['out_queries'].clone(), g.float()))
@@ -62,7 +94,7 @@ def _worker(rank, world, port, variant, V, K, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('variant,V,K', [('v1', 5, 3), ('v2', 4, 2)])
+@pytest.mark.parametrize('variant,V,K', [('v1', 5, 3), ('v2', 4, 2), ('v1', 'multi_ar', 4)])
 def test_two_rank_gloo_equals_single(variant, V, K):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -77,7 +109,14 @@ def test_two_rank_gloo_equals_single(variant, V, K):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ref, ref_scene = _scene(variant, V, K)
+    if V == 'multi_ar':
+        model = tiny.build(tiny.OracleNS, variant)
+        imgs = _multi_ar_images()
+        with torch.no_grad():
+            ref, ref_scene = run_scene(OracleBackend(model), lambda i: imgs[i], len(MULTI_AR), None, None, K, tiny.NAMES, shapes=MULTI_AR)
+        V = len(MULTI_AR)
+    else:
+        ref, ref_scene = _scene(variant, V, K)
     merged = {}
     for rank, res, outq, g in got:
         assert torch.equal(outq, ref_scene['out_queries'])                  # identical frozen queries on every rank

@@ -44,6 +44,8 @@ def _all_gather_rows(t, counts, world, group):
 def gather_keyframe_rows(local_rows, K, T, rank, world, group):
     """local_rows: [sum of this rank's keyframe token counts, C] (keyframes in deal order) -> all K keyframes' rows in
     keyframe-schedule order.  T: tokens per keyframe, an int or a per-keyframe list (multi-aspect-ratio scenes)."""
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local_rows                    # one rank owns every keyframe, already in schedule order
     Ts = [T] * K if isinstance(T, int) else list(T)
     counts = [sum(Ts[kf] for kf in range(r, K, world)) for r in range(world)]
     blocks = _all_gather_rows(local_rows, counts, world, group)
@@ -153,7 +155,7 @@ class SceneRunner:
 
     def gather1(self):
         kf = gather_keyframe_rows(self.enc_send, self.K, self.kf_T, rank=self.rank, world=self.world, group=self.group)
-        if self.enc_kf is None:
+        if self.enc_kf is None or self.enc_kf is kf:
             self.enc_kf = kf
         else:
             self.enc_kf.copy_(kf)
@@ -186,7 +188,7 @@ class SceneRunner:
 
     def gather2(self):
         kf = gather_keyframe_rows(self.both_send, self.K, self.kf_T, rank=self.rank, world=self.world, group=self.group)
-        if self.both_kf is None:
+        if self.both_kf is None or self.both_kf is kf:
             self.both_kf = kf
         else:
             self.both_kf.copy_(kf)

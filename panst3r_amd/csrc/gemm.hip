@@ -36,6 +36,98 @@ __device__ __forceinline__ int perm_row(int row) {
   return sub * (16 * F) + g * (4 * F) + 4 * f + r;
 }
 
+// Whole-row write-back of the LDS-staged C tile: thread -> (row, 16-B chunk); consecutive lanes = consecutive bytes of one
+// output row.  F32: fp32 output (residual values were prefetched into resv by the caller), else bf16 output.
+template <int BM, bool F32>
+__device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* smem, int tid, int m0, int n0, int pitch, int nch,
+                                          const float4 (&resv)[BM / 8]) {
+  const int c = tid % nch;                                  // 16-B chunk of the row
+  const int epc = F32 ? 4 : 8;                              // elements per chunk
+  const int n = n0 + c * epc;
+  const int seg = p.ps_p * p.ps_c;
+  const int rstep = 256 / nch;
+  const bool pre = F32 && p.res && !p.res_bf16 && p.ps_p == 0;
+#pragma unroll
+  for (int it = 0; it < (F32 ? BM / 8 : BM / 16); ++it) {
+    const int r = tid / nch + it * rstep;
+    const int m = m0 + r;
+    if (r >= BM || m >= p.M || n >= p.N) continue;
+    uint4 val = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
+    if (p.rope_hd == 64 && !F32) val = rope_chunk(p, val, *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4)), m, n);
+    int orow = m;
+    int64_t off;
+    int ps_v = 0, ps_y = 0, ps_x = 0;
+    if (p.ps_p > 0) {
+      const int hw = p.ps_h * p.ps_w;
+      ps_v = m / hw;
+      const int tt = m - ps_v * hw;
+      ps_y = tt / p.ps_w;
+      ps_x = tt - ps_y * p.ps_w;
+      const int dy = n / seg, rem = n - dy * seg;
+      off = ((int64_t)(ps_v * p.ps_p * p.ps_h + p.ps_p * ps_y + dy) * p.ps_w + ps_x) * seg + rem;
+    } else {
+      if (p.grp_in > 0) orow = (m / p.grp_in) * p.grp_out + p.grp_off + (m % p.grp_in);
+      off = (int64_t)orow * p.ldc + n;
+    }
+    const int64_t roff = p.res ? (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + n : 0;
+    const float* rp = (p.res && !p.res_bf16) ? p.res + roff : nullptr;
+    const bf16_t* rpb = (p.res && p.res_bf16) ? (const bf16_t*)p.res + roff : nullptr;
+    if (F32) {
+      if (rp) {
+        const float4 q = pre ? resv[it] : *(const float4*)rp;
+        float4 f = *(float4*)&val;
+        f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
+        *(float4*)((float*)p.C + off) = f;
+      } else if (rpb) {
+        const uint2 q = *(const uint2*)rpb;
+        float4 f = *(float4*)&val;
+        f.x += __uint_as_float(q.x << 16); f.y += __uint_as_float(q.x & 0xffff0000u);
+        f.z += __uint_as_float(q.y << 16); f.w += __uint_as_float(q.y & 0xffff0000u);
+        *(float4*)((float*)p.C + off) = f;
+      } else {
+        *(uint4*)((float*)p.C + off) = val;
+      }
+      continue;
+    }
+    if (rpb) {             // bf16 residual stream (LoftUp blocks): 16-byte load, add in fp32, one rounding
+      uint32_t* w32 = (uint32_t*)&val;
+      uint32_t rq[4] = {0u, 0u, 0u, 0u};
+      if (n + 8 <= p.N) { const uint4 t = *(const uint4*)rpb; rq[0] = t.x; rq[1] = t.y; rq[2] = t.z; rq[3] = t.w; }
+      else { const uint2 t = *(const uint2*)rpb; rq[0] = t.x; rq[1] = t.y; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        w32[q] = pack2bf(__uint_as_float(w32[q] << 16) + __uint_as_float(rq[q] << 16),
+                         __uint_as_float(w32[q] & 0xffff0000u) + __uint_as_float(rq[q] & 0xffff0000u));
+    }
+    if (rp) {              // bf16 output with an fp32 residual: add in fp32, round once more
+      uint32_t* w32 = (uint32_t*)&val;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float lo = __uint_as_float(w32[q] << 16) + ((n + 2 * q < p.N) ? rp[2 * q] : 0.f);
+        const float hi = __uint_as_float(w32[q] & 0xffff0000u) + ((n + 2 * q + 1 < p.N) ? rp[2 * q + 1] : 0.f);
+        w32[q] = pack2bf(lo, hi);
+      }
+    }
+    bf16_t* dst = (bf16_t*)p.C + off;
+    // a chunk is 8 columns; N % 4 == 0, so the last chunk of a row may hold only 4 valid columns, and a pixel-shuffle
+    // segment (a multiple of 4 columns) may end in the middle of a chunk: split into two 8-byte stores then.
+    const bool full = (n + 8 <= p.N) && (p.ps_p == 0 || ((n % seg) + 8 <= seg));
+    if (full && ((((uintptr_t)dst) & 15) == 0)) {
+      *(uint4*)dst = val;
+    } else {
+      *(uint2*)dst = make_uint2(val.x, val.y);
+      if (n + 8 <= p.N) {
+        int64_t off2 = off + 4;
+        if (p.ps_p > 0) {
+          const int n2 = n + 4, dy = n2 / seg, rem = n2 - dy * seg;
+          off2 = ((int64_t)(ps_v * p.ps_p * p.ps_h + p.ps_p * ps_y + dy) * p.ps_w + ps_x) * seg + rem;
+        }
+        *(uint2*)((bf16_t*)p.C + off2) = make_uint2(val.z, val.w);
+      }
+    }
+  }
+}
+
 // NST = number of LDS slab buffers.  NST = 2: classic double buffering (128x128 tiles: 64 KiB, 2 blocks/CU).
 // NST = 4 (64x64 tiles, the 768-row GEMMs of the sequential memory build): with only 8 MFMAs per K step those GEMMs
 // are bound by the global->LDS LATENCY of a one-deep prefetch, so three slabs are kept in flight and each step waits
@@ -164,6 +256,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, c
   }
 
   // ---------------------------------------------------------------- epilogue
+  // fp32 residual: all 16-B residual loads of this thread's whole-row phase are issued NOW, so their latency overlaps the
+  // accumulator -> LDS staging instead of forming up to 16 dependent load -> add -> store round trips per tile.
+  float4 resv[BM / 8];
+  if (!TRANS && p.res && !p.res_bf16 && p.out_fp32 && p.ps_p == 0) {
+    const int nchf = BN >> 2, cf = tid % nchf;
+    const int nf = n0 + cf * 4;
+#pragma unroll
+    for (int it = 0; it < BM / 8; ++it) {
+      const int r = tid / nchf + it * (256 / nchf);
+      const int m = m0 + r;
+      resv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < BM && m < p.M && nf < p.N) {
+        int orow = m;
+        if (p.grp_in > 0) orow = (m / p.grp_in) * p.grp_out + p.grp_off + (m % p.grp_in);
+        resv[it] = *(const float4*)(p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + nf);
+      }
+    }
+  }
   if (TRANS) {
     // lane: n = .. + l16 ; owns the 4*FM contiguous rows m = .. + g*4FM + 4i + r  ->  C^T[n][m..]
     bf16_t* Ct = (bf16_t*)p.C;
@@ -241,89 +351,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, c
     }
   }
   __syncthreads();
-  {
-    const int c = tid % nch;                                // 16-B chunk of the row
-    const int epc = f32o ? 4 : 8;                           // elements per chunk
-    const int n = n0 + c * epc;
-    const int seg = p.ps_p * p.ps_c;
-    for (int r = tid / nch; r < BM; r += 256 / nch) {
-      const int m = m0 + r;
-      if (m >= p.M || n >= p.N) continue;
-      uint4 val = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
-      if (p.rope_hd == 64 && !f32o) val = rope_chunk(p, val, *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4)), m, n);
-      int orow = m;
-      int64_t off;
-      int ps_v = 0, ps_y = 0, ps_x = 0;
-      if (p.ps_p > 0) {
-        const int hw = p.ps_h * p.ps_w;
-        ps_v = m / hw;
-        const int tt = m - ps_v * hw;
-        ps_y = tt / p.ps_w;
-        ps_x = tt - ps_y * p.ps_w;
-        const int dy = n / seg, rem = n - dy * seg;
-        off = ((int64_t)(ps_v * p.ps_p * p.ps_h + p.ps_p * ps_y + dy) * p.ps_w + ps_x) * seg + rem;
-      } else {
-        if (p.grp_in > 0) orow = (m / p.grp_in) * p.grp_out + p.grp_off + (m % p.grp_in);
-        off = (int64_t)orow * p.ldc + n;
-      }
-      const int64_t roff = p.res ? (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + n : 0;
-      const float* rp = (p.res && !p.res_bf16) ? p.res + roff : nullptr;
-      const bf16_t* rpb = (p.res && p.res_bf16) ? (const bf16_t*)p.res + roff : nullptr;
-      if (f32o) {
-        if (rp) {
-          const float4 q = *(const float4*)rp;
-          float4 f = *(float4*)&val;
-          f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
-          *(float4*)((float*)p.C + off) = f;
-        } else if (rpb) {
-          const uint2 q = *(const uint2*)rpb;
-          float4 f = *(float4*)&val;
-          f.x += __uint_as_float(q.x << 16); f.y += __uint_as_float(q.x & 0xffff0000u);
-          f.z += __uint_as_float(q.y << 16); f.w += __uint_as_float(q.y & 0xffff0000u);
-          *(float4*)((float*)p.C + off) = f;
-        } else {
-          *(uint4*)((float*)p.C + off) = val;
-        }
-        continue;
-      }
-      if (rpb) {             // bf16 residual stream (LoftUp blocks): 16-byte load, add in fp32, one rounding
-        uint32_t* w32 = (uint32_t*)&val;
-        uint32_t rq[4] = {0u, 0u, 0u, 0u};
-        if (n + 8 <= p.N) { const uint4 t = *(const uint4*)rpb; rq[0] = t.x; rq[1] = t.y; rq[2] = t.z; rq[3] = t.w; }
-        else { const uint2 t = *(const uint2*)rpb; rq[0] = t.x; rq[1] = t.y; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          w32[q] = pack2bf(__uint_as_float(w32[q] << 16) + __uint_as_float(rq[q] << 16),
-                           __uint_as_float(w32[q] & 0xffff0000u) + __uint_as_float(rq[q] & 0xffff0000u));
-      }
-      if (rp) {              // bf16 output with an fp32 residual: add in fp32, round once more
-        uint32_t* w32 = (uint32_t*)&val;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float lo = __uint_as_float(w32[q] << 16) + ((n + 2 * q < p.N) ? rp[2 * q] : 0.f);
-          const float hi = __uint_as_float(w32[q] & 0xffff0000u) + ((n + 2 * q + 1 < p.N) ? rp[2 * q + 1] : 0.f);
-          w32[q] = pack2bf(lo, hi);
-        }
-      }
-      bf16_t* dst = (bf16_t*)p.C + off;
-      // a chunk is 8 columns; N % 4 == 0, so the last chunk of a row may hold only 4 valid columns, and a pixel-shuffle
-      // segment (a multiple of 4 columns) may end in the middle of a chunk: split into two 8-byte stores then.
-      const bool full = (n + 8 <= p.N) && (p.ps_p == 0 || ((n % seg) + 8 <= seg));
-      if (full && ((((uintptr_t)dst) & 15) == 0)) {
-        *(uint4*)dst = val;
-      } else {
-        *(uint2*)dst = make_uint2(val.x, val.y);
-        if (n + 8 <= p.N) {
-          int64_t off2 = off + 4;
-          if (p.ps_p > 0) {
-            const int n2 = n + 4, dy = n2 / seg, rem = n2 - dy * seg;
-            off2 = ((int64_t)(ps_v * p.ps_p * p.ps_h + p.ps_p * ps_y + dy) * p.ps_w + ps_x) * seg + rem;
-          }
-          *(uint2*)((bf16_t*)p.C + off2) = make_uint2(val.z, val.w);
-        }
-      }
-    }
-  }
+  if (f32o) row_phase<BM, true>(p, smem, tid, m0, n0, pitch, nch, resv);
+  else row_phase<BM, false>(p, smem, tid, m0, n0, pitch, nch, resv);
 }
 
 static int num_cus() {

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 5
+#define PST_ABI_VERSION 6
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -129,6 +129,10 @@ int pst_l2norm_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows,
  * attn_mask_from_logits: mask[q,k] = logits[q,k] < 0, rows that are fully blocked are cleared
  *   (mask_transformer.py:172,272).  logits fp32 [Q, Nk] -> uint8 [Q, Nk]. */
 int pst_mean4_bf16(const void* F, void* Fm, int nimg, int Hm, int Wm, int C, void* stream);
+/* resize_bilinear: F [nimg, Hs, Ws, C] bf16 -> Fd [nimg, Hd, Wd, C] bf16, F.interpolate(mode='bilinear',
+ *   align_corners=False) semantics (mask_transformer.py:283-287 when the key grid of a portrait view is the transposed
+ *   one, utils.py:47-49, so the resize is anisotropic and mean4 does not apply). */
+int pst_resize_bilinear_bf16(const void* F, void* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, void* stream);
 int pst_attn_mask_from_logits(const float* logits, int64_t ldl, uint8_t* mask, int64_t ldm, int Q, int Nk,
                               void* stream);
 

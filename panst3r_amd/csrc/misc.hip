@@ -216,6 +216,36 @@ __global__ void mean4_kernel(const bf16_t* F, bf16_t* Fm, int nimg, int Hm, int 
   }
 }
 
+// ------------------------------------------------------------------ general bilinear resize of pixel-major features
+// F [nimg, Hs, Ws, C] bf16 -> Fd [nimg, Hd, Wd, C] bf16 with torch's align_corners=False, antialias=False rule:
+// src = (dst + 0.5) * (S / D) - 0.5 clamped at 0, taps floor(src) and min(floor(src) + 1, S - 1).
+__global__ void resize_bilinear_kernel(const bf16_t* F, bf16_t* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C) {
+  const int c4 = C / 4;
+  const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
+  const int64_t total = (int64_t)nimg * Hd * Wd * c4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4) * 4;
+    const int64_t pix = i / c4;
+    const int dx = (int)(pix % Wd), dy = (int)((pix / Wd) % Hd);
+    const int64_t n = pix / ((int64_t)Wd * Hd);
+    const float fy = fmaxf((dy + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf((dx + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = min((int)fy, Hs - 1), x0 = min((int)fx, Ws - 1);
+    const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const bf16_t* img = F + n * Hs * (int64_t)Ws * C + c;
+    float a[4], b[4], d[4], e[4];
+    load4(img, ((int64_t)y0 * Ws + x0) * C, false, a);
+    load4(img, ((int64_t)y0 * Ws + x1) * C, false, b);
+    load4(img, ((int64_t)y1 * Ws + x0) * C, false, d);
+    load4(img, ((int64_t)y1 * Ws + x1) * C, false, e);
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = (1.f - wy) * ((1.f - wx) * a[k] + wx * b[k]) + wy * ((1.f - wx) * d[k] + wx * e[k]);
+    store4(Fd, pix * C + c, false, o);
+  }
+}
+
 // ------------------------------------------------------------------ mask[q,k] = logit < 0, fully blocked rows cleared
 __global__ __launch_bounds__(256) void attn_mask_kernel(const float* logits, int64_t ldl, uint8_t* mask, int64_t ldm, int Nk) {
   __shared__ int any_open;
@@ -297,6 +327,13 @@ extern "C" int pst_mean4_bf16(const void* F, void* Fm, int nimg, int Hm, int Wm,
   const int64_t total = (int64_t)nimg * (Hm / 8) * (Wm / 8) * (C / 4);
   hipLaunchKernelGGL(mean4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)F, (bf16_t*)Fm, nimg, Hm, Wm, C);
   return check_launch("mean4");
+}
+
+extern "C" int pst_resize_bilinear_bf16(const void* F, void* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, void* stream) {
+  if (!F || !Fd || nimg <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || C <= 0 || C % 4) { set_error("resize_bilinear: bad argument"); return PST_EINVAL; }
+  const int64_t total = (int64_t)nimg * Hd * Wd * (C / 4);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)F, (bf16_t*)Fd, nimg, Hs, Ws, Hd, Wd, C);
+  return check_launch("resize_bilinear");
 }
 
 extern "C" int pst_attn_mask_from_logits(const float* logits, int64_t ldl, uint8_t* mask, int64_t ldm, int Q, int Nk, void* stream) {

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -38,7 +38,7 @@ class AttnParams(C.Structure):
 
 
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_rope2d_bf16',
-           'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16',
+           'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16', 'pst_resize_bilinear_bf16',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe']
 
@@ -287,6 +287,12 @@ def mean4(F, Fm, nimg, Hm, Wm, Cc):
     _dev(F, torch.bfloat16); _dev(Fm, torch.bfloat16)
     _check(lib().pst_mean4_bf16(_ptr(F), _ptr(Fm), nimg, Hm, Wm, Cc, _stream()), 'pst_mean4_bf16')
     return Fm
+
+
+def resize_bilinear(F, Fd, nimg, Hs, Ws, Hd, Wd, Cc):
+    _dev(F, torch.bfloat16); _dev(Fd, torch.bfloat16)
+    _check(lib().pst_resize_bilinear_bf16(_ptr(F), _ptr(Fd), nimg, Hs, Ws, Hd, Wd, Cc, _stream()), 'pst_resize_bilinear_bf16')
+    return Fd
 
 
 def attn_mask_from_logits(logits, mask):

@@ -199,12 +199,18 @@ class LoftUpUpscaler(HipModule):
     @torch.no_grad()
     def upscale_tokens(self, lr, imgs, V, h, w, fpn_out, mask_out):
         """lr bf16 [V*T, lr_width()] with the mixer tokens in columns [0, input_dim) (the rest is filled here);
-        imgs fp32 [V,3,H,W] landscape -> fpn_out bf16 [V*T, input_dim], mask_out bf16 [V, H/2, W/2, dim]."""
+        imgs fp32 [V,3,H,W] -> fpn_out bf16 [V*T, input_dim] (h x w raster), mask_out bf16 [V, H/2, W/2, dim].
+        A tall token grid (h > w) takes the guidance image transposed (loftup.py:147-149): the mask features then come
+        out landscape-shaped, mask_out bf16 [V, W/2, H/2, dim] (the low-res tokens only enter through cross-attention,
+        which does not care about their raster)."""
         dev = lr.device
         pk = self.packed(dev)
         T, D, C, Hh = h * w, self.input_dim, self.dim, self.num_heads
         hd = C // Hh
+        if h > w:
+            imgs = imgs.transpose(2, 3).contiguous()
         H2, W2 = imgs.shape[2] // 2, imgs.shape[3] // 2
+        assert tuple(mask_out.shape) == (V, H2, W2, C), (tuple(mask_out.shape), (V, H2, W2, C))
         P, CH = H2 * W2, self.start_dim
         hip.gemm(lr[:, :D], pk['pe'].w, fpn_out, bias=pk['pe'].b)
         lr[:, D:].zero_()
@@ -263,13 +269,11 @@ class LoftUpUpscaler(HipModule):
         tok, img = inputs
         V, T, _ = tok.shape
         H, W = img_shape
-        if H > W:
-            raise NotImplementedError('portrait guidance on the HIP LoftUp path: feed landscape views (round-1 scope)')
         h, w = H // self.patch_size, W // self.patch_size
         lr = torch.zeros(V * T, self.lr_width(), dtype=BF16, device=tok.device)
         lr[:, :self.input_dim] = tok.reshape(V * T, -1).to(BF16)
         fpn = torch.empty(V * T, self.fpn_dim, dtype=BF16, device=tok.device)
-        mf = torch.empty(V, H // 2, W // 2, self.dim, dtype=BF16, device=tok.device)
+        mf = torch.empty(V, min(H, W) // 2, max(H, W) // 2, self.dim, dtype=BF16, device=tok.device)   # loftup.py:147-149,184
         self.upscale_tokens(lr, img.float(), V, h, w, fpn, mf)
         return [fpn.float().reshape(V, h, w, -1).permute(0, 3, 1, 2)], mf.float().permute(0, 3, 1, 2)
 
@@ -417,12 +421,19 @@ class MaskTransformer(HipModule):
         return out
 
     @torch.no_grad()
-    def attn_feats(self, mask_feats):
-        """mean of the central 2x2 pixels of each 8x8 block: bf16 [n, Hm, Wm, C] -> [n*T, C] (the only part of the
-        full-resolution masks the 6 intermediate decoder layers look at, mask_transformer.py:283-287)."""
+    def attn_feats(self, mask_feats, grid=None):
+        """Mask features bilinearly resized to the key grid: bf16 [n, Hm, Wm, C] -> [n*T, C] (the only part of the
+        full-resolution masks the 6 intermediate decoder layers look at, mask_transformer.py:283-287; the resize is
+        linear, so resize(E.F) == E.resize(F)).  The usual 8x case is the mean of the central 2x2 pixels of each 8x8
+        block; `grid` = (rows, cols) of the FPN level when it differs (portrait views of the LoftUp variant: native
+        masks against the transposed key grid, utils.py:47-49)."""
         n, Hm, Wm, C = mask_feats.shape
-        fm = torch.empty(n * (Hm // 8) * (Wm // 8), C, dtype=BF16, device=mask_feats.device)
-        hip.mean4(mask_feats, fm, n, Hm, Wm, C)
+        gh, gw = grid if grid is not None else (Hm // 8, Wm // 8)
+        fm = torch.empty(n * gh * gw, C, dtype=BF16, device=mask_feats.device)
+        if (gh * 8, gw * 8) == (Hm, Wm):
+            hip.mean4(mask_feats, fm, n, Hm, Wm, C)
+        else:
+            hip.resize_bilinear(mask_feats, fm, n, Hm, Wm, gh, gw, C)
         return fm
 
     @torch.no_grad()
@@ -566,9 +577,19 @@ class PanopticDecoder(HipModule):
     def cat_width(self):
         return None
 
+    def fpn_grid(self, h, w):
+        """(rows, cols) of the FPN level / key grid the MaskTransformer sees for an h x w token grid, and whether the
+        view counts as portrait: `transpose_to_landscape(upscaler)` hands portrait results back transposed (utils.py:47-49)."""
+        portrait = bool(self.landscape_only and h > w)
+        return ((w, h) if portrait else (h, w)), portrait
+
     @torch.no_grad()
     def features_tokens(self, cat, imgs, V, h, w):
-        """cat bf16 [V*T, 2816] (enc | dec | dino) -> (fpn bf16 [V*T, d], mask_feats bf16 [V, Hm, Wm, C])."""
+        """cat bf16 [V*T, 2816] (enc | dec | dino) -> (fpn bf16 [V*T, d], mask_feats bf16 [V, Hm, Wm, C]).
+        Portrait views (h > w) with landscape_only=True follow `transpose_to_landscape(upscaler, dims=(2,3))`
+        (panoptic_decoder.py:26,56): the upscaler runs on the tall grid and both results are handed back transposed --
+        FPN tokens in the raster of the w x h grid; mask features [V, 4w, 4h, C] for the pixel-shuffle upscaler and
+        (its guidance image being transposed inside, loftup.py:147-149) native [V, H/2, W/2, C] for LoftUp."""
         dev = cat.device
         up = self.upscaler
         T = h * w
@@ -579,7 +600,8 @@ class PanopticDecoder(HipModule):
                 self.input_mixer.mix_tokens(cat, V, h, w, lr)
             else:
                 lr[:, :up.input_dim] = cat
-            mf = torch.empty(V, imgs.shape[2] // 2, imgs.shape[3] // 2, up.mask_dim, dtype=BF16, device=dev)
+            H2, W2 = imgs.shape[2] // 2, imgs.shape[3] // 2
+            mf = torch.empty(V, min(H2, W2) if h > w else H2, max(H2, W2) if h > w else W2, up.mask_dim, dtype=BF16, device=dev)
             up.upscale_tokens(lr, imgs, V, h, w, fpn, mf)
         else:
             x = cat
@@ -588,10 +610,13 @@ class PanopticDecoder(HipModule):
                 self.input_mixer.mix_tokens(cat, V, h, w, x)
             mf = torch.empty(V, 8 * h, 8 * w, up.mask_dim, dtype=BF16, device=dev)
             up.upscale_tokens(x, imgs, V, h, w, fpn, mf)
+        if self.fpn_grid(h, w)[1]:
+            fpn = fpn.view(V, h, w, -1).transpose(1, 2).reshape(V * T, -1)          # copies (pure data movement)
+            mf = mf.transpose(1, 2).contiguous()
         return fpn, mf
 
     def forward(self, in_feats, in_imgs, pos, true_shape, classes, max_bs=None, outdevice=None, memory_queries=None, multi_ar=False):
-        """Reference signature (panoptic_decoder.py:41) for one scene of same-shape landscape views:
+        """Reference signature (panoptic_decoder.py:41) for one scene of same-shape views (images in native orientation):
         in_feats = (x_enc, y_dec, x_dino) each [1,n,T,*]; returns pred_logits [1,Q,Ncls], pred_masks [1,n,Q,H/2,W/2], out_queries [Q,1,d].
         MinMaxScaler is applied per view (the demo's max_bs=1 convention)."""
         if multi_ar:
@@ -599,8 +624,6 @@ class PanopticDecoder(HipModule):
         B, n, T = in_feats[0].shape[:3]
         assert B == 1
         H, W = [int(v) for v in true_shape[0, 0].tolist()]
-        if H > W:
-            raise NotImplementedError('portrait views: round-1 HIP path is landscape-only')
         dev = in_feats[0].device
         p = self.upscaler.patch_size
         h, w = H // p, W // p
@@ -608,8 +631,9 @@ class PanopticDecoder(HipModule):
         fpn, mf = self.features_tokens(cat, in_imgs[0].float().contiguous(), n, h, w)
         cls = self.text_encoder.normalized_bf16(classes, dev)
         mt = self.mask_transformer
+        grid, portrait = self.fpn_grid(h, w)
         if memory_queries is None:
-            outq, hs = mt.decode_tokens(fpn, mt.attn_feats(mf), [(h, w)] * n, cls)
+            outq, hs = mt.decode_tokens(fpn, mt.attn_feats(mf, grid), [grid] * n, cls, [portrait] * n)
         else:
             outq = memory_queries.reshape(-1, mt.hidden_dim).float().to(dev).contiguous()
             hs = mt.head_state(outq, cls)

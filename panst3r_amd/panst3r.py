@@ -61,6 +61,8 @@ class PanSt3R(nn.Module):
             if enc:
                 self.must3r_encoder.encode_tokens(im, out=cat[sl])
             if dino:
+                if H > W and self.dino_encoder.landscape_only:
+                    im = im.transpose(2, 3).contiguous()         # dinov2_transpose (model/dino.py:15-47): portrait views run transposed
                 self.dino_encoder.encode_tokens(im, cat[sl], col0=De + Dd)
 
     @torch.no_grad()
@@ -111,8 +113,6 @@ class PanSt3R(nn.Module):
         V = len(imgs)
         dev = imgs[0].device
         shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
-        if any(hh > ww for hh, ww in shapes):
-            raise NotImplementedError('portrait views: the round-1 HIP pipeline handles landscape shapes only')
         H, W = shapes[0]
         from .scene import run_scene, HipBackend
         res, scene = run_scene(HipBackend(self), lambda i: imgs[i], V, H, W, num_keyframes, classes, outdevice=outdevice, shapes=shapes)

@@ -76,7 +76,8 @@ class SceneRunner:
     With `use_graphs=True` (GPU only) each stage is captured once into a HIP graph and replayed: a scene is ~4 700
     kernel launches, most of them 5-20 us kernels of the sequential memory build, so eager launching is host-bound.
     The collectives stay eager between the graph replays.  Shapes, keyframe schedule and class list are static.
-    Views may have different (landscape) shapes: they are batched per shape group (multi-aspect-ratio scenes)."""
+    Views may have different shapes (landscape or portrait, native orientation): they are batched per shape group
+    (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
     def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None):
         self.b, self.V, self.classes = backend, V, classes
@@ -85,9 +86,6 @@ class SceneRunner:
         if V < world:
             raise ValueError('need at least one view per rank (V=%d, world=%d)' % (V, world))
         self.shapes = [tuple(sh) for sh in shapes] if shapes is not None else [(H, W)] * V      # per view id
-        for (hh, ww) in self.shapes:
-            if hh > ww:
-                raise NotImplementedError('portrait views: the round-1 HIP scene runner handles landscape shapes only')
         self.keyframes, self.order, owner = assign_views(V, K, world)
         self.mine = [i for i in range(V) if owner[i] == rank]       # positions in `order`; keyframe positions first
         self.n_local = len(self.mine)
@@ -95,6 +93,8 @@ class SceneRunner:
         p = backend.patch_size
         self.kf_grids = [(self.shapes[v][0] // p, self.shapes[v][1] // p) for v in self.keyframes]     # schedule order
         self.kf_T = [a * c for a, c in self.kf_grids]
+        kf_fpn = [backend.fpn_grid(a, c) for a, c in self.kf_grids]        # key grid + portrait flag per keyframe
+        self.kf_fpn_grids, self.kf_portrait = [g for g, _ in kf_fpn], [pt for _, pt in kf_fpn]
         # shape groups of the local views (local index j = position in `mine`)
         self.groups = []
         by_shape = {}
@@ -181,7 +181,7 @@ class SceneRunner:
             n = len(g.idx)
             g.pointmaps = b.render(g.cat, n, g.h, g.w, bank)
             g.fpn, g.mf = b.features(g.cat, g.imgs, n, g.h, g.w)
-            fm = b.attn_feats(g.mf, g.k)
+            fm = b.attn_feats(g.mf, g.k, b.fpn_grid(g.h, g.w)[0])
             self.d = g.fpn.shape[1]
             rows.append(torch.cat([g.fpn[:g.k * g.T], fm], dim=1) if g.k else g.fpn.new_zeros(0, self.d + b.mask_dim))
         self.both_send = self._kf_rows(rows)
@@ -195,8 +195,8 @@ class SceneRunner:
 
     def stage3(self):
         b = self.b
-        outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.kf_grids,
-                              self.classes)
+        outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.kf_fpn_grids,
+                              self.classes, self.kf_portrait)
         masks = [None] * self.n_local
         for g in self.groups:
             for r, j in enumerate(g.idx):
@@ -295,16 +295,19 @@ class HipBackend:
     def features(self, cat, imgs, n, h, w):
         return self.m.panoptic_decoder.features_tokens(cat, imgs, n, h, w)
 
-    def attn_feats(self, mf, k_local):
+    def fpn_grid(self, h, w):
+        return self.m.panoptic_decoder.fpn_grid(h, w)
+
+    def attn_feats(self, mf, k_local, grid):
         mt = self.m.panoptic_decoder.mask_transformer
         if k_local == 0:
             return torch.zeros(0, mt.mask_dim, dtype=torch.bfloat16, device=mf.device)
-        return mt.attn_feats(mf[:k_local])
+        return mt.attn_feats(mf[:k_local], grid)
 
-    def decode(self, fpn_kf, fm_kf, K, grids, classes):
+    def decode(self, fpn_kf, fm_kf, K, grids, classes, portrait):
         pd = self.m.panoptic_decoder
         cls = pd.text_encoder.normalized_bf16(classes, fpn_kf.device)
-        return pd.mask_transformer.decode_tokens(fpn_kf, fm_kf, list(grids), cls)
+        return pd.mask_transformer.decode_tokens(fpn_kf, fm_kf, list(grids), cls, list(portrait))
 
     def masks(self, head, mf, j):
         return self.m.panoptic_decoder.mask_transformer.masks_for(head.embed, mf[j])

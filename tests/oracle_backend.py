@@ -68,20 +68,25 @@ class OracleBackend:
         fpn, mf = self.m.panoptic_decoder.features(cat.reshape(1, n, T, -1), imgs[None], pos, ts, max_bs=1)
         return fpn[0].flatten(2).transpose(1, 2).reshape(n * T, -1).contiguous(), mf[0]          # tokens, [n,C,Hm,Wm]
 
-    def attn_feats(self, mf, k_local):
+    def fpn_grid(self, h, w):
+        portrait = bool(self.m.panoptic_decoder.landscape_only and h > w)
+        return ((w, h) if portrait else (h, w)), portrait
+
+    def attn_feats(self, mf, k_local, grid):
         if k_local == 0:
             return torch.zeros(0, self.mask_dim)
-        Hm, Wm = mf.shape[-2:]
-        a = F.interpolate(mf[:k_local], size=(Hm // 8, Wm // 8), mode='bilinear', align_corners=False)
+        a = F.interpolate(mf[:k_local], size=tuple(grid), mode='bilinear', align_corners=False)
         return a.flatten(2).transpose(1, 2).reshape(-1, mf.shape[1]).contiguous()
 
-    def decode(self, fpn_kf, fm_kf, K, grids, classes):
+    def decode(self, fpn_kf, fm_kf, K, grids, classes, portrait):
         pd = self.m.panoptic_decoder
         mt = pd.mask_transformer
         cls = pd.text_encoder(classes)
         p = self.patch_size
         src = fpn_kf[:, None] + mt.level_embed.weight[0][None, None]
-        pos = torch.cat([mt._pos(torch.zeros(1, fpn_kf.shape[1], h, w), torch.tensor([[h * p, w * p]])) for h, w in grids])
+        # true_shape only decides the orientation flag here (mask_transformer.py:106-119); (h, w) is the key grid
+        pos = torch.cat([mt._pos(torch.zeros(1, fpn_kf.shape[1], h, w), torch.tensor([[w * p, h * p] if pt else [h * p, w * p]]))
+                         for (h, w), pt in zip(grids, portrait)])
         qpos = mt.query_embed.weight[:, None]
         out = mt.query_feat.weight[:, None]
 

@@ -162,3 +162,39 @@ def test_scene_multi_aspect_ratio(pair, K):
         assert rel_l2(pm_h[i].cpu(), pm_o[i]) < 2e-2
         assert rel_l2(pan_h['pred_masks'][i].cpu(), pan_o['pred_masks'][i]) < 6e-2
     assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 4e-2
+
+
+@pytest.mark.parametrize('K', [2, 5])
+def test_scene_portrait_views(pair, K):
+    """Portrait views in native orientation mixed with landscape ones: transposed DINOv2
+    input, transposed upscaler results, transposed-grid key PE, and (LoftUp) the anisotropic attention-mask resize."""
+    variant, o, h = pair
+    shapes = [(96, 64), (64, 96), (96, 64), (96, 32), (64, 96)]
+    imgs = [tiny.synth_image(i, a, b, 11) for i, (a, b) in enumerate(shapes)]
+    ts = torch.tensor(shapes)
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K)
+    pm_h, pan_h = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K)
+    for i, (a, b) in enumerate(shapes):
+        assert pm_h[i].shape == pm_o[i].shape == (1, a, b, 7)
+        assert pan_h['pred_masks'][i].shape == pan_o['pred_masks'][i].shape
+        assert rel_l2(pm_h[i].cpu(), pm_o[i]) < 2e-2
+        assert rel_l2(pan_h['pred_masks'][i].cpu(), pan_o['pred_masks'][i]) < 6e-2
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 4e-2
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.08
+
+
+def test_panoptic_decoder_portrait(pair):
+    """PanopticDecoder.forward (reference signature) on same-shape portrait views against the oracle."""
+    variant, o, h = pair
+    H, W, n, T = 96, 64, 2, 24
+    g = torch.Generator().manual_seed(5)
+    feats = tuple(torch.randn(1, n, T, 128, generator=g) for _ in range(3))
+    imgs = torch.stack([tiny.synth_image(i, H, W, 3) for i in range(n)])[None]
+    pos = grid_pos(6, 4)[None].expand(1, n, -1, -1).contiguous()
+    ts = torch.tensor([[[H, W]] * n])
+    with torch.no_grad():
+        ro = o.panoptic_decoder(feats, imgs, pos, ts, tiny.NAMES, max_bs=1)
+        rh = h.panoptic_decoder(tuple(f.to(DEV) for f in feats), imgs.to(DEV), pos.to(DEV), ts, tiny.NAMES, max_bs=1)
+    assert rh['pred_masks'].shape == ro['pred_masks'].shape
+    assert rel_l2(rh['out_queries'].cpu(), ro['out_queries']) < 3e-2
+    assert rel_l2(rh['pred_masks'].cpu(), ro['pred_masks']) < 4e-2

@@ -416,3 +416,17 @@ def test_loftup_guidance_and_groupnorm():
     hip.loftup_lr_pe(lr.biases.detach().to(dev()), o, 8, 2, 3, 5)
     assert float((o[:15, 8:28].float().cpu() - refl).abs().max()) < 2e-2
     assert torch.equal(o[:15], o[15:])
+
+
+@pytest.mark.parametrize('Hs,Ws,Hd,Wd', [(48, 32, 4, 6), (32, 48, 4, 6), (24, 40, 7, 3), (8, 8, 16, 12)])
+def test_resize_bilinear(Hs, Ws, Hd, Wd):
+    """pst_resize_bilinear_bf16 == F.interpolate(mode='bilinear', align_corners=False) on pixel-major features."""
+    from panst3r_amd import hip
+    n, C = 3, 32
+    DEV = 'cuda:0'
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, Hs, Ws, C, generator=g).to(torch.bfloat16)
+    ref = F.interpolate(x.float().permute(0, 3, 1, 2), size=(Hd, Wd), mode='bilinear', align_corners=False).permute(0, 2, 3, 1)
+    out = torch.empty(n * Hd * Wd, C, dtype=torch.bfloat16, device=DEV)
+    hip.resize_bilinear(x.to(DEV), out, n, Hs, Ws, Hd, Wd, C)
+    assert float((out.float().cpu().reshape(n, Hd, Wd, C) - ref).abs().max()) < 2e-2

@@ -71,6 +71,29 @@ def test_multi_aspect_ratio_scene_matches_reference_formulation(variant, K):
         assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
 
 
+PORTRAIT_AR = [(96, 64), (64, 96), (96, 64), (96, 32), (64, 96)]
+
+
+@pytest.mark.parametrize('variant,K', [('v1', 3), ('v2', 5), ('v2', 2)])
+def test_portrait_scene_matches_reference_formulation(variant, K):
+    """Portrait views (native orientation, true_shape = tensor shape as in tools/demo_panst3r.py:107) mixed with
+    landscape ones: DINOv2 runs on the transposed image (model/dino.py:15-47), the upscaler results are handed back
+    transposed (utils.py:47-49), the key PE is that of the transposed grid (mask_transformer.py:106-119) and, for LoftUp,
+    the attention-mask resize of the native masks to the transposed key grid is anisotropic (:283-287)."""
+    V = len(PORTRAIT_AR)
+    model = tiny.build(tiny.OracleNS, variant)
+    imgs = [tiny.synth_image(i, h, w, 11) for i, (h, w) in enumerate(PORTRAIT_AR)]
+    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor(PORTRAIT_AR), tiny.NAMES, num_keyframes=K)
+    with torch.no_grad():
+        res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], V, None, None, K, tiny.NAMES, shapes=PORTRAIT_AR)
+    assert rel_l2(scene['out_queries'], pan_ref['out_queries']) < 1e-4
+    assert rel_l2(scene['pred_logits'], pan_ref['pred_logits']) < 1e-4
+    for i in range(V):
+        assert res[i][0].shape == pm_ref[i].shape and res[i][1].shape == pan_ref['pred_masks'][i].shape
+        assert rel_l2(res[i][0], pm_ref[i]) < 1e-5
+        assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
+
+
 def _worker(rank, world, port, variant, V, K, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 6
+#define PST_ABI_VERSION 7
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -158,6 +158,32 @@ int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* sta
 /* lr_pe: low-res positional features of loftup.py:159-162 (ImplicitFeaturizer(color_feats=False, n_freqs=5)):
  * writes bf16 [h*w, 20] into columns [col0, col0+20) of a row-major buffer with ld (per view identical). */
 int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int nimg, int h, int w, void* stream);
+
+/* ---------------------------------------------------------------- panoptic post-processing
+ * GPU replacement of `panoptic_inference_v2` (engine/postprocess.py:14-130; called by tools/demo_panst3r.py:242 with
+ * device='cpu').  Everything stays on the device; the surviving-query set is a flag array, so a filter round needs no
+ * host sync.  Per scene:  pp_scores once;  per round {per view: pp_sigmoid, pp_argmax};  pp_select;  after the last
+ * round per view: pp_finalize.  Q <= 1024.
+ *   pp_scores   class logits fp32 [Q,Ncls] -> scores = max sigmoid (or softmax(sigmoid/T).max when temperature > 0),
+ *               labels = first argmax, keep = max sigmoid > cls_threshold                       (:40-47)
+ *   pp_sigmoid  mask logits fp32 [Q,P] of one view -> probabilities [Q,P] for queries with keep != 0  (:20)
+ *   pp_argmax   per pixel of the H x W output: bilinear (align_corners=False) taps of the h x w probabilities of every
+ *               kept query, best_q = argmax_q score_q * m_q (first maximum; -1 when nothing is kept), best_m = m of the
+ *               winner; cnt_orig[q] += #(m_q >= 0.5), cnt_mask[q] += #(best_q == q && m_q >= mask_threshold)
+ *               (integer atomics, accumulated over the views of the scene)                      (:21,64,78,86-88)
+ *   pp_select   keep_out[q] = keep[q] && cnt_mask > 0 && cnt_orig > 0 && !(cnt_mask / cnt_orig < overlap_threshold)
+ *               (double division), seg_id[q] = 1-based running count over the selected queries, 0 otherwise; the two
+ *               counters are reset to 0                                                          (:89-104)
+ *   pp_finalize pan = seg_id[best_q] if best_m >= mask_threshold else 0; conf = best_m or void_confidence (:105-106) */
+int pst_pp_scores(const float* logits, int Q, int Ncls, float cls_threshold, float temperature, float* scores,
+                  int* labels, int* keep, void* stream);
+int pst_pp_sigmoid(const float* logits, const int* keep, float* probs, int Q, int P, void* stream);
+int pst_pp_argmax(const float* probs, const float* scores, const int* keep, int Q, int Hm, int Wm, int H, int W,
+                  float mask_threshold, int* best_q, float* best_m, int* cnt_orig, int* cnt_mask, void* stream);
+int pst_pp_select(const int* keep, int* cnt_orig, int* cnt_mask, int Q, double overlap_threshold, int* keep_out,
+                  int* seg_id, void* stream);
+int pst_pp_finalize(const int* best_q, const float* best_m, const int* seg_id, int n, float mask_threshold,
+                    float void_confidence, int* pan, float* conf, void* stream);
 
 #ifdef __cplusplus
 }

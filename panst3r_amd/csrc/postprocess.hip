@@ -1,0 +1,220 @@
+// Panoptic post-processing on the GPU: `panoptic_inference_v2` (reference engine/postprocess.py:14-130).
+//
+// The reference materialises sigmoid + 2x bilinear up-sampled masks [Q, V, H, W] fp32 on the CPU (7.8 GB for 200 queries x
+// 50 views at 384x512) and walks the queries with .item() syncs.  Here the up-sampled probabilities never exist: per view,
+//   pp_sigmoid   low-res logits of the surviving queries -> probabilities (scratch [Q, h*w], reused by every view)
+//   pp_argmax    per output pixel: bilinear taps of every surviving query, score-weighted argmax (:78), and the two area
+//                counts per query (:86-88) -- wave ballots + LDS counters + integer atomics (deterministic)
+//   pp_select    area tests (:89-93) in double like Python's int/int division, segment ids = running count (:104)
+//   pp_finalize  panoptic ids / confidences of the last round (:105-106)
+// All HBM-bound integer / byte work: one coalesced pass over the low-res logits and over the output maps per round; the
+// 4 taps come from L2.  No host sync inside a round: the surviving-query set lives in a device flag array.
+#include "common.h"
+#include "../../include/panst3r_hip.h"
+
+namespace pst {
+
+// ------------------------------------------------------------------ per-query score / label / keep (:40-47)
+__global__ __launch_bounds__(64) void pp_scores_kernel(const float* logits, int Ncls, float cls_thr, float temperature,
+                                                       float* scores, int* labels, int* keep) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const float* row = logits + (int64_t)q * Ncls;
+  float best = -1.f;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < Ncls; c += 64) {
+    const float v = 1.0f / (1.0f + expf(-row[c]));
+    if (v > best) { best = v; bi = c; }                 // strict: first maximal index of this lane's stride
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  float score = best;
+  if (temperature > 0.f) {                               // softmax(sigmoid / T).max(-1) (:46-47): same argmax
+    float sum = 0.f;
+    for (int c = lane; c < Ncls; c += 64) sum += expf((1.0f / (1.0f + expf(-row[c])) - best) / temperature);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    score = 1.0f / sum;
+  }
+  if (lane == 0) {
+    scores[q] = score;
+    labels[q] = bi;
+    keep[q] = best > cls_thr ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------ sigmoid of the surviving queries of one view (:20)
+__global__ __launch_bounds__(256) void pp_sigmoid_kernel(const float* logits, const int* keep, float* probs, int P) {
+  const int q = blockIdx.y;
+  if (!keep[q]) return;
+  const float* src = logits + (int64_t)q * P;
+  float* dst = probs + (int64_t)q * P;
+  if ((P & 3) == 0) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P / 4; i += gridDim.x * 256) {
+      const float4 v = ((const float4*)src)[i];
+      ((float4*)dst)[i] = make_float4(1.0f / (1.0f + expf(-v.x)), 1.0f / (1.0f + expf(-v.y)), 1.0f / (1.0f + expf(-v.z)),
+                                      1.0f / (1.0f + expf(-v.w)));
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) dst[i] = 1.0f / (1.0f + expf(-src[i]));
+  }
+}
+
+// ------------------------------------------------------------------ argmax + area counts of one view (:21,64,78,86-88)
+__global__ __launch_bounds__(256) void pp_argmax_kernel(const float* probs, const float* scores, const int* keep, int Q, int Hm, int Wm,
+                                                        int H, int W, float mask_thr, int* best_q, float* best_m, int* cnt_orig,
+                                                        int* cnt_mask) {
+  extern __shared__ int cnt[];               // [2*Q]: >= 0.5 pixels, owned pixels; then [Q]: ordered list of kept queries
+  __shared__ int wave_cnt[4], nkept;
+  int* klist = cnt + 2 * Q;
+  for (int i = threadIdx.x; i < 2 * Q; i += 256) cnt[i] = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) nkept = 0;
+  __syncthreads();
+  for (int base = 0; base < Q; base += 256) {          // ordered compaction of the keep flags (ballot + 4-wave prefix)
+    const int q = base + threadIdx.x;
+    const bool k = q < Q && keep[q] != 0;
+    const unsigned long long bal = __ballot(k);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = nkept;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (k) klist[off + __popcll(bal & ((1ull << lane) - 1ull))] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) nkept += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  const int nk = nkept;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = pix < H * W;
+  const int y = valid ? pix / W : 0, x = valid ? pix - (pix / W) * W : 0;
+  // F.interpolate(mode='bilinear', align_corners=False): src = scale * (dst + 0.5) - 0.5 clamped at 0
+  const float sy = fmaxf(((float)Hm / (float)H) * ((float)y + 0.5f) - 0.5f, 0.f);
+  const float sx = fmaxf(((float)Wm / (float)W) * ((float)x + 0.5f) - 0.5f, 0.f);
+  const int y0 = min((int)sy, Hm - 1), x0 = min((int)sx, Wm - 1);
+  const int y1 = min(y0 + 1, Hm - 1), x1 = min(x0 + 1, Wm - 1);
+  const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const int o00 = y0 * Wm + x0, o01 = y0 * Wm + x1, o10 = y1 * Wm + x0, o11 = y1 * Wm + x1;
+  const int64_t plane = (int64_t)Hm * Wm;
+  float bp = -1.f, bm = 0.f;
+  int bq = -1;
+  constexpr int U = 4;                        // queries per step: 16 independent tap loads in flight
+  for (int j0 = 0; j0 < nk; j0 += U) {
+    float t[U][4];
+    int qs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      qs[u] = klist[min(j0 + u, nk - 1)];
+      const float* pq = probs + qs[u] * plane;
+      t[u][0] = pq[o00]; t[u][1] = pq[o01]; t[u][2] = pq[o10]; t[u][3] = pq[o11];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (j0 + u >= nk) break;               // uniform
+      const int q = qs[u];
+      const float m = hy * (hx * t[u][0] + lx * t[u][1]) + ly * (hx * t[u][2] + lx * t[u][3]);
+      const unsigned long long ge = __ballot(valid && m >= 0.5f);
+      if (lane == 0 && ge) atomicAdd(&cnt[q], __popcll(ge));
+      const float p = scores[q] * m;
+      if (p > bp) { bp = p; bq = q; bm = m; }  // strict: first maximal surviving query, like torch.argmax
+    }
+  }
+  if (valid) {
+    best_q[pix] = bq;
+    best_m[pix] = bm;
+    if (bq >= 0 && bm >= mask_thr) atomicAdd(&cnt[Q + bq], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Q; i += 256) {
+    if (cnt[i]) atomicAdd(cnt_orig + i, cnt[i]);
+    if (cnt[Q + i]) atomicAdd(cnt_mask + i, cnt[Q + i]);
+  }
+}
+
+// ------------------------------------------------------------------ area tests + segment ids (:89-104); counters re-armed
+__global__ __launch_bounds__(1024) void pp_select_kernel(const int* keep, int* cnt_orig, int* cnt_mask, int Q, double overlap_thr,
+                                                         int* keep_out, int* seg_id) {
+  __shared__ int sel[1024];
+  const int q = threadIdx.x;
+  int s = 0;
+  if (q < Q) {
+    const int co = cnt_orig[q], cm = cnt_mask[q];
+    s = keep[q] && cm > 0 && co > 0 && !((double)cm / (double)co < overlap_thr);
+    cnt_orig[q] = 0;
+    cnt_mask[q] = 0;
+  }
+  sel[q] = s;
+  __syncthreads();
+  if (q == 0) {
+    int run = 0;
+    for (int i = 0; i < Q; ++i) {
+      if (sel[i]) sel[i] = ++run;
+    }
+  }
+  __syncthreads();
+  if (q < Q) {
+    keep_out[q] = s;
+    seg_id[q] = sel[q];
+  }
+}
+
+// ------------------------------------------------------------------ panoptic ids + confidences of one view (:68-69,105-106)
+__global__ __launch_bounds__(256) void pp_finalize_kernel(const int* best_q, const float* best_m, const int* seg_id, int n, float mask_thr,
+                                                          float void_conf, int* pan, float* conf) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int q = best_q[i];
+  const float m = best_m[i];
+  const int id = (q >= 0 && m >= mask_thr) ? seg_id[q] : 0;
+  pan[i] = id;
+  conf[i] = id > 0 ? m : void_conf;
+}
+
+}  // namespace pst
+
+using namespace pst;
+
+extern "C" int pst_pp_scores(const float* logits, int Q, int Ncls, float cls_threshold, float temperature, float* scores, int* labels,
+                             int* keep, void* stream) {
+  if (!logits || !scores || !labels || !keep || Q <= 0 || Ncls <= 0) { set_error("pp_scores: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(pp_scores_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, logits, Ncls, cls_threshold, temperature, scores, labels, keep);
+  return check_launch("pp_scores");
+}
+
+extern "C" int pst_pp_sigmoid(const float* logits, const int* keep, float* probs, int Q, int P, void* stream) {
+  if (!logits || !keep || !probs || Q <= 0 || P <= 0 || Q > 65535) { set_error("pp_sigmoid: bad argument"); return PST_EINVAL; }
+  const int bx = max(1, min((P / 4 + 255) / 256, 64));
+  hipLaunchKernelGGL(pp_sigmoid_kernel, dim3(bx, Q), dim3(256), 0, (hipStream_t)stream, logits, keep, probs, P);
+  return check_launch("pp_sigmoid");
+}
+
+extern "C" int pst_pp_argmax(const float* probs, const float* scores, const int* keep, int Q, int Hm, int Wm, int H, int W,
+                             float mask_threshold, int* best_q, float* best_m, int* cnt_orig, int* cnt_mask, void* stream) {
+  if (!probs || !scores || !keep || !best_q || !best_m || !cnt_orig || !cnt_mask || Q <= 0 || Q > 1024 || Hm <= 0 || Wm <= 0 || H <= 0 ||
+      W <= 0 || (int64_t)Q * Hm * Wm >= (1ll << 40)) {
+    set_error("pp_argmax: bad argument (Q=%d)", Q); return PST_EINVAL;
+  }
+  const int n = H * W;
+  hipLaunchKernelGGL(pp_argmax_kernel, dim3((n + 255) / 256), dim3(256), 3 * Q * sizeof(int), (hipStream_t)stream, probs, scores, keep, Q,
+                     Hm, Wm, H, W, mask_threshold, best_q, best_m, cnt_orig, cnt_mask);
+  return check_launch("pp_argmax");
+}
+
+extern "C" int pst_pp_select(const int* keep, int* cnt_orig, int* cnt_mask, int Q, double overlap_threshold, int* keep_out, int* seg_id,
+                             void* stream) {
+  if (!keep || !cnt_orig || !cnt_mask || !keep_out || !seg_id || Q <= 0 || Q > 1024) { set_error("pp_select: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(pp_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, keep, cnt_orig, cnt_mask, Q, overlap_threshold, keep_out, seg_id);
+  return check_launch("pp_select");
+}
+
+extern "C" int pst_pp_finalize(const int* best_q, const float* best_m, const int* seg_id, int n, float mask_threshold, float void_confidence,
+                               int* pan, float* conf, void* stream) {
+  if (!best_q || !best_m || !seg_id || !pan || !conf || n <= 0) { set_error("pp_finalize: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(pp_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, best_q, best_m, seg_id, n, mask_threshold,
+                     void_confidence, pan, conf);
+  return check_launch("pp_finalize");
+}

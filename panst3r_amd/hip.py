@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -40,7 +40,7 @@ class AttnParams(C.Structure):
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_rope2d_bf16',
            'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16', 'pst_resize_bilinear_bf16',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
-           'pst_loftup_lr_pe']
+           'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_select', 'pst_pp_finalize']
 
 
 def lib():
@@ -332,3 +332,37 @@ def loftup_lr_pe(biases, out, col0, nimg, h, w):
     _dev(biases, torch.float32); _dev(out, torch.bfloat16)
     _check(lib().pst_loftup_lr_pe(_ptr(biases), _ptr(out), i64(_rowmajor(out)), col0, nimg, h, w, _stream()), 'pst_loftup_lr_pe')
     return out
+
+
+# ------------------------------------------------------------------ panoptic post-processing
+def pp_scores(logits, cls_threshold, temperature, scores, labels, keep):
+    _dev(logits, torch.float32); _dev(scores, torch.float32); _dev(labels, torch.int32); _dev(keep, torch.int32)
+    Q, Ncls = logits.shape
+    _check(lib().pst_pp_scores(_ptr(logits), Q, Ncls, C.c_float(cls_threshold), C.c_float(temperature or 0.0), _ptr(scores), _ptr(labels),
+                               _ptr(keep), _stream()), 'pst_pp_scores')
+
+
+def pp_sigmoid(logits, keep, probs, Q, P):
+    _dev(logits, torch.float32); _dev(keep, torch.int32); _dev(probs, torch.float32)
+    _check(lib().pst_pp_sigmoid(_ptr(logits), _ptr(keep), _ptr(probs), Q, P, _stream()), 'pst_pp_sigmoid')
+
+
+def pp_argmax(probs, scores, keep, Q, Hm, Wm, H, W, mask_threshold, best_q, best_m, cnt_orig, cnt_mask):
+    for t, dt in ((probs, torch.float32), (scores, torch.float32), (keep, torch.int32), (best_q, torch.int32), (best_m, torch.float32),
+                  (cnt_orig, torch.int32), (cnt_mask, torch.int32)):
+        _dev(t, dt)
+    _check(lib().pst_pp_argmax(_ptr(probs), _ptr(scores), _ptr(keep), Q, Hm, Wm, H, W, C.c_float(mask_threshold), _ptr(best_q), _ptr(best_m),
+                               _ptr(cnt_orig), _ptr(cnt_mask), _stream()), 'pst_pp_argmax')
+
+
+def pp_select(keep, cnt_orig, cnt_mask, Q, overlap_threshold, keep_out, seg_id):
+    for t in (keep, cnt_orig, cnt_mask, keep_out, seg_id):
+        _dev(t, torch.int32)
+    _check(lib().pst_pp_select(_ptr(keep), _ptr(cnt_orig), _ptr(cnt_mask), Q, C.c_double(overlap_threshold), _ptr(keep_out), _ptr(seg_id),
+                               _stream()), 'pst_pp_select')
+
+
+def pp_finalize(best_q, best_m, seg_id, n, mask_threshold, void_confidence, pan, conf):
+    _dev(best_q, torch.int32); _dev(best_m, torch.float32); _dev(seg_id, torch.int32); _dev(pan, torch.int32); _dev(conf, torch.float32)
+    _check(lib().pst_pp_finalize(_ptr(best_q), _ptr(best_m), _ptr(seg_id), n, C.c_float(mask_threshold), C.c_float(void_confidence), _ptr(pan),
+                                 _ptr(conf), _stream()), 'pst_pp_finalize')

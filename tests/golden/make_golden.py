@@ -205,19 +205,41 @@ def main():
     out_s = de(imgsq, torch.tensor([[80, 80]]))
     save('dino_tiny', img=npy(img), out=npy(out_l), imgsq=npy(imgsq), outsq=npy(out_s))
 
-    # ---------------- G6: panoptic_inference_v2 on fixed logits ("next" row 8(f)1)
+    golden_postprocess(R)
+
+
+def golden_postprocess(R):
+    """G6: panoptic_inference_v2 (engine/postprocess.py:14-130) on fixed logits.  The function
+    overwrites its mask list in place (:19-21), so the inputs are saved from clones taken before the call."""
     PP = R['postprocess']
-    logits = rnd(60, 1, 16, 5) * 2
-    masks = [rnd(61 + i, 1, 16, 16, 24) * 3 for i in range(3)]
-    size = np.array([[32, 48]] * 3)
-    try:
-        res = PP.panoptic_inference_v2(logits, masks, size, label_mode='sigmoid', device='cpu', multi_ar=True)
-        pan = res[0]
-        save('postprocess_v2', logits=npy(logits), masks=npy(masks), size=size,
-             pan=[np.asarray(p) for p in npy(pan['pan'])], conf=[np.asarray(c) for c in npy(pan['conf'])])
-    except Exception as e:  # pragma: no cover
-        print('postprocess golden skipped:', repr(e))
+
+    def case(tag, seed, Q, ncls, lowres, sizes, **kw):
+        g = np.random.Generator(np.random.PCG64(seed))
+        logits = rnd(seed, 1, Q, ncls) * 2
+        masks = []
+        for i, (h, w) in enumerate(lowres):                # blobs: rectangles at +3 over a -3 background, plus noise
+            m = rnd(seed + 1 + i, 1, Q, h, w) * 1.5 - 3.0
+            for q in range(Q):
+                y0, x0 = int(g.integers(0, h - 2)), int(g.integers(0, w - 2))
+                y1, x1 = int(g.integers(y0 + 2, h + 1)), int(g.integers(x0 + 2, w + 1))
+                m[0, q, y0:y1, x0:x1] += 6.0
+            m[0, 1] = m[0, 0] * 0.9 + 0.2                  # near-duplicate of query 0: loses the argmax almost everywhere
+            masks.append(m)
+        size = np.array(sizes)
+        res = PP.panoptic_inference_v2(logits.clone(), [m.clone() for m in masks], size, label_mode='sigmoid', device='cpu',
+                                       multi_ar=True, **kw)[0]
+        info = np.array([[d['id'], d['query_id'], d['category_id']] for d in res['segments_info']], dtype=np.int64).reshape(-1, 3)
+        save('postprocess_v2' + tag, logits=npy(logits), masks=npy(masks), size=size, info=info,
+             pan=[np.asarray(p) for p in npy(res['pan'])], conf=[np.asarray(c) for c in npy(res['conf'])])
+
+    case('', 60, 16, 5, [(16, 24)] * 3, [[32, 48]] * 3)
+    case('_multiar', 70, 24, 7, [(16, 24), (12, 24), (24, 16)], [[32, 48], [24, 48], [48, 32]])
+    case('_temp', 80, 12, 4, [(8, 12)] * 2, [[16, 24]] * 2, temperature=0.1, cls_threshold=0.3, overlap_threshold=0.6)
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'postprocess':      # regenerate G6 only
+        with torch.no_grad():
+            golden_postprocess(import_reference())
+    else:
+        main()

@@ -138,3 +138,21 @@ def test_dino_tiny(golden):
     de = fill_module_(OD.DinoV2Encoder(**cfg).eval(), seed=14)
     close(de(g.t('img'), torch.tensor([[64, 96], [64, 96]])), g.t('out'))
     close(de(g.t('imgsq'), torch.tensor([[80, 80]])), g.t('outsq'))
+
+
+PP_CASES = {'': {}, '_multiar': {}, '_temp': dict(temperature=0.1, cls_threshold=0.3, overlap_threshold=0.6)}
+
+
+@pytest.mark.parametrize('tag', list(PP_CASES))
+def test_postprocess_v2(golden, tag):
+    """oracle.postprocess.panoptic_inference_v2 == the reference's function (engine/postprocess.py:14-130) on the
+    fixed inputs of golden G6: identical segment ids / query ids / categories, identical panoptic maps, conf to 1e-6."""
+    from oracle.postprocess import panoptic_inference_v2
+    g = golden('postprocess_v2' + tag)
+    res = panoptic_inference_v2(g.t('logits'), g.lst('masks'), g.z['size'], **PP_CASES[tag])[0]
+    info = [[d['id'], d['query_id'], d['category_id']] for d in res['segments_info']]
+    assert info == g.z['info'].tolist()
+    for a, b in zip(res['pan'], g.lst('pan')):
+        assert torch.equal(a, b)
+    for a, b in zip(res['conf'], g.lst('conf')):
+        assert float((a - b).abs().max()) < 1e-6

@@ -109,7 +109,9 @@ def _worker(rank, world, port, variant, V, K, q):
             res, scene = _scene(variant, V, K, rank, world, None)
         t = torch.arange(6, dtype=torch.bfloat16).reshape(3, 2) + 10 * rank if rank == 0 else torch.arange(4, dtype=torch.bfloat16).reshape(2, 2) + 10
         g = gather_keyframe_rows(t, 5, 1, rank, world, None)                # K=5 dealt 3/2 over two ranks, bf16 payload
-        q.put((rank, {k: (v[0].clone(), v[1].clone()) for k, v in res.items()}, scene['out_queries'].clone(), g.float()))
+        # numpy payloads are pickled by value: torch tensors would travel as shared-memory fds that die with this process
+        q.put((rank, {k: (v[0].numpy().copy(), v[1].numpy().copy()) for k, v in res.items()}, scene['out_queries'].numpy().copy(),
+               g.float().numpy().copy()))
     except Exception as e:      # fail fast instead of letting the parent wait for the queue timeout
         q.put((rank, repr(e), None, None))
         raise
@@ -142,9 +144,9 @@ def test_two_rank_gloo_equals_single(variant, V, K):
         ref, ref_scene = _scene(variant, V, K)
     merged = {}
     for rank, res, outq, g in got:
-        assert torch.equal(outq, ref_scene['out_queries'])                  # identical frozen queries on every rank
-        assert torch.equal(g, torch.tensor([[0., 1.], [10., 11.], [2., 3.], [12., 13.], [4., 5.]]))
-        merged.update(res)
+        assert torch.equal(torch.from_numpy(outq), ref_scene['out_queries'])                  # identical frozen queries on every rank
+        assert torch.equal(torch.from_numpy(g), torch.tensor([[0., 1.], [10., 11.], [2., 3.], [12., 13.], [4., 5.]]))
+        merged.update({k: (torch.from_numpy(a), torch.from_numpy(b)) for k, (a, b) in res.items()})
     assert sorted(merged) == list(range(V))
     for i in range(V):
         assert torch.equal(merged[i][0], ref[i][0]) and torch.equal(merged[i][1], ref[i][1])

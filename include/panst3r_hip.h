@@ -171,6 +171,9 @@ int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int n
  *               kept query, best_q = argmax_q score_q * m_q (first maximum; -1 when nothing is kept), best_m = m of the
  *               winner; cnt_orig[q] += #(m_q >= 0.5), cnt_mask[q] += #(best_q == q && m_q >= mask_threshold)
  *               (integer atomics, accumulated over the views of the scene)                      (:21,64,78,86-88)
+ *   pp_argmax_logits  the same from the raw logits: one block per 8x32 output tile keeps the sigmoid of the tile's
+ *               low-res footprint in LDS (8 queries at a time), so the logits are read once and no probability scratch
+ *               exists.  Returns PST_EINVAL when the footprint does not fit (strong down-sampling): use the pair above.
  *   pp_select   keep_out[q] = keep[q] && cnt_mask > 0 && cnt_orig > 0 && !(cnt_mask / cnt_orig < overlap_threshold)
  *               (double division), seg_id[q] = 1-based running count over the selected queries, 0 otherwise; the two
  *               counters are reset to 0                                                          (:89-104)
@@ -180,6 +183,8 @@ int pst_pp_scores(const float* logits, int Q, int Ncls, float cls_threshold, flo
 int pst_pp_sigmoid(const float* logits, const int* keep, float* probs, int Q, int P, void* stream);
 int pst_pp_argmax(const float* probs, const float* scores, const int* keep, int Q, int Hm, int Wm, int H, int W,
                   float mask_threshold, int* best_q, float* best_m, int* cnt_orig, int* cnt_mask, void* stream);
+int pst_pp_argmax_logits(const float* logits, const float* scores, const int* keep, int Q, int Hm, int Wm, int H, int W,
+                         float mask_threshold, int* best_q, float* best_m, int* cnt_orig, int* cnt_mask, void* stream);
 int pst_pp_select(const int* keep, int* cnt_orig, int* cnt_mask, int Q, double overlap_threshold, int* keep_out,
                   int* seg_id, void* stream);
 int pst_pp_finalize(const int* best_q, const float* best_m, const int* seg_id, int n, float mask_threshold,

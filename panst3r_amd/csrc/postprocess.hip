@@ -135,6 +135,125 @@ __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* probs, cons
   }
 }
 
+// ------------------------------------------------------------------ fused variant: logits -> sigmoid -> LDS tile -> taps
+// One block owns a PP_TH x PP_TW output tile.  The low-res footprint of the tile (rh x rw input pixels, a 6 x 18 patch for
+// the usual 2x up-sampling) is loaded ONCE per query, coalesced, pushed through the sigmoid and kept in LDS, CH queries
+// at a time; the 4 bilinear taps of a thread's output pixel then come from LDS.  Against pp_sigmoid + pp_argmax this drops the
+// probability scratch round trip and ~10x of the global tap loads.
+constexpr int PP_TH = 8, PP_TW = 32;          // one output pixel per thread
+constexpr int PP_SLOTS = 4;                   // tile elements a thread stages per chunk: CH * rh * rw <= 256 * PP_SLOTS
+
+__device__ __forceinline__ void pp_compact_keep(const int* keep, int Q, int* klist, int* wave_cnt, int* nkept) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) *nkept = 0;
+  __syncthreads();
+  for (int base = 0; base < Q; base += 256) {          // ordered compaction of the keep flags (ballot + 4-wave prefix)
+    const int q = base + threadIdx.x;
+    const bool k = q < Q && keep[q] != 0;
+    const unsigned long long bal = __ballot(k);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = *nkept;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (k) klist[off + __popcll(bal & ((1ull << lane) - 1ull))] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) *nkept += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void pp_argmax_fused_kernel(const float* logits, const float* scores, const int* keep, int Q, int Hm, int Wm,
+                                                              int H, int W, float mask_thr, int rh, int rw, int CH, int* best_q,
+                                                              float* best_m, int* cnt_orig, int* cnt_mask) {
+  extern __shared__ int smem_i[];            // [2*Q] counters, [Q] kept list, then CH tiles of rh*rw floats
+  __shared__ int wave_cnt[4], nkept;
+  int* cnt = smem_i;
+  int* klist = smem_i + 2 * Q;
+  float* tile = (float*)(smem_i + 3 * Q);
+  for (int i = threadIdx.x; i < 2 * Q; i += 256) cnt[i] = 0;
+  pp_compact_keep(keep, Q, klist, wave_cnt, &nkept);
+  const int nk = nkept;
+  const int lane = threadIdx.x & 63;
+  const int tiles_x = (W + PP_TW - 1) / PP_TW;
+  const int ty0 = (blockIdx.x / tiles_x) * PP_TH, tx0 = (blockIdx.x % tiles_x) * PP_TW;
+  const float scy = (float)Hm / (float)H, scx = (float)Wm / (float)W;
+  // first input row / column any pixel of the tile touches (same formula as the per-pixel one below)
+  const int in_y0 = min((int)fmaxf(scy * ((float)ty0 + 0.5f) - 0.5f, 0.f), Hm - 1);
+  const int in_x0 = min((int)fmaxf(scx * ((float)tx0 + 0.5f) - 0.5f, 0.f), Wm - 1);
+  const int x = tx0 + (threadIdx.x & (PP_TW - 1)), y = ty0 + (threadIdx.x >> 5);
+  const bool valid = y < H && x < W;
+  const float sx = fmaxf(scx * ((float)x + 0.5f) - 0.5f, 0.f), sy = fmaxf(scy * ((float)y + 0.5f) - 0.5f, 0.f);
+  const int x0 = min((int)sx, Wm - 1), x1 = min(x0 + 1, Wm - 1);
+  const int y0 = min((int)sy, Hm - 1), y1 = min(y0 + 1, Hm - 1);
+  const float lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f), hx = 1.f - lx;
+  const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), hy = 1.f - ly;
+  // tile-local tap offsets (clamped: pixels beyond the image are never used)
+  const int r0 = min(y0 - in_y0, rh - 1) * rw, r1 = min(y1 - in_y0, rh - 1) * rw;
+  const int c0 = min(x0 - in_x0, rw - 1), c1 = min(x1 - in_x0, rw - 1);
+  const int t00 = r0 + c0, t01 = r0 + c1, t10 = r1 + c0, t11 = r1 + c1;
+  const int rsz = rh * rw;
+  const int64_t plane = (int64_t)Hm * Wm;
+  // staging slots of this thread: element idx = tid + 256*s of the chunk -> (query u of the chunk, global offset)
+  int su[PP_SLOTS], sg[PP_SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < PP_SLOTS; ++sl) {
+    const int idx = threadIdx.x + 256 * sl;
+    const int u = idx / rsz, r = idx - u * rsz;
+    const int iy = r / rw, ix = r - iy * rw;
+    su[sl] = idx < CH * rsz ? u : -1;
+    sg[sl] = min(in_y0 + iy, Hm - 1) * Wm + min(in_x0 + ix, Wm - 1);
+  }
+  float bp = -1.f, bm = 0.f;
+  int bq = -1;
+  float pre[PP_SLOTS];                        // next chunk's logits, in flight while the current chunk is consumed
+  auto fetch = [&](int j0) {
+    const int nq = min(CH, nk - j0);
+#pragma unroll
+    for (int sl = 0; sl < PP_SLOTS; ++sl)
+      pre[sl] = (su[sl] >= 0 && su[sl] < nq) ? logits[klist[j0 + su[sl]] * plane + sg[sl]] : 0.f;
+  };
+  if (nk > 0) fetch(0);
+  for (int j0 = 0; j0 < nk; j0 += CH) {
+    __syncthreads();                          // previous chunk fully consumed
+    const int nq = min(CH, nk - j0);
+#pragma unroll
+    for (int sl = 0; sl < PP_SLOTS; ++sl)
+      if (su[sl] >= 0 && su[sl] < nq) tile[threadIdx.x + 256 * sl] = 1.0f / (1.0f + expf(-pre[sl]));
+    __syncthreads();
+    if (j0 + CH < nk) fetch(j0 + CH);
+    for (int u = 0; u < nq; u += 2) {         // two queries per step: their 8 LDS taps are independent
+      const int qa = klist[j0 + u], qb = klist[j0 + min(u + 1, nq - 1)];
+      const float* ta = tile + u * rsz;
+      const float* tb = tile + min(u + 1, nq - 1) * rsz;
+      const float a00 = ta[t00], a01 = ta[t01], a10 = ta[t10], a11 = ta[t11];
+      const float b00 = tb[t00], b01 = tb[t01], b10 = tb[t10], b11 = tb[t11];
+      const float sa = scores[qa], sb = scores[qb];
+      const float ma = hy * (hx * a00 + lx * a01) + ly * (hx * a10 + lx * a11);
+      const float mb = hy * (hx * b00 + lx * b01) + ly * (hx * b10 + lx * b11);
+      const unsigned long long ga = __ballot(valid && ma >= 0.5f);
+      const unsigned long long gb = __ballot(valid && mb >= 0.5f && u + 1 < nq);
+      if (lane == 0) {
+        if (ga) atomicAdd(&cnt[qa], __popcll(ga));
+        if (gb) atomicAdd(&cnt[qb], __popcll(gb));
+      }
+      const float pa = sa * ma, pb = sb * mb;
+      if (pa > bp) { bp = pa; bq = qa; bm = ma; }
+      if (u + 1 < nq && pb > bp) { bp = pb; bq = qb; bm = mb; }
+    }
+  }
+  if (valid) {
+    const int pix = y * W + x;
+    best_q[pix] = bq;
+    best_m[pix] = bm;
+    if (bq >= 0 && bm >= mask_thr) atomicAdd(&cnt[Q + bq], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Q; i += 256) {
+    if (cnt[i]) atomicAdd(cnt_orig + i, cnt[i]);
+    if (cnt[Q + i]) atomicAdd(cnt_mask + i, cnt[Q + i]);
+  }
+}
+
 // ------------------------------------------------------------------ area tests + segment ids (:89-104); counters re-armed
 __global__ __launch_bounds__(1024) void pp_select_kernel(const int* keep, int* cnt_orig, int* cnt_mask, int Q, double overlap_thr,
                                                          int* keep_out, int* seg_id) {
@@ -202,6 +321,24 @@ extern "C" int pst_pp_argmax(const float* probs, const float* scores, const int*
   hipLaunchKernelGGL(pp_argmax_kernel, dim3((n + 255) / 256), dim3(256), 3 * Q * sizeof(int), (hipStream_t)stream, probs, scores, keep, Q,
                      Hm, Wm, H, W, mask_threshold, best_q, best_m, cnt_orig, cnt_mask);
   return check_launch("pp_argmax");
+}
+
+extern "C" int pst_pp_argmax_logits(const float* logits, const float* scores, const int* keep, int Q, int Hm, int Wm, int H, int W,
+                                    float mask_threshold, int* best_q, float* best_m, int* cnt_orig, int* cnt_mask, void* stream) {
+  if (!logits || !scores || !keep || !best_q || !best_m || !cnt_orig || !cnt_mask || Q <= 0 || Q > 1024 || Hm <= 0 || Wm <= 0 || H <= 0 ||
+      W <= 0 || (int64_t)Q * Hm * Wm >= (1ll << 40)) {
+    set_error("pp_argmax_logits: bad argument (Q=%d)", Q); return PST_EINVAL;
+  }
+  // low-res footprint of a PP_TH x PP_TW output tile (+1 row/column for the second tap, +1 for the fractional start)
+  const int rh = min(Hm, (int)ceilf((float)PP_TH * (float)Hm / (float)H) + 2);
+  const int rw = min(Wm, (int)ceilf((float)PP_TW * (float)Wm / (float)W) + 2);
+  const int CH = min(8, 256 * PP_SLOTS / (rh * rw));
+  if (CH < 1) { set_error("pp_argmax_logits: footprint %dx%d of an output tile exceeds the LDS budget (use pp_sigmoid + pp_argmax)", rh, rw); return PST_EINVAL; }
+  const int tiles = ((H + PP_TH - 1) / PP_TH) * ((W + PP_TW - 1) / PP_TW);
+  const size_t lds = 3 * Q * sizeof(int) + (size_t)CH * rh * rw * sizeof(float);
+  hipLaunchKernelGGL(pp_argmax_fused_kernel, dim3(tiles), dim3(256), lds, (hipStream_t)stream, logits, scores, keep, Q, Hm, Wm, H, W,
+                     mask_threshold, rh, rw, CH, best_q, best_m, cnt_orig, cnt_mask);
+  return check_launch("pp_argmax_logits");
 }
 
 extern "C" int pst_pp_select(const int* keep, int* cnt_orig, int* cnt_mask, int Q, double overlap_threshold, int* keep_out, int* seg_id,

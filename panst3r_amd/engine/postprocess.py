@@ -42,14 +42,22 @@ def panoptic_inference_v2(mask_cls, mask_pred, true_shape, label_mode='sigmoid',
     labels, keep = torch.empty(Q, **i32), torch.empty(Q, **i32)
     cnt_orig, cnt_mask, seg_id = torch.zeros(Q, **i32), torch.zeros(Q, **i32), torch.zeros(Q, **i32)
     hip.pp_scores(logits, cls_threshold, temperature, scores, labels, keep)
-    probs = torch.empty(Q * max(m.shape[-2] * m.shape[-1] for m in views), dtype=torch.float32, device=device)   # scratch, reused per view
+    fused = [hip.pp_fused_fits(Q, m.shape[-2], m.shape[-1], shapes[i][0], shapes[i][1]) for i, m in enumerate(views)]
+    probs = None
+    if not all(fused):     # strong down-sampling: the tile footprint does not fit in LDS -> probability scratch, reused per view
+        probs = torch.empty(Q * max(m.shape[-2] * m.shape[-1] for m in views), dtype=torch.float32, device=device)
     best_q = [torch.empty(h * w, **i32) for h, w in shapes]
     best_m = [torch.empty(h * w, dtype=torch.float32, device=device) for h, w in shapes]
     for _ in range(max(int(niters), 1)):
         for i, m in enumerate(views):
             hm, wm = m.shape[-2:]
-            hip.pp_sigmoid(m, keep, probs, Q, hm * wm)
-            hip.pp_argmax(probs, scores, keep, Q, hm, wm, shapes[i][0], shapes[i][1], mask_threshold, best_q[i], best_m[i], cnt_orig, cnt_mask)
+            if fused[i]:
+                hip.pp_argmax_logits(m, scores, keep, Q, hm, wm, shapes[i][0], shapes[i][1], mask_threshold, best_q[i], best_m[i], cnt_orig,
+                                     cnt_mask)
+            else:
+                hip.pp_sigmoid(m, keep, probs, Q, hm * wm)
+                hip.pp_argmax(probs, scores, keep, Q, hm, wm, shapes[i][0], shapes[i][1], mask_threshold, best_q[i], best_m[i], cnt_orig,
+                              cnt_mask)
         hip.pp_select(keep, cnt_orig, cnt_mask, Q, overlap_threshold, keep, seg_id)        # keep <- this round's selection
     pan, conf = [], []
     for i, (h, w) in enumerate(shapes):

@@ -40,7 +40,7 @@ class AttnParams(C.Structure):
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_rope2d_bf16',
            'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16', 'pst_resize_bilinear_bf16',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
-           'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_select', 'pst_pp_finalize']
+           'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize']
 
 
 def lib():
@@ -353,6 +353,22 @@ def pp_argmax(probs, scores, keep, Q, Hm, Wm, H, W, mask_threshold, best_q, best
         _dev(t, dt)
     _check(lib().pst_pp_argmax(_ptr(probs), _ptr(scores), _ptr(keep), Q, Hm, Wm, H, W, C.c_float(mask_threshold), _ptr(best_q), _ptr(best_m),
                                _ptr(cnt_orig), _ptr(cnt_mask), _stream()), 'pst_pp_argmax')
+
+
+def pp_fused_fits(Q, Hm, Wm, H, W):
+    """host copy of pst_pp_argmax_logits' footprint rule (8x32 output tiles, <= 1024 staged low-res pixels per query)."""
+    import math
+    rh = min(Hm, math.ceil(8 * Hm / H) + 2)
+    rw = min(Wm, math.ceil(32 * Wm / W) + 2)
+    return 1024 // (rh * rw) >= 1
+
+
+def pp_argmax_logits(logits, scores, keep, Q, Hm, Wm, H, W, mask_threshold, best_q, best_m, cnt_orig, cnt_mask):
+    for t, dt in ((logits, torch.float32), (scores, torch.float32), (keep, torch.int32), (best_q, torch.int32), (best_m, torch.float32),
+                  (cnt_orig, torch.int32), (cnt_mask, torch.int32)):
+        _dev(t, dt)
+    _check(lib().pst_pp_argmax_logits(_ptr(logits), _ptr(scores), _ptr(keep), Q, Hm, Wm, H, W, C.c_float(mask_threshold), _ptr(best_q),
+                                      _ptr(best_m), _ptr(cnt_orig), _ptr(cnt_mask), _stream()), 'pst_pp_argmax_logits')
 
 
 def pp_select(keep, cnt_orig, cnt_mask, Q, overlap_threshold, keep_out, seg_id):

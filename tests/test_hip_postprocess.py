@@ -80,3 +80,17 @@ def test_postprocess_stacked_and_cpu_inputs():
     _compare({'segments_info': res['segments_info'], 'pan': list(res['pan']), 'conf': list(res['conf'])}, ref)
     with pytest.raises(RuntimeError):
         panoptic_inference_v2(logits, torch.cat(masks), (48, 64), device='cpu')
+
+
+def test_postprocess_downsampling_fallback():
+    """true_shape smaller than the mask grid (4x down-sampling): the LDS-tiled kernel's footprint does not fit, the wrapper
+    takes the pp_sigmoid + pp_argmax pair; same result contract."""
+    from panst3r_amd.engine import panoptic_inference_v2
+    from panst3r_amd import hip
+    from oracle.postprocess import panoptic_inference_v2 as ref_fn
+    assert not hip.pp_fused_fits(24, 96, 256, 24, 64) and hip.pp_fused_fits(200, 192, 256, 384, 512)
+    logits, masks = _blobs(13, 24, 5, [(96, 256)] * 2, maxfrac=0.4)
+    size = np.array([[24, 64]] * 2)
+    ref = ref_fn(logits, [m.clone() for m in masks], size)[0]
+    res = panoptic_inference_v2(logits.to(DEV), [m.to(DEV) for m in masks], size, multi_ar=True)[0]
+    _compare(res, ref, frac=2e-3)

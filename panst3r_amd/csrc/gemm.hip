@@ -38,15 +38,45 @@ __device__ __forceinline__ int perm_row(int row) {
 
 // Whole-row write-back of the LDS-staged C tile: thread -> (row, 16-B chunk); consecutive lanes = consecutive bytes of one
 // output row.  F32: fp32 output (residual values were prefetched into resv by the caller), else bf16 output.
-template <int BM, bool F32>
-__device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* smem, int tid, int m0, int n0, int pitch, int nch,
+template <int BM, int BN, bool F32>
+__device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* smem, int tid, int m0, int n0,
                                           const float4 (&resv)[BM / 8]) {
+  constexpr int pitch = BN * (F32 ? 4 : 2);                 // bytes per LDS C row
+  constexpr int nch = pitch >> 4;                           // 16-B chunks per row (8 / 16 / 32)
+  constexpr int rstep = 256 / nch;
   const int c = tid % nch;                                  // 16-B chunk of the row
   const int epc = F32 ? 4 : 8;                              // elements per chunk
   const int n = n0 + c * epc;
   const int seg = p.ps_p * p.ps_c;
-  const int rstep = 256 / nch;
   const bool pre = F32 && p.res && !p.res_bf16 && p.ps_p == 0;
+  // ---- fast path: interior tile, row-major store (the bulk of the ViT GEMMs).  The padded-view row remap (grp) is
+  // carried incrementally (one integer division per thread instead of one per row), no per-row 64-bit multiplies.
+  if (p.ps_p == 0 && p.res_mod == 0 && m0 + BM <= p.M && n0 + BN <= p.N &&
+      (F32 ? (!p.res || pre) : (!p.res && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0))) {
+    const int r0 = tid / nch;
+    int quot = 0, rem = m0 + r0;
+    if (p.grp_in > 0) { quot = rem / p.grp_in; rem -= quot * p.grp_in; }
+    const bool rope = !F32 && p.rope_hd == 64;
+#pragma unroll
+    for (int it = 0; it < BM / rstep; ++it) {
+      const int r = r0 + it * rstep;
+      uint4 val = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
+      if (rope) val = rope_chunk(p, val, *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4)), m0 + r, n);
+      if (F32 && pre) {
+        float4 f = *(float4*)&val;
+        const float4 q = resv[it];
+        f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
+        val = *(uint4*)&f;
+      }
+      const int orow = p.grp_in > 0 ? quot * p.grp_out + p.grp_off + rem : rem;
+      *(uint4*)((char*)p.C + ((int64_t)orow * p.ldc + n) * (F32 ? 4 : 2)) = val;
+      rem += rstep;
+      if (p.grp_in > 0) {
+        while (rem >= p.grp_in) { rem -= p.grp_in; ++quot; }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < (F32 ? BM / 8 : BM / 16); ++it) {
     const int r = tid / nch + it * rstep;
@@ -260,17 +290,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, c
   // accumulator -> LDS staging instead of forming up to 16 dependent load -> add -> store round trips per tile.
   float4 resv[BM / 8];
   if (!TRANS && p.res && !p.res_bf16 && p.out_fp32 && p.ps_p == 0) {
-    const int nchf = BN >> 2, cf = tid % nchf;
+    constexpr int nchf = BN >> 2, rstepf = 256 / nchf;
+    const int cf = tid % nchf;
     const int nf = n0 + cf * 4;
+    int quot = 0, rem = m0 + tid / nchf;
+    if (p.grp_in > 0) { quot = rem / p.grp_in; rem -= quot * p.grp_in; }
 #pragma unroll
     for (int it = 0; it < BM / 8; ++it) {
-      const int r = tid / nchf + it * (256 / nchf);
+      const int r = tid / nchf + it * rstepf;
       const int m = m0 + r;
       resv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < BM && m < p.M && nf < p.N) {
-        int orow = m;
-        if (p.grp_in > 0) orow = (m / p.grp_in) * p.grp_out + p.grp_off + (m % p.grp_in);
+        const int orow = p.grp_in > 0 ? quot * p.grp_out + p.grp_off + rem : m;
         resv[it] = *(const float4*)(p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : orow) * p.ldr + nf);
+      }
+      rem += rstepf;
+      if (p.grp_in > 0) {
+        while (rem >= p.grp_in) { rem -= p.grp_in; ++quot; }
       }
     }
   }
@@ -351,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, c
     }
   }
   __syncthreads();
-  if (f32o) row_phase<BM, true>(p, smem, tid, m0, n0, pitch, nch, resv);
-  else row_phase<BM, false>(p, smem, tid, m0, n0, pitch, nch, resv);
+  if (f32o) row_phase<BM, BN, true>(p, smem, tid, m0, n0, resv);
+  else row_phase<BM, BN, false>(p, smem, tid, m0, n0, resv);
 }
 
 static int num_cus() {

@@ -178,6 +178,29 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
     const int c = tid % nch;
     const int epc = f32o ? 4 : 8;
     const int n = n0 + c * epc;
+    // ---- fast path (interior tile, row-major bf16 store without residual: fc1 / fused-RoPE q,k): compile-time
+    // chunking, padded-view row remap carried incrementally (one division per thread instead of one per row)
+    if (!f32o && p.ps_p == 0 && p.res_mod == 0 && !p.res && m0 + 256 <= p.M && n0 + 256 <= p.N && (p.ldc & 7) == 0 &&
+        ((uintptr_t)p.C & 15) == 0) {
+      const int cc = tid & 31, r0 = tid >> 5;                  // 32 chunks per 512-B row, 16 rows per sweep
+      const int nn = n0 + cc * 8;
+      int quot = 0, rem = m0 + r0;
+      if (p.grp_in > 0) { quot = rem / p.grp_in; rem -= quot * p.grp_in; }
+      const bool rope = p.rope_hd == 64;
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int rr = r0 + it * 16;
+        uint4 val = *(const uint4*)(smem + rr * 512 + ((cc ^ (rr & 31)) << 4));
+        if (rope) val = rope_chunk(p, val, *(const uint4*)(smem + rr * 512 + (((cc ^ 2) ^ (rr & 31)) << 4)), m0 + rr, nn);
+        const int orow = p.grp_in > 0 ? quot * p.grp_out + p.grp_off + rem : rem;
+        *(uint4*)((bf16_t*)p.C + (int64_t)orow * p.ldc + nn) = val;
+        rem += 16;
+        if (p.grp_in > 0) {
+          while (rem >= p.grp_in) { rem -= p.grp_in; ++quot; }
+        }
+      }
+      continue;
+    }
     for (int rr = tid / nch; rr < rows_pass; rr += 512 / nch) {
       const int m = m0 + pass * rows_pass + rr;
       if (m >= p.M || n >= p.N) continue;

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   for (int a = 0; a < QF; ++a) { m_run[a] = NEG; l_run[a] = 0.f; }
 
   const float c_exp = p.scale * 1.4426950408889634f;
+  const float lazy_thr = 8.0f / c_exp;               // 2^8 in the exp2 domain, in score units
   const int tiles_all = (p.Nk + KT - 1) / KT;
   const int tps = (tiles_all + nsplit - 1) / nsplit;
   const int kt_begin = split * tps;
@@ -178,28 +179,50 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][a][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[a], mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[a] - m_new) * c_exp);
-      m_run[a] = m_new;
+      // Lazy rescaling: the running reference m_run only moves when a score exceeds it by more than 2^8 in the exp2
+      // domain (softmax is invariant to the reference; exp values stay <= 256, exact enough in fp32 / bf16), and the
+      // O / l rescale is skipped for the whole wave unless some query column needs it.  Sentinel rows (m_run == NEG)
+      // always take the update when a real key arrives, which wipes their garbage with alpha == 0.
+      const float m_old = m_run[a];
+      const bool need = mx > m_old + lazy_thr;
+      if (__any(need)) {
+        const float m_new = need ? mx : m_old;
+        const float alpha = __builtin_amdgcn_exp2f((m_old - m_new) * c_exp);
+        m_run[a] = m_new;
+        l_run[a] *= alpha;
+#pragma unroll
+        for (int hf = 0; hf < NHF; ++hf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[hf][a][r] *= alpha;
+      }
+      const float m_ref = m_run[a];
       float ps = 0.f;
       float pv[4][4];
+      if (Mp || tail) {
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f((s[f][a][r] - m_ref) * c_exp);   // subtract first: sentinel - sentinel == 0 exactly
+            pv[f][r] = e;
+            ps += e;
+          }
+      } else {                                   // every score is finite, so is m_ref: one FMA per score
+        const float mc = -m_ref * c_exp;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
 #ifndef PST_ABL_NOEXP
-          const float e = __builtin_amdgcn_exp2f((s[f][a][r] - m_new) * c_exp);   // subtract first: sentinel - sentinel == 0 exactly
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[f][a][r], c_exp, mc));
 #else
-          const float e = (s[f][a][r] - m_new) * c_exp;
+            const float e = fmaf(s[f][a][r], c_exp, mc);
 #endif
-          pv[f][r] = e;
-          ps += e;
-        }
-      l_run[a] = l_run[a] * alpha + ps;
-#pragma unroll
-      for (int hf = 0; hf < NHF; ++hf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[hf][a][r] *= alpha;
+            pv[f][r] = e;
+            ps += e;
+          }
+      }
+      l_run[a] += ps;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         union { bf16x8 v; uint32_t u[4]; } pk;
@@ -271,6 +294,7 @@ __global__ void attn_combine_kernel(const pst_attn_params p, int hd) {
   const int per_row = hd / 4;
   const int64_t total = rows * per_row;
   const float c_exp = p.scale * 1.4426950408889634f;
+  const float lazy_thr = 8.0f / c_exp;               // 2^8 in the exp2 domain, in score units
   const float* ws_o = (const float*)p.ws;
   const float* ws_ml = ws_o + (int64_t)p.nsplit * rows * hd;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {

@@ -162,6 +162,10 @@ def main():
                        'scene_algorithmic_tflop': round(scene_flops / 1e12, 2),
                        'scene_mfma_frac': round(scene_flops / (elapsed / args.steps) / world / (PEAK_BF16_TFLOPS * 1e12), 4)},
         }
+        if timer is not None and os.environ.get('PST_SHAPE_PROFILE') == '1':      # per-shape table of the instrumented step (stderr)
+            rows = sorted(timer.by_tag().items(), key=lambda kv: -kv[1]['ms'])
+            for (name, tag), d in rows[:40]:
+                print('%-24s %-62s x%-4d %8.2f ms %7.1f TF' % (name, tag, d['launches'], d['ms'], d['flops'] / (d['ms'] * 1e-3) / 1e12), file=sys.stderr)
         if timer is not None:
             summ = timer.summary()
             dom = max(summ, key=lambda k: summ[k]['ms'])

@@ -52,13 +52,29 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
   // ---- fast path: interior tile, row-major store (the bulk of the ViT GEMMs).  The padded-view row remap (grp) is
   // carried incrementally (one integer division per thread instead of one per row), no per-row 64-bit multiplies.
   if (p.ps_p == 0 && p.res_mod == 0 && m0 + BM <= p.M && n0 + BN <= p.N &&
-      (F32 ? (!p.res || pre) : (!p.res && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0))) {
+      (F32 ? (!p.res || pre) : ((!p.res || p.res_bf16) && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0))) {
     const int r0 = tid / nch;
     int quot = 0, rem = m0 + r0;
     if (p.grp_in > 0) { quot = rem / p.grp_in; rem -= quot * p.grp_in; }
     const bool rope = !F32 && p.rope_hd == 64;
+    const bool resb = !F32 && p.res != nullptr;             // bf16 residual stream (LoftUp blocks, HBM-bound GEMMs)
+    constexpr int NIT = BM / rstep;
+    int orow[NIT];
 #pragma unroll
-    for (int it = 0; it < BM / rstep; ++it) {
+    for (int it = 0; it < NIT; ++it) {
+      orow[it] = p.grp_in > 0 ? quot * p.grp_out + p.grp_off + rem : rem;
+      rem += rstep;
+      if (p.grp_in > 0) {
+        while (rem >= p.grp_in) { rem -= p.grp_in; ++quot; }
+      }
+    }
+    uint4 rq[F32 ? 1 : NIT];                                // all residual chunks of the thread are requested up front
+    if (!F32 && resb) {                                     // (the output may alias the residual: no load is reordered past a store)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) rq[F32 ? 0 : it] = *(const uint4*)((const bf16_t*)p.res + (int64_t)orow[it] * p.ldr + n);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
       const int r = r0 + it * rstep;
       uint4 val = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
       if (rope) val = rope_chunk(p, val, *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4)), m0 + r, n);
@@ -68,12 +84,15 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
         f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
         val = *(uint4*)&f;
       }
-      const int orow = p.grp_in > 0 ? quot * p.grp_out + p.grp_off + rem : rem;
-      *(uint4*)((char*)p.C + ((int64_t)orow * p.ldc + n) * (F32 ? 4 : 2)) = val;
-      rem += rstep;
-      if (p.grp_in > 0) {
-        while (rem >= p.grp_in) { rem -= p.grp_in; ++quot; }
+      if (!F32 && resb) {                                   // add in fp32, one rounding
+        uint32_t* w32 = (uint32_t*)&val;
+        const uint32_t* q32 = (const uint32_t*)&rq[F32 ? 0 : it];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          w32[q] = pack2bf(__uint_as_float(w32[q] << 16) + __uint_as_float(q32[q] << 16),
+                           __uint_as_float(w32[q] & 0xffff0000u) + __uint_as_float(q32[q] & 0xffff0000u));
       }
+      *(uint4*)((char*)p.C + ((int64_t)orow[it] * p.ldc + n) * (F32 ? 4 : 2)) = val;
     }
     return;
   }

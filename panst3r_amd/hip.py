@@ -90,15 +90,26 @@ class KernelTimer:
     def __init__(self):
         self.records = []          # (kernel name, flops, start event, end event)
 
-    def bracket(self, name, flops):
+    def bracket(self, name, flops, tag=None):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.append((name, flops, a, b))
+        self.records.append((name, flops, a, b, tag))
         return a, b
+
+    def by_tag(self):
+        """per (kernel, shape tag): launches, ms, TFLOP/s -- for tools/shape_profile.py"""
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, a, b, tag in self.records:
+            d = out.setdefault((name, tag), dict(launches=0, ms=0.0, flops=0.0))
+            d['launches'] += 1
+            d['ms'] += a.elapsed_time(b)
+            d['flops'] += flops
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, a, b in self.records:
+        for name, flops, a, b, _tag in self.records:
             d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
             d['launches'] += 1
             d['ms'] += a.elapsed_time(b)
@@ -174,7 +185,8 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
         if (conv is None and not trans_out and kernel != 128 and N % 256 == 0 and K >= 1024 and (N >= 2048 or K >= 2048)
                 and ((Mv + 255) // 256) * ((N + 255) // 256) >= 3 * 256 - 64) or kernel == 256:
             name = 'gemm256_kernel'
-        ev = TIMER.bracket(name, 2.0 * Mv * N * K)
+        ev = TIMER.bracket(name, 2.0 * Mv * N * K, (Mv, N, K, 'f32' if out.dtype == torch.float32 else 'bf16', act or '', 'res' if res is not None else '',
+                                                   'grp' if grp is not None else '', 'rope' if rope is not None else '', 'conv' if conv is not None else ''))
         ev[0].record()
         _check(lib().pst_gemm_bf16(C.byref(p), _stream()), 'pst_gemm_bf16')
         ev[1].record()
@@ -213,7 +225,7 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
         p.nsplit, p.ws, p.ws_bytes = ns, _ptr(ws), ws.numel() * 4
     if TIMER is not None:
         big = ns == 1 and ((Nq + 127) // 128) * H * B >= 256
-        ev = TIMER.bracket('attn_kernel<%d,%d>' % (hd, 2 if big else 1), 4.0 * B * H * Nq * Nk * hd)
+        ev = TIMER.bracket('attn_kernel<%d,%d>' % (hd, 2 if big else 1), 4.0 * B * H * Nq * Nk * hd, (B, H, Nq, Nk, hd))
         ev[0].record()
         _check(lib().pst_attn_fwd_bf16(C.byref(p), _stream()), 'pst_attn_fwd_bf16')
         ev[1].record()

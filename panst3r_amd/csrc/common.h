@@ -61,27 +61,37 @@ namespace pst {
 // RoPE-2D fused into the whole-row phase of the GEMM epilogue (q,k projection, head dim 64): `own` = 8 bf16 columns
 // n..n+7 of row m, `partner` = the chunk 16 columns away inside the same 32-column half (y half: cols 0-31 of a head
 // rotate with pos y, x half: cols 32-63 with pos x; pairs (i, i+16)).  Table cs: fp32 [npos, 16, 2] (cos, sin).
-__device__ __forceinline__ uint4 rope_chunk(const pst_gemm_params& p, uint4 own, uint4 partner, int m, int n) {
+// split in two so that an epilogue can issue the table loads of several rows before its first store (the compiler may
+// not move a load above a store it cannot prove disjoint, which would serialise one load round trip per row)
+__device__ __forceinline__ void rope_table(const pst_gemm_params& p, int m, int n, float4 (&cs)[4]) {
   const int ch = n & 63;                         // column inside the head
-  const int half = ch >> 5;                      // 0: y, 1: x
-  const bool second = (ch & 16) != 0;            // this chunk holds the (i + 16) members of the pairs
-  const int i0 = ch & 15;                        // first frequency index of the chunk (0 or 8)
-  const int pos = p.rope_pos[2 * m + half];
-  const float4* t = (const float4*)(p.rope_cs + ((int64_t)pos * 16 + i0) * 2);
+  const int pos = p.rope_pos[2 * m + (ch >> 5)]; // half 0: y, 1: x
+  const float4* t = (const float4*)(p.rope_cs + ((int64_t)pos * 16 + (ch & 15)) * 2);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cs[q] = t[q];      // (cos, sin) of frequencies i0+2q, i0+2q+1
+}
+
+__device__ __forceinline__ uint4 rope_rotate(uint4 own, uint4 partner, const float4 (&cs)[4], int n) {
+  const bool second = (n & 16) != 0;             // this chunk holds the (i + 16) members of the pairs
   const uint32_t* a = (const uint32_t*)&own;
   const uint32_t* b = (const uint32_t*)&partner;
   uint4 out;
   uint32_t* o = (uint32_t*)&out;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 cs = t[q];                      // (cos, sin) of frequencies i0+2q, i0+2q+1
     const float x0 = __uint_as_float(a[q] << 16), x1 = __uint_as_float(a[q] & 0xffff0000u);
     const float y0 = __uint_as_float(b[q] << 16), y1 = __uint_as_float(b[q] & 0xffff0000u);
-    const float r0 = second ? x0 * cs.x + y0 * cs.y : x0 * cs.x - y0 * cs.y;
-    const float r1 = second ? x1 * cs.z + y1 * cs.w : x1 * cs.z - y1 * cs.w;
+    const float r0 = second ? x0 * cs[q].x + y0 * cs[q].y : x0 * cs[q].x - y0 * cs[q].y;
+    const float r1 = second ? x1 * cs[q].z + y1 * cs[q].w : x1 * cs[q].z - y1 * cs[q].w;
     o[q] = pack2bf(r0, r1);
   }
   return out;
+}
+
+__device__ __forceinline__ uint4 rope_chunk(const pst_gemm_params& p, uint4 own, uint4 partner, int m, int n) {
+  float4 cs[4];
+  rope_table(p, m, n, cs);
+  return rope_rotate(own, partner, cs, n);
 }
 
 // Bijective XCD-aware remap: hardware places block b on XCD b%8; give each XCD a contiguous chunk of tiles.

@@ -73,11 +73,27 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
 #pragma unroll
       for (int it = 0; it < NIT; ++it) rq[F32 ? 0 : it] = *(const uint4*)((const bf16_t*)p.res + (int64_t)orow[it] * p.ldr + n);
     }
+    if (rope) {                                             // fused RoPE: table loads of 4 rows in flight before their stores
+      constexpr int GRP = NIT < 4 ? NIT : 4;
+#pragma unroll
+      for (int g0 = 0; g0 < NIT; g0 += GRP) {
+        float4 cs[GRP][4];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) rope_table(p, m0 + r0 + (g0 + u) * rstep, n, cs[u]);
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+          const int r = r0 + (g0 + u) * rstep;
+          const uint4 own = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
+          const uint4 partner = *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4));
+          *(uint4*)((char*)p.C + ((int64_t)orow[g0 + u] * p.ldc + n) * 2) = rope_rotate(own, partner, cs[u], n);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int r = r0 + it * rstep;
       uint4 val = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
-      if (rope) val = rope_chunk(p, val, *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4)), m0 + r, n);
       if (F32 && pre) {
         float4 f = *(float4*)&val;
         const float4 q = resv[it];

@@ -187,16 +187,33 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
       int quot = 0, rem = m0 + r0;
       if (p.grp_in > 0) { quot = rem / p.grp_in; rem -= quot * p.grp_in; }
       const bool rope = p.rope_hd == 64;
-#pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int rr = r0 + it * 16;
-        uint4 val = *(const uint4*)(smem + rr * 512 + ((cc ^ (rr & 31)) << 4));
-        if (rope) val = rope_chunk(p, val, *(const uint4*)(smem + rr * 512 + (((cc ^ 2) ^ (rr & 31)) << 4)), m0 + rr, nn);
-        const int orow = p.grp_in > 0 ? quot * p.grp_out + p.grp_off + rem : rem;
-        *(uint4*)((bf16_t*)p.C + (int64_t)orow * p.ldc + nn) = val;
+      auto next_row = [&]() {                                 // output row of the current sweep, then advance by 16 rows
+        const int o = p.grp_in > 0 ? quot * p.grp_out + p.grp_off + rem : rem;
         rem += 16;
         if (p.grp_in > 0) {
           while (rem >= p.grp_in) { rem -= p.grp_in; ++quot; }
+        }
+        return o;
+      };
+      if (rope) {                                            // table loads of 2 rows in flight before their stores
+#pragma unroll 2
+        for (int g0 = 0; g0 < 16; g0 += 2) {
+          float4 cs[2][4];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) rope_table(p, m0 + r0 + (g0 + u) * 16, nn, cs[u]);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int rr = r0 + (g0 + u) * 16;
+            const uint4 own = *(const uint4*)(smem + rr * 512 + ((cc ^ (rr & 31)) << 4));
+            const uint4 partner = *(const uint4*)(smem + rr * 512 + (((cc ^ 2) ^ (rr & 31)) << 4));
+            *(uint4*)((bf16_t*)p.C + (int64_t)next_row() * p.ldc + nn) = rope_rotate(own, partner, cs[u], nn);
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int rr = r0 + it * 16;
+          *(uint4*)((bf16_t*)p.C + (int64_t)next_row() * p.ldc + nn) = *(const uint4*)(smem + rr * 512 + ((cc ^ (rr & 31)) << 4));
         }
       }
       continue;

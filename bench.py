@@ -176,7 +176,8 @@ def main():
             traffic = None
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_summary.json')))
-                e = pmc.get(dom.replace(',', ', '))
+                key = dom.replace(',', ', ')
+                e = pmc.get(key) or next((v for k, v in pmc.items() if k.startswith(key[:-1] + ',')), None)   # PMC names carry every template argument
                 if e and args.views == 50 and args.keyframes == 16 and args.variant == 'v2':
                     traffic = int(e['hbm_read_bytes_per_launch'] + e['hbm_write_bytes_per_launch'])
             except Exception:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 7
+#define PST_ABI_VERSION 8
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -60,6 +60,11 @@ typedef struct pst_gemm_params {
   const int32_t* rope_pos; const float* rope_cs; int32_t rope_hd;
   int32_t res_bf16;                  /* 1: `res` points to bf16 (same indexing, ldr in elements) instead of fp32 */
   int32_t kernel;                    /* 0 = auto; 128 / 256 force the 128x128 / 256x256 tile kernel (tests, benchmarks) */
+  /* strided batch: batch > 1 runs `batch` independent problems of this shape in ONE launch; problem i uses
+     A + i*a_bs, W + i*w_bs, C + i*c_bs (bf16 / output elements) and bias + i*bias_bs.  gamma / res / conv / rope must be
+     unused.  (The 12 per-layer K and V^T projections of a MUSt3R memory append are one launch each instead of 12.) */
+  int32_t batch;
+  int64_t a_bs, w_bs, c_bs, bias_bs;
 } pst_gemm_params;
 
 int pst_gemm_bf16(const pst_gemm_params* p, void* stream);
@@ -98,6 +103,11 @@ int pst_attn_fwd_bf16(const pst_attn_params* p, void* stream);
 int pst_layernorm(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy, int out_fp32,
                   const float* gamma, const float* beta, int rows, int D, float eps,
                   int grp_in, int grp_out, int grp_off, void* stream);
+/* y = LN(x + add): `add` fp32 rows with ld_add, indexed like x (the feedback term of the MUSt3R memory entries:
+ * entry_l = h_l + fb, then norm_y -- one launch instead of add_cast + layernorm). */
+int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const float* add, int64_t ld_add, void* y, int64_t ldy,
+                      int out_fp32, const float* gamma, const float* beta, int rows, int D, float eps,
+                      int grp_in, int grp_out, int grp_off, void* stream);
 
 /* ---------------------------------------------------------------- RoPE-2D (in place on bf16 q and k)
  * Replaces cuRoPE2D / RoPE2D 'RoPE100' (README.md:67-71, input_mixer.py:16): per head the first hd/2 channels

@@ -198,8 +198,16 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
 // are bound by the global->LDS LATENCY of a one-deep prefetch, so three slabs are kept in flight and each step waits
 // with a COUNTED s_waitcnt vmcnt (raw s_barrier: __syncthreads() would drain the LDS-DMA queue).
 template <int FM, int FN, bool TRANS, int NST>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in, const int ntiles, const int tiles_m, const int tiles_n) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
+  pst_gemm_params p = p_in;                 // strided batch: blockIdx.y selects the problem (all fields wave-uniform)
+  if (p.batch > 1) {
+    const int64_t bi = blockIdx.y;
+    p.A = (const bf16_t*)p.A + bi * p.a_bs;
+    p.W = (const bf16_t*)p.W + bi * p.w_bs;
+    p.C = p.out_fp32 ? (void*)((float*)p.C + bi * p.c_bs) : (void*)((bf16_t*)p.C + bi * p.c_bs);
+    if (p.bias) p.bias += bi * p.bias_bs;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                          // [NST][BM][128 B]
   char* Bs = smem + NST * BM * 128;         // [NST][BN][128 B]
@@ -443,7 +451,7 @@ static int launch(const pst_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
   const size_t lds = NST * (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS, NST>), dim3(tiles), dim3(256), lds, s, p, tiles, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS, NST>), dim3(tiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, tiles, tiles_m, tiles_n);
   return check_launch("gemm_bf16");
 }
 
@@ -477,8 +485,12 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
   }
   if (p.res && (p.ldr % (p.res_bf16 ? 8 : 4))) { set_error("gemm: ldr must be a multiple of 4 (fp32) / 8 (bf16)"); return PST_EINVAL; }
   if (p.res && p.res_bf16 && ((uintptr_t)p.res & 15)) { set_error("gemm: bf16 residual must be 16-byte aligned"); return PST_EINVAL; }
+  if (p.batch > 1 && (p.gamma || p.res || p.conv_c || p.rope_hd || p.ps_p || p.grp_in || p.kernel == 256 || p.batch > 65535 ||
+                      (p.a_bs | p.w_bs | p.c_bs) % 8 || p.bias_bs % 4)) {
+    set_error("gemm: strided batch supports bias/act/trans_out only, strides multiples of 8 elements (batch=%d)", p.batch); return PST_EINVAL;
+  }
   hipStream_t s = (hipStream_t)stream;
-  const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batch > 1 ? p.batch : 1);
   const bool small = p.kernel == 0 && big_tiles < 384;   // < 1.5 waves of the 256 CUs: prefer 64x64 tiles to fill the chip
   // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
   if (p.trans_out) return small ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
@@ -487,7 +499,7 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
   const bool fits32 = (int64_t)p.M * p.lda < (1ll << 31) && (int64_t)p.N * p.ldw < (1ll << 31);
   // measured on MI355X: the 256^2 kernel wins for deep K / wide N (v1 MLPs +10 %, 8192^3 +20 %), loses for K < 1024 or ragged N
   const bool shape256 = p.N % 256 == 0 && p.K >= 1024 && (p.N >= 2048 || p.K >= 2048) && tiles256 >= 3 * 256 - 64;
-  const int want256 = p.conv_c == 0 && fits32 && (p.kernel == 256 || (p.kernel == 0 && shape256));
+  const int want256 = p.conv_c == 0 && fits32 && p.batch <= 1 && (p.kernel == 256 || (p.kernel == 0 && shape256));
   if (want256) return launch_gemm256(p, s);
   return small ? launch<2, 2, false, 4>(p, s) : launch<4, 4, false, 2>(p, s);
 }

@@ -52,7 +52,8 @@ __device__ __forceinline__ void store4(void* base, int64_t idx, bool fp32, const
 template <int NIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy,
                                                         int out_fp32, const float* gamma, const float* beta, int rows,
-                                                        int D, float eps, int grp_in, int grp_out, int grp_off) {
+                                                        int D, float eps, int grp_in, int grp_out, int grp_off,
+                                                        const float* add, int64_t ld_add) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -64,6 +65,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t l
     const int c = it * 256 + lane * 4;
     if (c < D) {
       load4(x, (int64_t)irow * ldx + c, in_fp32, v[it]);
+      if (add) {
+        const float4 a4 = *(const float4*)(add + (int64_t)irow * ld_add + c);
+        v[it][0] += a4.x; v[it][1] += a4.y; v[it][2] += a4.z; v[it][3] += a4.w;
+      }
       s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
     } else {
       v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f;
@@ -274,18 +279,31 @@ using namespace pst;
 extern "C" int pst_abi_version(void) { return PST_ABI_VERSION; }
 extern "C" const char* pst_last_error(void) { return g_err; }
 
-extern "C" int pst_layernorm(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy, int out_fp32, const float* gamma,
-                             const float* beta, int rows, int D, float eps, int grp_in, int grp_out, int grp_off, void* stream) {
+static int launch_layernorm(const void* x, int64_t ldx, int in_fp32, const float* add, int64_t ld_add, void* y, int64_t ldy, int out_fp32,
+                            const float* gamma, const float* beta, int rows, int D, float eps, int grp_in, int grp_out, int grp_off,
+                            void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0) { set_error("layernorm: null/empty argument"); return PST_EINVAL; }
-  if (D <= 0 || D % 4 || D > 4096 || ldx % 4 || ldy % 4) { set_error("layernorm: need D%%4==0, D<=4096, ld%%4==0 (D=%d)", D); return PST_EINVAL; }
+  if (D <= 0 || D % 4 || D > 4096 || ldx % 4 || ldy % 4 || (add && ld_add % 4)) { set_error("layernorm: need D%%4==0, D<=4096, ld%%4==0 (D=%d)", D); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((rows + 3) / 4), block(256);
   const int nit = (D + 255) / 256;
-#define PST_LN(N) hipLaunchKernelGGL((layernorm_kernel<N>), grid, block, 0, s, x, ldx, in_fp32, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off)
+#define PST_LN(N) hipLaunchKernelGGL((layernorm_kernel<N>), grid, block, 0, s, x, ldx, in_fp32, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, add, ld_add)
   if (nit <= 1) PST_LN(1); else if (nit <= 2) PST_LN(2); else if (nit <= 3) PST_LN(3); else if (nit <= 4) PST_LN(4);
   else if (nit <= 8) PST_LN(8); else PST_LN(16);
 #undef PST_LN
   return check_launch("layernorm");
+}
+
+extern "C" int pst_layernorm(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy, int out_fp32, const float* gamma,
+                             const float* beta, int rows, int D, float eps, int grp_in, int grp_out, int grp_off, void* stream) {
+  return launch_layernorm(x, ldx, in_fp32, nullptr, 0, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, stream);
+}
+
+extern "C" int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const float* add, int64_t ld_add, void* y, int64_t ldy,
+                                 int out_fp32, const float* gamma, const float* beta, int rows, int D, float eps, int grp_in,
+                                 int grp_out, int grp_off, void* stream) {
+  if (!add) { set_error("layernorm_add: null addend"); return PST_EINVAL; }
+  return launch_layernorm(x, ldx, in_fp32, add, ld_add, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, stream);
 }
 
 extern "C" int pst_rope2d_bf16(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, void* stream) {

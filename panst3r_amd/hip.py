@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -24,7 +24,8 @@ class GemmParams(C.Structure):
                 ('act', i32), ('out_fp32', i32), ('trans_out', i32),
                 ('grp_in', i32), ('grp_out', i32), ('grp_off', i32),
                 ('ps_p', i32), ('ps_c', i32), ('ps_h', i32), ('ps_w', i32),
-                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('rope_pos', vp), ('rope_cs', vp), ('rope_hd', i32), ('res_bf16', i32), ('kernel', i32)]
+                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('rope_pos', vp), ('rope_cs', vp), ('rope_hd', i32), ('res_bf16', i32), ('kernel', i32),
+                ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('c_bs', i64), ('bias_bs', i64)]
 
 
 class AttnParams(C.Structure):
@@ -37,7 +38,7 @@ class AttnParams(C.Structure):
                 ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64)]
 
 
-EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_rope2d_bf16',
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add', 'pst_rope2d_bf16',
            'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16', 'pst_resize_bilinear_bf16',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize']
@@ -140,7 +141,7 @@ ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 
 
 def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
-         M=None, kernel=0, rope=None):
+         M=None, kernel=0, rope=None, batch=None):
     """out = epi(a @ w.T).  a [M,K] bf16 (row-major view), w [N,K] bf16, out bf16/fp32 2-D view (or raw buffer for ps)."""
     _dev(a, torch.bfloat16); _dev(w, torch.bfloat16); _dev(out, torch.bfloat16, torch.float32)
     p = GemmParams()
@@ -171,6 +172,8 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
     if res is not None:
         p.res, p.ldr, p.res_mod = _ptr(_dev(res, torch.float32, torch.bfloat16)), _rowmajor(res), res_mod
         p.res_bf16 = int(res.dtype == torch.bfloat16)
+    if batch is not None:        # (count, a_bs, w_bs, c_bs, bias_bs): `a`, `w`, `out`, `bias` are problem 0 of a strided batch
+        p.batch, p.a_bs, p.w_bs, p.c_bs, p.bias_bs = batch
     p.act = ACT[act]
     p.out_fp32 = int(out.dtype == torch.float32)
     p.trans_out = int(trans_out)
@@ -235,11 +238,18 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
 
 
 # ----------------------------------------------------------------------------------------------------------- the rest
-def layernorm(x, gamma, beta, out, eps, rows=None, grp=None):
+def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None):
+    """out = LN(x [+ add]); `add`: optional fp32 rows indexed like x (fused residual-style addend)."""
     _dev(x, torch.float32, torch.bfloat16); _dev(out, torch.float32, torch.bfloat16)
     D = gamma.numel()
     rows = out.shape[0] if rows is None else rows
     g = grp or (0, 0, 0)
+    if add is not None:
+        _check(lib().pst_layernorm_add(_ptr(x), i64(_rowmajor(x)), int(x.dtype == torch.float32), _ptr(_dev(add, torch.float32)),
+                                       i64(_rowmajor(add)), _ptr(out), i64(_rowmajor(out)), int(out.dtype == torch.float32),
+                                       _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)), rows, D, f32(eps),
+                                       g[0], g[1], g[2], _stream()), 'pst_layernorm_add')
+        return out
     _check(lib().pst_layernorm(_ptr(x), i64(_rowmajor(x)), int(x.dtype == torch.float32), _ptr(out), i64(_rowmajor(out)),
                                int(out.dtype == torch.float32), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)),
                                rows, D, f32(eps), g[0], g[1], g[2], _stream()), 'pst_layernorm')

@@ -430,3 +430,32 @@ def test_resize_bilinear(Hs, Ws, Hd, Wd):
     out = torch.empty(n * Hd * Wd, C, dtype=torch.bfloat16, device=DEV)
     hip.resize_bilinear(x.to(DEV), out, n, Hs, Ws, Hd, Wd, C)
     assert float((out.float().cpu().reshape(n, Hd, Wd, C) - ref).abs().max()) < 2e-2
+
+
+def test_gemm_strided_batch_and_layernorm_add():
+    """strided-batch GEMM (one launch, blockIdx.y = problem) == the per-problem launches, plain and transposed output;
+    pst_layernorm_add(x, add) == pst_layernorm(x + add)."""
+    from panst3r_amd import hip
+    L, M, N, K = 5, 200, 192, 128
+    a = bf(rn(300, L, M, K)).to(dev())
+    w = bf(rn(301, L, N, K, scale=K ** -0.5)).to(dev())
+    b = rn(302, L, N).to(dev())
+    ref = torch.zeros(L, M, N, dtype=torch.bfloat16, device=dev())
+    reft = torch.zeros(L, N, M + 8, dtype=torch.bfloat16, device=dev())
+    for l in range(L):
+        hip.gemm(a[l], w[l], ref[l], bias=b[l], act='gelu')
+        hip.gemm(a[l], w[l], reft[l], bias=b[l], trans_out=True)
+    out = torch.zeros_like(ref)
+    outt = torch.zeros_like(reft)
+    hip.gemm(a[0], w[0], out[0], bias=b[0], act='gelu', batch=(L, a.stride(0), w.stride(0), out.stride(0), b.stride(0)))
+    hip.gemm(a[0], w[0], outt[0], bias=b[0], trans_out=True, batch=(L, a.stride(0), w.stride(0), outt.stride(0), b.stride(0)))
+    assert torch.equal(out, ref) and torch.equal(outt, reft)
+    with pytest.raises(RuntimeError):
+        hip.gemm(a[0], w[0], out[0].float(), res=out[0].float(), batch=(L, a.stride(0), w.stride(0), out.stride(0), b.stride(0)))
+    x, add = rn(303, 50, 768).to(dev()), rn(304, 50, 768).to(dev())
+    g, bt = rn(305, 768).to(dev()), rn(306, 768).to(dev())
+    y1 = torch.empty(50, 768, dtype=torch.bfloat16, device=dev())
+    y2 = torch.empty_like(y1)
+    hip.layernorm(x + add, g, bt, y1, 1e-6)
+    hip.layernorm(x, g, bt, y2, 1e-6, add=add)
+    assert torch.equal(y1, y2)

@@ -491,7 +491,10 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batch > 1 ? p.batch : 1);
-  const bool small = p.kernel == 0 && big_tiles < 384;   // < 1.5 waves of the 256 CUs: prefer 64x64 tiles to fill the chip
+  // fewer 128x128 tiles than about one per CU: 64x64 tiles fill the chip better.  Measured crossover (M = 1536 .. 5376, the
+  // 2-7 views per rank of an 8-GPU scene): 192 tiles -> 64x64 wins for K = 1024 (348 vs 326 TFLOP/s) and loses for K = 4096
+  // (505 vs 536); 288 tiles -> 128x128 wins for both (397 vs 377, 614 vs 532).
+  const bool small = p.kernel == 0 && big_tiles < (p.K >= 2048 ? 176 : 256);
   // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
   if (p.trans_out) return small ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
   // large plain GEMMs: 256x256 tiles, 8 waves, counted-vmcnt pipeline (>= 3 full rounds of the 256 CUs, or forced)

@@ -183,7 +183,7 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
     if grp is not None:
         p.grp_in, p.grp_out, p.grp_off = grp
     if TIMER is not None:
-        big = ((Mv + 127) // 128) * ((N + 127) // 128) >= 384
+        big = ((Mv + 127) // 128) * ((N + 127) // 128) * (batch[0] if batch else 1) >= (176 if K >= 2048 else 256)    # mirrors pst_gemm_bf16's dispatch
         name = ('gemm_kernel<4,4,%s>' if big else 'gemm_kernel<2,2,%s>') % ('true' if trans_out else 'false')
         if (conv is None and not trans_out and kernel != 128 and N % 256 == 0 and K >= 1024 and (N >= 2048 or K >= 2048)
                 and ((Mv + 255) // 256) * ((N + 255) // 256) >= 3 * 256 - 64) or kernel == 256:

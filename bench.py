@@ -66,7 +66,7 @@ def cpu_baseline(variant, H, W, state, names, emb, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--variant', default='v2', choices=['v1', 'v2'])
     ap.add_argument('--views', type=int, default=50)

@@ -94,17 +94,24 @@ def test_portrait_scene_matches_reference_formulation(variant, K):
         assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
 
 
+def _scene_kind(kind):
+    """(shapes, images) of the mixed-shape scenes used by the 2-rank tests."""
+    if kind == 'multi_ar':
+        return MULTI_AR, _multi_ar_images()
+    return PORTRAIT_AR, [tiny.synth_image(i, h, w, 11) for i, (h, w) in enumerate(PORTRAIT_AR)]
+
+
 def _worker(rank, world, port, variant, V, K, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        if V == 'multi_ar':
+        if V in ('multi_ar', 'portrait'):
             torch.set_num_threads(2)
             model = tiny.build(tiny.OracleNS, variant)
-            imgs = _multi_ar_images()
+            shapes, imgs = _scene_kind(V)
             with torch.no_grad():
-                res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], len(MULTI_AR), None, None, K, tiny.NAMES, rank, world, None,
-                                       shapes=MULTI_AR)
+                res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], len(shapes), None, None, K, tiny.NAMES, rank, world, None,
+                                       shapes=shapes)
         else:
             res, scene = _scene(variant, V, K, rank, world, None)
         t = torch.arange(6, dtype=torch.bfloat16).reshape(3, 2) + 10 * rank if rank == 0 else torch.arange(4, dtype=torch.bfloat16).reshape(2, 2) + 10
@@ -119,7 +126,7 @@ def _worker(rank, world, port, variant, V, K, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('variant,V,K', [('v1', 5, 3), ('v2', 4, 2), ('v1', 'multi_ar', 4)])
+@pytest.mark.parametrize('variant,V,K', [('v1', 5, 3), ('v2', 4, 2), ('v1', 'multi_ar', 4), ('v2', 'portrait', 3)])
 def test_two_rank_gloo_equals_single(variant, V, K):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -134,12 +141,12 @@ def test_two_rank_gloo_equals_single(variant, V, K):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    if V == 'multi_ar':
+    if V in ('multi_ar', 'portrait'):
         model = tiny.build(tiny.OracleNS, variant)
-        imgs = _multi_ar_images()
+        shapes, imgs = _scene_kind(V)
         with torch.no_grad():
-            ref, ref_scene = run_scene(OracleBackend(model), lambda i: imgs[i], len(MULTI_AR), None, None, K, tiny.NAMES, shapes=MULTI_AR)
-        V = len(MULTI_AR)
+            ref, ref_scene = run_scene(OracleBackend(model), lambda i: imgs[i], len(shapes), None, None, K, tiny.NAMES, shapes=shapes)
+        V = len(shapes)
     else:
         ref, ref_scene = _scene(variant, V, K)
     merged = {}

@@ -459,3 +459,28 @@ def test_gemm_strided_batch_and_layernorm_add():
     hip.layernorm(x + add, g, bt, y1, 1e-6)
     hip.layernorm(x, g, bt, y2, 1e-6, add=add)
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize('M,N,K', [(192, 768, 768), (640, 1024, 1024), (200, 3072, 768), (768, 768, 3072), (1536, 1024, 4096)])
+def test_gemm64_bit_identical_to_gemm128(M, N, K):
+    """A rank that owns fewer views launches the same GEMMs with a smaller M, which can move them from 128x128 to 64x64 tiles
+    (pst_gemm_bf16's dispatch).  The view-sharded scene equals the 1-GPU scene bit for bit only if both tile sizes accumulate
+    every output element in the same order: auto (64x64 at these sizes) vs forced 128x128, every epilogue kind."""
+    from panst3r_amd import hip
+    a, w = bf(rn(400, M, K)).to(dev()), bf(rn(401, N, K, scale=K ** -0.5)).to(dev())
+    bias, res = rn(402, N).to(dev()), rn(403, M, N).to(dev())
+    assert ((M + 127) // 128) * ((N + 127) // 128) < (176 if K >= 2048 else 256)        # auto really is the 64x64 kernel here
+    for kw, dtype in [(dict(bias=bias, act='gelu'), torch.bfloat16), (dict(bias=bias, res=res), torch.float32), (dict(), torch.bfloat16),
+                      (dict(bias=bias), torch.float32)]:
+        outs = []
+        for kern in (0, 128):
+            out = torch.full((M, N), float('nan'), dtype=dtype, device=dev())
+            hip.gemm(a, w, out, kernel=kern, **kw)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (list(kw), dtype)
+    outs = []
+    for kern in (0, 128):                                     # transposed store (V^T)
+        out = torch.zeros(N, M + 8, dtype=torch.bfloat16, device=dev())
+        hip.gemm(a, w, out, bias=bias, trans_out=True, kernel=kern)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])

@@ -82,6 +82,10 @@ class SceneRunner:
     def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None):
         self.b, self.V, self.classes = backend, V, classes
         self.rank, self.world, self.group = rank, world, group
+        if V < 2:
+            # the memory build starts from a PAIR of views (schedule [2,1,1,...], panst3r.py:35-39,65-70; the reference's helper
+            # yields a negative batch for n < 2); the demo duplicates a lone image instead (tools/demo_panst3r.py:111-112)
+            raise ValueError('a scene needs at least 2 views (got %d): duplicate a single image as the reference demo does' % V)
         self.K = K = V if (K is None or K > V) else max(int(K), 2)
         if V < world:
             raise ValueError('need at least one view per rank (V=%d, world=%d)' % (V, world))

@@ -157,3 +157,16 @@ def test_two_rank_gloo_equals_single(variant, V, K):
     assert sorted(merged) == list(range(V))
     for i in range(V):
         assert torch.equal(merged[i][0], ref[i][0]) and torch.equal(merged[i][1], ref[i][1])
+
+
+def test_single_view_scene_is_refused_clearly():
+    """V = 1: the memory build needs a pair (reference quirk 4: get_must3r_mem_batches(n < 2) is broken, the demo duplicates
+    the image, tools/demo_panst3r.py:111-112) -> explicit ValueError instead of a failure deep inside; the duplicate works."""
+    model = tiny.build(tiny.OracleNS, 'v1')
+    img = tiny.images(1, H, W)[0]
+    with pytest.raises(ValueError, match='at least 2 views'):
+        run_scene(OracleBackend(model), lambda i: img, 1, H, W, None, tiny.NAMES)
+    with torch.no_grad():
+        res, _ = run_scene(OracleBackend(model), lambda i: img, 2, H, W, None, tiny.NAMES)
+    assert torch.equal(res[0][1], res[1][1]) or rel_l2(res[0][1], res[1][1]) < 1.0      # both copies are rendered
+    assert sorted(res) == [0, 1]

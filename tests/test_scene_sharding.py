@@ -170,3 +170,39 @@ def test_single_view_scene_is_refused_clearly():
         res, _ = run_scene(OracleBackend(model), lambda i: img, 2, H, W, None, tiny.NAMES)
     assert torch.equal(res[0][1], res[1][1]) or rel_l2(res[0][1], res[1][1]) < 1.0      # both copies are rendered
     assert sorted(res) == [0, 1]
+
+
+def test_eight_rank_bookkeeping_of_the_bench_scene(monkeypatch):
+    """The driver's scaling run: 50 views, 16 keyframes over 8 ranks.  Every rank's SceneRunner is built in this one process
+    (no process group) and the only collective, _all_gather_rows, is replaced by a fake that hands out what the other ranks
+    would send: ownership, per-rank keyframe counts and the reorder into keyframe-schedule order are checked for all 8 ranks."""
+    import panst3r_amd.scene as S
+    V, K, world, Hh, Ww, p = 50, 16, 8, 384, 512, 16
+    T = (Hh // p) * (Ww // p)
+
+    class Dummy:
+        patch_size, mask_dim = p, 8
+        def fpn_grid(self, h, w):
+            return (h, w), False
+
+    keyframes, order, owner = assign_views(V, K, world)
+    runners = []
+    for r in range(world):
+        mine = {order[i]: torch.zeros(3, 8, 8) for i in range(V) if owner[i] == r}
+        runners.append(S.SceneRunner(Dummy(), mine, V, Hh, Ww, K, tiny.NAMES, rank=r, world=world))
+    owned = sorted(v for rn in runners for v in (rn.order[i] for i in rn.mine))
+    assert owned == list(range(V))                                           # every view exactly once
+    assert [rn.n_local for rn in runners] == [7, 7, 6, 6, 6, 6, 6, 6] and sum(rn.k_local for rn in runners) == K
+    assert all(rn.k_local == 2 for rn in runners) and all(rn.kf_T == [T] * K for rn in runners)
+    # rank r's local keyframe rows carry the id of the keyframe (schedule position) they belong to
+    sends = []
+    for r, rn in enumerate(runners):
+        ids = [i for i in rn.mine if i < K]                                  # positions in `order` == keyframe schedule positions
+        assert ids == list(range(r, K, world))
+        sends.append(torch.cat([torch.full((T, 2), float(k)) for k in ids]))
+    monkeypatch.setattr(S, '_all_gather_rows', lambda t, counts, w, g: [s[:c] for s, c in zip(sends, counts)])
+    monkeypatch.setattr(S.dist, 'is_initialized', lambda: True)
+    for r in range(world):
+        out = gather_keyframe_rows(sends[r], K, [T] * K, r, world, None)
+        assert out.shape == (K * T, 2)
+        assert torch.equal(out[::T, 0], torch.arange(K, dtype=torch.float32))    # schedule order 0..K-1 on every rank

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 8
+#define PST_ABI_VERSION 9
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -160,6 +160,12 @@ int pst_attn_mask_from_logits(const float* logits, int64_t ldl, uint8_t* mask, i
    statistics are bit-reproducible). */
 int pst_loftup_guidance(const float* img, const float* biases, float* feats, float* stats, int nimg, int H, int W,
                         int nf, void* stream);
+/* guidance_gn: the same features followed by GroupNorm(1 group, affine) WITHOUT materialising them: a statistics pass and a
+ *   normalise-and-store pass both recompute the features per pixel (no fp32 feature round trip through HBM).
+ *   y bf16 [nimg*P, ldy], columns [10*nf+3, ldy) zero; scratch >= nimg*(3*P + 6) floats; stats as for pst_loftup_guidance.
+ *   (loftup.py:117-124: fourier_feat -> first GroupNorm of first_conv) */
+int pst_loftup_guidance_gn(const float* img, const float* biases, const float* gamma, const float* beta, float eps,
+                           float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, void* stream);
 int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float* stats, int nimg, int P, int C, int G,
                         void* stream);
 int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma,

@@ -294,7 +294,6 @@ __global__ void attn_combine_kernel(const pst_attn_params p, int hd) {
   const int per_row = hd / 4;
   const int64_t total = rows * per_row;
   const float c_exp = p.scale * 1.4426950408889634f;
-  const float lazy_thr = 8.0f / c_exp;               // 2^8 in the exp2 domain, in score units
   const float* ws_o = (const float*)p.ws;
   const float* ws_ml = ws_o + (int64_t)p.nsplit * rows * hd;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {

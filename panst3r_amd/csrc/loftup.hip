@@ -84,6 +84,92 @@ __global__ __launch_bounds__(256) void fourier_kernel(const float* img2, const f
   if (threadIdx.x == 0) { part[((int64_t)view * gridDim.x + blockIdx.x) * 2] = s; part[((int64_t)view * gridDim.x + blockIdx.x) * 2 + 1] = s2; }
 }
 
+// ------------------------------------------------------------------ fused guidance front end: features -> GroupNorm(1) -> bf16
+// Per-PIXEL formulation of fourier_kernel + gn_apply_kernel<1>: a block walks tiles of 64 pixels, thread = (pixel, channel group
+// cg = tid >> 6 owning the frequencies cg, cg+4, ...), so there is no per-element integer division and the nf frequencies come
+// from an LDS table.  Two passes that RECOMPUTE the features instead of a 639 MB fp32 round trip through HBM (16 views):
+//   APPLY = false: sum / sum of squares per block (fixed order, no atomics) -> reduce_partials_kernel -> GroupNorm(1) statistics
+//   APPLY = true : (v - mean) * rstd * gamma + beta -> bf16 through an LDS tile, stored as whole zero-padded rows (16 B / lane)
+template <bool APPLY>
+__global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, const float* mm, const float* biases, float* part,
+                                                          const float* stats, const float* gamma, const float* beta, float eps,
+                                                          bf16_t* y, int64_t ldy, int H2, int W2, int nf, float f_lo, float f_step) {
+  extern __shared__ float shm[];             // [nf] frequencies, [4] reduction scratch, then (APPLY) the [64][ldy] bf16 tile
+  float* freq = shm;
+  float* red = shm + nf;
+  bf16_t* tile = (bf16_t*)(shm + ((nf + 4 + 3) & ~3));       // 16-byte aligned for the uint4 row copies
+  const int view = blockIdx.y, P = H2 * W2, CH = 10 * nf + 3;
+  const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  if (threadIdx.x < nf) freq[threadIdx.x] = expf(f_lo + f_step * threadIdx.x);
+  float lo[3], sc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = mm[2 * (view * 3 + c)];
+    sc[c] = fmaxf(mm[2 * (view * 3 + c) + 1] - lo[c], 1e-4f);
+  }
+  float mean = 0.f, rstd = 0.f;
+  if (APPLY) {
+    const float inv_n = 1.0f / ((float)P * CH);
+    mean = stats[view * 2] * inv_n;
+    rstd = rsqrtf(fmaxf(stats[view * 2 + 1] * inv_n - mean * mean, 0.f) + eps);
+  }
+  __syncthreads();
+  float s = 0.f, s2 = 0.f;
+  const int ntile = (P + 63) / 64;
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int pix = t * 64 + px;
+    const bool ok = pix < P;
+    const int pc = ok ? pix : P - 1;
+    const int yy = pc / W2, xx = pc - yy * W2;
+    float base[5];
+    base[0] = H2 > 1 ? -1.f + 2.f * yy / (H2 - 1) : -1.f;
+    base[1] = W2 > 1 ? -1.f + 2.f * xx / (W2 - 1) : -1.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) base[2 + c] = (img2[((int64_t)(view * 3 + c)) * P + pc] - lo[c]) / sc[c] - 0.5f;
+    const int ts = (int)ldy + 8;            // tile row stride: +16 B so the 64 lanes' 2-byte writes to one column spread over 16 banks (4-way instead of 64-way conflicts)
+    bf16_t* trow = tile + (int64_t)px * ts;
+    for (int f = cg; f < nf; f += 4) {
+      const float fr = freq[f];
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        const float vs = sinf(base[d] * fr + biases[f * 5 + d]);
+        const float vc = cosf(base[d] * fr + biases[5 * nf + f * 5 + d]);
+        if (APPLY) {
+          trow[f * 5 + d] = f2bf((vs - mean) * rstd * gamma[f * 5 + d] + beta[f * 5 + d]);
+          trow[5 * nf + f * 5 + d] = f2bf((vc - mean) * rstd * gamma[5 * nf + f * 5 + d] + beta[5 * nf + f * 5 + d]);
+        } else if (ok) {
+          s += vs + vc;
+          s2 += vs * vs + vc * vc;
+        }
+      }
+    }
+    if (cg == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = base[2 + c];
+        if (APPLY) trow[10 * nf + c] = f2bf((v - mean) * rstd * gamma[10 * nf + c] + beta[10 * nf + c]);
+        else if (ok) { s += v; s2 += v * v; }
+      }
+    }
+    if (APPLY) {
+      for (int c = CH + cg; c < ldy; c += 4) trow[c] = 0;                  // zero padding up to the GEMM's K
+      __syncthreads();
+      const int cpr = (int)(ldy >> 3);                                       // 16-byte chunks per row
+      for (int i = threadIdx.x; i < 64 * cpr; i += 256) {
+        const int r = i / cpr, c = i - r * cpr;
+        if (t * 64 + r < P)
+          *(uint4*)(y + ((int64_t)view * P + t * 64 + r) * ldy + c * 8) = *(const uint4*)(tile + (int64_t)r * ts + c * 8);
+      }
+      __syncthreads();
+    }
+  }
+  if (!APPLY) {
+    s = block_reduce(s, red, false, false);
+    s2 = block_reduce(s2, red, false, false);
+    if (threadIdx.x == 0) { part[((int64_t)view * gridDim.x + blockIdx.x) * 2] = s; part[((int64_t)view * gridDim.x + blockIdx.x) * 2 + 1] = s2; }
+  }
+}
+
 // stats[view][g] = sum over blocks (in index order) of part[view][block][g]; one thread per (view, group, component)
 __global__ void reduce_partials_kernel(const float* part, float* stats, int nimg, int nb, int per) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,6 +285,31 @@ extern "C" int pst_loftup_guidance(const float* img, const float* biases, float*
   hipLaunchKernelGGL(fourier_kernel, dim3(gx, nimg), dim3(256), 0, s, img2, mm, biases, feats, part, H2, W2, nf, f_lo, f_step);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 63) / 64), dim3(64), 0, s, part, stats, nimg, gx, 2);
   return check_launch("loftup_guidance");
+}
+
+extern "C" int pst_loftup_guidance_gn(const float* img, const float* biases, const float* gamma, const float* beta, float eps,
+                                      float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, void* stream) {
+  const int CHc = 10 * nf + 3;
+  if (!img || !biases || !gamma || !beta || !scratch || !stats || !y || nimg <= 0 || H % 2 || W % 2 || nf < 2 || nf > 64 || ldy < CHc ||
+      ldy % 8 || ldy > 512 || ((uintptr_t)y & 15)) {
+    set_error("loftup_guidance_gn: bad argument (nf=%d ldy=%lld)", nf, (long long)ldy); return PST_EINVAL;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = H / 2, W2 = W / 2, P = H2 * W2;
+  float* img2 = scratch;                                 // [nimg][3][P]
+  float* mm = img2 + (int64_t)nimg * 3 * P;              // [nimg][3][2]
+  hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(256), 0, s, img, img2, mm, H, W);
+  const float f_lo = -2.f, f_step = 12.f / (nf - 1);
+  const int ntile = (P + 63) / 64;
+  const int gx = ntile < PST_STATS_BLOCKS ? ntile : PST_STATS_BLOCKS;
+  float* part = stats + 2 * nimg;                        // [nimg][gx][2] partial sums behind the result
+  const size_t lds0 = ((nf + 4 + 3) & ~3) * sizeof(float);
+  hipLaunchKernelGGL((guidance_px_kernel<false>), dim3(gx, nimg), dim3(256), lds0, s, img2, mm, biases, part, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, 0.f, (bf16_t*)nullptr, ldy, H2, W2, nf, f_lo, f_step);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 63) / 64), dim3(64), 0, s, part, stats, nimg, gx, 2);
+  hipLaunchKernelGGL((guidance_px_kernel<true>), dim3(ntile, nimg), dim3(256), lds0 + 64 * (ldy + 8) * sizeof(bf16_t), s, img2, mm, biases,
+                     (float*)nullptr, stats, gamma, beta, eps, (bf16_t*)y, ldy, H2, W2, nf, f_lo, f_step);
+  return check_launch("loftup_guidance_gn");
 }
 
 extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float* stats, int nimg, int P, int C, int G, void* stream) {

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -40,7 +40,7 @@ class AttnParams(C.Structure):
 
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add', 'pst_rope2d_bf16',
            'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16', 'pst_resize_bilinear_bf16',
-           'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
+           'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize']
 
 
@@ -335,6 +335,17 @@ def loftup_guidance(img, biases, feats, stats, nf):
     n, _, h, w = img.shape
     assert img.is_contiguous()
     _check(lib().pst_loftup_guidance(_ptr(img), _ptr(biases), _ptr(feats), _ptr(stats), n, h, w, nf, _stream()), 'pst_loftup_guidance')
+
+
+def loftup_guidance_gn(img, biases, gamma, beta, eps, scratch, stats, out, nf):
+    """Fourier guidance features + GroupNorm(1) straight to bf16 `out` [nimg*P, ld] (zero-padded columns); no fp32 feature buffer."""
+    _dev(img, torch.float32); _dev(biases, torch.float32); _dev(scratch, torch.float32); _dev(stats, torch.float32); _dev(out, torch.bfloat16)
+    n, _, h, w = img.shape
+    assert img.is_contiguous() and scratch.numel() >= n * (3 * (h // 2) * (w // 2) + 6)
+    _check(lib().pst_loftup_guidance_gn(_ptr(img), _ptr(biases), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)), f32(eps),
+                                        _ptr(scratch), _ptr(stats), _ptr(out), i64(_rowmajor(out)), n, h, w, nf, _stream()),
+           'pst_loftup_guidance_gn')
+    return out
 
 
 def groupnorm_stats(x, stats, nimg, P, Cc, G):

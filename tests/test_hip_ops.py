@@ -397,6 +397,16 @@ def test_loftup_guidance_and_groupnorm():
     refn = F.group_norm(got.permute(0, 2, 1).reshape(2, CH, H // 2, W // 2), 1, gamma, beta, 1e-5).permute(0, 2, 3, 1).reshape(2 * P, CH)
     assert rel_l2(out[:, :CH].float().cpu(), refn) < 5e-3
     assert float(out[:, CH:].abs().max()) == 0.0
+    # fused path: the same features + GroupNorm(1) without the fp32 feature buffer (two recomputing passes)
+    out2 = torch.full((2 * P, 256), 7.0, dtype=torch.bfloat16, device=dev())
+    scratch = torch.zeros(2 * (3 * P + 6) + 16, device=dev())
+    st2 = hip.stats_buffer(2, 1, dev())
+    hip.loftup_guidance_gn(img.to(dev()), feat.biases.detach().to(dev()), gamma.to(dev()), beta.to(dev()), 1e-5, scratch, st2, out2, nf)
+    assert rel_l2(st2[:4].cpu(), stats[:4].cpu()) < 1e-5                       # same statistics (different summation order)
+    refn2 = F.group_norm(refp.permute(0, 2, 1).reshape(2, CH, H // 2, W // 2), 1, gamma, beta, 1e-5).permute(0, 2, 3, 1).reshape(2 * P, CH)
+    assert rel_l2(out2[:, :CH].float().cpu(), refn) < 5e-3 and float((out2[:, :CH].float().cpu() - refn2).abs().max()) < 6e-2
+    assert float(out2[:, CH:].abs().max()) == 0.0
+    assert float((out2.float() - out.float()).abs().max()) < 4e-2              # vs the two-kernel path: bf16 rounding only
     # GroupNorm(8) statistics + apply + ReLU on a conv-like map
     Cc = 64
     x = rn(84, 2 * P, Cc) * 2 + 0.3

@@ -494,3 +494,26 @@ def test_gemm64_bit_identical_to_gemm128(M, N, K):
         hip.gemm(a, w, out, bias=bias, trans_out=True, kernel=kern)
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm_strided_batch_production_shape_128_tiles():
+    """The memory append's real launch: 12 problems of 768 x 768 x 768 in one strided-batch launch = 432 tiles, i.e. the 128x128-tile
+    kernel with blockIdx.y = problem (the small-shape test above only reaches the 64x64 kernel).  Bit-identical to 12 single launches,
+    plain and transposed (V^T) output, with the bank-like strides (output slices of a larger per-layer cache)."""
+    from panst3r_amd import hip
+    L, M, D, cap = 12, 768, 768, 2048
+    a = bf(rn(500, L, M, D)).to(dev())
+    w = bf(rn(501, L, D, D, scale=D ** -0.5)).to(dev())
+    b = rn(502, L, D).to(dev())
+    n0 = 512                                                    # append position inside the caches
+    K_all = torch.zeros(L, cap, D, dtype=torch.bfloat16, device=dev())
+    Vt_all = torch.zeros(L, D, cap + 8, dtype=torch.bfloat16, device=dev())
+    K_ref, Vt_ref = torch.zeros_like(K_all), torch.zeros_like(Vt_all)
+    for l in range(L):
+        hip.gemm(a[l], w[l], K_ref[l, n0:n0 + M], bias=b[l])
+        hip.gemm(a[l], w[l], Vt_ref[l][:, n0:], bias=b[l], trans_out=True)
+    assert ((M + 127) // 128) * ((D + 127) // 128) * L >= 256   # the batched launch is dispatched to the 128x128 kernel
+    hip.gemm(a[0], w[0], K_all[0, n0:n0 + M], bias=b[0], batch=(L, a.stride(0), w.stride(0), K_all.stride(0), b.stride(0)))
+    hip.gemm(a[0], w[0], Vt_all[0][:, n0:], bias=b[0], trans_out=True, batch=(L, a.stride(0), w.stride(0), Vt_all.stride(0), b.stride(0)))
+    assert torch.equal(K_all, K_ref) and torch.equal(Vt_all, Vt_ref)
+    assert float(K_all[:, :n0].abs().max()) == 0.0 and float(K_all[:, n0 + M:].abs().max()) == 0.0      # nothing outside the slices

@@ -25,24 +25,32 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max, b
   return r;
 }
 
-// one block per (view, channel): 2x2 mean (== bilinear x0.5, align_corners=False) and min / max of the result
-__global__ __launch_bounds__(256) void down2_minmax_kernel(const float* img, float* img2, float* mm, int H, int W) {
-  __shared__ float sh[4];
+// one 1024-thread block per (view, channel): 2x2 mean (== bilinear x0.5, align_corners=False) and min / max of the result
+// (min / max are order-independent, so the wider block changes no bits)
+__global__ __launch_bounds__(1024) void down2_minmax_kernel(const float* img, float* img2, float* mm, int H, int W) {
+  __shared__ float shlo[16], shhi[16];
   const int vc = blockIdx.x, H2 = H / 2, W2 = W / 2;
   const float* src = img + (int64_t)vc * H * W;
   float* dst = img2 + (int64_t)vc * H2 * W2;
   float lo = 3.4e38f, hi = -3.4e38f;
-  for (int i = threadIdx.x; i < H2 * W2; i += 256) {
+  for (int i = threadIdx.x; i < H2 * W2; i += 1024) {
     const int y = i / W2, x = i - y * W2;
-    const float* p = src + (int64_t)(2 * y) * W + 2 * x;
-    const float v = 0.25f * (p[0] + p[1] + p[W] + p[W + 1]);
+    const float2 a = *(const float2*)(src + (int64_t)(2 * y) * W + 2 * x);
+    const float2 b = *(const float2*)(src + (int64_t)(2 * y + 1) * W + 2 * x);
+    const float v = 0.25f * (a.x + a.y + b.x + b.y);
     dst[i] = v;
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);
   }
-  lo = block_reduce(lo, sh, false, true);
-  hi = block_reduce(hi, sh, true, false);
-  if (threadIdx.x == 0) { mm[2 * vc] = lo; mm[2 * vc + 1] = hi; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+  if ((threadIdx.x & 63) == 0) { shlo[threadIdx.x >> 6] = lo; shhi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) { lo = fminf(lo, shlo[i]); hi = fmaxf(hi, shhi[i]); }
+    mm[2 * vc] = lo;
+    mm[2 * vc + 1] = hi;
+  }
 }
 
 // thread = (pixel, output channel).  Channels: [0,5nf) sin, [5nf,10nf) cos with index f*5+d, then 3 scaled rgb.
@@ -170,14 +178,17 @@ __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, con
   }
 }
 
-// stats[view][g] = sum over blocks (in index order) of part[view][block][g]; one thread per (view, group, component)
-__global__ void reduce_partials_kernel(const float* part, float* stats, int nimg, int nb, int per) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// stats[view][c] = sum over blocks of part[view][block][c].  One WAVE per output: lane l adds the partials l, l+64, ... in index
+// order, then a fixed xor-shuffle tree -- deterministic, and 128 dependent loads shorter than the one-thread-per-output version.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part, float* stats, int nimg, int nb, int per) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= nimg * per) return;
   const int view = i / per, c = i - view * per;
   float a = 0.f;
-  for (int b = 0; b < nb; ++b) a += part[((int64_t)view * nb + b) * per + c];
-  stats[i] = a;
+  for (int b = lane; b < nb; b += 64) a += part[((int64_t)view * nb + b) * per + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) stats[i] = a;
 }
 
 // (sum, sumsq) per (view, group): thread owns one 4-channel chunk (one group) and a fixed set of rows; threads of a
@@ -277,13 +288,13 @@ extern "C" int pst_loftup_guidance(const float* img, const float* biases, float*
   // keep it explicit -- img2 and min/max live at the END of `feats` (caller allocates nimg*(P*CH + 3*P + 8) floats).
   float* img2 = feats + (int64_t)nimg * P * CH;
   float* mm = img2 + (int64_t)nimg * 3 * P;
-  hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(256), 0, s, img, img2, mm, H, W);
+  hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(1024), 0, s, img, img2, mm, H, W);
   const float f_lo = -2.f, f_step = 12.f / (nf - 1);
   int gx = (int)(((int64_t)P * CH + 255) / 256);
   if (gx > PST_STATS_BLOCKS) gx = PST_STATS_BLOCKS;
   float* part = stats + 2 * nimg;                      // [nimg][gx][2] partial sums behind the result
   hipLaunchKernelGGL(fourier_kernel, dim3(gx, nimg), dim3(256), 0, s, img2, mm, biases, feats, part, H2, W2, nf, f_lo, f_step);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 63) / 64), dim3(64), 0, s, part, stats, nimg, gx, 2);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 3) / 4), dim3(256), 0, s, part, stats, nimg, gx, 2);
   return check_launch("loftup_guidance");
 }
 
@@ -298,7 +309,7 @@ extern "C" int pst_loftup_guidance_gn(const float* img, const float* biases, con
   const int H2 = H / 2, W2 = W / 2, P = H2 * W2;
   float* img2 = scratch;                                 // [nimg][3][P]
   float* mm = img2 + (int64_t)nimg * 3 * P;              // [nimg][3][2]
-  hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(256), 0, s, img, img2, mm, H, W);
+  hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(1024), 0, s, img, img2, mm, H, W);
   const float f_lo = -2.f, f_step = 12.f / (nf - 1);
   const int ntile = (P + 63) / 64;
   const int gx = ntile < PST_STATS_BLOCKS ? ntile : PST_STATS_BLOCKS;
@@ -306,7 +317,7 @@ extern "C" int pst_loftup_guidance_gn(const float* img, const float* biases, con
   const size_t lds0 = ((nf + 4 + 3) & ~3) * sizeof(float);
   hipLaunchKernelGGL((guidance_px_kernel<false>), dim3(gx, nimg), dim3(256), lds0, s, img2, mm, biases, part, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, 0.f, (bf16_t*)nullptr, ldy, H2, W2, nf, f_lo, f_step);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 63) / 64), dim3(64), 0, s, part, stats, nimg, gx, 2);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 3) / 4), dim3(256), 0, s, part, stats, nimg, gx, 2);
   hipLaunchKernelGGL((guidance_px_kernel<true>), dim3(ntile, nimg), dim3(256), lds0 + 64 * (ldy + 8) * sizeof(bf16_t), s, img2, mm, biases,
                      (float*)nullptr, stats, gamma, beta, eps, (bf16_t*)y, ldy, H2, W2, nf, f_lo, f_step);
   return check_launch("loftup_guidance_gn");
@@ -324,7 +335,7 @@ extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float
   const int rows_per_block = (P + nb - 1) / nb;
   float* part = stats + (int64_t)2 * G * nimg;         // [nimg][nb][G][2] partial sums behind the result
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nb, nimg), dim3(threads), sizeof(float) * 2 * threads, s, x, ldx, x_fp32, part, P, C, G, rows_per_block);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 * G + 63) / 64), dim3(64), 0, s, part, stats, nimg, nb, 2 * G);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 * G + 3) / 4), dim3(256), 0, s, part, stats, nimg, nb, 2 * G);
   return check_launch("groupnorm_stats");
 }
 

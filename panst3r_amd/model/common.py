@@ -111,7 +111,7 @@ def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
     hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True)
     o = empty(lay.rows, D, BF16, dev)
     if lay.Tp != lay.N:
-        o.zero_()                     # pad rows stay finite
+        o.view(lay.V, lay.Tp, D)[:, lay.N:].zero_()      # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
     ldq, ldv = qk.stride(0), vt.stride(0)
     hip.attention(qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd,
                   q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq),

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 9
+#define PST_ABI_VERSION 10
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -108,6 +108,13 @@ int pst_layernorm(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy,
 int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const float* add, int64_t ld_add, void* y, int64_t ldy,
                       int out_fp32, const float* gamma, const float* beta, int rows, int D, float eps,
                       int grp_in, int grp_out, int grp_off, void* stream);
+
+/* strided batch of the above: problem i uses x + i*x_bs, y + i*y_bs, gamma/beta + i*w_bs (elements); `add` (optional) is shared.
+ * One launch for the 12 per-layer `norm_y(h_l + feedback)` of a MUSt3R memory append. */
+int pst_layernorm_add_batch(const void* x, int64_t ldx, int in_fp32, const float* add, int64_t ld_add, void* y, int64_t ldy,
+                            int out_fp32, const float* gamma, const float* beta, int rows, int D, float eps,
+                            int grp_in, int grp_out, int grp_off, int nbatch, int64_t x_bs, int64_t y_bs, int64_t w_bs,
+                            void* stream);
 
 /* ---------------------------------------------------------------- RoPE-2D (in place on bf16 q and k)
  * Replaces cuRoPE2D / RoPE2D 'RoPE100' (README.md:67-71, input_mixer.py:16): per head the first hd/2 channels

@@ -53,7 +53,14 @@ template <int NIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy,
                                                         int out_fp32, const float* gamma, const float* beta, int rows,
                                                         int D, float eps, int grp_in, int grp_out, int grp_off,
-                                                        const float* add, int64_t ld_add) {
+                                                        const float* add, int64_t ld_add, int64_t x_bs, int64_t y_bs, int64_t w_bs) {
+  if (gridDim.y > 1) {          // strided batch: problem blockIdx.y has its own input, output and affine parameters (the addend is shared)
+    const int64_t bi = blockIdx.y;
+    x = in_fp32 ? (const void*)((const float*)x + bi * x_bs) : (const void*)((const bf16_t*)x + bi * x_bs);
+    y = out_fp32 ? (void*)((float*)y + bi * y_bs) : (void*)((bf16_t*)y + bi * y_bs);
+    gamma += bi * w_bs;
+    beta += bi * w_bs;
+  }
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -281,13 +288,14 @@ extern "C" const char* pst_last_error(void) { return g_err; }
 
 static int launch_layernorm(const void* x, int64_t ldx, int in_fp32, const float* add, int64_t ld_add, void* y, int64_t ldy, int out_fp32,
                             const float* gamma, const float* beta, int rows, int D, float eps, int grp_in, int grp_out, int grp_off,
-                            void* stream) {
+                            void* stream, int nbatch = 1, int64_t x_bs = 0, int64_t y_bs = 0, int64_t w_bs = 0) {
+  if (nbatch < 1 || nbatch > 65535 || (nbatch > 1 && ((x_bs | y_bs | w_bs) % 4))) { set_error("layernorm: bad batch (n=%d)", nbatch); return PST_EINVAL; }
   if (!x || !y || !gamma || !beta || rows <= 0) { set_error("layernorm: null/empty argument"); return PST_EINVAL; }
   if (D <= 0 || D % 4 || D > 4096 || ldx % 4 || ldy % 4 || (add && ld_add % 4)) { set_error("layernorm: need D%%4==0, D<=4096, ld%%4==0 (D=%d)", D); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((rows + 3) / 4), block(256);
+  const dim3 grid((rows + 3) / 4, nbatch), block(256);
   const int nit = (D + 255) / 256;
-#define PST_LN(N) hipLaunchKernelGGL((layernorm_kernel<N>), grid, block, 0, s, x, ldx, in_fp32, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, add, ld_add)
+#define PST_LN(N) hipLaunchKernelGGL((layernorm_kernel<N>), grid, block, 0, s, x, ldx, in_fp32, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, add, ld_add, x_bs, y_bs, w_bs)
   if (nit <= 1) PST_LN(1); else if (nit <= 2) PST_LN(2); else if (nit <= 3) PST_LN(3); else if (nit <= 4) PST_LN(4);
   else if (nit <= 8) PST_LN(8); else PST_LN(16);
 #undef PST_LN
@@ -297,6 +305,13 @@ static int launch_layernorm(const void* x, int64_t ldx, int in_fp32, const float
 extern "C" int pst_layernorm(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy, int out_fp32, const float* gamma,
                              const float* beta, int rows, int D, float eps, int grp_in, int grp_out, int grp_off, void* stream) {
   return launch_layernorm(x, ldx, in_fp32, nullptr, 0, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, stream);
+}
+
+extern "C" int pst_layernorm_add_batch(const void* x, int64_t ldx, int in_fp32, const float* add, int64_t ld_add, void* y, int64_t ldy,
+                                       int out_fp32, const float* gamma, const float* beta, int rows, int D, float eps, int grp_in,
+                                       int grp_out, int grp_off, int nbatch, int64_t x_bs, int64_t y_bs, int64_t w_bs, void* stream) {
+  return launch_layernorm(x, ldx, in_fp32, add, ld_add, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, stream, nbatch,
+                          x_bs, y_bs, w_bs);
 }
 
 extern "C" int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const float* add, int64_t ld_add, void* y, int64_t ldy,

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -38,7 +38,7 @@ class AttnParams(C.Structure):
                 ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64)]
 
 
-EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add', 'pst_rope2d_bf16',
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add', 'pst_layernorm_add_batch', 'pst_rope2d_bf16',
            'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16', 'pst_resize_bilinear_bf16',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize']
@@ -238,6 +238,21 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
 
 
 # ----------------------------------------------------------------------------------------------------------- the rest
+def layernorm_batch(x_all, gamma_all, beta_all, out_all, eps, rows=None, grp=None, add=None):
+    """out_all[i] = LN(x_all[i] [+ add]) * gamma_all[i] + beta_all[i] for i < n in ONE launch; x_all [n, R, D], out_all [n, rows, D]."""
+    _dev(x_all, torch.float32, torch.bfloat16); _dev(out_all, torch.float32, torch.bfloat16)
+    n, D = x_all.shape[0], gamma_all.shape[1]
+    assert x_all.dim() == 3 and out_all.dim() == 3 and x_all.stride(2) == 1 and out_all.stride(2) == 1 and gamma_all.is_contiguous() and beta_all.is_contiguous()
+    rows = out_all.shape[1] if rows is None else rows
+    g = grp or (0, 0, 0)
+    _check(lib().pst_layernorm_add_batch(_ptr(x_all), i64(x_all.stride(1)), int(x_all.dtype == torch.float32),
+                                         _ptr(_dev(add, torch.float32)) if add is not None else vp(0), i64(_rowmajor(add)) if add is not None else i64(0),
+                                         _ptr(out_all), i64(out_all.stride(1)), int(out_all.dtype == torch.float32),
+                                         _ptr(_dev(gamma_all, torch.float32)), _ptr(_dev(beta_all, torch.float32)), rows, D, f32(eps),
+                                         g[0], g[1], g[2], n, i64(x_all.stride(0)), i64(out_all.stride(0)), i64(D), _stream()), 'pst_layernorm_add_batch')
+    return out_all
+
+
 def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None):
     """out = LN(x [+ add]); `add`: optional fp32 rows indexed like x (fused residual-style addend)."""
     _dev(x, torch.float32, torch.bfloat16); _dev(out, torch.float32, torch.bfloat16)

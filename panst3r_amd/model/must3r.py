@@ -112,6 +112,8 @@ class MUSt3R(HipModule):
         pk['mem_kb'] = torch.stack([bw.cross['k'].b for bw in blocks]).contiguous()
         pk['mem_vw'] = torch.stack([bw.cross['v'].w for bw in blocks]).contiguous()
         pk['mem_vb'] = torch.stack([bw.cross['v'].b for bw in blocks]).contiguous()
+        pk['mem_ng'] = torch.stack([bw.cross['norm_y'][0] for bw in blocks]).contiguous()
+        pk['mem_nb'] = torch.stack([bw.cross['norm_y'][1] for bw in blocks]).contiguous()
         if self.feedback_type:
             pk['fb_norm'] = pack_norm(self.feedback_norm, device)
             pk['fb1'] = Packed(self.feedback_layer.fc1.weight, self.feedback_layer.fc1.bias, device)
@@ -127,9 +129,9 @@ class MUSt3R(HipModule):
         return MemoryBank(self.depth, self.embed_dim, cap_tokens, device)
 
     # ------------------------------------------------------------------ core
-    def _embed(self, pk, x_enc, lay, first_is_ref):
+    def _embed(self, pk, x_enc, lay, first_is_ref, out=None):
         dev = x_enc.device
-        x = torch.zeros(lay.rows, self.embed_dim, dtype=torch.float32, device=dev)
+        x = torch.zeros(lay.rows, self.embed_dim, dtype=torch.float32, device=dev) if out is None else out.zero_()
         hip.gemm(x_enc, pk['e2d'].w, x, bias=pk['bias_other'], grp=lay.grp)
         if first_is_ref:       # scene image 0 carries no image2_embed
             hip.gemm(x_enc[:lay.T], pk['e2d'].w, x[:lay.Tp], bias=pk['bias_ref'])
@@ -203,7 +205,9 @@ class MUSt3R(HipModule):
         if not ((n == 2 and bank.n == 0) or (n == 1 and bank.n > 0)):
             raise NotImplementedError('memory batches other than [2,1,1,...] are not on the HIP path')
         lay = Layout(n, T)
-        x = self._embed(pk, x_enc, lay, first_is_ref=(bank.nimgs == 0))
+        # hs_all[l] = tokens entering block l, hs_all[L] = final stream: ONE tensor, so the append normalises all layers in one launch
+        hs_all = torch.empty(L + 1, lay.rows, D, dtype=torch.float32, device=dev)
+        x = self._embed(pk, x_enc, lay, first_is_ref=(bank.nimgs == 0), out=hs_all[0])
         pos = grid_pos(n, h, w, lay.Tp, 0, dev)
         rope = self._rope(pk, max(h, w), dev)
         # hs[l] = tokens entering block l (the candidate memory entries).  No copies: block l reads its residual from
@@ -213,7 +217,7 @@ class MUSt3R(HipModule):
         xn = empty(lay.rows, D, BF16, dev)
         for l, bw in enumerate(pk['blocks']):
             x_in = hs[l]
-            x = empty(lay.rows, D, torch.float32, dev)
+            x = hs_all[l + 1]
             if lay.Tp != lay.T:
                 x.zero_()
             hip.layernorm(x_in, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
@@ -244,7 +248,7 @@ class MUSt3R(HipModule):
             hip.gemm(o, c['proj'].w, x, bias=c['proj'].b, res=x)
             self._mlp(x, bw, xn)
             hs.append(x)
-        out = self._append(pk, bank, hs, lay, n, T)
+        out = self._append(pk, bank, hs, lay, n, T, hs_all=hs_all)
         if not want_outputs:
             return bank
         feat = empty(n * T, D, BF16, dev)       # first-pass outputs of the update call (engine/must3r.py:45-46)
@@ -302,7 +306,7 @@ class MUSt3R(HipModule):
             self._append(pk, bank, hs[i], lays[i], 1, Ts[i])
         return bank
 
-    def _append(self, pk, bank, hs, lay, n, T):
+    def _append(self, pk, bank, hs, lay, n, T, hs_all=None):
         """feedback + append of n same-shape images whose per-layer inputs are hs[0..L] (hs[L] = final stream)."""
         dev, D = hs[0].device, self.embed_dim
         out = empty(lay.rows, D, torch.float32, dev)
@@ -321,9 +325,12 @@ class MUSt3R(HipModule):
         # (Spreading the 12 independent layer chains over side streams was measured SLOWER inside a captured HIP graph.)
         L, rows = len(pk['blocks']), n * T
         y = torch.empty(L, rows, D, dtype=BF16, device=dev)
-        for l, bw in enumerate(pk['blocks']):
-            c = bw.cross
-            hip.layernorm(hs[l], c['norm_y'][0], c['norm_y'][1], y[l], c['norm_y'][2], rows=rows, grp=lay.grp, add=fb)
+        if hs_all is not None:                            # all layers' norm_y(h_l + fb) in one strided-batch launch
+            hip.layernorm_batch(hs_all[:L], pk['mem_ng'], pk['mem_nb'], y, pk['blocks'][0].cross['norm_y'][2], rows=rows, grp=lay.grp, add=fb)
+        else:
+            for l, bw in enumerate(pk['blocks']):
+                c = bw.cross
+                hip.layernorm(hs[l], c['norm_y'][0], c['norm_y'][1], y[l], c['norm_y'][2], rows=rows, grp=lay.grp, add=fb)
         hip.gemm(y[0], pk['mem_kw'][0], bank.K_all[0, bank.n: bank.n + rows], bias=pk['mem_kb'][0],
                  batch=(L, rows * D, pk['mem_kw'].stride(0), bank.K_all.stride(0), D))
         hip.gemm(y[0], pk['mem_vw'][0], bank.Vt_all[0][:, bank.n:], bias=pk['mem_vb'][0], trans_out=True,

@@ -517,3 +517,20 @@ def test_gemm_strided_batch_production_shape_128_tiles():
     hip.gemm(a[0], w[0], Vt_all[0][:, n0:], bias=b[0], trans_out=True, batch=(L, a.stride(0), w.stride(0), Vt_all.stride(0), b.stride(0)))
     assert torch.equal(K_all, K_ref) and torch.equal(Vt_all, Vt_ref)
     assert float(K_all[:, :n0].abs().max()) == 0.0 and float(K_all[:, n0 + M:].abs().max()) == 0.0      # nothing outside the slices
+
+
+def test_layernorm_strided_batch():
+    """pst_layernorm_add_batch == one pst_layernorm_add per problem (own input / affine parameters / output, shared addend), with the
+    padded-view row remap the memory append uses."""
+    from panst3r_amd import hip
+    L, R, D, T, Tp = 5, 2 * 200, 768, 196, 200
+    x = rn(600, L + 1, R, D).to(dev())
+    add = rn(601, R, D).to(dev())
+    g, b = (1 + 0.1 * rn(602, L, D)).to(dev()), (0.1 * rn(603, L, D)).to(dev())
+    grp = (T, Tp, 0)
+    ref = torch.zeros(L, 2 * T, D, dtype=torch.bfloat16, device=dev())
+    for l in range(L):
+        hip.layernorm(x[l], g[l], b[l], ref[l], 1e-6, rows=2 * T, grp=grp, add=add)
+    out = torch.zeros_like(ref)
+    hip.layernorm_batch(x[:L], g, b, out, 1e-6, rows=2 * T, grp=grp, add=add)
+    assert torch.equal(out, ref)

@@ -197,32 +197,22 @@ class LoftUpUpscaler(HipModule):
         return ceil_to(self.input_dim + 20, 64)
 
     @torch.no_grad()
-    def upscale_tokens(self, lr, imgs, V, h, w, fpn_out, mask_out):
-        """lr bf16 [V*T, lr_width()] with the mixer tokens in columns [0, input_dim) (the rest is filled here);
-        imgs fp32 [V,3,H,W] -> fpn_out bf16 [V*T, input_dim] (h x w raster), mask_out bf16 [V, H/2, W/2, dim].
-        A tall token grid (h > w) takes the guidance image transposed (loftup.py:147-149): the mask features then come
-        out landscape-shaped, mask_out bf16 [V, W/2, H/2, dim] (the low-res tokens only enter through cross-attention,
-        which does not care about their raster)."""
-        dev = lr.device
+    def guidance_tokens(self, imgs, h, w):
+        """Guidance branch (loftup.py:154-156,117-130): Fourier features -> GN(1) -> conv3x3 -> GN(8)+ReLU -> conv3x3 -> GN(8)+ReLU.
+        imgs fp32 [V,3,H,W] -> bf16 [V*P, dim] pixel-major, P = H/2 * W/2.  It depends on the IMAGES only (not on the memory, the
+        decoder or the mixer), so the scene runner computes it on the side stream while the memory build has the GPU mostly idle.
+        A tall token grid (h > w) takes the image transposed (loftup.py:147-149)."""
+        dev = imgs.device
         pk = self.packed(dev)
-        T, D, C, Hh = h * w, self.input_dim, self.dim, self.num_heads
-        hd = C // Hh
+        C = self.dim
         if h > w:
             imgs = imgs.transpose(2, 3).contiguous()
+        V = imgs.shape[0]
         H2, W2 = imgs.shape[2] // 2, imgs.shape[3] // 2
-        assert tuple(mask_out.shape) == (V, H2, W2, C), (tuple(mask_out.shape), (V, H2, W2, C))
-        P, CH = H2 * W2, self.start_dim
-        hip.gemm(lr[:, :D], pk['pe'].w, fpn_out, bias=pk['pe'].b)
-        lr[:, D:].zero_()
-        hip.loftup_lr_pe(pk['lr_bias'], lr, D, V, h, w)
-        lay = Layout(V, T)
-        kv = torch.zeros(lay.rows, C, dtype=torch.float32, device=dev)
-        hip.gemm(lr, pk['lr_proj'].w, kv, bias=pk['lr_proj'].b, grp=lay.grp)
-        kvn = empty(lay.rows, C, torch.float32, dev)
-        hip.layernorm(kv, pk['lr_norm'][0], pk['lr_norm'][1], kvn, pk['lr_norm'][2])
+        P = H2 * W2
+        out = empty(V * P, C, BF16, dev)
         for v0 in range(0, V, VIEW_CHUNK):
             n = min(VIEW_CHUNK, V - v0)
-            # ---- guidance branch: Fourier features -> GN(1) -> conv3x3 -> GN(8)+ReLU -> conv3x3 -> GN(8)+ReLU
             # Fourier features + GroupNorm(1) in two recomputing passes straight to bf16: no [n, P, 203] fp32 feature buffer
             # (pst_loftup_guidance + pst_groupnorm_apply did the same through a 639 MB round trip: 1076 -> 254 us per 16 views)
             st0 = hip.stats_buffer(n, 1, dev)
@@ -235,16 +225,46 @@ class LoftUpUpscaler(HipModule):
             hip.gemm(g0, pk['conv1'].w, c1, bias=pk['conv1'].b, conv=(pk['c0'], H2, W2))
             st = hip.stats_buffer(n, 8, dev)
             hip.groupnorm_stats(c1, st, n, P, C, 8)
-            g1 = empty(n * P, C, BF16, dev)
+            g1 = out[v0 * P:(v0 + n) * P]
             hip.groupnorm_apply(c1, st, pk['gn1'][0], pk['gn1'][1], g1, n, P, C, 8, pk['gn1'][2], True)
             hip.gemm(g1, pk['conv2'].w, c1, bias=pk['conv2'].b, conv=(C, H2, W2))
             hip.groupnorm_stats(c1, st, n, P, C, 8)
             hip.groupnorm_apply(c1, st, pk['gn2'][0], pk['gn2'][1], g1, n, P, C, 8, pk['gn2'][2], True)
+            del g0, c1
+        return out
+
+    @torch.no_grad()
+    def upscale_tokens(self, lr, imgs, V, h, w, fpn_out, mask_out, guidance=None):
+        """lr bf16 [V*T, lr_width()] with the mixer tokens in columns [0, input_dim) (the rest is filled here);
+        imgs fp32 [V,3,H,W] -> fpn_out bf16 [V*T, input_dim] (h x w raster), mask_out bf16 [V, H/2, W/2, dim].
+        A tall token grid (h > w) takes the guidance image transposed (loftup.py:147-149): the mask features then come
+        out landscape-shaped, mask_out bf16 [V, W/2, H/2, dim] (the low-res tokens only enter through cross-attention,
+        which does not care about their raster).  `guidance`: guidance_tokens(imgs, h, w) when the caller computed it earlier
+        (it is consumed: the two blocks update it in place as their residual stream)."""
+        dev = lr.device
+        pk = self.packed(dev)
+        T, D, C, Hh = h * w, self.input_dim, self.dim, self.num_heads
+        hd = C // Hh
+        H2, W2 = (imgs.shape[3] // 2, imgs.shape[2] // 2) if h > w else (imgs.shape[2] // 2, imgs.shape[3] // 2)
+        assert tuple(mask_out.shape) == (V, H2, W2, C), (tuple(mask_out.shape), (V, H2, W2, C))
+        P = H2 * W2
+        if guidance is None:
+            guidance = self.guidance_tokens(imgs, h, w)
+        assert tuple(guidance.shape) == (V * P, C)
+        hip.gemm(lr[:, :D], pk['pe'].w, fpn_out, bias=pk['pe'].b)
+        lr[:, D:].zero_()
+        hip.loftup_lr_pe(pk['lr_bias'], lr, D, V, h, w)
+        lay = Layout(V, T)
+        kv = torch.zeros(lay.rows, C, dtype=torch.float32, device=dev)
+        hip.gemm(lr, pk['lr_proj'].w, kv, bias=pk['lr_proj'].b, grp=lay.grp)
+        kvn = empty(lay.rows, C, torch.float32, dev)
+        hip.layernorm(kv, pk['lr_norm'][0], pk['lr_norm'][1], kvn, pk['lr_norm'][2])
+        for v0 in range(0, V, VIEW_CHUNK):
+            n = min(VIEW_CHUNK, V - v0)
             # ---- 2 x cross-only blocks: 49k queries per view attend to the view's T low-res tokens (hd 96).
             # The residual stream of these two blocks is kept in bf16: they are HBM-bound over P x C elements per view
             # (fp32 would double the read-modify-write traffic of both residual GEMMs and of every LayerNorm).
-            x = g1
-            del g0, c1
+            x = guidance[v0 * P:(v0 + n) * P]
             xn, q, o = empty(n * P, C, BF16, dev), empty(n * P, C, BF16, dev), empty(n * P, C, BF16, dev)
             rows0, rows1 = v0 * lay.Tp, (v0 + n) * lay.Tp
             for bw in pk['blocks']:
@@ -264,7 +284,7 @@ class LoftUpUpscaler(HipModule):
                 hip.gemm(xn, bw['fc1'].w, q, bias=bw['fc1'].b, act='gelu')
                 hip.gemm(q, bw['fc2'].w, x, bias=bw['fc2'].b, res=x)
             hip.layernorm(x, pk['norm'][0], pk['norm'][1], mask_out[v0:v0 + n].view(n * P, C), pk['norm'][2])
-            del x, xn, q, o, g1
+            del x, xn, q, o
         return fpn_out, mask_out
 
     def forward(self, inputs, img_shape):
@@ -586,7 +606,13 @@ class PanopticDecoder(HipModule):
         return ((w, h) if portrait else (h, w)), portrait
 
     @torch.no_grad()
-    def features_tokens(self, cat, imgs, V, h, w):
+    def guidance_tokens(self, imgs, h, w):
+        """Image-only part of the upscaler (LoftUp's guidance branch) or None: can run before / beside anything token-dependent."""
+        up = self.upscaler
+        return up.guidance_tokens(imgs, h, w) if isinstance(up, LoftUpUpscaler) else None
+
+    @torch.no_grad()
+    def features_tokens(self, cat, imgs, V, h, w, guidance=None):
         """cat bf16 [V*T, 2816] (enc | dec | dino) -> (fpn bf16 [V*T, d], mask_feats bf16 [V, Hm, Wm, C]).
         Portrait views (h > w) with landscape_only=True follow `transpose_to_landscape(upscaler, dims=(2,3))`
         (panoptic_decoder.py:26,56): the upscaler runs on the tall grid and both results are handed back transposed --
@@ -604,7 +630,7 @@ class PanopticDecoder(HipModule):
                 lr[:, :up.input_dim] = cat
             H2, W2 = imgs.shape[2] // 2, imgs.shape[3] // 2
             mf = torch.empty(V, min(H2, W2) if h > w else H2, max(H2, W2) if h > w else W2, up.mask_dim, dtype=BF16, device=dev)
-            up.upscale_tokens(lr, imgs, V, h, w, fpn, mf)
+            up.upscale_tokens(lr, imgs, V, h, w, fpn, mf, guidance=guidance)
         else:
             x = cat
             if self.input_mixer is not None:

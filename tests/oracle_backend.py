@@ -61,7 +61,10 @@ class OracleBackend:
             pms.append(pm[0][0])
         return torch.stack(pms)
 
-    def features(self, cat, imgs, n, h, w):
+    def guidance(self, imgs, h, w):
+        return None            # the oracle computes the guidance branch inside features()
+
+    def features(self, cat, imgs, n, h, w, guidance=None):
         T, p = h * w, self.patch_size
         ts = torch.tensor([[[h * p, w * p]] * n])
         pos = self._pos(h, w)[None].expand(1, n, -1, -1)

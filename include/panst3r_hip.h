@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 10
+#define PST_ABI_VERSION 11
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -115,6 +115,12 @@ int pst_layernorm_add_batch(const void* x, int64_t ldx, int in_fp32, const float
                             int out_fp32, const float* gamma, const float* beta, int rows, int D, float eps,
                             int grp_in, int grp_out, int grp_off, int nbatch, int64_t x_bs, int64_t y_bs, int64_t w_bs,
                             void* stream);
+
+/* split3: fp32 x [rows, K] -> bf16 [rows, 3K] = [x_hi | x_hi | x_lo] with x_hi = bf16(x), x_lo = bf16(x - x_hi).  Multiplied by
+ * weights packed as [W_hi | W_lo | W_hi] (one pst_gemm_bf16 over 3K, fp32 output) this evaluates x W^T with ~16 mantissa bits on
+ * the bf16 MFMA path.  Used for the 200-query mask-embedding MLP (mask_transformer.py:230), whose result is one factor of the
+ * ill-conditioned query x pixel product. */
+int pst_split3_bf16(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, void* stream);
 
 /* ---------------------------------------------------------------- RoPE-2D (in place on bf16 q and k)
  * Replaces cuRoPE2D / RoPE2D 'RoPE100' (README.md:67-71, input_mixer.py:16): per head the first hd/2 channels

@@ -105,6 +105,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t l
   }
 }
 
+// ------------------------------------------------------------------ split-precision operand: fp32 x -> [x_hi | x_hi | x_lo] bf16
+// x = x_hi + x_lo with x_hi = bf16(x), x_lo = bf16(x - x_hi).  Against weights packed as [W_hi | W_lo | W_hi] one bf16 MFMA GEMM over
+// 3K computes x_hi W_hi + x_hi W_lo + x_lo W_hi ~ x W with ~16 mantissa bits (the lo x lo term is dropped).  Used for the 200-row mask
+// embedding head, whose output multiplies every mask feature in an ill-conditioned dot product.
+__global__ void split3_kernel(const float* x, int64_t ldx, bf16_t* out, int64_t ldo, int rows, int K) {
+  const int64_t total = (int64_t)rows * (K / 4);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (K / 4)), c = (int)(i - (int64_t)r * (K / 4)) * 4;
+    const float4 v = *(const float4*)(x + (int64_t)r * ldx + c);
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    bf16_t hi[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hi[k] = f2bf(f[k]); lo[k] = f2bf(f[k] - bf2f(hi[k])); }
+    const uint2 h2 = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+    const uint2 l2 = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+    bf16_t* o = out + (int64_t)r * ldo + c;
+    *(uint2*)o = h2;
+    *(uint2*)(o + K) = h2;
+    *(uint2*)(o + 2 * K) = l2;
+  }
+}
+
 // ------------------------------------------------------------------ RoPE-2D in place
 // thread = (row, head, half, 4 consecutive frequencies): rotates pairs (i, i + hd/4) of that half.
 __global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd) {
@@ -319,6 +341,12 @@ extern "C" int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const 
                                  int grp_out, int grp_off, void* stream) {
   if (!add) { set_error("layernorm_add: null addend"); return PST_EINVAL; }
   return launch_layernorm(x, ldx, in_fp32, add, ld_add, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, stream);
+}
+
+extern "C" int pst_split3_bf16(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, void* stream) {
+  if (!x || !out || rows <= 0 || K <= 0 || K % 4 || ldx % 4 || ldo % 4 || ldo < 3 * (int64_t)K) { set_error("split3: bad argument (K=%d)", K); return PST_EINVAL; }
+  hipLaunchKernelGGL(split3_kernel, dim3(grid_for((int64_t)rows * (K / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)out, ldo, rows, K);
+  return check_launch("split3");
 }
 
 extern "C" int pst_rope2d_bf16(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, void* stream) {

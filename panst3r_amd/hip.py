@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -38,7 +38,7 @@ class AttnParams(C.Structure):
                 ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64)]
 
 
-EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add', 'pst_layernorm_add_batch', 'pst_rope2d_bf16',
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add', 'pst_layernorm_add_batch', 'pst_split3_bf16', 'pst_rope2d_bf16',
            'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16', 'pst_resize_bilinear_bf16',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize']
@@ -269,6 +269,22 @@ def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None):
                                int(out.dtype == torch.float32), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)),
                                rows, D, f32(eps), g[0], g[1], g[2], _stream()), 'pst_layernorm')
     return out
+
+
+def split3(x, out):
+    """fp32 x [rows, K] -> bf16 out [rows, 3K] = [x_hi | x_hi | x_lo] (operand of a split-precision GEMM, see pack_split3)."""
+    _dev(x, torch.float32); _dev(out, torch.bfloat16)
+    rows, K = x.shape
+    _check(lib().pst_split3_bf16(_ptr(x), i64(_rowmajor(x)), _ptr(out), i64(_rowmajor(out)), rows, K, _stream()), 'pst_split3_bf16')
+    return out
+
+
+def pack_split3(weight):
+    """fp32 weight [N, K] -> bf16 [N, 3K] = [W_hi | W_lo | W_hi] (pack time): with split3(x) one GEMM gives x_hi W_hi + x_hi W_lo + x_lo W_hi."""
+    w = weight.detach().float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo, hi], dim=1).contiguous()
 
 
 def rope2d_(x, pos, table, nheads, hd):

@@ -386,6 +386,8 @@ class MaskTransformer(HipModule):
                     qe=f32(self.query_embed.weight, device), lvl=f32(self.level_embed.weight, device),
                     lang=Packed(self.lang_embed.weight, self.lang_embed.bias, device),
                     me=[Packed(l.weight, l.bias, device) for l in self.mask_embed.layers],
+                    # the same MLP for split-precision evaluation: weights [W_hi | W_lo | W_hi] bf16, fp32 bias
+                    me3=[(hip.pack_split3(l.weight).to(device), f32(l.bias, device)) for l in self.mask_embed.layers],
                     scale=float(self.cls_logit_scale.detach().exp()), pe={})
 
     def _pe(self, pk, h, w, portrait, device):
@@ -402,12 +404,20 @@ class MaskTransformer(HipModule):
         Q, d = out.shape
         dn = empty(Q, d, BF16, dev)
         hip.layernorm(out, pk['dn'][0], pk['dn'][1], dn, pk['dn'][2])
-        a = dn
-        for j, l in enumerate(pk['me']):
-            b = empty(Q, l.n, BF16, dev)
-            hip.gemm(a, l.w, b, bias=l.b, act=None if j == len(pk['me']) - 1 else 'relu')
+        # mask_embed MLP in split precision (x = x_hi + x_lo, W = W_hi + W_lo, fp32 between the layers): its 200 x C result is one
+        # factor of the ill-conditioned query x pixel product, where an embedding error of 8e-3 shows up as 1.9e-2 on the mask logits
+        # (tools/parity_maskhead.py).  The three GEMMs are tiny, so the 3x longer K costs nothing.
+        a = empty(Q, d, torch.float32, dev)
+        hip.layernorm(out, pk['dn'][0], pk['dn'][1], a, pk['dn'][2])
+        for j, (w3, b3) in enumerate(pk['me3']):
+            a3 = empty(Q, w3.shape[1], BF16, dev)
+            hip.split3(a, a3)
+            b = empty(Q, w3.shape[0], torch.float32, dev)
+            hip.gemm(a3, w3, b, bias=b3, act=None if j == len(pk['me3']) - 1 else 'relu')
             a = b
-        return dn, a
+        emb = empty(Q, a.shape[1], BF16, dev)
+        hip.add_cast(a, emb)
+        return dn, emb
 
     def _class_logits(self, pk, dn, cls_bf16):
         dev = dn.device

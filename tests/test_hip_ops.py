@@ -534,3 +534,24 @@ def test_layernorm_strided_batch():
     out = torch.zeros_like(ref)
     hip.layernorm_batch(x[:L], g, b, out, 1e-6, rows=2 * T, grp=grp, add=add)
     assert torch.equal(out, ref)
+
+
+def test_split3_gemm_is_near_fp32():
+    """split3(x) x pack_split3(W): hi + lo reconstructs x to ~2^-16 and the 3K-long bf16 MFMA GEMM tracks the float64 product two
+    orders of magnitude closer than the plain bf16 GEMM (the mask-embedding head relies on this)."""
+    from panst3r_amd import hip
+    M, N, K = 200, 384, 768
+    x, w, b = rn(700, M, K), rn(701, N, K, scale=K ** -0.5), rn(702, N)
+    x3 = torch.zeros(M, 3 * K, dtype=torch.bfloat16, device=dev())
+    hip.split3(x.to(dev()), x3)
+    hi, hi2, lo = x3[:, :K].float().cpu(), x3[:, K:2 * K].float().cpu(), x3[:, 2 * K:].float().cpu()
+    assert torch.equal(hi, hi2) and torch.equal(hi, x.to(torch.bfloat16).float())
+    assert rel_l2(hi + lo, x) < 2e-5
+    w3 = hip.pack_split3(w).to(dev())
+    out = torch.empty(M, N, dtype=torch.float32, device=dev())
+    hip.gemm(x3, w3, out, bias=b.to(dev()))
+    ref = x.double() @ w.double().T + b.double()
+    plain = torch.empty(M, N, dtype=torch.float32, device=dev())
+    hip.gemm(bf(x).to(dev()), bf(w).to(dev()), plain, bias=b.to(dev()))
+    e_split, e_plain = rel_l2(out.cpu(), ref), rel_l2(plain.cpu(), ref)
+    assert e_split < 5e-5 and e_plain > 20 * e_split, (e_split, e_plain)

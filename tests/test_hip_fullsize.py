@@ -3,7 +3,7 @@ the fp32 CPU oracle with the same synthetic weights: 2 views / 2 keyframes at 38
 leg times, reused here through the same helpers.  The other -m gpu tests use tiny configurations.
 
 Tolerances are the ones SURVEY 8(d) states for bf16 MFMA vs the fp32 oracle.  Four of the five hold; the mask sign agreement
-(>= 99.5 %) does not at full size (99.0 % measured) and is kept as an explicit xfail, not relaxed."""
+(>= 99.5 %) does not at full size (99.3 % measured) and is kept as an explicit xfail, not relaxed."""
 import pytest
 import torch
 
@@ -38,7 +38,7 @@ def test_full_size_outputs_within_stated_tolerance(parity):
     assert parity['mask_sign_agreement'] >= 0.985, parity          # floor actually held; the stated 99.5 % is the xfail below
 
 
-@pytest.mark.xfail(reason='known gap: 99.0 % measured vs the 99.5 % of SURVEY 8(d); follows from the ~3e-2 rel-L2 of zero-centred '
+@pytest.mark.xfail(reason='known gap: 99.3 % measured vs the 99.5 % of SURVEY 8(d); follows from the ~2e-2 rel-L2 of zero-centred '
                           'random-init mask logits (DESIGN.md section 6)', strict=False)
 def test_full_size_mask_sign_agreement_meets_survey_criterion(parity):
     assert parity['mask_sign_agreement'] >= parity['tolerance']['mask_sign_agreement'], parity

@@ -67,6 +67,25 @@ with torch.no_grad():
         fpn_h, mf_h = pdh.features_tokens(cat_in, img_d, V, h, w)
         out['fpn tokens, ' + tag] = rel(fpn_h.float().view(V, h, w, -1).permute(0, 3, 1, 2), fpn_o[0])
         out['mask features, ' + tag] = rel(mf_h.float().permute(0, 3, 1, 2), mf_o[0])
+# ---- inside the LoftUp stage: the image-only guidance branch (per-view min-max scaling like the demo's max_bs = 1) and the query decoder
+with torch.no_grad():
+    import torch.nn.functional as F
+    up_o, up_h = pd.upscaler, pdh.upscaler
+    g_o = torch.cat([up_o.first_conv(up_o.fourier_feat(F.interpolate(st[i:i + 1], scale_factor=0.5, mode='bilinear', align_corners=False)))
+                     for i in range(V)])                                                  # [V,C,H2,W2]
+    g_h = up_h.guidance_tokens(img_d, h, w)                                                # [V*P, C]
+    out['loftup guidance branch (image only)'] = rel(g_h.float().view(V, H // 2, W // 2, -1).permute(0, 3, 1, 2), g_o)
+    # query decoder fed with the ORACLE's keyframe features: its own error, vs fed with the HIP features
+    mt_o, mt_h = pd.mask_transformer, pdh.mask_transformer
+    cls_o = pd.text_encoder(names)
+    ref = mt_o([[fpn_o[0][None][:, i] for i in range(V)]] if False else [[fpn_o[:, i:i + 1][0][None] for i in range(V)]],
+               [mf_o[:, i:i + 1][0][None] for i in range(V)], [ts[i:i + 1][None] for i in range(V)], cls_o, multi_ar=True)
+    q_o = ref['out_queries'].reshape(-1, ref['out_queries'].shape[-1])
+    cls_h = pdh.text_encoder.normalized_bf16(names, dev)
+    fpn_tok_o = fpn_o[0].flatten(2).transpose(1, 2).reshape(V * T, -1).to(BF).to(dev)
+    mf_tok_o = mf_o[0].permute(0, 2, 3, 1).contiguous().to(BF).to(dev)
+    q_h_own, _ = mt_h.decode_tokens(fpn_tok_o, mt_h.attn_feats(mf_tok_o), [(h, w)] * V, cls_h)
+    out['query decoder, own error (oracle features in)'] = rel(q_h_own, q_o)
 for k, v in out.items():
     print('%-52s rel-L2 %.2e' % (k, v))
 print(json.dumps(out))

@@ -406,7 +406,7 @@ class MaskTransformer(HipModule):
         hip.layernorm(out, pk['dn'][0], pk['dn'][1], dn, pk['dn'][2])
         # mask_embed MLP in split precision (x = x_hi + x_lo, W = W_hi + W_lo, fp32 between the layers): its 200 x C result is one
         # factor of the ill-conditioned query x pixel product, where an embedding error of 8e-3 shows up as 1.9e-2 on the mask logits
-        # (tools/parity_maskhead.py).  The three GEMMs are tiny, so the 3x longer K costs nothing.
+        # (tests/diag/parity_maskhead.py).  The three GEMMs are tiny, so the 3x longer K costs nothing.
         a = empty(Q, d, torch.float32, dev)
         hip.layernorm(out, pk['dn'][0], pk['dn'][1], a, pk['dn'][2])
         for j, (w3, b3) in enumerate(pk['me3']):

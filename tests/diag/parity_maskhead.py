@@ -3,7 +3,7 @@
 2-view cpu_baseline sample; E and F are taken from the fp32 CPU oracle and from the HIP path and recombined in float64.
 Diagnostic; the oracle is only the checker."""
 import sys, os, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench
@@ -42,7 +42,6 @@ with torch.no_grad():
     L_h = pan_h['pred_masks'][0][0].cpu().double()
     Q, H2, W2 = L_o.shape
     # F from the logits is not available directly: recover F by re-running the feature stages
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
 out = {'E (HIP vs oracle)': rel(E_h, E_o), 'E (HIP head on oracle queries vs oracle)': rel(E_h_oq, E_o), 'logits (HIP vs oracle)': rel(L_h, L_o)}
 # F: least-squares is ill-posed; instead use the identity L = E F  =>  compare (E_h - E_o) F_o contribution through the oracle logits:
 # project: L_h - L_o = (E_h - E_o) F_o + E_o (F_h - F_o) + second order.  With F_o unknown here, estimate the E-part from the

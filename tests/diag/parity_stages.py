@@ -2,7 +2,7 @@
 """Where does the bf16 error enter?  Full-size v2 model, 2 views / 2 keyframes at 384x512 (the bench's cpu_baseline sample):
 the HIP path and the fp32 CPU oracle (same weights) are compared stage by stage.  Diagnostic; the oracle is only the checker."""
 import sys, os, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from panst3r_amd.panst3r import CONFIG_V2, build_from_config

@@ -3,7 +3,7 @@
 200 queries x V views at 384x512 (mask logits [1,200,192,256] per view), synthetic blob masks, 100 classes.
 Prints one JSON line (ms per scene, per-kernel HIP-event times are taken with rocprofv3 separately)."""
 import sys, os, json, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from panst3r_amd.engine import panoptic_inference_v2

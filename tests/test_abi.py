@@ -60,3 +60,18 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_only_the_allowed_places_import_the_oracle():
+    """oracle/ is test infrastructure: besides tests/ only __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+    tools/ must not (oracle-checking diagnostics live in tests/diag/), and bench.py only inside cpu_baseline()."""
+    pat = re.compile(r'^(\s*)(from|import)\s+oracle\b', flags=re.M)
+    for f in os.listdir(os.path.join(ROOT, 'tools')):
+        if f.endswith('.py'):
+            assert not pat.search(open(os.path.join(ROOT, 'tools', f)).read()), f
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    hits = [m for m in pat.finditer(src)]
+    assert hits and all(len(m.group(1)) > 0 for m in hits)                      # function-level imports only
+    body = src[src.index('def cpu_baseline('):src.index('def full_size_parity(')]
+    assert all(body.find(m.group(0).strip()) >= 0 for m in hits) and len(hits) == len(pat.findall(body))
+    # (__graft_entry__.build() import-checks the Python oracle as its "build the checker" step, which is allowed; smoke() uses it)

@@ -61,6 +61,9 @@ def gather_keyframe_rows(local_rows, K, T, rank, world, group):
     return out
 
 
+EAGER_SIDE_STREAM = False     # True re-enables the two-stream EAGER launch (unsafe, see SceneRunner.stage2); only tests/diag/determinism.py sets it
+
+
 class _Group:
     """The views of one image shape owned by this rank (keyframes first)."""
     __slots__ = ('H', 'W', 'h', 'w', 'T', 'idx', 'k', 'imgs', 'cat', 'pointmaps', 'fpn', 'mf', 'guid')
@@ -171,7 +174,11 @@ class SceneRunner:
         bulk work (_encode_rest) runs concurrently on a second stream (a parallel branch of the captured graph)."""
         b = self.b
         dev = self.groups[0].imgs.device
-        side = None if self.serial else b.side_stream(dev)
+        # Two streams ONLY inside a HIP-graph capture.  Launched eagerly with the caching allocator, the side branch showed an intermittent
+        # cross-stream hazard at full size (DINOv2 tokens of whole views deviating in 11 of 30 scenes; 0 of 30 with allocator caching
+        # disabled, 0 in serial eager, 0 in graph replay: tests/diag/determinism.py), so eager runs execute the branches back to back.
+        capturing = hasattr(torch.cuda, 'is_current_stream_capturing') and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        side = b.side_stream(dev) if ((capturing or EAGER_SIDE_STREAM) and not self.serial) else None
         if side is None:
             self._encode_rest()
             bank = b.build_memory(self.enc_kf, self.K, self.kf_grids)

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Full-size determinism probe: graph replay vs eager vs eager-serial, each run twice; reports which outputs differ and by how much.
+
+Finding (round 1): graph replay and serial eager are bit-identical and reproducible; an EAGER launch with the two branches of stage 2 on
+two streams is not (DINOv2 tokens of whole views deviate in a fraction of the scenes; none with PYTORCH_NO_CUDA_MEMORY_CACHING=1), so
+SceneRunner uses the side stream only while capturing.  PST_DET_FORCE_SIDE=1 re-enables the unsafe eager two-stream launch to reproduce it."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from panst3r_amd.panst3r import CONFIG_V2, CONFIG_V1, build_from_config
+from panst3r_amd.synthetic import fill_module_, synth_image, synth_class_embeddings
+
+variant = sys.argv[1] if len(sys.argv) > 1 else 'v2'
+V, K = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (16, 4)
+H, W = 384, 512
+dev = torch.device('cuda:0')
+model = build_from_config(CONFIG_V2 if variant == 'v2' else CONFIG_V1).eval()
+fill_module_(model, seed=1)
+names, emb = synth_class_embeddings(100)
+model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
+model.to(dev)
+imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
+NOGRAPH = os.environ.get('PST_DET_NOGRAPH') == '1'
+import panst3r_amd.scene as _scene
+_scene.EAGER_SIDE_STREAM = os.environ.get('PST_DET_FORCE_SIDE') == '1'
+runner = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=not NOGRAPH)
+
+def snap(kw):
+    r, s = runner.run(**kw)
+    torch.cuda.synchronize()
+    return ({k: (a.clone(), b.clone()) for k, (a, b) in r.items()}, s['out_queries'].clone(), s['pred_logits'].clone())
+
+def diff(x, y):
+    pm = max(float((x[0][k][0] - y[0][k][0]).abs().max()) for k in x[0])
+    mk = max(float((x[0][k][1] - y[0][k][1]).abs().max()) for k in x[0])
+    return 'pointmaps %.3g  masks %.3g  out_queries %.3g' % (pm, mk, float((x[1] - y[1]).abs().max()))
+
+if NOGRAPH:
+    N = 0
+runs = {}
+runs['capture'] = snap(dict(eager=True, serial=True) if NOGRAPH else {})
+for name, kw in (() if NOGRAPH else (('graph1', {}), ('graph2', {}), ('eager1', dict(eager=True)), ('eager2', dict(eager=True)),
+                 ('serial1', dict(eager=True, serial=True)), ('serial2', dict(eager=True, serial=True)), ('graph3', {}))):
+    runs[name] = snap(kw)
+for a, b in (() if NOGRAPH else (('capture', 'graph1'), ('graph1', 'graph2'), ('graph1', 'graph3'), ('eager1', 'eager2'), ('serial1', 'serial2'), ('graph1', 'eager1'),
+             ('graph1', 'serial1'), ('eager1', 'serial1'))):
+    print('%-8s vs %-8s max |diff|: %s' % (a, b, diff(runs[a], runs[b])))
+
+N = 0 if NOGRAPH else int(os.environ.get('PST_DET_N', '24'))
+bad = collections = 0
+worst = (0.0, 0.0, 0.0)
+cnt = {'pointmaps': 0, 'masks': 0, 'out_queries': 0}
+g = runs.get('graph1', runs['capture'])
+for i in range(N):
+    e = snap(dict(eager=True))
+    pm = max(float((e[0][k][0] - g[0][k][0]).abs().max()) for k in g[0])
+    mk = max(float((e[0][k][1] - g[0][k][1]).abs().max()) for k in g[0])
+    oq = float((e[1] - g[1]).abs().max())
+    cnt['pointmaps'] += pm > 0; cnt['masks'] += mk > 0; cnt['out_queries'] += oq > 0
+    worst = (max(worst[0], pm), max(worst[1], mk), max(worst[2], oq))
+print('%d concurrent eager scenes vs graph: deviating in pointmaps %d, masks %d, out_queries %d; worst |diff| %s' % (N, cnt['pointmaps'], cnt['masks'], cnt['out_queries'], worst))
+
+# ---- which intermediate diverges first?  (the runner keeps its per-group buffers as attributes)
+def stage_snap(kw):
+    runner.run(**kw)
+    torch.cuda.synchronize()
+    grp = runner.groups[0]
+    De, Dd = 1024, 768
+    return {'cat: encoder cols': grp.cat[:, :De].clone(), 'cat: decoder cols': grp.cat[:, De:De + Dd].clone(), 'cat: dinov2 cols': grp.cat[:, De + Dd:].clone(),
+            'fpn tokens': grp.fpn.clone(), 'mask feats': grp.mf.clone(), 'keyframe encoder rows (build input)': runner.enc_kf.clone()}
+base = stage_snap(dict(eager=True, serial=True) if NOGRAPH else {})
+hits = {k: 0 for k in base}
+M = int(os.environ.get('PST_DET_M', '30'))
+first = None
+for i in range(M):
+    cur = stage_snap(dict(eager=True))
+    for k in base:
+        if not torch.equal(cur[k], base[k]):
+            hits[k] += 1
+            if k == 'cat: dinov2 cols' and first is None:
+                d = (cur[k].float() - base[k].float()).abs()
+                rows = torch.nonzero(d.amax(1) > 0)[:, 0]
+                first = 'dinov2 cols: %d of %d rows differ, first rows %s, last rows %s, max |diff| %.3g' % (rows.numel(), d.shape[0], rows[:6].tolist(), rows[-3:].tolist(), float(d.max()))
+print('%d concurrent eager scenes, buffers deviating from the graph run:' % M, hits)
+print(first)

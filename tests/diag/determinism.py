@@ -22,6 +22,22 @@ model.to(dev)
 imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
 NOGRAPH = os.environ.get('PST_DET_NOGRAPH') == '1'
 import panst3r_amd.scene as _scene
+PADB = int(os.environ.get('PST_DET_PAD', '0'))          # bytes of tail guard behind every torch.empty / torch.zeros (out-of-bounds-write test)
+if PADB:
+    import math
+    _e, _z = torch.empty, torch.zeros
+    def _padded(fn):
+        def wrapped(*shape, **kw):
+            if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+                shape = tuple(shape[0])
+            if not kw.get('device') or 'cuda' not in str(kw.get('device')) or not all(isinstance(v, int) for v in shape) or not shape:
+                return fn(*shape, **kw)
+            n = math.prod(shape)
+            es = torch.empty(0, dtype=kw.get('dtype', torch.float32)).element_size()
+            base = fn(n + PADB // es, **kw)
+            return base[:n].view(*shape)
+        return wrapped
+    torch.empty, torch.zeros = _padded(_e), _padded(_z)
 _scene.EAGER_SIDE_STREAM = os.environ.get('PST_DET_FORCE_SIDE') == '1'
 runner = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=not NOGRAPH)
 

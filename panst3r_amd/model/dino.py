@@ -85,6 +85,9 @@ class _Dinov2P(nn.Module):
         self.layernorm = nn.LayerNorm(hidden_size, eps=layer_norm_eps)
 
 
+TAPS = None        # diagnostics (tests/diag): a list that receives clones of the residual stream after every block
+
+
 class DinoV2Encoder(HipModule):
     def __init__(self, dino_model='facebook/dinov2-large', output_stride=16, landscape_only=True, hidden_size=1024,
                  num_hidden_layers=24, num_attention_heads=16, mlp_ratio=4, patch_size=14, image_size=518, layer_norm_eps=1e-6):
@@ -142,8 +145,12 @@ class DinoV2Encoder(HipModule):
         x = torch.zeros(lay.rows, D, dtype=torch.float32, device=dev)
         x.view(V, lay.Tp, D)[:, 0] = cls
         hip.gemm(patches, pk['patch'].w, x, bias=pk['patch'].b, res=pospatch, res_mod=lay.T, grp=lay.grp)
-        for bw in pk['blocks']:
+        if TAPS is not None:
+            TAPS.append(('pre', pre.clone())); TAPS.append(('patches', patches.clone())); TAPS.append(('embed', x.clone()))
+        for i, bw in enumerate(pk['blocks']):
             vit_block(x, bw, lay, Hh, D // Hh)
+            if TAPS is not None:
+                TAPS.append(('block %d' % i, x.clone()))
         hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, col0:col0 + D], pk['norm'][2], rows=V * lay.T, grp=lay.grp)
         return out
 

@@ -129,13 +129,15 @@ class PanSt3R(nn.Module):
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
         return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice)
 
-    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None):
+    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None):
         """Static-shape scene runner (panst3r_amd/scene.py): `images` = {view_id: [3,H,W] device tensor} of the views
-        this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True."""
+        this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True.
+        `overlap=True` runs the memory build beside the bulk encoder work on a second stream (faster, NOT reproducible on this
+        platform - scene.OVERLAP_DEFAULT); the default runs them back to back."""
         import torch.distributed as dist
         from .scene import SceneRunner, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes)
+        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap)
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Full-size determinism probe: graph replay vs eager vs eager-serial, each run twice; reports which outputs differ and by how much.
 
-Finding (round 1): graph replay and serial eager are bit-identical and reproducible; an EAGER launch with the two branches of stage 2 on
-two streams is not (DINOv2 tokens of whole views deviate in a fraction of the scenes; none with PYTORCH_NO_CUDA_MEMORY_CACHING=1), so
-SceneRunner uses the side stream only while capturing.  PST_DET_FORCE_SIDE=1 re-enables the unsafe eager two-stream launch to reproduce it."""
+Finding (round 1): with the two branches of stage 2 on two streams (PST_DET_FORCE_SIDE=1) neither eager launches nor graph replays are
+reproducible (DINOv2 tokens of whole views deviate; shape dependent: 13 views / 4 keyframes and 25 / 16 in most replays, 50 / 16 and 16 / 4
+only in eager launches); one stream (the default since) is reproducible in every trial.  See dino_taps.py for the localisation."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -38,7 +38,7 @@ if PADB:
             return base[:n].view(*shape)
         return wrapped
     torch.empty, torch.zeros = _padded(_e), _padded(_z)
-_scene.EAGER_SIDE_STREAM = os.environ.get('PST_DET_FORCE_SIDE') == '1'
+_scene.OVERLAP_DEFAULT = os.environ.get('PST_DET_FORCE_SIDE') == '1'      # two-stream stage 2 (graphs and eager launches alike)
 runner = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=not NOGRAPH)
 
 def snap(kw):

@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""First DINOv2 layer whose residual stream differs between a graph replay (two concurrent branches) and serial eager.  `dino_taps.py 13 4`"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from panst3r_amd.panst3r import CONFIG_V2, build_from_config
+from panst3r_amd.synthetic import fill_module_, synth_image, synth_class_embeddings
+import panst3r_amd.model.dino as dino
+
+V, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (13, 4)
+H, W = 384, 512
+dev = torch.device('cuda:0')
+model = build_from_config(CONFIG_V2).eval()
+fill_module_(model, seed=1)
+names, emb = synth_class_embeddings(100)
+model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
+model.to(dev)
+imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
+runner = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=False)
+runner.run(eager=True, serial=True)                      # warm-up (weight packing)
+dino.TAPS = []
+runner.run(eager=True, serial=True); torch.cuda.synchronize()
+ref = [(n, t.clone()) for n, t in dino.TAPS]
+dino.TAPS = []
+runner.run(eager=True, serial=True); torch.cuda.synchronize()
+print('serial vs serial:', 'identical' if all(torch.equal(a[1], b[1]) for a, b in zip(ref, dino.TAPS)) else 'DIFFERENT')
+import panst3r_amd.scene as _scene
+from panst3r_amd import hip
+MODE = os.environ.get('PST_MAIN', 'build')
+_a = torch.randn(4096, 4096, device=dev).bfloat16(); _b = torch.randn(4096, 4096, device=dev).bfloat16(); _c = torch.empty(4096, 4096, device=dev, dtype=torch.bfloat16)
+_x = torch.zeros(1 << 16, device=dev)
+_ga = torch.randn(768, 1024, device=dev).bfloat16(); _gw = torch.randn(1024, 1024, device=dev).bfloat16(); _go = torch.empty(768, 1024, device=dev, dtype=torch.bfloat16)
+def _torchmm():
+    for _ in range(300):
+        torch.mm(_a, _b, out=_c)
+def _tiny():
+    for _ in range(4000):
+        _x.add_(1.0)
+def _hipgemm():
+    for _ in range(3000):
+        hip.gemm(_ga, _gw, _go)
+_ln_x = torch.randn(768, 1024, device=dev); _ln_g = torch.ones(1024, device=dev); _ln_b = torch.zeros(1024, device=dev); _ln_o = torch.empty(768, 1024, device=dev, dtype=torch.bfloat16)
+def _hipln():
+    for _ in range(3000):
+        hip.layernorm(_ln_x, _ln_g, _ln_b, _ln_o, 1e-6)
+_gA = torch.randn(4096, 1024, device=dev).bfloat16(); _gO = torch.empty(4096, 1024, device=dev, dtype=torch.bfloat16)
+def _hipgemm128():
+    for _ in range(1500):
+        hip.gemm(_gA, _gw, _gO, kernel=128)
+def _hipgemm256():
+    for _ in range(1500):
+        hip.gemm(_gA, _gw, _gO, kernel=256)
+_q = torch.randn(768, 2048, device=dev).bfloat16(); _vt = torch.randn(1024, 768, device=dev).bfloat16(); _ao = torch.empty(768, 1024, device=dev, dtype=torch.bfloat16)
+def _hipattn():
+    for _ in range(3000):
+        hip.attention(_q, _q[:, 1024:], _vt, _ao, 1, 16, 768, 768, 64, (0, 64, 2048), (0, 64, 2048), (0, 64 * 768, 768), (0, 64, 1024), nsplit=1)
+if MODE == 'torchmm':
+    _torchmm(); torch.cuda.synchronize()            # hipBLASLt initialises outside the capture
+_m1 = torch.randn(768, 1024, device=dev).bfloat16(); _m2 = torch.randn(1024, 1024, device=dev).bfloat16(); _m3 = torch.empty(768, 1024, device=dev, dtype=torch.bfloat16)
+def _torchmm_small():
+    for _ in range(3000):
+        torch.mm(_m1, _m2, out=_m3)
+if MODE == 'torchmm_small':
+    _torchmm_small(); torch.cuda.synchronize()
+_scene.DIAG_CONCURRENT = {'hipln': _hipln, 'hipgemm128': _hipgemm128, 'hipgemm256': _hipgemm256, 'hipattn': _hipattn, 'torchmm_small': _torchmm_small, 'build': None, 'torchmm': _torchmm, 'tiny': _tiny, 'hipgemm': _hipgemm, 'none': (lambda: None)}[MODE]
+print('main-branch workload beside the side branch:', MODE)
+# capture with the taps in place: the clones live in the graph pool and hold the values of the latest replay
+dino.TAPS = []
+runner2 = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=True, overlap=True)
+taps = dino.TAPS
+runner2.run(); torch.cuda.synchronize()                 # warm-up + capture happen in the first run()
+dino.TAPS = None
+T = 768 + 1
+for rep in range(int(os.environ.get('PST_R', '4'))):
+    runner2.run(); torch.cuda.synchronize()
+    line = []
+    for (n, a), (n2, b) in zip(ref, taps[-len(ref):]):
+        if not torch.equal(a, b):
+            d = (a.float() - b.float()).abs()
+            d2 = d.reshape(V, -1)
+            views = torch.nonzero(d2.amax(1) > 0)[:, 0].tolist()
+            if n not in ('pre', 'patches'):
+                dv = d.reshape(V, -1, d.shape[-1])
+                v0 = views[0]
+                rows = torch.nonzero(dv[v0].amax(1) > 0)[:, 0]
+                cols = torch.nonzero(dv[v0].amax(0) > 0)[:, 0]
+                extra = ' view %d: %d rows [%d..%d], %d cols [%d..%d]' % (v0, rows.numel(), rows[0], rows[-1], cols.numel(), cols[0], cols[-1])
+            else:
+                extra = ''
+            line.append('%s: views %s max %.3g%s' % (n, views, float(d.max()), extra))
+    nbad = globals().get('nbad', 0) + bool(line)
+    if line and nbad <= 3:
+        print('replay %d:' % rep, ' | '.join(line[:3]))
+print('%s: %d of %d replays deviate from serial' % (MODE, globals().get('nbad', 0), int(os.environ.get('PST_R', '4'))))

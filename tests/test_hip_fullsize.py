@@ -37,20 +37,22 @@ def parity(full):
 
 
 def test_full_size_graph_replay_equals_eager(full):
-    """Size-independent property at the real shapes: a 16-view / 4-keyframe 384x512 scene (padded 769-token DINOv2 layout, 256x256- and
-    128x128-tile GEMM dispatch, split-K attention in the memory build, two-stream stage 2) gives the same bits when its three captured
-    HIP graphs are replayed, when it is launched eagerly, and when the two branches of stage 2 run back-to-back instead of concurrently."""
+    """Size-independent property at the real shapes: a 13-view / 4-keyframe 384x512 scene (padded 769-token DINOv2 layout, 256x256- and
+    128x128-tile GEMM dispatch, split-K attention in the memory build) gives the same bits every time its three captured HIP graphs are
+    replayed and when it is launched eagerly.  13 / 4 is the shape at which the former two-stream stage 2 lost cache-line-sized fragments
+    of side-stream buffers in most replays (tests/diag/dino_taps.py); the shipped one-stream schedule must be reproducible there."""
     from panst3r_amd.synthetic import synth_image
     model, _, names, _ = full
     dev = torch.device('cuda:0')
-    V, K, H, W = 16, 4, 384, 512
+    V, K, H, W = 13, 4, 384, 512
     imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
     runner = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=True)
+    assert runner.serial, 'the two-stream stage 2 must stay opt-in'
     r1, s1 = runner.run()                                   # warm-up + capture (the captured pass itself is executed)
     ref = {k: (a.clone(), b.clone()) for k, (a, b) in r1.items()}
     q = s1['out_queries'].clone()
     assert all(torch.isfinite(a).all() and torch.isfinite(b).all() for a, b in ref.values())
-    for kw in (dict(), dict(eager=True), dict(eager=True, serial=True)):
+    for kw in (dict(),) * 6 + (dict(eager=True),) * 2:
         r, s = runner.run(**kw)
         assert torch.equal(s['out_queries'], q), kw
         for k in range(V):

@@ -206,3 +206,19 @@ def test_eight_rank_bookkeeping_of_the_bench_scene(monkeypatch):
         out = gather_keyframe_rows(sends[r], K, [T] * K, r, world, None)
         assert out.shape == (K * T, 2)
         assert torch.equal(out[::T, 0], torch.arange(K, dtype=torch.float32))    # schedule order 0..K-1 on every rank
+
+
+def test_two_stream_stage2_is_opt_in():
+    """The memory build beside the bulk branch on a second stream is not reproducible on MI355X: every
+    runner executes the two branches back to back unless `overlap=True` is passed explicitly."""
+    import panst3r_amd.scene as S
+
+    class Dummy:
+        patch_size, mask_dim = 16, 8
+        def fpn_grid(self, h, w):
+            return (h, w), False
+
+    imgs = {i: torch.zeros(3, 8, 8) for i in range(4)}
+    assert S.OVERLAP_DEFAULT is False
+    assert S.SceneRunner(Dummy(), imgs, 4, 64, 64, 2, tiny.NAMES).serial is True
+    assert S.SceneRunner(Dummy(), imgs, 4, 64, 64, 2, tiny.NAMES, overlap=True).serial is False

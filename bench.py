@@ -100,7 +100,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--overlap', action='store_true', help='MEASUREMENT ONLY: run the memory build beside the independent encoder/DINOv2 work on a second stream '
-                    '(about +5 %% frames/s, but results are not reproducible on this platform: DESIGN.md section 4); default: back to back')
+                    '(+8 %% frames/s; was not reproducible until one kernel was fixed, mechanism not understood: DESIGN.md section 4); default: back to back')
     ap.add_argument('--no-overlap', action='store_true', help=argparse.SUPPRESS)       # former switch; serial is the default now
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying HIP graphs')
     args = ap.parse_args()
@@ -182,8 +182,8 @@ def main():
                        'variant': args.variant, 'views': V, 'keyframes': K, 'resolution': [H, W],
                        'parallelism': 'views sharded over %d rank(s)' % world,
                        'launch': 'eager' if args.eager else 'HIP-graph replay (3 graphs per scene; last timed step eager + HIP-event instrumented)',
-                       'overlap': 'memory build || non-keyframe encoder + DINOv2 (2 streams; measurement only, not reproducible)' if (args.overlap and not args.no_overlap)
-                                  else 'off (one stream: the two-stream variant is not reproducible on this platform, DESIGN.md section 4)',
+                       'overlap': 'memory build || non-keyframe encoder + DINOv2 (2 streams; opt-in, DESIGN.md section 4)' if (args.overlap and not args.no_overlap)
+                                  else 'off (one stream; the two-stream variant is opt-in, DESIGN.md section 4)',
                        'scene_algorithmic_tflop': round(scene_flops / 1e12, 2),
                        'scene_mfma_frac': round(scene_flops / (elapsed / args.steps) / world / (PEAK_BF16_TFLOPS * 1e12), 4)},
         }

@@ -179,22 +179,40 @@ __global__ void patchify_kernel(const float* img, bf16_t* out, int64_t ld, int n
 }
 
 // ------------------------------------------------------------------ DINOv2 preprocessing (normalise + bilinear resize)
+// one thread = VEC consecutive output pixels of a row, stored as one 4*VEC-byte write (Wo % VEC == 0)
+template <int VEC>
 __global__ void dino_pre_kernel(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo) {
-  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   const float sy = (float)H / Ho, sx = (float)W / Wo;
-  const int64_t total = (int64_t)nimg * 3 * Ho * Wo;
+  const int wq = Wo / VEC;
+  const int64_t total = (int64_t)nimg * 3 * Ho * wq;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho), c = (int)((i / ((int64_t)Wo * Ho)) % 3);
-    const int64_t n = i / ((int64_t)Wo * Ho * 3);
-    const float fy = fmaxf((oy + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-    const float ly = fy - y0, lx = fx - x0;
+    const int oq = (int)(i % wq), oy = (int)((i / wq) % Ho), c = (int)((i / ((int64_t)wq * Ho)) % 3);
+    const int64_t n = i / ((int64_t)wq * Ho * 3);
+    const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f), stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    const float fy = fmaxf((oy + 0.5f) * sy - 0.5f, 0.f);
+    const int y0 = (int)fy;
+    const int y1 = min(y0 + 1, H - 1);
+    const float ly = fy - y0;
     const float* pl = img + (n * 3 + c) * (int64_t)H * W;
-    auto nv = [&](int yy, int xx) { return ((pl[(int64_t)yy * W + xx] * 0.5f + 0.5f) - mean[c]) / stdv[c]; };
-    const float top = nv(y0, x0) * (1.f - lx) + nv(y0, x1) * lx;
-    const float bot = nv(y1, x0) * (1.f - lx) + nv(y1, x1) * lx;
-    out[i] = top * (1.f - ly) + bot * ly;
+    const float* r0 = pl + (int64_t)y0 * W;
+    const float* r1 = pl + (int64_t)y1 * W;
+    auto nv = [&](float v) { return ((v * 0.5f + 0.5f) - mean) / stdv; };
+    float op[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int ox = oq * VEC + k;
+      const float fx = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+      const int x0 = (int)fx;
+      const int x1 = min(x0 + 1, W - 1);
+      const float lx = fx - x0;
+      const float top = nv(r0[x0]) * (1.f - lx) + nv(r0[x1]) * lx;
+      const float bot = nv(r1[x0]) * (1.f - lx) + nv(r1[x1]) * lx;
+      op[k] = top * (1.f - ly) + bot * ly;
+    }
+    float* dst = out + (((n * 3 + c) * (int64_t)Ho + oy) * Wo + oq * VEC);
+    if constexpr (VEC == 4) *(float4*)dst = make_float4(op[0], op[1], op[2], op[3]);
+    else if constexpr (VEC == 2) *(float2*)dst = make_float2(op[0], op[1]);
+    else dst[0] = op[0];
   }
 }
 
@@ -366,7 +384,11 @@ extern "C" int pst_patchify_bf16(const float* img, void* out, int64_t ld, int ni
 
 extern "C" int pst_dino_preprocess(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, void* stream) {
   if (!img || !out || nimg <= 0 || Ho <= 0 || Wo <= 0) { set_error("dino_preprocess: bad argument"); return PST_EINVAL; }
-  hipLaunchKernelGGL(dino_pre_kernel, dim3(grid_for((int64_t)nimg * 3 * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, img, out, nimg, H, W, Ho, Wo);
+  const int vec = (Wo % 4 == 0 && !((uintptr_t)out & 15)) ? 4 : ((Wo % 2 == 0 && !((uintptr_t)out & 7)) ? 2 : 1);
+  const dim3 grid(grid_for((int64_t)nimg * 3 * Ho * (Wo / vec)));
+  if (vec == 4) hipLaunchKernelGGL(dino_pre_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, img, out, nimg, H, W, Ho, Wo);
+  else if (vec == 2) hipLaunchKernelGGL(dino_pre_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, img, out, nimg, H, W, Ho, Wo);
+  else hipLaunchKernelGGL(dino_pre_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, img, out, nimg, H, W, Ho, Wo);
   return check_launch("dino_preprocess");
 }
 

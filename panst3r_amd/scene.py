@@ -62,12 +62,11 @@ def gather_keyframe_rows(local_rows, K, T, rank, world, group):
 
 
 # Run the two independent branches of stage 2 (sequential memory build || bulk encoder + DINOv2) on two streams.  OFF by default:
-# with two HIP queues active, buffers written on the side stream intermittently lose cache-line-sized fragments (first seen as
-# DINOv2 tokens of whole views deviating; traced to the output of the first DINOv2 kernel).  It happens in captured graphs as well
-# as eager launches, depends on the scene shape (13 views / 4 keyframes: most replays; 50 / 16: none seen), and is triggered just as
-# well by a rocBLAS GEMM loop on private buffers in place of our memory build (tests/diag/dino_taps.py) -
-# so it is not an aliasing bug of this code base that we could fix, and results must not depend on it.  Serial execution is
-# reproducible in every trial.  `overlap=True` (bench.py --overlap) re-enables it for measurements only.
+# with two HIP queues active, the output of the first DINOv2 kernel intermittently lost 64-byte half-lines (seen as DINOv2 tokens of
+# whole views deviating), in captured graphs as well as eager launches, depending on the scene shape, and triggered just as well by a
+# rocBLAS GEMM loop on private buffers in place of our memory build.  Rewriting that kernel to store 16 B per lane removed every
+# deviation seen so far (tests/diag/dino_taps.py), but the mechanism is inferred, not understood, so results must
+# not depend on it.  One stream is reproducible in every trial.  `overlap=True` (bench.py --overlap) re-enables the two streams.
 OVERLAP_DEFAULT = False
 DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a callable run on the main stream beside the side branch
 

@@ -26,6 +26,25 @@ runner.run(eager=True, serial=True); torch.cuda.synchronize()
 print('serial vs serial:', 'identical' if all(torch.equal(a[1], b[1]) for a, b in zip(ref, dino.TAPS)) else 'DIFFERENT')
 import panst3r_amd.scene as _scene
 from panst3r_amd import hip
+PRE = os.environ.get('PST_PRE', '')            # 'canary': fill the buffer with 12345 before dino_pre_kernel;  'torch': produce it with torch ops instead
+_orig_pre = hip.dino_preprocess
+if PRE == 'canary':
+    def _pre(img, out):
+        out.fill_(12345.0)
+        return _orig_pre(img, out)
+    hip.dino_preprocess = _pre
+elif PRE == 'torch':
+    import torch.nn.functional as _F
+    _mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1); _std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+    def _pre(img, out):
+        out.copy_(((_F.interpolate(img, size=out.shape[2:], mode='bilinear', align_corners=False) * 0.5 + 0.5) - _mean) / _std)
+    hip.dino_preprocess = _pre
+print('producer of the first DINOv2 buffer:', PRE or 'dino_pre_kernel')
+if PRE:
+    dino.TAPS = []
+    runner.run(eager=True, serial=True); torch.cuda.synchronize()
+    ref = [(n, t.clone()) for n, t in dino.TAPS]
+    dino.TAPS = None
 MODE = os.environ.get('PST_MAIN', 'build')
 _a = torch.randn(4096, 4096, device=dev).bfloat16(); _b = torch.randn(4096, 4096, device=dev).bfloat16(); _c = torch.empty(4096, 4096, device=dev, dtype=torch.bfloat16)
 _x = torch.zeros(1 << 16, device=dev)
@@ -79,6 +98,17 @@ for rep in range(int(os.environ.get('PST_R', '4'))):
             d = (a.float() - b.float()).abs()
             d2 = d.reshape(V, -1)
             views = torch.nonzero(d2.amax(1) > 0)[:, 0].tolist()
+            if n == 'pre' and globals().get('dumped', 0) < 4:
+                globals()['dumped'] = globals().get('dumped', 0) + 1
+                idx = torch.nonzero(d.reshape(-1) > 0)[:, 0]
+                runs, st = [], int(idx[0])
+                for u, w in zip(idx[:-1].tolist(), idx[1:].tolist()):
+                    if w != u + 1:
+                        runs.append((st, u - st + 1)); st = w
+                runs.append((st, int(idx[-1]) - st + 1))
+                got = b.reshape(-1)[idx[:6]].tolist(); want = a.reshape(-1)[idx[:6]].tolist()
+                print('   pre: %d differing floats in %d run(s): (start, length, start %% 32) %s; values read %s, expected %s; data_ptr %% 128 = %d'
+                      % (idx.numel(), len(runs), [(r0, ln, r0 % 32) for r0, ln in runs[:6]], ['%.4g' % v for v in got], ['%.4g' % v for v in want], b.data_ptr() % 128))
             if n not in ('pre', 'patches'):
                 dv = d.reshape(V, -1, d.shape[-1])
                 v0 = views[0]

@@ -182,6 +182,7 @@ __global__ void patchify_kernel(const float* img, bf16_t* out, int64_t ld, int n
 // one thread = VEC consecutive output pixels of a row, stored as one 4*VEC-byte write (Wo % VEC == 0)
 template <int VEC>
 __global__ void dino_pre_kernel(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo) {
+#pragma clang fp contract(off)            // same bits from the 4-, 2- and 1-wide variants
   const float sy = (float)H / Ho, sx = (float)W / Wo;
   const int wq = Wo / VEC;
   const int64_t total = (int64_t)nimg * 3 * Ho * wq;

@@ -21,11 +21,15 @@ class PanSt3R(nn.Module):
 
     @torch.no_grad()
     def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=1,
-                                   outdevice=None, amp=False):
-        assert not use_retrieval and not amp
+                                   outdevice=None, amp=False, keyframes=None):
+        """`keyframes`: the list `_get_keyframes_retrieval` would return (:179-180, use_retrieval=True; the ASMK retriever itself is
+        not restated) - an explicit keyframe list in memory-build order; otherwise the linspace / all-views choice of :183-186."""
+        assert not amp and (not use_retrieval or keyframes is not None)
         N = len(imgs)
         x_enc, pos = encoder_multi_ar(self.must3r_encoder, imgs, true_shape)                       # :174-175
-        if num_keyframes is None or num_keyframes > N:                                             # :183-186
+        if keyframes is not None:
+            keyframes = [int(k) for k in keyframes]
+        elif num_keyframes is None or num_keyframes > N:                                           # :183-186
             keyframes = list(range(N))
         else:
             keyframes = np.linspace(0, N - 1, num_keyframes, dtype=int).tolist()

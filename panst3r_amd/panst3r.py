@@ -105,17 +105,24 @@ class PanSt3R(nn.Module):
     # ------------------------------------------------------------------ reference API
     @torch.no_grad()
     def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=None,
-                                   outdevice=None, amp=False):
+                                   outdevice=None, amp=False, sim_matrix=None, keyframes=None):
         """imgs: list[V] of [3,H,W] in [-1,1]; true_shape [V,2]; returns (pointmaps list[V] of [1,H,W,7],
-        {'pred_logits' [1,Q,Ncls], 'pred_masks' list[V] of [1,Q,H/2,W/2], 'out_queries' [Q,1,768]})."""
-        if use_retrieval:
-            raise NotImplementedError('retrieval keyframes need asmk/faiss (outside the hot path, SURVEY 8(f)3)')
+        {'pred_logits' [1,Q,Ncls], 'pred_masks' list[V] of [1,Q,H/2,W/2], 'out_queries' [Q,1,768]}).
+        Keyframes: linspace over the views (panst3r.py:183-186) by default.  `use_retrieval=True` (panst3r.py:179-180) takes the
+        V x V image-similarity matrix as `sim_matrix` - the ASMK retriever that produces it in the reference needs asmk / faiss and
+        is outside this build - and applies the reference's selection (schedule.keyframes_from_similarity: farthest-point sampling
+        on 1 - sim, then the greedy overlap ordering of panst3r.py:105-123).  `keyframes=` passes an explicit list instead."""
+        if use_retrieval and keyframes is None:
+            if sim_matrix is None:
+                raise NotImplementedError('use_retrieval=True needs sim_matrix= (the ASMK / faiss retriever is outside this build, SURVEY 8(f)3)')
+            from .schedule import keyframes_from_similarity
+            keyframes = keyframes_from_similarity(sim_matrix, num_keyframes)
         V = len(imgs)
         dev = imgs[0].device
         shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
         H, W = shapes[0]
         from .scene import run_scene, HipBackend
-        res, scene = run_scene(HipBackend(self), lambda i: imgs[i], V, H, W, num_keyframes, classes, outdevice=outdevice, shapes=shapes)
+        res, scene = run_scene(HipBackend(self), lambda i: imgs[i], V, H, W, num_keyframes, classes, outdevice=outdevice, shapes=shapes, keyframes=keyframes)
         panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
                   'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
         return [res[i][0] for i in range(V)], panout
@@ -129,7 +136,7 @@ class PanSt3R(nn.Module):
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
         return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice)
 
-    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None):
+    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None, keyframes=None):
         """Static-shape scene runner (panst3r_amd/scene.py): `images` = {view_id: [3,H,W] device tensor} of the views
         this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True.
         `overlap=True` runs the memory build beside the bulk encoder work on a second stream (faster, NOT reproducible on this
@@ -137,7 +144,7 @@ class PanSt3R(nn.Module):
         import torch.distributed as dist
         from .scene import SceneRunner, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap)
+        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes)
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):

@@ -19,10 +19,16 @@ import torch.distributed as dist
 from .schedule import select_keyframes, view_order
 
 
-def assign_views(V, K, world):
+def assign_views(V, K, world, keyframes=None):
     """keyframes (in schedule order) dealt round-robin to ranks, then the remaining views continue the deal.
-    Returns (keyframes, order, owner) with owner[i] = rank of order[i]."""
-    keyframes = select_keyframes(V, K)
+    Returns (keyframes, order, owner) with owner[i] = rank of order[i].  `keyframes`: an explicit list of distinct view ids in
+    memory-build order (e.g. schedule.keyframes_from_similarity, the reference's retrieval mode) instead of the linspace schedule."""
+    if keyframes is None:
+        keyframes = select_keyframes(V, K)
+    else:
+        keyframes = [int(k) for k in keyframes]
+        if len(set(keyframes)) != len(keyframes) or not all(0 <= k < V for k in keyframes) or len(keyframes) < 2:
+            raise ValueError('keyframes must be >= 2 distinct view ids in [0, %d): %s' % (V, keyframes))
     order, _ = view_order(V, keyframes)
     owner = [i % world for i in range(V)]
     return keyframes, order, owner
@@ -89,18 +95,18 @@ class SceneRunner:
     Views may have different shapes (landscape or portrait, native orientation): they are batched per shape group
     (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
-    def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None):
+    def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None):
         self.b, self.V, self.classes = backend, V, classes
         self.rank, self.world, self.group = rank, world, group
         if V < 2:
             # the memory build starts from a PAIR of views (schedule [2,1,1,...], panst3r.py:35-39,65-70; the reference's helper
             # yields a negative batch for n < 2); the demo duplicates a lone image instead (tools/demo_panst3r.py:111-112)
             raise ValueError('a scene needs at least 2 views (got %d): duplicate a single image as the reference demo does' % V)
-        self.K = K = V if (K is None or K > V) else max(int(K), 2)
+        self.K = K = len(keyframes) if keyframes is not None else (V if (K is None or K > V) else max(int(K), 2))
         if V < world:
             raise ValueError('need at least one view per rank (V=%d, world=%d)' % (V, world))
         self.shapes = [tuple(sh) for sh in shapes] if shapes is not None else [(H, W)] * V      # per view id
-        self.keyframes, self.order, owner = assign_views(V, K, world)
+        self.keyframes, self.order, owner = assign_views(V, K, world, keyframes)
         self.mine = [i for i in range(V) if owner[i] == rank]       # positions in `order`; keyframe positions first
         self.n_local = len(self.mine)
         self.k_local = sum(1 for i in self.mine if i < K)
@@ -273,14 +279,15 @@ class SceneRunner:
 
 
 @torch.no_grad()
-def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None):
+def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None, keyframes=None):
     """Run one scene eagerly.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
     Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
-    {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W)."""
+    {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W);
+    `keyframes`: optional explicit keyframe list in memory-build order (overrides the linspace schedule of K)."""
     Kc = V if (K is None or K > V) else max(int(K), 2)
-    _, order, owner = assign_views(V, Kc, world)
+    _, order, owner = assign_views(V, Kc, world, keyframes)
     images = {order[i]: get_image(order[i]) for i in range(V) if owner[i] == rank}
-    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes).run(outdevice)
+    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes).run(outdevice)
 
 
 class HipBackend:

@@ -2,6 +2,7 @@
 """Generate golden vectors by importing the REFERENCE's own modules (build container only).
 
 Run:  python tests/golden/make_golden.py          (needs /root/reference; never runs on the GPU box)
+      python tests/golden/make_golden.py retrieval   (G8, keyframes by retrieval: separate invocation, different stubs)
 
 Recipe: `import panst3r` fails because must3r/croco/dust3r are not installed, so the
 reference-owned files are imported through bare package stubs, and the five croco/must3r symbols they need
@@ -237,8 +238,79 @@ def golden_postprocess(R):
     case('_temp', 80, 12, 4, [(8, 12)] * 2, [[16, 24]] * 2, temperature=0.1, cls_threshold=0.3, overlap_threshold=0.6)
 
 
+def golden_retrieval():
+    """G8: keyframes by retrieval.  Executes the reference's own `PanSt3R._get_keyframes_retrieval`
+    (panst3r.py:88-125) on prepared similarity matrices.  Everything that method imports from must3r / asmk is stubbed:
+      * the retriever (`PanSt3RRetriever`, ASMK + faiss) is a stand-in that returns the prepared matrix;
+      * `must3r.demo.inference.farthest_point_sampling` is NOT vendored: the stand-in is panst3r_amd.schedule's restatement with a
+        fixed first index, and its output (`anchors`) is stored as an INPUT of the fixture.
+    So the fixture pins the reference-owned greedy ordering (:105-123) and the `1 - sim` / N=K call convention, not the sampling."""
+    from panst3r_amd.schedule import farthest_point_sampling as fps
+
+    def pkg(name, path=None, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = [path] if path else []
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    state = {}
+
+    class Retriever:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, feats, device=None):
+            state['n_feats'] = len(feats)
+            return state['sim'].copy()
+
+    def fps_stub(dist, N=None, dist_thresh=None):
+        state['fps_args'] = (np.array(dist), N, dist_thresh)
+        idx, d = fps(dist, N=N, dist_thresh=dist_thresh, start=state['start'])
+        state['anchors'] = idx.copy()
+        return idx, d
+
+    dummy = lambda *a, **k: None
+    pkg('panst3r', REF)
+    pkg('must3r'); pkg('must3r.model', __all__=[]); pkg('must3r.demo'); pkg('must3r.engine')
+    pkg('must3r.demo.inference', farthest_point_sampling=fps_stub)
+    pkg('must3r.engine.inference', inference_multi_ar=dummy, stack_views=dummy)
+    pkg('panst3r.engine', None, __all__=[])
+    pkg('panst3r.engine.retrieval', PanSt3RRetriever=Retriever)
+    pkg('panst3r.engine.must3r', inference_encoder=dummy, inference_decoder_memory=dummy, inference_decoder_render=dummy)
+    pkg('panst3r.engine.dino', inference_dino=dummy)
+    pkg('panst3r.model', None, __all__=['PanopticDecoder'], PanopticDecoder=object)
+    sys.modules.pop('panst3r.panst3r', None)
+    P = importlib.import_module('panst3r.panst3r')
+    me = types.SimpleNamespace(retrieval=object(), must3r_encoder=None, verbose=False)
+    out = {}
+    cases = [('a', 11, 12, 5, 3, np.float64), ('b', 12, 20, 8, 0, np.float32), ('c', 13, 9, 9, 4, np.float64), ('d', 14, 30, 2, 7, np.float32),
+             ('ties', 15, 10, 6, 1, np.float64)]
+    for tag, seed, V, K, start, dt in cases:
+        g = np.random.Generator(np.random.PCG64(seed))
+        f = g.random((V, 6))
+        sim = f @ f.T
+        sim = sim / sim.max()
+        if tag == 'ties':
+            sim = np.round(sim * 4) / 4                      # many equal entries: pins the first-maximum tie-breaking of argmax
+        np.fill_diagonal(sim, 1.0)
+        sim = sim.astype(dt)
+        state.update(sim=sim, start=start)
+        feats = torch.zeros(1, V, 4, 8)                      # a stacked tensor: the method unbinds it into V entries (:94-95)
+        kf = P.PanSt3R._get_keyframes_retrieval(me, feats, K)
+        assert state['n_feats'] == V and state['fps_args'][1] == K and state['fps_args'][2] is None
+        assert np.array_equal(state['fps_args'][0], 1 - sim)
+        out['sim_' + tag] = sim
+        out['anchors_' + tag] = np.asarray(state['anchors'], dtype=np.int64)
+        out['keyframes_' + tag] = np.asarray([int(k) for k in kf], dtype=np.int64)
+        print(tag, 'anchors', state['anchors'].tolist(), '-> keyframes', [int(k) for k in kf])
+    save('keyframes_retrieval', **out)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'postprocess':      # regenerate G6 only
+    if len(sys.argv) > 1 and sys.argv[1] == 'retrieval':         # G8 only (separate process: it replaces the package stubs)
+        golden_retrieval()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'postprocess':      # regenerate G6 only
         with torch.no_grad():
             golden_postprocess(import_reference())
     else:

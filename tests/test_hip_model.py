@@ -4,6 +4,7 @@ Tolerances (bf16 MFMA / fp32 accumulate vs fp32 oracle): rel-L2 <= 
 <= 3e-2 on mask logits with >= 99 % sign agreement, class logits abs <= 0.05.
 """
 import pytest
+import numpy as np
 import torch
 
 from conftest import rel_l2
@@ -110,6 +111,42 @@ def test_scene_end_to_end(pair, V, K):
         assert rel_l2(a.cpu(), b) < 6e-2
         agree.append(float(((a.cpu() > 0) == (b > 0)).float().mean()))
     assert min(agree) > 0.985
+
+
+def test_scene_keyframes_by_retrieval(pair):
+    """use_retrieval=True with a similarity matrix -> keyframes in the reference's greedy overlap order (not
+    sorted: the memory is built in that order and the other views follow ascending); HIP path vs the oracle pipeline given the
+    same keyframe list, and the static-shape runner (HIP graphs) vs the eager entry point."""
+    from panst3r_amd.schedule import keyframes_from_similarity
+    variant, o, h = pair
+    V, K, H, W = 6, 3, 64, 96
+    imgs = tiny.images(V, H, W)
+    ts = torch.tensor([[H, W]] * V)
+    g = np.random.Generator(np.random.PCG64(5))
+    f = g.random((V, 4))
+    sim = f @ f.T
+    sim /= sim.max()
+    np.fill_diagonal(sim, 1.0)
+    np.random.seed(3)                                       # the sampler's first pick is random, as upstream
+    kf = keyframes_from_similarity(sim, K)
+    assert len(kf) == K and len(set(kf)) == K
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K, use_retrieval=True, keyframes=kf)
+    np.random.seed(3)
+    pm_h, pan_h = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K, use_retrieval=True, sim_matrix=sim)
+    for a, b in zip(pm_h, pm_o):
+        assert rel_l2(a.cpu(), b) < 2e-2
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 4e-2
+    for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
+        assert rel_l2(a.cpu(), b) < 6e-2
+    runner = h.scene_runner({i: im.to(DEV) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, keyframes=kf, use_graphs=True)
+    assert runner.keyframes == kf and runner.order[:K] == kf
+    runner.run()
+    res, scene = runner.run()
+    assert torch.equal(scene['out_queries'], pan_h['out_queries'])
+    for i in range(V):
+        assert torch.equal(res[i][0], pm_h[i]) and torch.equal(res[i][1], pan_h['pred_masks'][i])
+    with pytest.raises(NotImplementedError):
+        h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K, use_retrieval=True)
 
 
 def test_graph_replay_equals_eager(pair):

@@ -62,6 +62,29 @@ def test_keyframe_schedule(golden):
     assert mem_batches(2) == [2] and mem_batches(5) == [2, 1, 1, 1]
 
 
+def test_keyframes_by_retrieval(golden):
+    """the fixture holds what the reference's own `_get_keyframes_retrieval` returned for prepared similarity
+    matrices (retriever and the un-vendored farthest-point sampler stubbed, tests/golden/make_golden.py retrieval)."""
+    from panst3r_amd.schedule import order_keyframes_by_overlap, keyframes_from_similarity, farthest_point_sampling
+    g = golden('keyframes_retrieval')
+    tags = sorted(k[4:] for k in g.z.files if k.startswith('sim_'))
+    assert tags == ['a', 'b', 'c', 'd', 'ties']
+    for tag in tags:
+        sim, anchors, want = g.z['sim_' + tag], g.z['anchors_' + tag].tolist(), g.z['keyframes_' + tag].tolist()
+        keep = sim.copy()
+        assert order_keyframes_by_overlap(sim, anchors) == want, tag
+        assert np.array_equal(sim, keep)                                        # the caller's matrix is not modified
+        assert keyframes_from_similarity(sim, len(want), start=anchors[0]) == want, tag
+        assert sorted(want) == sorted(anchors) and len(set(want)) == len(want)
+    # farthest-point sampling (restated from memory, unpinned): spread-out picks, early stop on the threshold, fixed start
+    d = np.abs(np.subtract.outer(np.arange(10.), np.arange(10.)))
+    idx, dist = farthest_point_sampling(d, N=4, start=0)
+    assert idx.tolist() == [0, 9, 4, 2] and dist.tolist() == [0.0, 9.0, 4.0, 2.0]
+    assert farthest_point_sampling(d, dist_thresh=4.0, start=0)[0].tolist() == [0, 9, 4]
+    with pytest.raises(ValueError):
+        keyframes_from_similarity(np.eye(4), 3, start=0)                        # no overlap at all: the greedy ordering degenerates
+
+
 def _mt():
     m = OP.MaskTransformer([64], 64, 128, 32, 16, 4, 2, lang_dim=48, num_feature_levels=1, landscape_only=True).eval()
     return fill_module_(m, seed=11)

@@ -47,6 +47,28 @@ def test_plan_matches_reference_formulation(variant):
         assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
 
 
+@pytest.mark.parametrize('variant', ['v1', 'v2'])
+def test_explicit_keyframe_order_matches_reference_formulation(variant):
+    """Keyframes as the reference's retrieval mode hands them over (panst3r.py:179-180): an unsorted list in memory-build order."""
+    V, kf = 5, [3, 0, 4]
+    model = tiny.build(tiny.OracleNS, variant)
+    imgs = tiny.images(V, H, W)
+    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor([[H, W]] * V), tiny.NAMES, num_keyframes=3, use_retrieval=True, keyframes=kf)
+    with torch.no_grad():
+        res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], V, H, W, 3, tiny.NAMES, keyframes=kf)
+    assert rel_l2(scene['out_queries'], pan_ref['out_queries']) < 1e-4
+    for i in range(V):
+        assert rel_l2(res[i][0], pm_ref[i]) < 1e-5
+        assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
+    lin = model.forward_inference_multi_ar(imgs, torch.tensor([[H, W]] * V), tiny.NAMES, num_keyframes=3)[1]
+    assert rel_l2(lin['out_queries'], pan_ref['out_queries']) > 1e-3            # a different memory than the linspace choice [0, 2, 4]
+    kfs, order, owner = assign_views(V, 3, 2, kf)
+    assert kfs == kf and order == [3, 0, 4, 1, 2] and owner == [0, 1, 0, 1, 0]
+    for bad in ([0], [0, 0], [0, 7]):
+        with pytest.raises(ValueError):
+            assign_views(V, 3, 1, bad)
+
+
 MULTI_AR = [(64, 96), (32, 96), (64, 96), (64, 64), (32, 96)]
 
 

@@ -267,6 +267,10 @@ class SceneRunner:
                 self.graphs[0].replay(); self.gather1(); self.graphs[1].replay(); self.gather2(); self.graphs[2].replay()
         else:
             self._eager()
+        return self.results(outdevice)
+
+    def results(self, outdevice=None):
+        """({view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} of this rank's views, scene dict) after stage 3."""
         outq, logits, masks = self.out
         res = {}
         for j, i in enumerate(self.mine):

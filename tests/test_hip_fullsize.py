@@ -72,3 +72,55 @@ def test_full_size_outputs_within_stated_tolerance(parity):
                           'random-init mask logits (DESIGN.md section 6)', strict=False)
 def test_full_size_mask_sign_agreement_meets_survey_criterion(parity):
     assert parity['mask_sign_agreement'] >= parity['tolerance']['mask_sign_agreement'], parity
+
+
+def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, keyframes=None):
+    """N ranks of the view-sharded plan on ONE GPU: N SceneRunners stepped in lock-step, the two all-gathers replaced by a fake that
+    hands every rank the rows the others would send (the RCCL transport itself is covered by PST_FORCE_DIST / the driver's runs)."""
+    import panst3r_amd.scene as S
+    order_owner = S.assign_views(V, V if (K is None or K > V) else max(int(K), 2), world, keyframes)
+    runners = []
+    for r in range(world):
+        mine = {order_owner[1][i]: imgs[order_owner[1][i]] for i in range(V) if order_owner[2][i] == r}
+        runners.append(S.SceneRunner(S.HipBackend(model), mine, V, H, W, K, names, rank=r, world=world, keyframes=keyframes))
+    sends = []
+    monkeypatch.setattr(S, '_all_gather_rows', lambda t, counts, w, g: [s[:c] for s, c in zip(sends, counts)])
+    with torch.no_grad():
+        for rn in runners:
+            rn.stage1()
+        sends[:] = [rn.enc_send for rn in runners]
+        for rn in runners:
+            rn.gather1()
+        for rn in runners:
+            rn.stage2()
+        sends[:] = [rn.both_send for rn in runners]
+        for rn in runners:
+            rn.gather2()
+        res, scenes = {}, []
+        for rn in runners:
+            rn.stage3()
+            r, s = rn.results()
+            res.update(r)
+            scenes.append(s)
+    return res, scenes
+
+
+@pytest.mark.parametrize('V,K,world', [(13, 4, 2), (50, 16, 8)])
+def test_full_size_sharded_equals_unsharded_on_one_gpu(full, monkeypatch, V, K, world):
+    """what `bench.py --gpus 8` computes (50 views, 16 keyframes, 6-7 views per rank) equals the 1-GPU scene BIT FOR BIT -
+    every launch is row-independent and the smaller per-rank launches pick bit-compatible kernel variants (GEMM tile sizes, attention
+    split-K choice).  All ranks must also hold identical frozen queries / class logits."""
+    from panst3r_amd.synthetic import synth_image
+    model, _, names, _ = full
+    dev = torch.device('cuda:0')
+    H, W = 384, 512
+    imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
+    with torch.no_grad():
+        ref, sref = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=False).run()
+    res, scenes = run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch)
+    assert sorted(res) == list(range(V))
+    for s in scenes:
+        assert torch.equal(s['out_queries'], sref['out_queries']) and torch.equal(s['pred_logits'], sref['pred_logits'])
+    for i in range(V):
+        assert torch.equal(res[i][0], ref[i][0]), ('pointmap', i)
+        assert torch.equal(res[i][1], ref[i][1]), ('masks', i)

@@ -149,6 +149,22 @@ def test_scene_keyframes_by_retrieval(pair):
         h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K, use_retrieval=True)
 
 
+@pytest.mark.parametrize('V,K,world', [(5, 3, 2), (7, 4, 3)])
+def test_sharded_equals_unsharded_on_one_gpu(pair, monkeypatch, V, K, world):
+    """the view-sharded plan on the HIP path (ranks simulated in lock-step on one GPU) == the 1-rank scene, bit for bit."""
+    from test_hip_fullsize import run_sharded_on_one_gpu
+    variant, o, h = pair
+    H, W = 64, 96
+    imgs = {i: im.to(DEV) for i, im in enumerate(tiny.images(V, H, W))}
+    with torch.no_grad():
+        ref, sref = h.scene_runner(imgs, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=False).run()
+    res, scenes = run_sharded_on_one_gpu(h, imgs, V, H, W, K, tiny.NAMES, world, monkeypatch)
+    for s in scenes:
+        assert torch.equal(s['out_queries'], sref['out_queries'])
+    for i in range(V):
+        assert torch.equal(res[i][0], ref[i][0]) and torch.equal(res[i][1], ref[i][1]), i
+
+
 def test_graph_replay_equals_eager(pair):
     """The three captured HIP graphs of a scene reproduce the eager launch sequence bit for bit (all reductions,
     incl. the GroupNorm statistics, run in a fixed order: no float atomics anywhere on the path)."""

@@ -87,6 +87,9 @@ def full_size_parity(model, dev, ref, imgs, ts, names):
     return res
 
 
+REAL_STDOUT = 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -218,11 +221,17 @@ def main():
             out['parity'] = full_size_parity(model, dev, ref, ref_imgs, ref_ts, names)
             if not out['parity']['within_tolerance']:
                 print('WARNING: full-size parity outside the stated tolerance: %s' % out['parity'], file=sys.stderr)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(REAL_STDOUT, (json.dumps(out) + '\n').encode())      # the one line on stdout
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == '__main__':
+    # stdout carries exactly ONE line, the JSON result: everything else any library prints there (RCCL's version banner comes through C
+    # stdio at process exit) is routed to stderr by pointing fd 1 at fd 2 and keeping the real stdout aside for the final write.
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     main()

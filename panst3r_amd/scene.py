@@ -70,9 +70,10 @@ def gather_keyframe_rows(local_rows, K, T, rank, world, group):
 # Run the two independent branches of stage 2 (sequential memory build || bulk encoder + DINOv2) on two streams.  OFF by default:
 # with two HIP queues active, the output of the first DINOv2 kernel intermittently lost 64-byte half-lines (seen as DINOv2 tokens of
 # whole views deviating), in captured graphs as well as eager launches, depending on the scene shape, and triggered just as well by a
-# rocBLAS GEMM loop on private buffers in place of our memory build.  Rewriting that kernel to store 16 B per lane removed every
-# deviation seen so far (tests/diag/dino_taps.py), but the mechanism is inferred, not understood, so results must
-# not depend on it.  One stream is reproducible in every trial.  `overlap=True` (bench.py --overlap) re-enables the two streams.
+# rocBLAS GEMM loop on private buffers in place of our memory build.  After a rewrite of that kernel no deviation has been seen, but
+# probe variants show the rewrite is not a causal fix (the same instructions fail in one library and pass in another:
+# tests/diag/dino_taps.py); the mechanism is not understood, so results must not depend on it.
+# One stream is reproducible in every trial.  `overlap=True` (bench.py --overlap) re-enables the two streams.
 OVERLAP_DEFAULT = False
 DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a callable run on the main stream beside the side branch
 

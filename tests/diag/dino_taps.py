@@ -39,6 +39,25 @@ elif PRE == 'torch':
     def _pre(img, out):
         out.copy_(((_F.interpolate(img, size=out.shape[2:], mode='bilinear', align_corners=False) * 0.5 + 0.5) - _mean) / _std)
     hip.dino_preprocess = _pre
+if PRE.startswith('probe:'):
+    # store-pattern variants of the kernel, compiled here with hipcc (tests/diag/store_probe/variants.hip); nothing of this is product code
+    import ctypes, subprocess, tempfile
+    _variant = int(PRE.split(':')[1])
+    _so = os.path.join(tempfile.gettempdir(), 'libstoreprobe.so')
+    _src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'store_probe', 'variants.hip')
+    if not os.path.exists(_so):
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', _so, _src])
+    _lib = ctypes.CDLL(_so)
+    _lib.probe_pre.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    def _pre(img, out):
+        n, _, h, w = img.shape
+        rc = _lib.probe_pre(_variant, img.data_ptr(), out.data_ptr(), n, h, w, out.shape[-2], out.shape[-1], torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+        return out
+    hip.dino_preprocess = _pre
+    PRE += ' ' + ['scalar stores, capped grid-stride loop (the former product kernel)', 'scalar stores, one element per thread', '8-byte stores', '16-byte stores',
+                  'scalar non-temporal stores', 'scalar stores interleaved over a 64-float span',
+                  'FORMER PRODUCT KERNEL: per-channel constants in a .rodata table read by every lane', 'former product kernel source with the constants as ternaries'][_variant]
 print('producer of the first DINOv2 buffer:', PRE or 'dino_pre_kernel')
 if PRE:
     dino.TAPS = []

@@ -1,0 +1,105 @@
+// Variants of the DINOv2 preprocessing kernel that differ ONLY in how the result is stored (tests/diag/store_width_probe.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+template <int VEC, bool LOOP, bool NT, bool SPLIT>
+__global__ void pre_kernel(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo) {
+#pragma clang fp contract(off)
+  const float sy = (float)H / Ho, sx = (float)W / Wo;
+  const int wq = Wo / VEC;
+  const int64_t total = (int64_t)nimg * 3 * Ho * wq;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (SPLIT) {                       // scalar stores, but a wave's 64 results are NOT contiguous: lane l handles element 2*(l%32) + l/32 of a 64-float span
+    const int64_t base = i & ~(int64_t)63;
+    const int l = (int)(i & 63);
+    i = base + 2 * (l & 31) + (l >> 5);
+  }
+  for (; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int oq = (int)(i % wq), oy = (int)((i / wq) % Ho), c = (int)((i / ((int64_t)wq * Ho)) % 3);
+    const int64_t n = i / ((int64_t)wq * Ho * 3);
+    const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f), stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    const float fy = fmaxf((oy + 0.5f) * sy - 0.5f, 0.f);
+    const int y0 = (int)fy;
+    const int y1 = min(y0 + 1, H - 1);
+    const float ly = fy - y0;
+    const float* pl = img + (n * 3 + c) * (int64_t)H * W;
+    const float* r0 = pl + (int64_t)y0 * W;
+    const float* r1 = pl + (int64_t)y1 * W;
+    float op[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int ox = oq * VEC + k;
+      const float fx = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+      const int x0 = (int)fx;
+      const int x1 = min(x0 + 1, W - 1);
+      const float lx = fx - x0;
+      const float a = ((r0[x0] * 0.5f + 0.5f) - mean) / stdv, b = ((r0[x1] * 0.5f + 0.5f) - mean) / stdv;
+      const float cc = ((r1[x0] * 0.5f + 0.5f) - mean) / stdv, d = ((r1[x1] * 0.5f + 0.5f) - mean) / stdv;
+      op[k] = (a * (1.f - lx) + b * lx) * (1.f - ly) + (cc * (1.f - lx) + d * lx) * ly;
+    }
+    float* dst = out + (((n * 3 + c) * (int64_t)Ho + oy) * Wo + oq * VEC);
+    if constexpr (VEC == 4) *(float4*)dst = make_float4(op[0], op[1], op[2], op[3]);
+    else if constexpr (VEC == 2) *(float2*)dst = make_float2(op[0], op[1]);
+    else if constexpr (NT) __builtin_nontemporal_store(op[0], dst);
+    else dst[0] = op[0];
+    if (!LOOP) break;
+  }
+}
+
+// The former product kernel, verbatim in its essentials: per-channel constants in LOCAL ARRAYS indexed by the runtime channel.  The compiler
+// turns those into a .rodata table inside the code object that every lane reads with global_load_dword.  TABLE = false: same code, ternaries.
+template <bool TABLE>
+__global__ void pre_kernel_table(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo) {
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  const float sy = (float)H / Ho, sx = (float)W / Wo;
+  const int64_t total = (int64_t)nimg * 3 * Ho * Wo;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho), c = (int)((i / ((int64_t)Wo * Ho)) % 3);
+    const int64_t n = i / ((int64_t)Wo * Ho * 3);
+    const float m = TABLE ? mean[c] : (c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f));
+    const float sd = TABLE ? stdv[c] : (c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f));
+    const float fy = fmaxf((oy + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    const float* pl = img + (n * 3 + c) * (int64_t)H * W;
+    auto nv = [&](int yy, int xx) { return ((pl[(int64_t)yy * W + xx] * 0.5f + 0.5f) - m) / sd; };
+    const float top = nv(y0, x0) * (1.f - lx) + nv(y0, x1) * lx;
+    const float bot = nv(y1, x0) * (1.f - lx) + nv(y1, x1) * lx;
+    out[i] = top * (1.f - ly) + bot * ly;
+  }
+}
+
+template <bool TABLE>
+static int launch_table(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, void* stream) {
+  int64_t g = ((int64_t)nimg * 3 * Ho * Wo + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(pre_kernel_table<TABLE>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, out, nimg, H, W, Ho, Wo);
+  return (int)hipGetLastError();
+}
+
+template <int VEC, bool LOOP, bool NT, bool SPLIT>
+static int launch(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, void* stream) {
+  const int64_t total = (int64_t)nimg * 3 * Ho * (Wo / VEC);
+  int64_t g = (total + 255) / 256;
+  if (LOOP && g > 8192) g = 8192;
+  hipLaunchKernelGGL((pre_kernel<VEC, LOOP, NT, SPLIT>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, out, nimg, H, W, Ho, Wo);
+  return (int)hipGetLastError();
+}
+
+// variant: 0 scalar + capped grid-stride loop (the former product kernel) | 1 scalar, one element per thread | 2 8-byte stores | 3 16-byte stores
+//          4 scalar non-temporal | 5 scalar, a wave's stores interleaved over a 64-float span (two half-filled passes per sector pair)
+//          6 the former product kernel (constants in a .rodata table read by every lane) | 7 the same source, constants as ternaries
+extern "C" int probe_pre(int variant, const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, void* stream) {
+  switch (variant) {
+    case 0: return launch<1, true, false, false>(img, out, nimg, H, W, Ho, Wo, stream);
+    case 1: return launch<1, false, false, false>(img, out, nimg, H, W, Ho, Wo, stream);
+    case 2: return launch<2, true, false, false>(img, out, nimg, H, W, Ho, Wo, stream);
+    case 3: return launch<4, true, false, false>(img, out, nimg, H, W, Ho, Wo, stream);
+    case 4: return launch<1, true, true, false>(img, out, nimg, H, W, Ho, Wo, stream);
+    case 5: return launch<1, true, false, true>(img, out, nimg, H, W, Ho, Wo, stream);
+    case 6: return launch_table<true>(img, out, nimg, H, W, Ho, Wo, stream);      // the former product kernel: constants from a .rodata table
+    case 7: return launch_table<false>(img, out, nimg, H, W, Ho, Wo, stream);     // the same source with the constants as ternaries
+  }
+  return -1;
+}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Pure-PyTorch attempt at the two-queue lost-write effect of DESIGN.md section 4 (no kernel of this repository involved).
+"""Stand-alone attempt at the two-queue lost-write effect of DESIGN.md section 4 (no PanSt3R model; pure PyTorch, or with PST_PROBE=<n> one probe kernel).
 
 A captured graph with two parallel branches: the main branch loops a small torch.mm (rocBLAS / hipBLASLt) on private buffers; the side
 branch recycles big temporaries (like an encoder pass would), then writes a fresh fp32 buffer with an elementwise kernel and reads it
@@ -21,6 +21,26 @@ def main_branch():
     for _ in range(MM):
         torch.mm(a, b, out=c)
 
+PROBE = os.environ.get('PST_PROBE')          # e.g. 7: produce the buffer with variant <n> of tests/diag/store_probe/variants.hip instead of torch ops
+if PROBE is not None:
+    import ctypes, subprocess, tempfile
+    _so = os.path.join(tempfile.gettempdir(), 'libstoreprobe.so')
+    if not os.path.exists(_so):
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', _so,
+                               os.path.join(os.path.dirname(os.path.abspath(__file__)), 'store_probe', 'variants.hip')])
+    _lib = ctypes.CDLL(_so)
+    _lib.probe_pre.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+
+
+def produce():
+    if PROBE is None:
+        return ((F.interpolate(img, size=(336, 448), mode='bilinear', align_corners=False) * 0.5 + 0.5) - mean) / std
+    pre = torch.empty(2 if PROBE == '8' else 1, 13, 3, 336, 448, device=dev)      # variant 8 stores every result twice
+    rc = _lib.probe_pre(int(PROBE), img.data_ptr(), pre.data_ptr(), 13, 384, 512, 336, 448, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    return pre
+
+
 def side_branch(outs):
     x = A
     for _ in range(6):                                   # big recycled temporaries: every h / x below is freed and its block reused
@@ -28,7 +48,7 @@ def side_branch(outs):
         x = torch.mm(h, W2) * 0.01
     del h
     for _ in range(8):                                   # producer / consumer pairs on fresh buffers (the first DINOv2 kernels in the real scene)
-        pre = ((F.interpolate(img, size=(336, 448), mode='bilinear', align_corners=False) * 0.5 + 0.5) - mean) / std
+        pre = produce()
         outs.append(pre.clone())
         del pre
         t = torch.mm(x, W1); del t
@@ -65,5 +85,10 @@ for mode in ('one stream', 'two streams'):
                 hit = True
                 worst = max(worst, float(d.max()))
                 sizes.append(int((d > 0).sum()))
+                if PROBE == '8' and not globals().get('told'):
+                    globals()['told'] = True
+                    a, b = (d[0] > 0), (d[1] > 0)
+                    print('   twice-stored result: %d damaged floats in copy 0, %d in copy 1, %d at the same position; values equal at those positions: %s'
+                          % (int(a.sum()), int(b.sum()), int((a & b).sum()), bool(torch.equal(o[0][a & b], o[1][a & b]))))
         bad += hit
     print('%-11s: %d of %d replays deviate from the serial reference; worst |diff| %.3g; differing elements per damaged buffer %s' % (mode, bad, R, worst, sizes[:8]))

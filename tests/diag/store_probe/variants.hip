@@ -48,7 +48,7 @@ __global__ void pre_kernel(const float* img, float* out, int nimg, int H, int W,
 
 // The former product kernel, verbatim in its essentials: per-channel constants in LOCAL ARRAYS indexed by the runtime channel.  The compiler
 // turns those into a .rodata table inside the code object that every lane reads with global_load_dword.  TABLE = false: same code, ternaries.
-template <bool TABLE>
+template <bool TABLE, bool TWICE = false, bool NODIV = false>
 __global__ void pre_kernel_table(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo) {
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   const float sy = (float)H / Ho, sx = (float)W / Wo;
@@ -63,18 +63,21 @@ __global__ void pre_kernel_table(const float* img, float* out, int nimg, int H, 
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float ly = fy - y0, lx = fx - x0;
     const float* pl = img + (n * 3 + c) * (int64_t)H * W;
-    auto nv = [&](int yy, int xx) { return ((pl[(int64_t)yy * W + xx] * 0.5f + 0.5f) - m) / sd; };
+    const float rs = c == 0 ? 1.f / 0.229f : (c == 1 ? 1.f / 0.224f : 1.f / 0.225f);          // NODIV: multiply by a constant reciprocal, no v_div_* sequence
+    auto nv = [&](int yy, int xx) { const float v = (pl[(int64_t)yy * W + xx] * 0.5f + 0.5f) - m; return NODIV ? v * rs : v / sd; };
     const float top = nv(y0, x0) * (1.f - lx) + nv(y0, x1) * lx;
     const float bot = nv(y1, x0) * (1.f - lx) + nv(y1, x1) * lx;
-    out[i] = top * (1.f - ly) + bot * ly;
+    const float r = top * (1.f - ly) + bot * ly;
+    out[i] = r;
+    if (TWICE) out[total + i] = r;            // the same register stored a second time, `total` floats further on
   }
 }
 
-template <bool TABLE>
+template <bool TABLE, bool TWICE = false, bool NODIV = false>
 static int launch_table(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, void* stream) {
   int64_t g = ((int64_t)nimg * 3 * Ho * Wo + 255) / 256;
   if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(pre_kernel_table<TABLE>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, out, nimg, H, W, Ho, Wo);
+  hipLaunchKernelGGL((pre_kernel_table<TABLE, TWICE, NODIV>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, out, nimg, H, W, Ho, Wo);
   return (int)hipGetLastError();
 }
 
@@ -100,6 +103,8 @@ extern "C" int probe_pre(int variant, const float* img, float* out, int nimg, in
     case 5: return launch<1, true, false, true>(img, out, nimg, H, W, Ho, Wo, stream);
     case 6: return launch_table<true>(img, out, nimg, H, W, Ho, Wo, stream);      // the former product kernel: constants from a .rodata table
     case 7: return launch_table<false>(img, out, nimg, H, W, Ho, Wo, stream);     // the same source with the constants as ternaries
+    case 8: return launch_table<false, true>(img, out, nimg, H, W, Ho, Wo, stream);          // 7 + every result stored twice (out must hold 2x the floats)
+    case 9: return launch_table<false, false, true>(img, out, nimg, H, W, Ho, Wo, stream);   // 7 with the IEEE division replaced by a multiplication
   }
   return -1;
 }

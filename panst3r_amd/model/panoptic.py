@@ -200,7 +200,7 @@ class LoftUpUpscaler(HipModule):
     def guidance_tokens(self, imgs, h, w):
         """Guidance branch (loftup.py:154-156,117-130): Fourier features -> GN(1) -> conv3x3 -> GN(8)+ReLU -> conv3x3 -> GN(8)+ReLU.
         imgs fp32 [V,3,H,W] -> bf16 [V*P, dim] pixel-major, P = H/2 * W/2.  It depends on the IMAGES only (not on the memory, the
-        decoder or the mixer), so the scene runner computes it on the side stream while the memory build has the GPU mostly idle.
+        decoder or the mixer), so the scene runner computes it with the other memory-independent work (SceneRunner._encode_rest).
         A tall token grid (h > w) takes the image transposed (loftup.py:147-149)."""
         dev = imgs.device
         pk = self.packed(dev)

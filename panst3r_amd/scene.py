@@ -173,8 +173,8 @@ class SceneRunner:
             if len(g.idx) > g.k:
                 b.encode_enc(g.imgs[g.k:], g.cat[g.k * g.T:])
             b.encode_dino(g.imgs, g.cat)
-        for g in self.groups:         # image-only part of the upscaler (LoftUp guidance convs, SURVEY 8(e) phase A): fills the tail of
-            g.guid = b.guidance(g.imgs, g.h, g.w)     # the memory build (measured +0.9 %: work beside the build also stretches the build)
+        for g in self.groups:         # image-only part of the upscaler (LoftUp guidance convs, SURVEY 8(e) phase A): memory-independent,
+            g.guid = b.guidance(g.imgs, g.h, g.w)     # so it belongs to this branch (with overlap=True it fills the tail of the memory build)
 
     def gather1(self):
         kf = gather_keyframe_rows(self.enc_send, self.K, self.kf_T, rank=self.rank, world=self.world, group=self.group)

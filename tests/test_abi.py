@@ -75,3 +75,13 @@ def test_only_the_allowed_places_import_the_oracle():
     body = src[src.index('def cpu_baseline('):src.index('def full_size_parity(')]
     assert all(body.find(m.group(0).strip()) >= 0 for m in hits) and len(hits) == len(pat.findall(body))
     # (__graft_entry__.build() import-checks the Python oracle as its "build the checker" step, which is allowed; smoke() uses it)
+
+
+def test_diag_and_tool_scripts_compile():
+    """tests/diag, tools/ and the golden generator only run by hand (GPU box / build container): keep them at least syntactically valid."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'tests', 'diag', '*.py')) + glob.glob(os.path.join(ROOT, 'tools', '*.py')) +
+                   [os.path.join(ROOT, 'tests', 'golden', 'make_golden.py'), os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')])
+    assert len(files) >= 12
+    for f in files:
+        compile(open(f).read(), f, 'exec')            # syntax only: nothing is executed or written

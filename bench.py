@@ -63,16 +63,16 @@ def cpu_baseline(variant, H, W, state, names, emb, threads):
                       % (H, W, variant, threads, dt)}, ref, imgs, ts
 
 
-def full_size_parity(model, dev, ref, imgs, ts, names):
+def full_size_parity(model, dev, ref, imgs, ts, names, amp='fp16'):
     """The oracle outputs of the cpu_baseline sample double as a FULL-SIZE parity check (the -m gpu tests use tiny
     configurations): the HIP path runs the same 2-view scene with the same weights and the deviations are reported.
     Tolerances of SURVEY 8(d) for bf16 MFMA vs the fp32 oracle.  The oracle is only the checker here."""
     pm_o, pan_o = ref
-    pm_h, pan_h = model.forward_inference_multi_ar([i.to(dev) for i in imgs], ts, names, num_keyframes=2)
+    pm_h, pan_h = model.forward_inference_multi_ar([i.to(dev) for i in imgs], ts, names, num_keyframes=2, amp=amp)
     torch.cuda.synchronize()
     rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
     mk = [(a.cpu(), b) for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks'])]
-    res = {'scene': '2 views / 2 keyframes, full-size weights (the cpu_baseline sample)',
+    res = {'scene': '2 views / 2 keyframes, full-size weights (the cpu_baseline sample)', 'amp': amp,
            'pointmaps_rel_l2': round(max(rel(a, b) for a, b in zip(pm_h, pm_o)), 5),
            'mask_logits_rel_l2': round(max(rel(a, b) for a, b in mk), 5),
            'mask_sign_agreement': round(min(float(((a > 0) == (b > 0)).float().mean()) for a, b in mk), 5),
@@ -100,6 +100,7 @@ def main():
     ap.add_argument('--keyframes', type=int, default=16)
     ap.add_argument('--height', type=int, default=384)
     ap.add_argument('--width', type=int, default=512)
+    ap.add_argument('--amp', default='fp16', choices=['fp16', 'bf16'], help="16-bit MFMA operand format (reference --amp, tools/demo_panst3r.py:88)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--overlap', action='store_true', help='MEASUREMENT ONLY: run the memory build beside the independent encoder/DINOv2 work on a second stream '
@@ -140,12 +141,12 @@ def main():
     mine = {order[i] for i in range(V) if owner[i] == rank}
     images = {i: synth_image(i, H, W).to(dev) for i in sorted(mine)}        # inputs resident in HBM before timing
 
-    runner = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager, overlap=args.overlap and not args.no_overlap)
+    runner = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager, overlap=args.overlap and not args.no_overlap, amp=args.amp)
 
     def step(eager=False):
         # the instrumented eager step always runs the two branches of stage 2 back-to-back (also under --overlap): per-kernel
         # HIP-event durations are then not inflated by kernels of the other branch sharing the CUs
-        return runner.run(eager=eager, serial=True) if eager else runner.run()
+        return runner.run(eager=eager, serial=True, copy=False) if eager else runner.run(copy=False)
 
     def fence():
         if use_dist:
@@ -179,7 +180,7 @@ def main():
         out = {
             'metric': 'frames/sec (whole node), N-view 512px panoptic inference', 'value': round(fps, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
-            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f16' if args.amp == 'fp16' else 'bf16', 'data': 'synthetic',
             'config': {'workload': 'PanSt3R_%s_512 scene: %d views, %d keyframes, %dx%d, 100 classes, random-init full-size weights'
                                    % (args.variant, V, K, H, W),
                        'variant': args.variant, 'views': V, 'keyframes': K, 'resolution': [H, W],
@@ -218,7 +219,7 @@ def main():
                                   'tflops': round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1)} for k, v in sorted(summ.items())}
         if state is not None:
             out['cpu_baseline'], ref, ref_imgs, ref_ts = cpu_baseline(args.variant, H, W, state, names, emb, usable_cores())
-            out['parity'] = full_size_parity(model, dev, ref, ref_imgs, ref_ts, names)
+            out['parity'] = full_size_parity(model, dev, ref, ref_imgs, ref_ts, names, args.amp)
             if not out['parity']['within_tolerance']:
                 print('WARNING: full-size parity outside the stated tolerance: %s' % out['parity'], file=sys.stderr)
         sys.stdout.flush()

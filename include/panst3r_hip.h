@@ -10,8 +10,9 @@
  * no native code of its own: its "FFI" for this path are the torch ops / optional fused extensions listed in
  * SURVEY.md 2.1 (cuRoPE2D, xFormers memory-efficient attention, nn.MultiheadAttention, the einsum).
  *
- * Conventions: bf16 = raw uint16 bfloat16; activations are token-major [rows, channels] row-major with an
- * explicit leading dimension (elements); weights are torch nn.Linear layout [N, K] (K contiguous).
+ * Conventions: "16-bit" tensors are raw uint16 in ONE of two formats chosen per call by `dtype16` (PST_BF16 / PST_F16; all 16-bit
+ * operands of a call share it; "bf16" in the text below reads "the 16-bit format"); activations are token-major [rows, channels]
+ * row-major with an explicit leading dimension (elements); weights are torch nn.Linear layout [N, K] (K contiguous).
  */
 #ifndef PANST3R_HIP_H
 #define PANST3R_HIP_H
@@ -20,13 +21,18 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 11
+#define PST_ABI_VERSION 12
+
+/* element type codes: every `*_type` / `dtype16` argument below (and the former `*_fp32` flags: 0 and 1 keep their meaning) */
+#define PST_BF16 0   /* bfloat16, raw uint16 */
+#define PST_F32  1   /* float */
+#define PST_F16  2   /* IEEE half, raw uint16 (amp="fp16": tools/demo_panst3r.py:88, src/panst3r/utils.py:206-215) */
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
 
 /* ---------------------------------------------------------------- GEMM (+ fused epilogues, implicit 3x3 conv)
- * C[m, n] = epi( sum_k A[m,k] * W[n,k] ),  bf16 MFMA 16x16x32, fp32 accumulate.
+ * C[m, n] = epi( sum_k A[m,k] * W[n,k] ),  v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate.
  *   epi(x) = res + gamma[n] * act(x + bias[n])        (each part optional)
  * Replaces: every nn.Linear / 1x1 conv / patch-embed conv / 3x3 conv on the path -- croco Mlp/Attention/
  * CrossAttention projections (model/blocks.py:18-26, input_mixer.py:13-20, pixel_shuffle.py:17-27), LoftUp convs
@@ -65,9 +71,13 @@ typedef struct pst_gemm_params {
      unused.  (The 12 per-layer K and V^T projections of a MUSt3R memory append are one launch each instead of 12.) */
   int32_t batch;
   int64_t a_bs, w_bs, c_bs, bias_bs;
+  int32_t dtype16;                   /* PST_BF16 / PST_F16: format of A, W, a 16-bit C and a 16-bit residual */
 } pst_gemm_params;
 
-int pst_gemm_bf16(const pst_gemm_params* p, void* stream);
+int pst_gemm(const pst_gemm_params* p, void* stream);
+/* name of the kernel variant pst_gemm dispatches `p` to ("gemm_kernel<4,4,false>", "gemm256_kernel", ...), without launching:
+ * what a profiler row of this call is called (bench.py attributes its HIP-event timings with it). NULL for a rejected argument. */
+const char* pst_gemm_variant(const pst_gemm_params* p);
 
 /* ---------------------------------------------------------------- fused attention forward (flash style)
  * O[b,h,q,:] = softmax_k( scale * Q[b,h,q,:] . K[b,h,k,:]  (+ -inf where mask[b,q,k]) ) V[b,h,k,:]
@@ -89,15 +99,17 @@ typedef struct pst_attn_params {
      query block; partial (O, max, sum) go to `ws` (fp32, >= pst_attn_workspace_bytes) and a combine kernel merges. */
   int32_t nsplit;
   void* ws; int64_t ws_bytes;
+  int32_t dtype16;                             /* PST_BF16 / PST_F16: format of Q, K, Vt, O */
 } pst_attn_params;
 
 int64_t pst_attn_workspace_bytes(int B, int H, int Nq, int hd, int nsplit);
 
-int pst_attn_fwd_bf16(const pst_attn_params* p, void* stream);
+int pst_attn_fwd(const pst_attn_params* p, void* stream);
+const char* pst_attn_variant(const pst_attn_params* p);   /* as pst_gemm_variant */
 
 /* ---------------------------------------------------------------- LayerNorm
  * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dim D (D % 4 == 0, D <= 4096), fp32 statistics.
- * in_fp32/out_fp32 select element types; input row remap as in GEMM (grp_*), output leading dim ldy.
+ * in_fp32/out_fp32 are element type codes (PST_BF16 / PST_F32 / PST_F16); input row remap as in GEMM (grp_*), output leading dim ldy.
  * Replaces nn.LayerNorm everywhere on the path (eps 1e-6 backbones, 1e-5 PanSt3R-owned modules).
  */
 int pst_layernorm(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy, int out_fp32,
@@ -120,15 +132,15 @@ int pst_layernorm_add_batch(const void* x, int64_t ldx, int in_fp32, const float
  * weights packed as [W_hi | W_lo | W_hi] (one pst_gemm_bf16 over 3K, fp32 output) this evaluates x W^T with ~16 mantissa bits on
  * the bf16 MFMA path.  Used for the 200-query mask-embedding MLP (mask_transformer.py:230), whose result is one factor of the
  * ill-conditioned query x pixel product. */
-int pst_split3_bf16(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, void* stream);
+int pst_split3(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, int dtype16, void* stream);
 
 /* ---------------------------------------------------------------- RoPE-2D (in place on bf16 q and k)
  * Replaces cuRoPE2D / RoPE2D 'RoPE100' (README.md:67-71, input_mixer.py:16): per head the first hd/2 channels
  * rotate with pos y, the last hd/2 with pos x.  x: [rows, nheads*hd] slices of a row-major buffer with ld;
  * pos int32 [rows, 2] (y, x); cs: fp32 table [npos, hd/4, 2] (cos, sin).
  */
-int pst_rope2d_bf16(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd,
-                    void* stream);
+int pst_rope2d(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, int dtype16,
+               void* stream);
 
 /* ---------------------------------------------------------------- image -> patch rows
  * patchify: img fp32 [nimg, C, H, W] -> bf16 rows [nimg*(H/p)*(W/p), ld] with column (c*p + dy)*p + dx,
@@ -136,26 +148,26 @@ int pst_rope2d_bf16(void* x, int64_t ld, const int32_t* pos, const float* cs, in
  * dino_preprocess: reference model/dino.py:61-66 -- [-1,1] -> ImageNet normalise -> bilinear resize
  * (align_corners=False) to [nimg, 3, Ho, Wo] fp32.
  */
-int pst_patchify_bf16(const float* img, void* out, int64_t ld, int nimg, int C, int H, int W, int p, void* stream);
+int pst_patchify(const float* img, void* out, int64_t ld, int nimg, int C, int H, int W, int p, int dtype16, void* stream);
 int pst_dino_preprocess(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------- elementwise helpers
- * add_cast: y = a + (b ? b[row % b_mod] : 0), fp32 or bf16 in, bf16 or fp32 out, [rows, D] with leading dims. */
+ * add_cast: y = a + (b ? b[row % b_mod] : 0); a_fp32 / b_fp32 / y_fp32 are element type codes; [rows, D] with leading dims. */
 int pst_add_cast(const void* a, int64_t lda, int a_fp32, const void* b, int64_t ldb, int b_fp32, int b_mod,
                  void* y, int64_t ldy, int y_fp32, int rows, int D, void* stream);
 /* l2norm_rows: y = x / (||x|| + eps) per row (fp32 in, bf16 out) -- mask_transformer.py:225 */
-int pst_l2norm_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps, void* stream);
+int pst_l2norm_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps, int dtype16, void* stream);
 
 /* ---------------------------------------------------------------- panoptic query-decoder helpers
  * mean4: Fm[v, t, :] = mean of the central 2x2 pixels of token t's 8x8 block of the pixel-major mask features
  *   F [nimg, Hm, Wm, C] bf16  (== the 8x bilinear down-sampling of mask_transformer.py:283-287, exact).
  * attn_mask_from_logits: mask[q,k] = logits[q,k] < 0, rows that are fully blocked are cleared
  *   (mask_transformer.py:172,272).  logits fp32 [Q, Nk] -> uint8 [Q, Nk]. */
-int pst_mean4_bf16(const void* F, void* Fm, int nimg, int Hm, int Wm, int C, void* stream);
+int pst_mean4(const void* F, void* Fm, int nimg, int Hm, int Wm, int C, int dtype16, void* stream);
 /* resize_bilinear: F [nimg, Hs, Ws, C] bf16 -> Fd [nimg, Hd, Wd, C] bf16, F.interpolate(mode='bilinear',
  *   align_corners=False) semantics (mask_transformer.py:283-287 when the key grid of a portrait view is the transposed
  *   one, utils.py:47-49, so the resize is anisotropic and mean4 does not apply). */
-int pst_resize_bilinear_bf16(const void* F, void* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, void* stream);
+int pst_resize_bilinear(const void* F, void* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, int dtype16, void* stream);
 int pst_attn_mask_from_logits(const float* logits, int64_t ldl, uint8_t* mask, int64_t ldm, int Q, int Nk,
                               void* stream);
 
@@ -171,22 +183,20 @@ int pst_attn_mask_from_logits(const float* logits, int64_t ldl, uint8_t* mask, i
    guidance stats >= nimg*2*(1 + PST_STATS_BLOCKS);  groupnorm stats >= nimg*G*2*(1 + PST_STATS_BLOCKS).
    The result occupies the first nimg*2 / nimg*G*2 floats; the rest holds per-block partial sums (no atomics: the
    statistics are bit-reproducible). */
-int pst_loftup_guidance(const float* img, const float* biases, float* feats, float* stats, int nimg, int H, int W,
-                        int nf, void* stream);
 /* guidance_gn: the same features followed by GroupNorm(1 group, affine) WITHOUT materialising them: a statistics pass and a
  *   normalise-and-store pass both recompute the features per pixel (no fp32 feature round trip through HBM).
  *   y bf16 [nimg*P, ldy], columns [10*nf+3, ldy) zero; scratch >= nimg*(3*P + 6) floats; stats as for pst_loftup_guidance.
  *   (loftup.py:117-124: fourier_feat -> first GroupNorm of first_conv) */
 int pst_loftup_guidance_gn(const float* img, const float* biases, const float* gamma, const float* beta, float eps,
-                           float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, void* stream);
+                           float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, int dtype16, void* stream);
 int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float* stats, int nimg, int P, int C, int G,
                         void* stream);
 int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma,
                         const float* beta, void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu,
-                        void* stream);
+                        int dtype16, void* stream);
 /* lr_pe: low-res positional features of loftup.py:159-162 (ImplicitFeaturizer(color_feats=False, n_freqs=5)):
  * writes bf16 [h*w, 20] into columns [col0, col0+20) of a row-major buffer with ld (per view identical). */
-int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int nimg, int h, int w, void* stream);
+int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int nimg, int h, int w, int dtype16, void* stream);
 
 /* ---------------------------------------------------------------- panoptic post-processing
  * GPU replacement of `panoptic_inference_v2` (engine/postprocess.py:14-130; called by tools/demo_panst3r.py:242 with

@@ -37,7 +37,7 @@ struct AttnCfg {
   __device__ static __forceinline__ int kswz(int row) { return (HD == 64) ? ((row >> 1) & 7) : (row & 15); }
 };
 
-template <int HD, int QF>
+template <int HD, int QF, bool F16>
 __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   using C = AttnCfg<HD>;
   constexpr int NKK = HD / 32;      // K-steps of the QK^T contraction
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
         const int kc = kk * 4 + g;
         const bf16x8 kf = *(const bf16x8*)(kb_ + row * C::KPITCH + ((kc ^ C::kswz(row)) << 4));
 #pragma unroll
-        for (int a = 0; a < QF; ++a) s[f][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[a][kk], s[f][a], 0, 0, 0);
+        for (int a = 0; a < QF; ++a) s[f][a] = H16<F16>::mfma(kf, qf[a][kk], s[f][a]);
       }
     }
 
@@ -226,10 +226,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         union { bf16x8 v; uint32_t u[4]; } pk;
-        pk.u[0] = pack2bf(pv[2 * kb][0], pv[2 * kb][1]);
-        pk.u[1] = pack2bf(pv[2 * kb][2], pv[2 * kb][3]);
-        pk.u[2] = pack2bf(pv[2 * kb + 1][0], pv[2 * kb + 1][1]);
-        pk.u[3] = pack2bf(pv[2 * kb + 1][2], pv[2 * kb + 1][3]);
+        pk.u[0] = H16<F16>::pack(pv[2 * kb][0], pv[2 * kb][1]);
+        pk.u[1] = H16<F16>::pack(pv[2 * kb][2], pv[2 * kb][3]);
+        pk.u[2] = H16<F16>::pack(pv[2 * kb + 1][0], pv[2 * kb + 1][1]);
+        pk.u[3] = H16<F16>::pack(pv[2 * kb + 1][2], pv[2 * kb + 1][3]);
         pb[a][kb] = pk.v;
       }
     }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
         const int vc = kb * 4 + g;
         const bf16x8 vf = *(const bf16x8*)(vb_ + row * 128 + ((vc ^ ((row >> 1) & 7)) << 4));
 #pragma unroll
-        for (int a = 0; a < QF; ++a) o[hf][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[a][kb], o[hf][a], 0, 0, 0);
+        for (int a = 0; a < QF; ++a) o[hf][a] = H16<F16>::mfma(vf, pb[a][kb], o[hf][a]);
       }
     }
   }
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
       bf16_t* dst = Op + (int64_t)q * p.o_rs + 4 * g;
 #pragma unroll
       for (int hf = 0; hf < NHF; ++hf)
-        *(uint2*)(dst + hf * 16) = make_uint2(pack2bf(o[hf][a][0] * inv, o[hf][a][1] * inv),
-                                              pack2bf(o[hf][a][2] * inv, o[hf][a][3] * inv));
+        *(uint2*)(dst + hf * 16) = make_uint2(H16<F16>::pack(o[hf][a][0] * inv, o[hf][a][1] * inv),
+                                              H16<F16>::pack(o[hf][a][2] * inv, o[hf][a][3] * inv));
     }
   }
 }
@@ -313,31 +313,32 @@ __global__ void attn_combine_kernel(const pst_attn_params p, int hd) {
     const int q = (int)(row % p.Nq);
     const int bh = (int)(row / p.Nq), h = bh % p.H, b = bh / p.H;
     bf16_t* dst = (bf16_t*)p.O + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)q * p.o_rs + d;
-    *(uint2*)dst = make_uint2(pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv));
+    *(uint2*)dst = make_uint2(pack2(acc[0] * inv, acc[1] * inv, p.dtype16), pack2(acc[2] * inv, acc[3] * inv, p.dtype16));
   }
 }
 
-template <int HD, int QF>
+template <int HD, int QF, bool F16>
 static int launch_attn(const pst_attn_params& p, hipStream_t s) {
   const int qblocks = (p.Nq + 64 * QF - 1) / (64 * QF);
   const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
   const long grid = (long)qblocks * p.H * p.B * nsplit;
-  hipLaunchKernelGGL((attn_kernel<HD, QF>), dim3((unsigned)grid), dim3(256), 2 * AttnCfg<HD>::BUF, s, p);
+  hipLaunchKernelGGL((attn_kernel<HD, QF, F16>), dim3((unsigned)grid), dim3(256), 2 * AttnCfg<HD>::BUF, s, p);
   if (nsplit > 1) {
     const int64_t total = (int64_t)p.B * p.H * p.Nq * (HD / 4);
     int64_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)g), dim3(256), 0, s, p, HD);
   }
-  return check_launch("attn_fwd_bf16");
+  return check_launch("attn_fwd");
 }
 
 }  // namespace pst
 
-extern "C" int pst_attn_fwd_bf16(const pst_attn_params* pp, void* stream) {
+static int attn_validate(const pst_attn_params* pp) {
   using namespace pst;
   if (!pp) { set_error("attn: null params"); return PST_EINVAL; }
   const pst_attn_params& p = *pp;
+  if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("attn: dtype16 must be PST_BF16 or PST_F16"); return PST_EINVAL; }
   if (p.hd != 64 && p.hd != 96) { set_error("attn: head dim %d unsupported (64 or 96)", p.hd); return PST_EINVAL; }
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) { set_error("attn: bad shape"); return PST_EINVAL; }
   if (!p.Q || !p.K || !p.Vt || !p.O || !p.zeros) { set_error("attn: null operand"); return PST_EINVAL; }
@@ -354,10 +355,31 @@ extern "C" int pst_attn_fwd_bf16(const pst_attn_params* pp, void* stream) {
     if (!p.ws || p.ws_bytes < need || ((uintptr_t)p.ws & 15)) { set_error("attn: split-K needs a 16-byte aligned workspace of %lld bytes", (long long)need); return PST_EINVAL; }
     if (p.nsplit > 64) { set_error("attn: nsplit <= 64"); return PST_EINVAL; }
   }
+  return PST_OK;
+}
+
+// the ONE dispatch rule (launch and variant name): 128-query blocks once they fill the chip; split-K always uses 64-query blocks
+static bool attn_big(const pst_attn_params& p) { return p.nsplit <= 1 && (long)((p.Nq + 127) / 128) * p.H * p.B >= 256; }
+
+extern "C" int pst_attn_fwd(const pst_attn_params* pp, void* stream) {
+  using namespace pst;
+  if (int rc = attn_validate(pp)) return rc;
+  const pst_attn_params& p = *pp;
   hipStream_t s = (hipStream_t)stream;
-  const long big = p.nsplit > 1 ? 0 : (long)((p.Nq + 127) / 128) * p.H * p.B;     // split-K always uses 64-query blocks
-  if (p.hd == 64) return big >= 256 ? launch_attn<64, 2>(p, s) : launch_attn<64, 1>(p, s);
-  return big >= 256 ? launch_attn<96, 2>(p, s) : launch_attn<96, 1>(p, s);
+  const bool big = attn_big(p), h = p.dtype16 == DT_F16;
+  if (p.hd == 64) {
+    if (big) return h ? launch_attn<64, 2, true>(p, s) : launch_attn<64, 2, false>(p, s);
+    return h ? launch_attn<64, 1, true>(p, s) : launch_attn<64, 1, false>(p, s);
+  }
+  if (big) return h ? launch_attn<96, 2, true>(p, s) : launch_attn<96, 2, false>(p, s);
+  return h ? launch_attn<96, 1, true>(p, s) : launch_attn<96, 1, false>(p, s);
+}
+
+extern "C" const char* pst_attn_variant(const pst_attn_params* pp) {
+  if (attn_validate(pp)) return nullptr;
+  const bool big = attn_big(*pp);
+  if (pp->hd == 64) return big ? "attn_kernel<64,2>" : "attn_kernel<64,1>";
+  return big ? "attn_kernel<96,2>" : "attn_kernel<96,1>";
 }
 
 extern "C" int64_t pst_attn_workspace_bytes(int B, int H, int Nq, int hd, int nsplit) {

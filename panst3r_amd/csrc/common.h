@@ -36,6 +36,50 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
   return *(const uint32_t*)&r;
 }
 
+// ---------------------------------------------------------------- 16-bit storage formats
+// Every 16-bit tensor on the path is either bfloat16 (8-bit mantissa, fp32 range; amp='bf16') or IEEE half (11-bit mantissa,
+// |x| <= 65504; amp='fp16', tools/demo_panst3r.py:88, src/panst3r/utils.py:206-215).  Both feed v_mfma_f32_16x16x32_{bf16,f16} at
+// the same rate with fp32 accumulation.  Element type codes of the C ABI: 0 = bf16, 1 = fp32, 2 = f16.
+enum { DT_BF16 = 0, DT_F32 = 1, DT_F16 = 2 };
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {       // one v_cvt_pk_f16_f32 (round-to-nearest-even; overflow -> inf)
+  const f16x2_t r = __builtin_convertvector(f32x2_t{a, b}, f16x2_t);
+  return *(const uint32_t*)&r;
+}
+__device__ __forceinline__ float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+
+// compile-time format selection (MFMA kernels)
+template <bool F16>
+struct H16 {
+  static __device__ __forceinline__ float lo(uint32_t w) {
+    if constexpr (F16) { const f16x2_t q = *(const f16x2_t*)&w; return (float)q[0]; } else return __uint_as_float(w << 16);
+  }
+  static __device__ __forceinline__ float hi(uint32_t w) {
+    if constexpr (F16) { const f16x2_t q = *(const f16x2_t*)&w; return (float)q[1]; } else return __uint_as_float(w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {
+    if constexpr (F16) return pack2h(a, b); else return pack2bf(a, b);
+  }
+  static __device__ __forceinline__ uint16_t from_f(float f) {
+    if constexpr (F16) return f2h(f); else return f2bf(f);
+  }
+  static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8_t*)&a, *(const f16x8_t*)&b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// run-time format selection (HBM-bound streaming kernels: the branch is wave-uniform and free next to the memory traffic)
+__device__ __forceinline__ float ld16(uint16_t v, int tc) { return tc == DT_F16 ? h2f(v) : bf2f(v); }
+__device__ __forceinline__ uint16_t st16(float f, int tc) { return tc == DT_F16 ? f2h(f) : f2bf(f); }
+__device__ __forceinline__ uint32_t pack2(float a, float b, int tc) { return tc == DT_F16 ? pack2h(a, b) : pack2bf(a, b); }
+__device__ __forceinline__ void unpack2(uint32_t w, int tc, float& a, float& b) {
+  if (tc == DT_F16) { a = H16<true>::lo(w); b = H16<true>::hi(w); } else { a = H16<false>::lo(w); b = H16<false>::hi(w); }
+}
+
 // LDS-DMA: every lane copies 16 B from its own global address to (wave-uniform LDS base + lane*16).
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -71,6 +115,7 @@ __device__ __forceinline__ void rope_table(const pst_gemm_params& p, int m, int 
   for (int q = 0; q < 4; ++q) cs[q] = t[q];      // (cos, sin) of frequencies i0+2q, i0+2q+1
 }
 
+template <bool F16>
 __device__ __forceinline__ uint4 rope_rotate(uint4 own, uint4 partner, const float4 (&cs)[4], int n) {
   const bool second = (n & 16) != 0;             // this chunk holds the (i + 16) members of the pairs
   const uint32_t* a = (const uint32_t*)&own;
@@ -79,19 +124,20 @@ __device__ __forceinline__ uint4 rope_rotate(uint4 own, uint4 partner, const flo
   uint32_t* o = (uint32_t*)&out;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float x0 = __uint_as_float(a[q] << 16), x1 = __uint_as_float(a[q] & 0xffff0000u);
-    const float y0 = __uint_as_float(b[q] << 16), y1 = __uint_as_float(b[q] & 0xffff0000u);
+    const float x0 = H16<F16>::lo(a[q]), x1 = H16<F16>::hi(a[q]);
+    const float y0 = H16<F16>::lo(b[q]), y1 = H16<F16>::hi(b[q]);
     const float r0 = second ? x0 * cs[q].x + y0 * cs[q].y : x0 * cs[q].x - y0 * cs[q].y;
     const float r1 = second ? x1 * cs[q].z + y1 * cs[q].w : x1 * cs[q].z - y1 * cs[q].w;
-    o[q] = pack2bf(r0, r1);
+    o[q] = H16<F16>::pack(r0, r1);
   }
   return out;
 }
 
+template <bool F16>
 __device__ __forceinline__ uint4 rope_chunk(const pst_gemm_params& p, uint4 own, uint4 partner, int m, int n) {
   float4 cs[4];
   rope_table(p, m, n, cs);
-  return rope_rotate(own, partner, cs, n);
+  return rope_rotate<F16>(own, partner, cs, n);
 }
 
 // Bijective XCD-aware remap: hardware places block b on XCD b%8; give each XCD a contiguous chunk of tiles.

@@ -38,7 +38,7 @@ __device__ __forceinline__ int perm_row(int row) {
 
 // Whole-row write-back of the LDS-staged C tile: thread -> (row, 16-B chunk); consecutive lanes = consecutive bytes of one
 // output row.  F32: fp32 output (residual values were prefetched into resv by the caller), else bf16 output.
-template <int BM, int BN, bool F32>
+template <int BM, int BN, bool F32, bool F16>
 __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* smem, int tid, int m0, int n0,
                                           const float4 (&resv)[BM / 8]) {
   constexpr int pitch = BN * (F32 ? 4 : 2);                 // bytes per LDS C row
@@ -85,7 +85,7 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
           const int r = r0 + (g0 + u) * rstep;
           const uint4 own = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
           const uint4 partner = *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4));
-          *(uint4*)((char*)p.C + ((int64_t)orow[g0 + u] * p.ldc + n) * 2) = rope_rotate(own, partner, cs[u], n);
+          *(uint4*)((char*)p.C + ((int64_t)orow[g0 + u] * p.ldc + n) * 2) = rope_rotate<F16>(own, partner, cs[u], n);
         }
       }
       return;
@@ -105,8 +105,7 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
         const uint32_t* q32 = (const uint32_t*)&rq[F32 ? 0 : it];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          w32[q] = pack2bf(__uint_as_float(w32[q] << 16) + __uint_as_float(q32[q] << 16),
-                           __uint_as_float(w32[q] & 0xffff0000u) + __uint_as_float(q32[q] & 0xffff0000u));
+          w32[q] = H16<F16>::pack(H16<F16>::lo(w32[q]) + H16<F16>::lo(q32[q]), H16<F16>::hi(w32[q]) + H16<F16>::hi(q32[q]));
       }
       *(uint4*)((char*)p.C + ((int64_t)orow[it] * p.ldc + n) * (F32 ? 4 : 2)) = val;
     }
@@ -118,7 +117,7 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
     const int m = m0 + r;
     if (r >= BM || m >= p.M || n >= p.N) continue;
     uint4 val = *(const uint4*)(smem + r * pitch + ((c ^ (r & (nch - 1))) << 4));
-    if (p.rope_hd == 64 && !F32) val = rope_chunk(p, val, *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4)), m, n);
+    if (p.rope_hd == 64 && !F32) val = rope_chunk<F16>(p, val, *(const uint4*)(smem + r * pitch + (((c ^ 2) ^ (r & (nch - 1))) << 4)), m, n);
     int orow = m;
     int64_t off;
     int ps_v = 0, ps_y = 0, ps_x = 0;
@@ -146,8 +145,8 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
       } else if (rpb) {
         const uint2 q = *(const uint2*)rpb;
         float4 f = *(float4*)&val;
-        f.x += __uint_as_float(q.x << 16); f.y += __uint_as_float(q.x & 0xffff0000u);
-        f.z += __uint_as_float(q.y << 16); f.w += __uint_as_float(q.y & 0xffff0000u);
+        f.x += H16<F16>::lo(q.x); f.y += H16<F16>::hi(q.x);
+        f.z += H16<F16>::lo(q.y); f.w += H16<F16>::hi(q.y);
         *(float4*)((float*)p.C + off) = f;
       } else {
         *(uint4*)((float*)p.C + off) = val;
@@ -161,16 +160,15 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
       else { const uint2 t = *(const uint2*)rpb; rq[0] = t.x; rq[1] = t.y; }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        w32[q] = pack2bf(__uint_as_float(w32[q] << 16) + __uint_as_float(rq[q] << 16),
-                         __uint_as_float(w32[q] & 0xffff0000u) + __uint_as_float(rq[q] & 0xffff0000u));
+        w32[q] = H16<F16>::pack(H16<F16>::lo(w32[q]) + H16<F16>::lo(rq[q]), H16<F16>::hi(w32[q]) + H16<F16>::hi(rq[q]));
     }
     if (rp) {              // bf16 output with an fp32 residual: add in fp32, round once more
       uint32_t* w32 = (uint32_t*)&val;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float lo = __uint_as_float(w32[q] << 16) + ((n + 2 * q < p.N) ? rp[2 * q] : 0.f);
-        const float hi = __uint_as_float(w32[q] & 0xffff0000u) + ((n + 2 * q + 1 < p.N) ? rp[2 * q + 1] : 0.f);
-        w32[q] = pack2bf(lo, hi);
+        const float lo = H16<F16>::lo(w32[q]) + ((n + 2 * q < p.N) ? rp[2 * q] : 0.f);
+        const float hi = H16<F16>::hi(w32[q]) + ((n + 2 * q + 1 < p.N) ? rp[2 * q + 1] : 0.f);
+        w32[q] = H16<F16>::pack(lo, hi);
       }
     }
     bf16_t* dst = (bf16_t*)p.C + off;
@@ -197,7 +195,7 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
 // NST = 4 (64x64 tiles, the 768-row GEMMs of the sequential memory build): with only 8 MFMAs per K step those GEMMs
 // are bound by the global->LDS LATENCY of a one-deep prefetch, so three slabs are kept in flight and each step waits
 // with a COUNTED s_waitcnt vmcnt (raw s_barrier: __syncthreads() would drain the LDS-DMA queue).
-template <int FM, int FN, bool TRANS, int NST>
+template <int FM, int FN, bool TRANS, int NST, bool F16>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in, const int ntiles, const int tiles_m, const int tiles_n) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   pst_gemm_params p = p_in;                 // strided batch: blockIdx.y selects the problem (all fields wave-uniform)
@@ -322,8 +320,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
-          else       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[j], af[i], acc[i][j], 0, 0, 0);
+          if (TRANS) acc[i][j] = H16<F16>::mfma(af[i], bfv[j], acc[i][j]);
+          else       acc[i][j] = H16<F16>::mfma(bfv[j], af[i], acc[i][j]);
         }
     }
   }
@@ -375,14 +373,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
       if (mb + 4 * FM <= p.M && (((uintptr_t)dst) & 15) == 0) {
 #pragma unroll
         for (int q = 0; q < FM / 2; ++q)
-          *(uint4*)(dst + 8 * q) = make_uint4(pack2bf(v[8 * q], v[8 * q + 1]), pack2bf(v[8 * q + 2], v[8 * q + 3]),
-                                              pack2bf(v[8 * q + 4], v[8 * q + 5]), pack2bf(v[8 * q + 6], v[8 * q + 7]));
+          *(uint4*)(dst + 8 * q) = make_uint4(H16<F16>::pack(v[8 * q], v[8 * q + 1]), H16<F16>::pack(v[8 * q + 2], v[8 * q + 3]),
+                                              H16<F16>::pack(v[8 * q + 4], v[8 * q + 5]), H16<F16>::pack(v[8 * q + 6], v[8 * q + 7]));
       } else if (mb + 4 * FM <= p.M) {
 #pragma unroll
         for (int q = 0; q < FM; ++q)
-          *(uint2*)(dst + 4 * q) = make_uint2(pack2bf(v[4 * q], v[4 * q + 1]), pack2bf(v[4 * q + 2], v[4 * q + 3]));
+          *(uint2*)(dst + 4 * q) = make_uint2(H16<F16>::pack(v[4 * q], v[4 * q + 1]), H16<F16>::pack(v[4 * q + 2], v[4 * q + 3]));
       } else {
-        for (int r = 0; r < 4 * FM && mb + r < p.M; ++r) dst[r] = f2bf(v[r]);
+        for (int r = 0; r < 4 * FM && mb + r < p.M; ++r) dst[r] = H16<F16>::from_f(v[r]);
       }
     }
     return;
@@ -425,13 +423,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
         v[0] *= gam4[j].x; v[1] *= gam4[j].y; v[2] *= gam4[j].z; v[3] *= gam4[j].w;
         const int col = cb + 4 * j;
         if (f32o) *(float4*)(rowp + ((((col >> 2) ^ key)) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
-        else *(uint2*)(rowp + ((((col >> 3) ^ key)) << 4) + ((col & 4) << 1)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        else *(uint2*)(rowp + ((((col >> 3) ^ key)) << 4) + ((col & 4) << 1)) = make_uint2(H16<F16>::pack(v[0], v[1]), H16<F16>::pack(v[2], v[3]));
       }
     }
   }
   __syncthreads();
-  if (f32o) row_phase<BM, BN, true>(p, smem, tid, m0, n0, resv);
-  else row_phase<BM, BN, false>(p, smem, tid, m0, n0, resv);
+  if (f32o) row_phase<BM, BN, true, F16>(p, smem, tid, m0, n0, resv);
+  else row_phase<BM, BN, false, F16>(p, smem, tid, m0, n0, resv);
 }
 
 static int num_cus() {
@@ -445,22 +443,28 @@ static int num_cus() {
   return cus;
 }
 
-template <int FM, int FN, bool TRANS, int NST>
-static int launch(const pst_gemm_params& p, hipStream_t s) {
+template <int FM, int FN, bool TRANS, int NST, bool F16>
+static int launch_t(const pst_gemm_params& p, hipStream_t s) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
   const size_t lds = NST * (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS, NST>), dim3(tiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, tiles, tiles_m, tiles_n);
-  return check_launch("gemm_bf16");
+  hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS, NST, F16>), dim3(tiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, tiles, tiles_m, tiles_n);
+  return check_launch("gemm");
+}
+
+template <int FM, int FN, bool TRANS, int NST>
+static int launch(const pst_gemm_params& p, hipStream_t s) {
+  return p.dtype16 == DT_F16 ? launch_t<FM, FN, TRANS, NST, true>(p, s) : launch_t<FM, FN, TRANS, NST, false>(p, s);
 }
 
 }  // namespace pst
 
-extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
+static int gemm_validate(const pst_gemm_params* pp) {
   using namespace pst;
   if (!pp) { set_error("gemm: null params"); return PST_EINVAL; }
   const pst_gemm_params& p = *pp;
+  if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("gemm: dtype16 must be PST_BF16 or PST_F16"); return PST_EINVAL; }
   if (p.kernel != 0 && p.kernel != 128 && p.kernel != 256) { set_error("gemm: kernel must be 0 (auto), 128 or 256"); return PST_EINVAL; }
   if (p.kernel == 256 && (p.conv_c > 0 || p.trans_out)) { set_error("gemm: the 256x256 kernel has no conv / trans_out mode"); return PST_EINVAL; }
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) { set_error("gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K); return PST_EINVAL; }
@@ -489,20 +493,41 @@ extern "C" int pst_gemm_bf16(const pst_gemm_params* pp, void* stream) {
                       (p.a_bs | p.w_bs | p.c_bs) % 8 || p.bias_bs % 4)) {
     set_error("gemm: strided batch supports bias/act/trans_out only, strides multiples of 8 elements (batch=%d)", p.batch); return PST_EINVAL;
   }
-  hipStream_t s = (hipStream_t)stream;
+  return PST_OK;
+}
+
+// the ONE dispatch rule, shared by the launch and by pst_gemm_variant: 0 = 64x64 tiles, 1 = 128x128, 2 = 256x256
+static int gemm_choice(const pst_gemm_params& p) {
   const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batch > 1 ? p.batch : 1);
   // fewer 128x128 tiles than about one per CU: 64x64 tiles fill the chip better.  Measured crossover (M = 1536 .. 5376, the
   // 2-7 views per rank of an 8-GPU scene): 192 tiles -> 64x64 wins for K = 1024 (348 vs 326 TFLOP/s) and loses for K = 4096
   // (505 vs 536); 288 tiles -> 128x128 wins for both (397 vs 377, 614 vs 532).
   const bool small = p.kernel == 0 && big_tiles < (p.K >= 2048 ? 176 : 256);
-  // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
-  if (p.trans_out) return small ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
+  if (p.trans_out) return small ? 0 : 1;
   // large plain GEMMs: 256x256 tiles, 8 waves, counted-vmcnt pipeline (>= 3 full rounds of the 256 CUs, or forced)
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool fits32 = (int64_t)p.M * p.lda < (1ll << 31) && (int64_t)p.N * p.ldw < (1ll << 31);
   // measured on MI355X: the 256^2 kernel wins for deep K / wide N (v1 MLPs +10 %, 8192^3 +20 %), loses for K < 1024 or ragged N
   const bool shape256 = p.N % 256 == 0 && p.K >= 1024 && (p.N >= 2048 || p.K >= 2048) && tiles256 >= 3 * 256 - 64;
-  const int want256 = p.conv_c == 0 && fits32 && p.batch <= 1 && (p.kernel == 256 || (p.kernel == 0 && shape256));
-  if (want256) return launch_gemm256(p, s);
-  return small ? launch<2, 2, false, 4>(p, s) : launch<4, 4, false, 2>(p, s);
+  if (p.conv_c == 0 && fits32 && p.batch <= 1 && (p.kernel == 256 || (p.kernel == 0 && shape256))) return 2;
+  return small ? 0 : 1;
+}
+
+extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
+  using namespace pst;
+  if (int rc = gemm_validate(pp)) return rc;
+  const pst_gemm_params& p = *pp;
+  hipStream_t s = (hipStream_t)stream;
+  const int c = gemm_choice(p);
+  // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
+  if (p.trans_out) return c == 0 ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
+  if (c == 2) return launch_gemm256(p, s);
+  return c == 0 ? launch<2, 2, false, 4>(p, s) : launch<4, 4, false, 2>(p, s);
+}
+
+extern "C" const char* pst_gemm_variant(const pst_gemm_params* pp) {
+  if (gemm_validate(pp)) return nullptr;
+  const int c = gemm_choice(*pp);
+  if (pp->trans_out) return c == 0 ? "gemm_kernel<2,2,true>" : "gemm_kernel<4,4,true>";
+  return c == 2 ? "gemm256_kernel" : (c == 0 ? "gemm_kernel<2,2,false>" : "gemm_kernel<4,4,false>");
 }

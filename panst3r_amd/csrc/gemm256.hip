@@ -27,6 +27,7 @@ __device__ __forceinline__ int perm_row4(int row) {      // see gemm.hip perm_ro
 
 #define PST_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+template <bool F16>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[mi * 4 + i][ni * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j], 0, 0, 0);
+          acc[mi * 4 + i][ni * 2 + j] = H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
           v[0] *= gam4.x; v[1] *= gam4.y; v[2] *= gam4.z; v[3] *= gam4.w;
           const int col = cb + 4 * j;
           if (f32o) *(float4*)(rowp + (((col >> 2) ^ rkey) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
-          else *(uint2*)(rowp + (((col >> 3) ^ rkey) << 4) + ((col & 4) << 1)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          else *(uint2*)(rowp + (((col >> 3) ^ rkey) << 4) + ((col & 4) << 1)) = make_uint2(H16<F16>::pack(v[0], v[1]), H16<F16>::pack(v[2], v[3]));
         }
       }
     }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
             const int rr = r0 + (g0 + u) * 16;
             const uint4 own = *(const uint4*)(smem + rr * 512 + ((cc ^ (rr & 31)) << 4));
             const uint4 partner = *(const uint4*)(smem + rr * 512 + (((cc ^ 2) ^ (rr & 31)) << 4));
-            *(uint4*)((bf16_t*)p.C + (int64_t)next_row() * p.ldc + nn) = rope_rotate(own, partner, cs[u], nn);
+            *(uint4*)((bf16_t*)p.C + (int64_t)next_row() * p.ldc + nn) = rope_rotate<F16>(own, partner, cs[u], nn);
           }
         }
       } else {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
       const int m = m0 + pass * rows_pass + rr;
       if (m >= p.M || n >= p.N) continue;
       uint4 val = *(const uint4*)(smem + rr * pitch + ((c ^ (rr & (nch - 1))) << 4));
-      if (p.rope_hd == 64 && !f32o) val = rope_chunk(p, val, *(const uint4*)(smem + rr * pitch + (((c ^ 2) ^ (rr & (nch - 1))) << 4)), m, n);
+      if (p.rope_hd == 64 && !f32o) val = rope_chunk<F16>(p, val, *(const uint4*)(smem + rr * pitch + (((c ^ 2) ^ (rr & (nch - 1))) << 4)), m, n);
       int orow = m;
       int64_t off;
       int ps_v = 0, ps_y = 0, ps_x = 0;
@@ -250,8 +251,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
         } else if (rpb) {
           const uint2 q = *(const uint2*)rpb;
           float4 f = *(float4*)&val;
-          f.x += __uint_as_float(q.x << 16); f.y += __uint_as_float(q.x & 0xffff0000u);
-          f.z += __uint_as_float(q.y << 16); f.w += __uint_as_float(q.y & 0xffff0000u);
+          f.x += H16<F16>::lo(q.x); f.y += H16<F16>::hi(q.x);
+          f.z += H16<F16>::lo(q.y); f.w += H16<F16>::hi(q.y);
           *(float4*)((float*)p.C + off) = f;
         } else {
           *(uint4*)((float*)p.C + off) = val;
@@ -265,16 +266,15 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
         else { const uint2 t = *(const uint2*)rpb; rq[0] = t.x; rq[1] = t.y; }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          w32[q] = pack2bf(__uint_as_float(w32[q] << 16) + __uint_as_float(rq[q] << 16),
-                           __uint_as_float(w32[q] & 0xffff0000u) + __uint_as_float(rq[q] & 0xffff0000u));
+          w32[q] = H16<F16>::pack(H16<F16>::lo(w32[q]) + H16<F16>::lo(rq[q]), H16<F16>::hi(w32[q]) + H16<F16>::hi(rq[q]));
       }
       if (rp) {
         uint32_t* w32 = (uint32_t*)&val;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float lo = __uint_as_float(w32[q] << 16) + ((n + 2 * q < p.N) ? rp[2 * q] : 0.f);
-          const float hi = __uint_as_float(w32[q] & 0xffff0000u) + ((n + 2 * q + 1 < p.N) ? rp[2 * q + 1] : 0.f);
-          w32[q] = pack2bf(lo, hi);
+          const float lo = H16<F16>::lo(w32[q]) + ((n + 2 * q < p.N) ? rp[2 * q] : 0.f);
+          const float hi = H16<F16>::hi(w32[q]) + ((n + 2 * q + 1 < p.N) ? rp[2 * q + 1] : 0.f);
+          w32[q] = H16<F16>::pack(lo, hi);
         }
       }
       bf16_t* dst = (bf16_t*)p.C + off;
@@ -301,11 +301,13 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
   const int tiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm256_kernel, dim3(tiles), dim3(512), 2 * BUF_BYTES, s, p, tiles, tiles_m, tiles_n);
-  return check_launch("gemm256_bf16");
+  if (p.dtype16 == DT_F16) hipLaunchKernelGGL(gemm256_kernel<true>, dim3(tiles), dim3(512), 2 * BUF_BYTES, s, p, tiles, tiles_m, tiles_n);
+  else hipLaunchKernelGGL(gemm256_kernel<false>, dim3(tiles), dim3(512), 2 * BUF_BYTES, s, p, tiles, tiles_m, tiles_n);
+  return check_launch("gemm256");
 }
 
 }  // namespace pst

@@ -53,47 +53,9 @@ __global__ __launch_bounds__(1024) void down2_minmax_kernel(const float* img, fl
   }
 }
 
-// thread = (pixel, output channel).  Channels: [0,5nf) sin, [5nf,10nf) cos with index f*5+d, then 3 scaled rgb.
-// d: 0 = y grid, 1 = x grid, 2..4 = scaled rgb.  Bias storage is [2][5][nf] read flat as [2][nf*5] (loftup.py:62-63).
-__global__ __launch_bounds__(256) void fourier_kernel(const float* img2, const float* mm, const float* biases, float* feats,
-                                                      float* part, int H2, int W2, int nf, float f_lo, float f_step) {
-  __shared__ float sh[4];
-  const int view = blockIdx.y, P = H2 * W2, CH = 10 * nf + 3;
-  const int64_t total = (int64_t)P * CH;
-  float s = 0.f, s2 = 0.f;
-  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int pix = (int)(i / CH), ch = (int)(i - (int64_t)pix * CH);
-    const int y = pix / W2, x = pix - y * W2;
-    int d, f = 0, kind;   // kind 0 sin, 1 cos, 2 copy
-    if (ch < 5 * nf) { kind = 0; f = ch / 5; d = ch - f * 5; }
-    else if (ch < 10 * nf) { kind = 1; f = (ch - 5 * nf) / 5; d = ch - 5 * nf - f * 5; }
-    else { kind = 2; d = 2 + ch - 10 * nf; }
-    float base;
-    if (d == 0) base = H2 > 1 ? -1.f + 2.f * y / (H2 - 1) : -1.f;
-    else if (d == 1) base = W2 > 1 ? -1.f + 2.f * x / (W2 - 1) : -1.f;
-    else {
-      const int c = d - 2;
-      const float lo = mm[2 * (view * 3 + c)], hi = mm[2 * (view * 3 + c) + 1];
-      base = (img2[((int64_t)(view * 3 + c)) * P + pix] - lo) / fmaxf(hi - lo, 1e-4f) - 0.5f;
-    }
-    float v;
-    if (kind == 2) v = base;
-    else {
-      const float ph = base * expf(f_lo + f_step * f) + biases[kind * 5 * nf + f * 5 + d];
-      v = kind == 0 ? sinf(ph) : cosf(ph);
-    }
-    feats[(int64_t)view * total + i] = v;
-    s += v;
-    s2 += v * v;
-  }
-  // deterministic: fixed per-thread element order, fixed-tree block reduction, per-block partial (no atomics)
-  s = block_reduce(s, sh, false, false);
-  s2 = block_reduce(s2, sh, false, false);
-  if (threadIdx.x == 0) { part[((int64_t)view * gridDim.x + blockIdx.x) * 2] = s; part[((int64_t)view * gridDim.x + blockIdx.x) * 2 + 1] = s2; }
-}
-
 // ------------------------------------------------------------------ fused guidance front end: features -> GroupNorm(1) -> bf16
-// Per-PIXEL formulation of fourier_kernel + gn_apply_kernel<1>: a block walks tiles of 64 pixels, thread = (pixel, channel group
+// Per-PIXEL formulation (channels: [0,5nf) sin, [5nf,10nf) cos with index f*5+d, then 3 scaled rgb; d: 0 = y grid, 1 = x grid,
+// 2..4 = scaled rgb; bias storage [2][5][nf] read flat as [2][nf*5], loftup.py:62-63): a block walks tiles of 64 pixels, thread = (pixel, channel group
 // cg = tid >> 6 owning the frequencies cg, cg+4, ...), so there is no per-element integer division and the nf frequencies come
 // from an LDS table.  Two passes that RECOMPUTE the features instead of a 639 MB fp32 round trip through HBM (16 views):
 //   APPLY = false: sum / sum of squares per block (fixed order, no atomics) -> reduce_partials_kernel -> GroupNorm(1) statistics
@@ -101,7 +63,7 @@ __global__ __launch_bounds__(256) void fourier_kernel(const float* img2, const f
 template <bool APPLY>
 __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, const float* mm, const float* biases, float* part,
                                                           const float* stats, const float* gamma, const float* beta, float eps,
-                                                          bf16_t* y, int64_t ldy, int H2, int W2, int nf, float f_lo, float f_step) {
+                                                          bf16_t* y, int64_t ldy, int H2, int W2, int nf, float f_lo, float f_step, int tc) {
   extern __shared__ float shm[];             // [nf] frequencies, [4] reduction scratch, then (APPLY) the [64][ldy] bf16 tile
   float* freq = shm;
   float* red = shm + nf;
@@ -143,8 +105,8 @@ __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, con
         const float vs = sinf(base[d] * fr + biases[f * 5 + d]);
         const float vc = cosf(base[d] * fr + biases[5 * nf + f * 5 + d]);
         if (APPLY) {
-          trow[f * 5 + d] = f2bf((vs - mean) * rstd * gamma[f * 5 + d] + beta[f * 5 + d]);
-          trow[5 * nf + f * 5 + d] = f2bf((vc - mean) * rstd * gamma[5 * nf + f * 5 + d] + beta[5 * nf + f * 5 + d]);
+          trow[f * 5 + d] = st16((vs - mean) * rstd * gamma[f * 5 + d] + beta[f * 5 + d], tc);
+          trow[5 * nf + f * 5 + d] = st16((vc - mean) * rstd * gamma[5 * nf + f * 5 + d] + beta[5 * nf + f * 5 + d], tc);
         } else if (ok) {
           s += vs + vc;
           s2 += vs * vs + vc * vc;
@@ -155,7 +117,7 @@ __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, con
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float v = base[2 + c];
-        if (APPLY) trow[10 * nf + c] = f2bf((v - mean) * rstd * gamma[10 * nf + c] + beta[10 * nf + c]);
+        if (APPLY) trow[10 * nf + c] = st16((v - mean) * rstd * gamma[10 * nf + c] + beta[10 * nf + c], tc);
         else if (ok) { s += v; s2 += v * v; }
       }
     }
@@ -202,10 +164,8 @@ __global__ void gn_stats_kernel(const void* x, int64_t ldx, int x_fp32, float* p
   for (int r = r0 + rsub; r < r1; r += rpb) {
     const int64_t idx = ((int64_t)view * P + r) * ldx + chunk * 4;
     float v[4];
-    if (x_fp32) { const float4 t = *(const float4*)((const float*)x + idx); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-    else { const uint2 t = *(const uint2*)((const bf16_t*)x + idx);
-           v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-           v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+    if (x_fp32 == DT_F32) { const float4 t = *(const float4*)((const float*)x + idx); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else { const uint2 t = *(const uint2*)((const bf16_t*)x + idx); unpack2(t.x, x_fp32, v[0], v[1]); unpack2(t.y, x_fp32, v[2], v[3]); }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s += v[k]; s2 += v[k] * v[k]; }
   }
@@ -226,7 +186,7 @@ __global__ void gn_stats_kernel(const void* x, int64_t ldx, int x_fp32, float* p
 // VEC=4: one thread = 4 consecutive channels (8-16 B loads, 8 B stores); VEC=1 is the generic path (C = 203).
 template <int VEC>
 __global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
-                                bf16_t* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu) {
+                                bf16_t* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, int tc) {
   const int64_t cols = ldy / VEC;
   const int64_t total = (int64_t)nimg * P * cols;
   const float inv_n = 1.0f / ((float)P * (C / G));
@@ -243,12 +203,10 @@ __global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const fl
       const float rstd = rsqrtf(fmaxf(sq * inv_n - mean * mean, 0.f) + eps);
       float v[VEC];
       if (VEC == 4) {
-        if (x_fp32) { const float4 t = *(const float4*)((const float*)x + row * ldx + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-        else { const uint2 t = *(const uint2*)((const bf16_t*)x + row * ldx + c);
-               v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-               v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+        if (x_fp32 == DT_F32) { const float4 t = *(const float4*)((const float*)x + row * ldx + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else { const uint2 t = *(const uint2*)((const bf16_t*)x + row * ldx + c); unpack2(t.x, x_fp32, v[0], v[1]); unpack2(t.y, x_fp32, v[2], v[3]); }
       } else {
-        v[0] = x_fp32 ? ((const float*)x)[row * ldx + c] : bf2f(((const bf16_t*)x)[row * ldx + c]);
+        v[0] = x_fp32 == DT_F32 ? ((const float*)x)[row * ldx + c] : ld16(((const bf16_t*)x)[row * ldx + c], x_fp32);
       }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
@@ -256,13 +214,13 @@ __global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const fl
         if (relu) o[k] = fmaxf(o[k], 0.f);
       }
     }
-    if (VEC == 4) *(uint2*)(y + row * ldy + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-    else y[row * ldy + c] = f2bf(o[0]);
+    if (VEC == 4) *(uint2*)(y + row * ldy + c) = make_uint2(pack2(o[0], o[1], tc), pack2(o[2], o[3], tc));
+    else y[row * ldy + c] = st16(o[0], tc);
   }
 }
 
 // low-res positional features: 20 channels = sin(f*2+d) x10, cos x10 on the (h, w) token grid
-__global__ void lr_pe_kernel(const float* biases, bf16_t* out, int64_t ld, int col0, int nimg, int h, int w) {
+__global__ void lr_pe_kernel(const float* biases, bf16_t* out, int64_t ld, int col0, int nimg, int h, int w, int tc) {
   const int64_t total = (int64_t)nimg * h * w * 20;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int ch = (int)(i % 20);
@@ -271,7 +229,7 @@ __global__ void lr_pe_kernel(const float* biases, bf16_t* out, int64_t ld, int c
     const int kind = ch / 10, r = ch - kind * 10, f = r / 2, d = r - f * 2;
     const float base = d == 0 ? (h > 1 ? -1.f + 2.f * y / (h - 1) : -1.f) : (w > 1 ? -1.f + 2.f * x / (w - 1) : -1.f);
     const float ph = base * expf(-2.f + 3.f * f) + biases[kind * 10 + f * 2 + d];
-    out[tok * ld + col0 + ch] = f2bf(kind == 0 ? sinf(ph) : cosf(ph));
+    out[tok * ld + col0 + ch] = st16(kind == 0 ? sinf(ph) : cosf(ph), tc);
   }
 }
 
@@ -279,29 +237,10 @@ __global__ void lr_pe_kernel(const float* biases, bf16_t* out, int64_t ld, int c
 
 using namespace pst;
 
-extern "C" int pst_loftup_guidance(const float* img, const float* biases, float* feats, float* stats, int nimg, int H, int W,
-                                   int nf, void* stream) {
-  if (!img || !biases || !feats || !stats || nimg <= 0 || H % 2 || W % 2 || nf < 2) { set_error("loftup_guidance: bad argument"); return PST_EINVAL; }
-  hipStream_t s = (hipStream_t)stream;
-  const int H2 = H / 2, W2 = W / 2, P = H2 * W2, CH = 10 * nf + 3;
-  // scratch: the fp32 feature buffer is large enough to host img2 + min/max behind the features of the last view?  No:
-  // keep it explicit -- img2 and min/max live at the END of `feats` (caller allocates nimg*(P*CH + 3*P + 8) floats).
-  float* img2 = feats + (int64_t)nimg * P * CH;
-  float* mm = img2 + (int64_t)nimg * 3 * P;
-  hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(1024), 0, s, img, img2, mm, H, W);
-  const float f_lo = -2.f, f_step = 12.f / (nf - 1);
-  int gx = (int)(((int64_t)P * CH + 255) / 256);
-  if (gx > PST_STATS_BLOCKS) gx = PST_STATS_BLOCKS;
-  float* part = stats + 2 * nimg;                      // [nimg][gx][2] partial sums behind the result
-  hipLaunchKernelGGL(fourier_kernel, dim3(gx, nimg), dim3(256), 0, s, img2, mm, biases, feats, part, H2, W2, nf, f_lo, f_step);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 3) / 4), dim3(256), 0, s, part, stats, nimg, gx, 2);
-  return check_launch("loftup_guidance");
-}
-
 extern "C" int pst_loftup_guidance_gn(const float* img, const float* biases, const float* gamma, const float* beta, float eps,
-                                      float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, void* stream) {
+                                      float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, int dtype16, void* stream) {
   const int CHc = 10 * nf + 3;
-  if (!img || !biases || !gamma || !beta || !scratch || !stats || !y || nimg <= 0 || H % 2 || W % 2 || nf < 2 || nf > 64 || ldy < CHc ||
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !img || !biases || !gamma || !beta || !scratch || !stats || !y || nimg <= 0 || H % 2 || W % 2 || nf < 2 || nf > 64 || ldy < CHc ||
       ldy % 8 || ldy > 512 || ((uintptr_t)y & 15)) {
     set_error("loftup_guidance_gn: bad argument (nf=%d ldy=%lld)", nf, (long long)ldy); return PST_EINVAL;
   }
@@ -316,10 +255,10 @@ extern "C" int pst_loftup_guidance_gn(const float* img, const float* biases, con
   float* part = stats + 2 * nimg;                        // [nimg][gx][2] partial sums behind the result
   const size_t lds0 = ((nf + 4 + 3) & ~3) * sizeof(float);
   hipLaunchKernelGGL((guidance_px_kernel<false>), dim3(gx, nimg), dim3(256), lds0, s, img2, mm, biases, part, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, 0.f, (bf16_t*)nullptr, ldy, H2, W2, nf, f_lo, f_step);
+                     (const float*)nullptr, (const float*)nullptr, 0.f, (bf16_t*)nullptr, ldy, H2, W2, nf, f_lo, f_step, dtype16);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 3) / 4), dim3(256), 0, s, part, stats, nimg, gx, 2);
   hipLaunchKernelGGL((guidance_px_kernel<true>), dim3(ntile, nimg), dim3(256), lds0 + 64 * (ldy + 8) * sizeof(bf16_t), s, img2, mm, biases,
-                     (float*)nullptr, stats, gamma, beta, eps, (bf16_t*)y, ldy, H2, W2, nf, f_lo, f_step);
+                     (float*)nullptr, stats, gamma, beta, eps, (bf16_t*)y, ldy, H2, W2, nf, f_lo, f_step, dtype16);
   return check_launch("loftup_guidance_gn");
 }
 
@@ -340,22 +279,22 @@ extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float
 }
 
 extern "C" int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
-                                   void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, void* stream) {
-  if (!x || !stats || !gamma || !beta || !y || nimg <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G || ldy < C) { set_error("groupnorm_apply: bad argument"); return PST_EINVAL; }
+                                   void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, int dtype16, void* stream) {
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !x || !stats || !gamma || !beta || !y || nimg <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G || ldy < C) { set_error("groupnorm_apply: bad argument"); return PST_EINVAL; }
   const bool vec = (C % 4 == 0) && ((C / G) % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0);
   const int64_t total = (int64_t)nimg * P * (vec ? ldy / 4 : ldy);
   int64_t g = (total + 255) / 256;
   if (g > 16384) g = 16384;
-  if (vec) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu);
-  else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu);
+  if (vec) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu, dtype16);
+  else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu, dtype16);
   return check_launch("groupnorm_apply");
 }
 
-extern "C" int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int nimg, int h, int w, void* stream) {
-  if (!biases || !out || nimg <= 0 || h <= 0 || w <= 0 || col0 < 0 || col0 + 20 > ld) { set_error("loftup_lr_pe: bad argument"); return PST_EINVAL; }
+extern "C" int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int nimg, int h, int w, int dtype16, void* stream) {
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !biases || !out || nimg <= 0 || h <= 0 || w <= 0 || col0 < 0 || col0 + 20 > ld) { set_error("loftup_lr_pe: bad argument"); return PST_EINVAL; }
   const int64_t total = (int64_t)nimg * h * w * 20;
   int64_t g = (total + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(lr_pe_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, biases, (bf16_t*)out, ld, col0, nimg, h, w);
+  hipLaunchKernelGGL(lr_pe_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, biases, (bf16_t*)out, ld, col0, nimg, h, w, dtype16);
   return check_launch("loftup_lr_pe");
 }

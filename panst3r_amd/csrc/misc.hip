@@ -32,20 +32,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ void load4(const void* base, int64_t idx, bool fp32, float (&v)[4]) {
-  if (fp32) {
+// tc = element type code (DT_BF16 / DT_F32 / DT_F16), wave-uniform
+__device__ __forceinline__ void load4(const void* base, int64_t idx, int tc, float (&v)[4]) {
+  if (tc == DT_F32) {
     const float4 t = *(const float4*)((const float*)base + idx);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   } else {
     const uint2 t = *(const uint2*)((const bf16_t*)base + idx);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    unpack2(t.x, tc, v[0], v[1]);
+    unpack2(t.y, tc, v[2], v[3]);
   }
 }
 
-__device__ __forceinline__ void store4(void* base, int64_t idx, bool fp32, const float (&v)[4]) {
-  if (fp32) *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
-  else *(uint2*)((bf16_t*)base + idx) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+__device__ __forceinline__ void store4(void* base, int64_t idx, int tc, const float (&v)[4]) {
+  if (tc == DT_F32) *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+  else *(uint2*)((bf16_t*)base + idx) = make_uint2(pack2(v[0], v[1], tc), pack2(v[2], v[3], tc));
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row, row in registers
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t l
                                                         const float* add, int64_t ld_add, int64_t x_bs, int64_t y_bs, int64_t w_bs) {
   if (gridDim.y > 1) {          // strided batch: problem blockIdx.y has its own input, output and affine parameters (the addend is shared)
     const int64_t bi = blockIdx.y;
-    x = in_fp32 ? (const void*)((const float*)x + bi * x_bs) : (const void*)((const bf16_t*)x + bi * x_bs);
-    y = out_fp32 ? (void*)((float*)y + bi * y_bs) : (void*)((bf16_t*)y + bi * y_bs);
+    x = in_fp32 == DT_F32 ? (const void*)((const float*)x + bi * x_bs) : (const void*)((const bf16_t*)x + bi * x_bs);
+    y = out_fp32 == DT_F32 ? (void*)((float*)y + bi * y_bs) : (void*)((bf16_t*)y + bi * y_bs);
     gamma += bi * w_bs;
     beta += bi * w_bs;
   }
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t l
 // x = x_hi + x_lo with x_hi = bf16(x), x_lo = bf16(x - x_hi).  Against weights packed as [W_hi | W_lo | W_hi] one bf16 MFMA GEMM over
 // 3K computes x_hi W_hi + x_hi W_lo + x_lo W_hi ~ x W with ~16 mantissa bits (the lo x lo term is dropped).  Used for the 200-row mask
 // embedding head, whose output multiplies every mask feature in an ill-conditioned dot product.
-__global__ void split3_kernel(const float* x, int64_t ldx, bf16_t* out, int64_t ldo, int rows, int K) {
+__global__ void split3_kernel(const float* x, int64_t ldx, bf16_t* out, int64_t ldo, int rows, int K, int tc) {
   const int64_t total = (int64_t)rows * (K / 4);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / (K / 4)), c = (int)(i - (int64_t)r * (K / 4)) * 4;
@@ -117,7 +118,7 @@ __global__ void split3_kernel(const float* x, int64_t ldx, bf16_t* out, int64_t 
     const float f[4] = {v.x, v.y, v.z, v.w};
     bf16_t hi[4], lo[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { hi[k] = f2bf(f[k]); lo[k] = f2bf(f[k] - bf2f(hi[k])); }
+    for (int k = 0; k < 4; ++k) { hi[k] = st16(f[k], tc); lo[k] = st16(f[k] - ld16(hi[k], tc), tc); }
     const uint2 h2 = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
     const uint2 l2 = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
     bf16_t* o = out + (int64_t)r * ldo + c;
@@ -129,7 +130,7 @@ __global__ void split3_kernel(const float* x, int64_t ldx, bf16_t* out, int64_t 
 
 // ------------------------------------------------------------------ RoPE-2D in place
 // thread = (row, head, half, 4 consecutive frequencies): rotates pairs (i, i + hd/4) of that half.
-__global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd) {
+__global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, int tc) {
   const int nf = hd / 4;                 // frequencies per half
   const int per_row = nheads * 2 * (nf / 4);
   const int64_t total = (int64_t)rows * per_row;
@@ -141,8 +142,8 @@ __global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const f
     const int pp = pos[2 * row + half];
     bf16_t* base = x + (int64_t)row * ld + head * hd + half * (hd / 2) + fq;
     float a[4], b[4];
-    load4(base, 0, false, a);
-    load4(base, nf, false, b);
+    load4(base, 0, tc, a);
+    load4(base, nf, tc, b);
     const float* t = cs + ((int64_t)pp * nf + fq) * 2;
     float oa[4], ob[4];
 #pragma unroll
@@ -151,13 +152,13 @@ __global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const f
       oa[k] = a[k] * c - b[k] * s;
       ob[k] = b[k] * c + a[k] * s;
     }
-    store4(base, 0, false, oa);
-    store4(base, nf, false, ob);
+    store4(base, 0, tc, oa);
+    store4(base, nf, tc, ob);
   }
 }
 
 // ------------------------------------------------------------------ patchify: thread = (token, c, dy) -> p pixels
-__global__ void patchify_kernel(const float* img, bf16_t* out, int64_t ld, int nimg, int C, int H, int W, int p) {
+__global__ void patchify_kernel(const float* img, bf16_t* out, int64_t ld, int nimg, int C, int H, int W, int p, int tc) {
   const int gh = H / p, gw = W / p;
   const int per_tok = C * p + 1;                       // +1: the thread that zero-fills the K padding
   const int64_t total = (int64_t)nimg * gh * gw * per_tok;
@@ -174,7 +175,7 @@ __global__ void patchify_kernel(const float* img, bf16_t* out, int64_t ld, int n
     const int ty = t / gw, tx = t - ty * gw;
     const float* src = img + (((int64_t)n * C + c) * H + ty * p + dy) * W + tx * p;
     bf16_t* dst = orow + (c * p + dy) * p;
-    for (int dx = 0; dx < p; ++dx) dst[dx] = f2bf(src[dx]);
+    for (int dx = 0; dx < p; ++dx) dst[dx] = st16(src[dx], tc);
   }
 }
 
@@ -237,18 +238,18 @@ __global__ void add_cast_kernel(const void* a, int64_t lda, int a_fp32, const vo
 }
 
 // ------------------------------------------------------------------ y = x / (||x|| + eps), one wave per row
-__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, int64_t ldx, bf16_t* y, int64_t ldy, int rows, int D, float eps) {
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, int64_t ldx, bf16_t* y, int64_t ldy, int rows, int D, float eps, int tc) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float s = 0.f;
   for (int c = lane; c < D; c += 64) { const float v = x[(int64_t)row * ldx + c]; s += v * v; }
   const float inv = 1.0f / (sqrtf(wave_sum(s)) + eps);
-  for (int c = lane; c < D; c += 64) y[(int64_t)row * ldy + c] = f2bf(x[(int64_t)row * ldx + c] * inv);
+  for (int c = lane; c < D; c += 64) y[(int64_t)row * ldy + c] = st16(x[(int64_t)row * ldx + c] * inv, tc);
 }
 
 // ------------------------------------------------------------------ mean of the central 2x2 pixels of every 8x8 block
-__global__ void mean4_kernel(const bf16_t* F, bf16_t* Fm, int nimg, int Hm, int Wm, int C) {
+__global__ void mean4_kernel(const bf16_t* F, bf16_t* Fm, int nimg, int Hm, int Wm, int C, int tc) {
   const int th = Hm / 8, tw = Wm / 8, c4 = C / 4;
   const int64_t total = (int64_t)nimg * th * tw * c4;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -258,21 +259,21 @@ __global__ void mean4_kernel(const bf16_t* F, bf16_t* Fm, int nimg, int Hm, int 
     const int64_t n = tok / ((int64_t)tw * th);
     const bf16_t* base = F + ((n * Hm + ty * 8 + 3) * Wm + tx * 8 + 3) * (int64_t)C + c;
     float a[4], b[4], d[4], e[4];
-    load4(base, 0, false, a);
-    load4(base, C, false, b);
-    load4(base, (int64_t)Wm * C, false, d);
-    load4(base, (int64_t)Wm * C + C, false, e);
+    load4(base, 0, tc, a);
+    load4(base, C, tc, b);
+    load4(base, (int64_t)Wm * C, tc, d);
+    load4(base, (int64_t)Wm * C + C, tc, e);
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = 0.25f * (a[k] + b[k] + d[k] + e[k]);
-    store4(Fm, tok * C + c, false, o);
+    store4(Fm, tok * C + c, tc, o);
   }
 }
 
 // ------------------------------------------------------------------ general bilinear resize of pixel-major features
 // F [nimg, Hs, Ws, C] bf16 -> Fd [nimg, Hd, Wd, C] bf16 with torch's align_corners=False, antialias=False rule:
 // src = (dst + 0.5) * (S / D) - 0.5 clamped at 0, taps floor(src) and min(floor(src) + 1, S - 1).
-__global__ void resize_bilinear_kernel(const bf16_t* F, bf16_t* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C) {
+__global__ void resize_bilinear_kernel(const bf16_t* F, bf16_t* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, int tc) {
   const int c4 = C / 4;
   const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
   const int64_t total = (int64_t)nimg * Hd * Wd * c4;
@@ -287,15 +288,15 @@ __global__ void resize_bilinear_kernel(const bf16_t* F, bf16_t* Fd, int nimg, in
     const float wy = fy - (float)y0, wx = fx - (float)x0;
     const bf16_t* img = F + n * Hs * (int64_t)Ws * C + c;
     float a[4], b[4], d[4], e[4];
-    load4(img, ((int64_t)y0 * Ws + x0) * C, false, a);
-    load4(img, ((int64_t)y0 * Ws + x1) * C, false, b);
-    load4(img, ((int64_t)y1 * Ws + x0) * C, false, d);
-    load4(img, ((int64_t)y1 * Ws + x1) * C, false, e);
+    load4(img, ((int64_t)y0 * Ws + x0) * C, tc, a);
+    load4(img, ((int64_t)y0 * Ws + x1) * C, tc, b);
+    load4(img, ((int64_t)y1 * Ws + x0) * C, tc, d);
+    load4(img, ((int64_t)y1 * Ws + x1) * C, tc, e);
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       o[k] = (1.f - wy) * ((1.f - wx) * a[k] + wx * b[k]) + wy * ((1.f - wx) * d[k] + wx * e[k]);
-    store4(Fd, pix * C + c, false, o);
+    store4(Fd, pix * C + c, tc, o);
   }
 }
 
@@ -332,6 +333,7 @@ static int launch_layernorm(const void* x, int64_t ldx, int in_fp32, const float
                             void* stream, int nbatch = 1, int64_t x_bs = 0, int64_t y_bs = 0, int64_t w_bs = 0) {
   if (nbatch < 1 || nbatch > 65535 || (nbatch > 1 && ((x_bs | y_bs | w_bs) % 4))) { set_error("layernorm: bad batch (n=%d)", nbatch); return PST_EINVAL; }
   if (!x || !y || !gamma || !beta || rows <= 0) { set_error("layernorm: null/empty argument"); return PST_EINVAL; }
+  if ((in_fp32 != DT_BF16 && in_fp32 != DT_F32 && in_fp32 != DT_F16) || (out_fp32 != DT_BF16 && out_fp32 != DT_F32 && out_fp32 != DT_F16)) { set_error("layernorm: bad element type code"); return PST_EINVAL; }
   if (D <= 0 || D % 4 || D > 4096 || ldx % 4 || ldy % 4 || (add && ld_add % 4)) { set_error("layernorm: need D%%4==0, D<=4096, ld%%4==0 (D=%d)", D); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((rows + 3) / 4, nbatch), block(256);
@@ -362,24 +364,27 @@ extern "C" int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const 
   return launch_layernorm(x, ldx, in_fp32, add, ld_add, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, stream);
 }
 
-extern "C" int pst_split3_bf16(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, void* stream) {
-  if (!x || !out || rows <= 0 || K <= 0 || K % 4 || ldx % 4 || ldo % 4 || ldo < 3 * (int64_t)K) { set_error("split3: bad argument (K=%d)", K); return PST_EINVAL; }
-  hipLaunchKernelGGL(split3_kernel, dim3(grid_for((int64_t)rows * (K / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)out, ldo, rows, K);
+static inline bool bad16(int tc) { return tc != DT_BF16 && tc != DT_F16; }
+static inline bool badtc(int tc) { return tc != DT_BF16 && tc != DT_F32 && tc != DT_F16; }
+
+extern "C" int pst_split3(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, int dtype16, void* stream) {
+  if (bad16(dtype16) || !x || !out || rows <= 0 || K <= 0 || K % 4 || ldx % 4 || ldo % 4 || ldo < 3 * (int64_t)K) { set_error("split3: bad argument (K=%d)", K); return PST_EINVAL; }
+  hipLaunchKernelGGL(split3_kernel, dim3(grid_for((int64_t)rows * (K / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)out, ldo, rows, K, dtype16);
   return check_launch("split3");
 }
 
-extern "C" int pst_rope2d_bf16(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, void* stream) {
-  if (!x || !pos || !cs || rows <= 0 || nheads <= 0) { set_error("rope2d: null/empty argument"); return PST_EINVAL; }
+extern "C" int pst_rope2d(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, int dtype16, void* stream) {
+  if (bad16(dtype16) || !x || !pos || !cs || rows <= 0 || nheads <= 0) { set_error("rope2d: null/empty argument"); return PST_EINVAL; }
   if (hd % 16 || ld % 4) { set_error("rope2d: need hd%%16==0 and ld%%4==0 (hd=%d)", hd); return PST_EINVAL; }
   const int64_t total = (int64_t)rows * nheads * 2 * (hd / 16);
-  hipLaunchKernelGGL(rope2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ld, pos, cs, rows, nheads, hd);
+  hipLaunchKernelGGL(rope2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ld, pos, cs, rows, nheads, hd, dtype16);
   return check_launch("rope2d");
 }
 
-extern "C" int pst_patchify_bf16(const float* img, void* out, int64_t ld, int nimg, int C, int H, int W, int p, void* stream) {
-  if (!img || !out || nimg <= 0 || p <= 0 || H % p || W % p || ld < (int64_t)C * p * p) { set_error("patchify: bad argument"); return PST_EINVAL; }
+extern "C" int pst_patchify(const float* img, void* out, int64_t ld, int nimg, int C, int H, int W, int p, int dtype16, void* stream) {
+  if (bad16(dtype16) || !img || !out || nimg <= 0 || p <= 0 || H % p || W % p || ld < (int64_t)C * p * p) { set_error("patchify: bad argument"); return PST_EINVAL; }
   const int64_t total = (int64_t)nimg * (H / p) * (W / p) * (C * p + 1);
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, ld, nimg, C, H, W, p);
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, ld, nimg, C, H, W, p, dtype16);
   return check_launch("patchify");
 }
 
@@ -395,28 +400,28 @@ extern "C" int pst_dino_preprocess(const float* img, float* out, int nimg, int H
 
 extern "C" int pst_add_cast(const void* a, int64_t lda, int a_fp32, const void* b, int64_t ldb, int b_fp32, int b_mod, void* y,
                             int64_t ldy, int y_fp32, int rows, int D, void* stream) {
-  if (!a || !y || rows <= 0 || D <= 0 || D % 4 || lda % 4 || ldy % 4 || (b && ldb % 4)) { set_error("add_cast: bad argument (D=%d)", D); return PST_EINVAL; }
+  if (badtc(a_fp32) || badtc(y_fp32) || (b && badtc(b_fp32)) || !a || !y || rows <= 0 || D <= 0 || D % 4 || lda % 4 || ldy % 4 || (b && ldb % 4)) { set_error("add_cast: bad argument (D=%d)", D); return PST_EINVAL; }
   hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for((int64_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream, a, lda, a_fp32, b, ldb, b_fp32, b_mod, y, ldy, y_fp32, rows, D);
   return check_launch("add_cast");
 }
 
-extern "C" int pst_l2norm_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps, void* stream) {
-  if (!x || !y || rows <= 0 || D <= 0) { set_error("l2norm_rows: bad argument"); return PST_EINVAL; }
-  hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, rows, D, eps);
+extern "C" int pst_l2norm_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps, int dtype16, void* stream) {
+  if (bad16(dtype16) || !x || !y || rows <= 0 || D <= 0) { set_error("l2norm_rows: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, rows, D, eps, dtype16);
   return check_launch("l2norm_rows");
 }
 
-extern "C" int pst_mean4_bf16(const void* F, void* Fm, int nimg, int Hm, int Wm, int C, void* stream) {
-  if (!F || !Fm || nimg <= 0 || Hm % 8 || Wm % 8 || C % 4) { set_error("mean4: bad argument"); return PST_EINVAL; }
+extern "C" int pst_mean4(const void* F, void* Fm, int nimg, int Hm, int Wm, int C, int dtype16, void* stream) {
+  if (bad16(dtype16) || !F || !Fm || nimg <= 0 || Hm % 8 || Wm % 8 || C % 4) { set_error("mean4: bad argument"); return PST_EINVAL; }
   const int64_t total = (int64_t)nimg * (Hm / 8) * (Wm / 8) * (C / 4);
-  hipLaunchKernelGGL(mean4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)F, (bf16_t*)Fm, nimg, Hm, Wm, C);
+  hipLaunchKernelGGL(mean4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)F, (bf16_t*)Fm, nimg, Hm, Wm, C, dtype16);
   return check_launch("mean4");
 }
 
-extern "C" int pst_resize_bilinear_bf16(const void* F, void* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, void* stream) {
-  if (!F || !Fd || nimg <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || C <= 0 || C % 4) { set_error("resize_bilinear: bad argument"); return PST_EINVAL; }
+extern "C" int pst_resize_bilinear(const void* F, void* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, int dtype16, void* stream) {
+  if (bad16(dtype16) || !F || !Fd || nimg <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || C <= 0 || C % 4) { set_error("resize_bilinear: bad argument"); return PST_EINVAL; }
   const int64_t total = (int64_t)nimg * Hd * Wd * (C / 4);
-  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)F, (bf16_t*)Fd, nimg, Hs, Ws, Hd, Wd, C);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)F, (bf16_t*)Fd, nimg, Hs, Ws, Hd, Wd, C, dtype16);
   return check_launch("resize_bilinear");
 }
 

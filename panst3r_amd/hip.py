@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -25,7 +25,7 @@ class GemmParams(C.Structure):
                 ('grp_in', i32), ('grp_out', i32), ('grp_off', i32),
                 ('ps_p', i32), ('ps_c', i32), ('ps_h', i32), ('ps_w', i32),
                 ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('rope_pos', vp), ('rope_cs', vp), ('rope_hd', i32), ('res_bf16', i32), ('kernel', i32),
-                ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('c_bs', i64), ('bias_bs', i64)]
+                ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('c_bs', i64), ('bias_bs', i64), ('dtype16', i32)]
 
 
 class AttnParams(C.Structure):
@@ -35,12 +35,13 @@ class AttnParams(C.Structure):
                 ('O', vp), ('o_bs', i64), ('o_hs', i64), ('o_rs', i64),
                 ('mask', vp), ('m_bs', i64), ('m_rs', i64),
                 ('B', i32), ('H', i32), ('Nq', i32), ('Nk', i32), ('hd', i32),
-                ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64)]
+                ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64), ('dtype16', i32)]
 
 
-EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm_bf16', 'pst_attn_fwd_bf16', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add', 'pst_layernorm_add_batch', 'pst_split3_bf16', 'pst_rope2d_bf16',
-           'pst_patchify_bf16', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4_bf16', 'pst_resize_bilinear_bf16',
-           'pst_attn_mask_from_logits', 'pst_loftup_guidance', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
+           'pst_layernorm_add_batch', 'pst_split3', 'pst_rope2d',
+           'pst_patchify', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
+           'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize']
 
 
@@ -54,6 +55,9 @@ def lib():
                            'The HIP path has no fallback.' % LIB_PATH)
     L = C.CDLL(LIB_PATH)
     L.pst_last_error.restype = C.c_char_p
+    L.pst_gemm_variant.restype = C.c_char_p
+    L.pst_attn_variant.restype = C.c_char_p
+    L.pst_attn_workspace_bytes.restype = C.c_int64
     L.pst_abi_version.restype = C.c_int
     if L.pst_abi_version() != ABI_VERSION:
         raise RuntimeError('libpanst3r_hip.so ABI %d != expected %d; rebuild' % (L.pst_abi_version(), ABI_VERSION))
@@ -74,6 +78,22 @@ def _stream():
 
 def _ptr(t):
     return vp(t.data_ptr()) if t is not None else vp(0)
+
+
+H16 = (torch.bfloat16, torch.float16)        # the two 16-bit storage formats (amp='bf16' / amp='fp16'); all 16-bit operands of a call share one
+_TC = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}     # element type codes of the C ABI (PST_BF16 / PST_F32 / PST_F16)
+
+
+def _tc(t):
+    return _TC[t.dtype]
+
+
+def _same16(*ts):
+    """dtype16 code of a call: every 16-bit operand must use the same format."""
+    dts = {t.dtype for t in ts if t is not None and t.dtype in H16}
+    if len(dts) != 1:
+        raise RuntimeError('16-bit operands of one call must share one format, got %s' % sorted(str(d) for d in dts))
+    return _TC[dts.pop()]
 
 
 def _dev(t, *dtypes):
@@ -143,8 +163,9 @@ ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
          M=None, kernel=0, rope=None, batch=None):
     """out = epi(a @ w.T).  a [M,K] bf16 (row-major view), w [N,K] bf16, out bf16/fp32 2-D view (or raw buffer for ps)."""
-    _dev(a, torch.bfloat16); _dev(w, torch.bfloat16); _dev(out, torch.bfloat16, torch.float32)
+    _dev(a, *H16); _dev(w, *H16); _dev(out, torch.bfloat16, torch.float16, torch.float32)
     p = GemmParams()
+    p.dtype16 = _same16(a, w, out, res)
     N, K = w.shape
     if conv is not None:
         cc, ch, cw = conv
@@ -170,8 +191,8 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
     if gamma is not None:
         p.gamma = _ptr(_dev(gamma, torch.float32))
     if res is not None:
-        p.res, p.ldr, p.res_mod = _ptr(_dev(res, torch.float32, torch.bfloat16)), _rowmajor(res), res_mod
-        p.res_bf16 = int(res.dtype == torch.bfloat16)
+        p.res, p.ldr, p.res_mod = _ptr(_dev(res, torch.float32, *H16)), _rowmajor(res), res_mod
+        p.res_bf16 = int(res.dtype in H16)
     if batch is not None:        # (count, a_bs, w_bs, c_bs, bias_bs): `a`, `w`, `out`, `bias` are problem 0 of a strided batch
         p.batch, p.a_bs, p.w_bs, p.c_bs, p.bias_bs = batch
     p.act = ACT[act]
@@ -183,18 +204,15 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
     if grp is not None:
         p.grp_in, p.grp_out, p.grp_off = grp
     if TIMER is not None:
-        big = ((Mv + 127) // 128) * ((N + 127) // 128) * (batch[0] if batch else 1) >= (176 if K >= 2048 else 256)    # mirrors pst_gemm_bf16's dispatch
-        name = ('gemm_kernel<4,4,%s>' if big else 'gemm_kernel<2,2,%s>') % ('true' if trans_out else 'false')
-        if (conv is None and not trans_out and kernel != 128 and N % 256 == 0 and K >= 1024 and (N >= 2048 or K >= 2048)
-                and ((Mv + 255) // 256) * ((N + 255) // 256) >= 3 * 256 - 64) or kernel == 256:
-            name = 'gemm256_kernel'
-        ev = TIMER.bracket(name, 2.0 * Mv * N * K, (Mv, N, K, 'f32' if out.dtype == torch.float32 else 'bf16', act or '', 'res' if res is not None else '',
-                                                   'grp' if grp is not None else '', 'rope' if rope is not None else '', 'conv' if conv is not None else ''))
+        name = lib().pst_gemm_variant(C.byref(p))          # the C side names the kernel it dispatches to (no re-derived rule here)
+        ev = TIMER.bracket(name.decode() if name else 'gemm?', 2.0 * Mv * N * K * (batch[0] if batch else 1),
+                           (Mv, N, K, 'f32' if out.dtype == torch.float32 else '16', act or '', 'res' if res is not None else '',
+                            'grp' if grp is not None else '', 'rope' if rope is not None else '', 'conv' if conv is not None else ''))
         ev[0].record()
-        _check(lib().pst_gemm_bf16(C.byref(p), _stream()), 'pst_gemm_bf16')
+        _check(lib().pst_gemm(C.byref(p), _stream()), 'pst_gemm')
         ev[1].record()
         return out
-    _check(lib().pst_gemm_bf16(C.byref(p), _stream()), 'pst_gemm_bf16')
+    _check(lib().pst_gemm(C.byref(p), _stream()), 'pst_gemm')
     return out
 
 
@@ -208,10 +226,11 @@ def auto_nsplit(B, H, Nq, Nk):
 
 
 def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale=None, mask=None,
-              mask_strides=(0, 0), nsplit=None):
+              mask_strides=(0, 0), nsplit=None, ws=None):
     """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row)."""
-    _dev(q, torch.bfloat16); _dev(k, torch.bfloat16); _dev(vt, torch.bfloat16); _dev(out, torch.bfloat16)
+    _dev(q, *H16); _dev(k, *H16); _dev(vt, *H16); _dev(out, *H16)
     p = AttnParams()
+    p.dtype16 = _same16(q, k, vt, out)
     p.Q, (p.q_bs, p.q_hs, p.q_rs) = _ptr(q), q_strides
     p.K, (p.k_bs, p.k_hs, p.k_rs) = _ptr(k), k_strides
     p.Vt, (p.v_bs, p.v_hs, p.v_ds) = _ptr(vt), v_strides
@@ -224,30 +243,39 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
     p.zeros = _ptr(zeros_page(q.device))
     ns = auto_nsplit(B, H, Nq, Nk) if nsplit is None else nsplit
     if ns > 1:
-        ws = torch.empty(ns * B * H * Nq * (hd + 2), dtype=torch.float32, device=q.device)
+        n = ns * B * H * Nq * (hd + 2)
+        if ws is None:          # caller-owned workspace preferred (C ABI: the caller owns every buffer); else one from torch's caching allocator
+            ws = torch.empty(n, dtype=torch.float32, device=q.device)
+        assert ws.dtype == torch.float32 and ws.numel() >= n
         p.nsplit, p.ws, p.ws_bytes = ns, _ptr(ws), ws.numel() * 4
     if TIMER is not None:
-        big = ns == 1 and ((Nq + 127) // 128) * H * B >= 256
-        ev = TIMER.bracket('attn_kernel<%d,%d>' % (hd, 2 if big else 1), 4.0 * B * H * Nq * Nk * hd, (B, H, Nq, Nk, hd))
+        name = lib().pst_attn_variant(C.byref(p))
+        ev = TIMER.bracket(name.decode() if name else 'attn?', 4.0 * B * H * Nq * Nk * hd, (B, H, Nq, Nk, hd))
         ev[0].record()
-        _check(lib().pst_attn_fwd_bf16(C.byref(p), _stream()), 'pst_attn_fwd_bf16')
+        _check(lib().pst_attn_fwd(C.byref(p), _stream()), 'pst_attn_fwd')
         ev[1].record()
         return out
-    _check(lib().pst_attn_fwd_bf16(C.byref(p), _stream()), 'pst_attn_fwd_bf16')
+    _check(lib().pst_attn_fwd(C.byref(p), _stream()), 'pst_attn_fwd')
     return out
+
+
+def attn_workspace_floats(B, H, Nq, Nk, hd, nsplit=None):
+    """fp32 elements of split-K workspace `attention` needs for this call (0 when it does not split)."""
+    ns = auto_nsplit(B, H, Nq, Nk) if nsplit is None else nsplit
+    return ns * B * H * Nq * (hd + 2) if ns > 1 else 0
 
 
 # ----------------------------------------------------------------------------------------------------------- the rest
 def layernorm_batch(x_all, gamma_all, beta_all, out_all, eps, rows=None, grp=None, add=None):
     """out_all[i] = LN(x_all[i] [+ add]) * gamma_all[i] + beta_all[i] for i < n in ONE launch; x_all [n, R, D], out_all [n, rows, D]."""
-    _dev(x_all, torch.float32, torch.bfloat16); _dev(out_all, torch.float32, torch.bfloat16)
+    _dev(x_all, torch.float32, *H16); _dev(out_all, torch.float32, *H16)
     n, D = x_all.shape[0], gamma_all.shape[1]
     assert x_all.dim() == 3 and out_all.dim() == 3 and x_all.stride(2) == 1 and out_all.stride(2) == 1 and gamma_all.is_contiguous() and beta_all.is_contiguous()
     rows = out_all.shape[1] if rows is None else rows
     g = grp or (0, 0, 0)
-    _check(lib().pst_layernorm_add_batch(_ptr(x_all), i64(x_all.stride(1)), int(x_all.dtype == torch.float32),
+    _check(lib().pst_layernorm_add_batch(_ptr(x_all), i64(x_all.stride(1)), _tc(x_all),
                                          _ptr(_dev(add, torch.float32)) if add is not None else vp(0), i64(_rowmajor(add)) if add is not None else i64(0),
-                                         _ptr(out_all), i64(out_all.stride(1)), int(out_all.dtype == torch.float32),
+                                         _ptr(out_all), i64(out_all.stride(1)), _tc(out_all),
                                          _ptr(_dev(gamma_all, torch.float32)), _ptr(_dev(beta_all, torch.float32)), rows, D, f32(eps),
                                          g[0], g[1], g[2], n, i64(x_all.stride(0)), i64(out_all.stride(0)), i64(D), _stream()), 'pst_layernorm_add_batch')
     return out_all
@@ -255,43 +283,43 @@ def layernorm_batch(x_all, gamma_all, beta_all, out_all, eps, rows=None, grp=Non
 
 def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None):
     """out = LN(x [+ add]); `add`: optional fp32 rows indexed like x (fused residual-style addend)."""
-    _dev(x, torch.float32, torch.bfloat16); _dev(out, torch.float32, torch.bfloat16)
+    _dev(x, torch.float32, *H16); _dev(out, torch.float32, *H16)
     D = gamma.numel()
     rows = out.shape[0] if rows is None else rows
     g = grp or (0, 0, 0)
     if add is not None:
-        _check(lib().pst_layernorm_add(_ptr(x), i64(_rowmajor(x)), int(x.dtype == torch.float32), _ptr(_dev(add, torch.float32)),
-                                       i64(_rowmajor(add)), _ptr(out), i64(_rowmajor(out)), int(out.dtype == torch.float32),
+        _check(lib().pst_layernorm_add(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(_dev(add, torch.float32)),
+                                       i64(_rowmajor(add)), _ptr(out), i64(_rowmajor(out)), _tc(out),
                                        _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)), rows, D, f32(eps),
                                        g[0], g[1], g[2], _stream()), 'pst_layernorm_add')
         return out
-    _check(lib().pst_layernorm(_ptr(x), i64(_rowmajor(x)), int(x.dtype == torch.float32), _ptr(out), i64(_rowmajor(out)),
-                               int(out.dtype == torch.float32), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)),
+    _check(lib().pst_layernorm(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(out), i64(_rowmajor(out)),
+                               _tc(out), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)),
                                rows, D, f32(eps), g[0], g[1], g[2], _stream()), 'pst_layernorm')
     return out
 
 
 def split3(x, out):
     """fp32 x [rows, K] -> bf16 out [rows, 3K] = [x_hi | x_hi | x_lo] (operand of a split-precision GEMM, see pack_split3)."""
-    _dev(x, torch.float32); _dev(out, torch.bfloat16)
+    _dev(x, torch.float32); _dev(out, *H16)
     rows, K = x.shape
-    _check(lib().pst_split3_bf16(_ptr(x), i64(_rowmajor(x)), _ptr(out), i64(_rowmajor(out)), rows, K, _stream()), 'pst_split3_bf16')
+    _check(lib().pst_split3(_ptr(x), i64(_rowmajor(x)), _ptr(out), i64(_rowmajor(out)), rows, K, _tc(out), _stream()), 'pst_split3')
     return out
 
 
-def pack_split3(weight):
-    """fp32 weight [N, K] -> bf16 [N, 3K] = [W_hi | W_lo | W_hi] (pack time): with split3(x) one GEMM gives x_hi W_hi + x_hi W_lo + x_lo W_hi."""
+def pack_split3(weight, dtype=torch.bfloat16):
+    """fp32 weight [N, K] -> 16-bit [N, 3K] = [W_hi | W_lo | W_hi] (pack time): with split3(x) one GEMM gives x_hi W_hi + x_hi W_lo + x_lo W_hi."""
     w = weight.detach().float()
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
+    hi = w.to(dtype)
+    lo = (w - hi.float()).to(dtype)
     return torch.cat([hi, lo, hi], dim=1).contiguous()
 
 
 def rope2d_(x, pos, table, nheads, hd):
     """In-place RoPE-2D on the first nheads*hd columns of the row-major bf16 view x; pos int32 [rows,2]."""
-    _dev(x, torch.bfloat16); _dev(pos, torch.int32); _dev(table, torch.float32)
-    _check(lib().pst_rope2d_bf16(_ptr(x), i64(_rowmajor(x)), _ptr(pos), _ptr(table), x.shape[0], nheads, hd, _stream()),
-           'pst_rope2d_bf16')
+    _dev(x, *H16); _dev(pos, torch.int32); _dev(table, torch.float32)
+    _check(lib().pst_rope2d(_ptr(x), i64(_rowmajor(x)), _ptr(pos), _ptr(table), x.shape[0], nheads, hd, _tc(x), _stream()),
+           'pst_rope2d')
     return x
 
 
@@ -304,10 +332,10 @@ def rope_table(npos, hd, base=100.0, device='cuda'):
 
 
 def patchify(img, out, p):
-    _dev(img, torch.float32); _dev(out, torch.bfloat16)
+    _dev(img, torch.float32); _dev(out, *H16)
     n, c, h, w = img.shape
     assert img.is_contiguous()
-    _check(lib().pst_patchify_bf16(_ptr(img), _ptr(out), i64(_rowmajor(out)), n, c, h, w, p, _stream()), 'pst_patchify_bf16')
+    _check(lib().pst_patchify(_ptr(img), _ptr(out), i64(_rowmajor(out)), n, c, h, w, p, _tc(out), _stream()), 'pst_patchify')
     return out
 
 
@@ -322,7 +350,7 @@ def dino_preprocess(img, out):
 def add_cast(a, out, b=None, b_mod=0):
     _dev(a); _dev(out)
     rows, D = out.shape
-    fp = lambda t: int(t.dtype == torch.float32)
+    fp = _tc
     _check(lib().pst_add_cast(_ptr(a), i64(_rowmajor(a)), fp(a), _ptr(b), i64(_rowmajor(b) if b is not None else 0),
                               fp(b) if b is not None else 0, b_mod, _ptr(out), i64(_rowmajor(out)), fp(out), rows, D, _stream()),
            'pst_add_cast')
@@ -330,21 +358,21 @@ def add_cast(a, out, b=None, b_mod=0):
 
 
 def l2norm_rows(x, out, eps):
-    _dev(x, torch.float32); _dev(out, torch.bfloat16)
+    _dev(x, torch.float32); _dev(out, *H16)
     _check(lib().pst_l2norm_rows(_ptr(x), i64(_rowmajor(x)), _ptr(out), i64(_rowmajor(out)), x.shape[0], x.shape[1], f32(eps),
-                                 _stream()), 'pst_l2norm_rows')
+                                 _tc(out), _stream()), 'pst_l2norm_rows')
     return out
 
 
 def mean4(F, Fm, nimg, Hm, Wm, Cc):
-    _dev(F, torch.bfloat16); _dev(Fm, torch.bfloat16)
-    _check(lib().pst_mean4_bf16(_ptr(F), _ptr(Fm), nimg, Hm, Wm, Cc, _stream()), 'pst_mean4_bf16')
+    _dev(F, *H16); _dev(Fm, *H16)
+    _check(lib().pst_mean4(_ptr(F), _ptr(Fm), nimg, Hm, Wm, Cc, _same16(F, Fm), _stream()), 'pst_mean4')
     return Fm
 
 
 def resize_bilinear(F, Fd, nimg, Hs, Ws, Hd, Wd, Cc):
-    _dev(F, torch.bfloat16); _dev(Fd, torch.bfloat16)
-    _check(lib().pst_resize_bilinear_bf16(_ptr(F), _ptr(Fd), nimg, Hs, Ws, Hd, Wd, Cc, _stream()), 'pst_resize_bilinear_bf16')
+    _dev(F, *H16); _dev(Fd, *H16)
+    _check(lib().pst_resize_bilinear(_ptr(F), _ptr(Fd), nimg, Hs, Ws, Hd, Wd, Cc, _same16(F, Fd), _stream()), 'pst_resize_bilinear')
     return Fd
 
 
@@ -361,40 +389,33 @@ def stats_buffer(nimg, G, device):
     return torch.empty(nimg * G * 2 * (1 + STATS_BLOCKS), dtype=torch.float32, device=device)
 
 
-def loftup_guidance(img, biases, feats, stats, nf):
-    _dev(img, torch.float32); _dev(biases, torch.float32); _dev(feats, torch.float32); _dev(stats, torch.float32)
-    n, _, h, w = img.shape
-    assert img.is_contiguous()
-    _check(lib().pst_loftup_guidance(_ptr(img), _ptr(biases), _ptr(feats), _ptr(stats), n, h, w, nf, _stream()), 'pst_loftup_guidance')
-
-
 def loftup_guidance_gn(img, biases, gamma, beta, eps, scratch, stats, out, nf):
     """Fourier guidance features + GroupNorm(1) straight to bf16 `out` [nimg*P, ld] (zero-padded columns); no fp32 feature buffer."""
-    _dev(img, torch.float32); _dev(biases, torch.float32); _dev(scratch, torch.float32); _dev(stats, torch.float32); _dev(out, torch.bfloat16)
+    _dev(img, torch.float32); _dev(biases, torch.float32); _dev(scratch, torch.float32); _dev(stats, torch.float32); _dev(out, *H16)
     n, _, h, w = img.shape
     assert img.is_contiguous() and scratch.numel() >= n * (3 * (h // 2) * (w // 2) + 6)
     _check(lib().pst_loftup_guidance_gn(_ptr(img), _ptr(biases), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)), f32(eps),
-                                        _ptr(scratch), _ptr(stats), _ptr(out), i64(_rowmajor(out)), n, h, w, nf, _stream()),
+                                        _ptr(scratch), _ptr(stats), _ptr(out), i64(_rowmajor(out)), n, h, w, nf, _tc(out), _stream()),
            'pst_loftup_guidance_gn')
     return out
 
 
 def groupnorm_stats(x, stats, nimg, P, Cc, G):
     _dev(x); _dev(stats, torch.float32)
-    _check(lib().pst_groupnorm_stats(_ptr(x), i64(_rowmajor(x)), int(x.dtype == torch.float32), _ptr(stats), nimg, P, Cc, G, _stream()),
+    _check(lib().pst_groupnorm_stats(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(stats), nimg, P, Cc, G, _stream()),
            'pst_groupnorm_stats')
 
 
 def groupnorm_apply(x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu):
-    _dev(x); _dev(out, torch.bfloat16)
-    _check(lib().pst_groupnorm_apply(_ptr(x), i64(_rowmajor(x)), int(x.dtype == torch.float32), _ptr(stats), _ptr(gamma), _ptr(beta),
-                                     _ptr(out), i64(_rowmajor(out)), nimg, P, Cc, G, f32(eps), int(relu), _stream()), 'pst_groupnorm_apply')
+    _dev(x); _dev(out, *H16)
+    _check(lib().pst_groupnorm_apply(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(stats), _ptr(gamma), _ptr(beta),
+                                     _ptr(out), i64(_rowmajor(out)), nimg, P, Cc, G, f32(eps), int(relu), _tc(out), _stream()), 'pst_groupnorm_apply')
     return out
 
 
 def loftup_lr_pe(biases, out, col0, nimg, h, w):
-    _dev(biases, torch.float32); _dev(out, torch.bfloat16)
-    _check(lib().pst_loftup_lr_pe(_ptr(biases), _ptr(out), i64(_rowmajor(out)), col0, nimg, h, w, _stream()), 'pst_loftup_lr_pe')
+    _dev(biases, torch.float32); _dev(out, *H16)
+    _check(lib().pst_loftup_lr_pe(_ptr(biases), _ptr(out), i64(_rowmajor(out)), col0, nimg, h, w, _tc(out), _stream()), 'pst_loftup_lr_pe')
     return out
 
 

@@ -10,6 +10,46 @@ import torch.nn as nn
 from .. import hip
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+
+
+class _Precision:
+    """The 16-bit storage / MFMA operand format of everything the HIP path computes: bfloat16 (amp='bf16') or IEEE half
+    (amp='fp16'; reference tools/demo_panst3r.py:88, utils.py:206-215).  Accumulation, residual streams, softmax and normalisation
+    statistics are fp32 in both.  Process-wide, switched by the `precision(...)` context (a SceneRunner enters it around every
+    stage, so graphs are captured - and weights packed - in the runner's format)."""
+    dtype = torch.float16
+
+
+PREC = _Precision()
+AMP_DTYPES = {'bf16': torch.bfloat16, 'fp16': torch.float16, torch.bfloat16: torch.bfloat16, torch.float16: torch.float16}
+
+
+def adt():
+    """activation / weight storage dtype in effect"""
+    return PREC.dtype
+
+
+def amp_dtype(amp):
+    """`amp` argument of the reference API (False | 'bf16' | 'fp16', utils.py:206-215) -> storage dtype.  amp=False is the
+    reference's fp32 mode: the HIP path has no fp32 MFMA variant, it runs its default (most precise) 16-bit format, f16."""
+    if amp is None or amp is False:
+        return torch.float16
+    if amp not in AMP_DTYPES:
+        raise ValueError("amp must be False, 'bf16' or 'fp16' (got %r)" % (amp,))
+    return AMP_DTYPES[amp]
+
+
+class precision:
+    def __init__(self, dtype):
+        self.dtype = amp_dtype(dtype)
+
+    def __enter__(self):
+        self.prev, PREC.dtype = PREC.dtype, self.dtype
+        return self
+
+    def __exit__(self, *a):
+        PREC.dtype = self.prev
 
 
 def ceil_to(x, m):
@@ -28,8 +68,10 @@ class Packed:
             b = None if b is None else b[row_perm]
         n, k = w.shape
         kp = ceil_to(k, 64)
-        wp = torch.zeros(n, kp, dtype=BF16, device=device)
-        wp[:, :k] = w.to(device=device, dtype=BF16)
+        wp = torch.zeros(n, kp, dtype=adt(), device=device)
+        wp[:, :k] = w.to(device=device, dtype=adt())
+        if adt() == F16 and not bool(torch.isfinite(wp).all()):
+            raise OverflowError('a weight exceeds the f16 range (max |w| = %.3g): use amp=\'bf16\' for this checkpoint' % float(w.abs().max()))
         self.w, self.n, self.k = wp, n, kp
         self.b = None if b is None else b.to(device).contiguous()
 
@@ -45,34 +87,49 @@ def f32(t, device):
 
 
 class HipModule(nn.Module):
-    """nn.Module whose forward runs on the HIP library; `self.pk` caches packed weights per device."""
+    """nn.Module whose forward runs on the HIP library.  Packed weights are cached per (device, 16-bit format) and per weight
+    GENERATION: loading a state dict starts a new generation instead of mutating the old pack, because a captured HIP graph holds raw
+    pointers into the pack it was captured with.  A SceneRunner records `pack_refs()` of every module it touched, which keeps that
+    generation alive for as long as the runner lives; tables that grow (RoPE, sine PE, class embeddings) live in keyed dicts inside
+    the pack and entries are never replaced in place."""
 
     def __init__(self):
         super().__init__()
-        self._pk = None
-        self._pk_device = None
+        self._packs = {}          # (device, dtype) -> pack dict of the CURRENT weight generation
+        self.generation = 0
 
     def _pack(self, device):      # override
         raise NotImplementedError
 
     def packed(self, device):
-        if self._pk is None or self._pk_device != device:
+        key = (str(device), adt())
+        pk = self._packs.get(key)
+        if pk is None:
             if device.type != 'cuda':
                 raise RuntimeError('%s runs on the GPU only (HIP path, no CPU fallback); got device %s'
                                    % (type(self).__name__, device))
             hip.lib()
-            self._pk = self._pack(device)
-            self._pk_device = device
-        return self._pk
+            pk = self._packs[key] = self._pack(device)
+        return pk
+
+    def pack_refs(self):
+        """references to every live pack of this module tree (a runner keeps them so its captured graphs never see freed memory)"""
+        refs = [dict(self._packs)]
+        for m in self.children():
+            if isinstance(m, HipModule):
+                refs.extend(m.pack_refs())
+        return refs
 
     def invalidate(self):
-        self._pk = None
+        self._packs = {}          # old packs stay alive for as long as a runner holds pack_refs()
+        self.generation += 1
         for m in self.children():
             if isinstance(m, HipModule):
                 m.invalidate()
 
     def _load_from_state_dict(self, *a, **k):
-        self._pk = None
+        self._packs = {}
+        self.generation += 1
         return super()._load_from_state_dict(*a, **k)
 
 
@@ -90,6 +147,16 @@ class Layout:
         return None if (self.Tp == self.T and self.extra == 0) else (self.T, self.Tp, self.extra)
 
 
+def grow_table(cache, n, make):
+    """position-indexed table with at least n rows from the keyed dict `cache` (a bigger one serves: row i does not depend on the
+    table size).  Entries are only ever ADDED: a captured HIP graph may hold the address of any table handed out before."""
+    for m, t in cache.items():
+        if m >= n:
+            return t
+    t = cache[n] = make(n)
+    return t
+
+
 def empty(rows, cols, dtype, device):
     return torch.empty(rows, cols, dtype=dtype, device=device)
 
@@ -99,7 +166,7 @@ def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
     `vt`: optional caller-owned V^T scratch [D, >= lay.rows + 8] (saves an allocation per layer)."""
     dev = xn.device
     D = H * hd
-    qk = empty(lay.rows, 2 * D, BF16, dev)
+    qk = empty(lay.rows, 2 * D, adt(), dev)
     if rope is not None and hd == 64:
         hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, rope=(pos, rope))      # RoPE-2D applied in the GEMM's store phase
     else:
@@ -107,9 +174,9 @@ def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
         if rope is not None:
             hip.rope2d_(qk, pos, rope, 2 * H, hd)
     if vt is None:
-        vt = torch.empty(D, lay.rows + 8, dtype=BF16, device=dev)
+        vt = torch.empty(D, lay.rows + 8, dtype=adt(), device=dev)
     hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True)
-    o = empty(lay.rows, D, BF16, dev)
+    o = empty(lay.rows, D, adt(), dev)
     if lay.Tp != lay.N:
         o.view(lay.V, lay.Tp, D)[:, lay.N:].zero_()      # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
     ldq, ldv = qk.stride(0), vt.stride(0)
@@ -143,12 +210,12 @@ def vit_block(x, bw, lay, H, hd, pos=None, rope=None):
     """x fp32 [lay.rows, D] residual stream, updated in place."""
     dev = x.device
     D = H * hd
-    xn = empty(lay.rows, D, BF16, dev)
+    xn = empty(lay.rows, D, adt(), dev)
     hip.layernorm(x, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
     o = self_attention(xn, lay, H, hd, bw.qk, bw.v, pos, rope)
     hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, gamma=bw.ls1, res=x)
     hip.layernorm(x, bw.norm2[0], bw.norm2[1], xn, bw.norm2[2])
-    h = empty(lay.rows, bw.fc1.n, BF16, dev)
+    h = empty(lay.rows, bw.fc1.n, adt(), dev)
     hip.gemm(xn, bw.fc1.w, h, bias=bw.fc1.b, act='gelu')
     hip.gemm(h, bw.fc2.w, x, bias=bw.fc2.b, gamma=bw.ls2, res=x)
     return x

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
-from .common import HipModule, Packed, Layout, BF16, BlockW, empty, vit_block, pack_norm, f32, ParamLinear
+from .common import HipModule, Packed, Layout, adt, BlockW, empty, vit_block, pack_norm, f32, ParamLinear
 
 
 class _Proj(nn.Module):
@@ -139,7 +139,7 @@ class DinoV2Encoder(HipModule):
         pre = torch.empty(V, 3, gh * p, gw * p, dtype=torch.float32, device=dev)
         hip.dino_preprocess(img.contiguous(), pre)
         lay = Layout(V, gh * gw, extra=1)
-        patches = empty(V * lay.T, pk['patch'].k, BF16, dev)
+        patches = empty(V * lay.T, pk['patch'].k, adt(), dev)
         hip.patchify(pre, patches, p)
         cls, pospatch = self._pos(pk, gh, gw, dev)
         x = torch.zeros(lay.rows, D, dtype=torch.float32, device=dev)
@@ -165,6 +165,6 @@ class DinoV2Encoder(HipModule):
                 raise NotImplementedError('mixed-orientation batches: call once per orientation')
             x = x.transpose(2, 3).contiguous()      # dinov2_transpose (model/dino.py:15-47): portrait views run transposed
         out = torch.empty(V * (x.shape[2] // self.output_stride) * (x.shape[3] // self.output_stride), self.embed_dim,
-                          dtype=BF16, device=x.device)
+                          dtype=adt(), device=x.device)
         self.encode_tokens(x, out)
         return out.float().reshape(V, -1, self.embed_dim)

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .common import (HipModule, Packed, Layout, BF16, empty, vit_block, pack_croco_block, pack_norm, grid_pos)
+from .common import (HipModule, Packed, Layout, adt, empty, vit_block, pack_croco_block, pack_norm, grid_pos, grow_table)
 from .params import BlockP
 
 
@@ -35,9 +35,7 @@ class Dust3rEncoder(HipModule):
                     norm=pack_norm(self.norm_enc, device), rope={})
 
     def rope_table(self, pk, n, hd, device):
-        if pk['rope'].get('n', 0) < n:
-            pk['rope'] = dict(n=n, t=hip.rope_table(n, hd, self.rope_base, device))
-        return pk['rope']['t']
+        return grow_table(pk['rope'], n, lambda m: hip.rope_table(m, hd, self.rope_base, device))
 
     @torch.no_grad()
     def encode_tokens(self, img, out=None):
@@ -49,7 +47,7 @@ class Dust3rEncoder(HipModule):
         p, D, Hh = self.patch_size, self.embed_dim, self.num_heads
         gh, gw = H // p, W // p
         lay = Layout(V, gh * gw)
-        patches = empty(V * lay.T, pk['patch'].k, BF16, dev)
+        patches = empty(V * lay.T, pk['patch'].k, adt(), dev)
         hip.patchify(img.contiguous(), patches, p)
         x = torch.zeros(lay.rows, D, dtype=torch.float32, device=dev)
         hip.gemm(patches, pk['patch'].w, x, bias=pk['patch'].b, grp=lay.grp)
@@ -58,7 +56,7 @@ class Dust3rEncoder(HipModule):
         for bw in pk['blocks']:
             vit_block(x, bw, lay, Hh, D // Hh, pos, rope)
         if out is None:
-            out = empty(V * lay.T, D, BF16, dev)
+            out = empty(V * lay.T, D, adt(), dev)
         hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, :D] if out.shape[1] != D else out, pk['norm'][2],
                       rows=V * lay.T, grp=lay.grp)
         return out, grid_pos(V, gh, gw, lay.T, 0, dev)

@@ -16,8 +16,8 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .common import (HipModule, Packed, Layout, BF16, BlockW, empty, pack_norm, pack_croco_block, self_attention, f32,
-                     ParamLinear, grid_pos)
+from .common import (HipModule, Packed, Layout, adt, BlockW, empty, pack_norm, pack_croco_block, self_attention, f32,
+                     ParamLinear, grid_pos, grow_table)
 from .params import BlockP, CrossAttnP, MlpP, AttnP
 
 
@@ -51,8 +51,8 @@ class MemoryBank:
     def _alloc(self, cap, device):
         # one allocation per kind: the L per-layer caches are equally strided slices, so an append projects the new
         # entries of all layers with ONE strided-batch GEMM launch for K and one for V^T
-        self.K_all = torch.zeros(self.L, cap, self.D, dtype=BF16, device=device)
-        self.Vt_all = torch.zeros(self.L, self.D, (cap + 7) // 8 * 8 + 8, dtype=BF16, device=device)      # 16-byte rows
+        self.K_all = torch.zeros(self.L, cap, self.D, dtype=adt(), device=device)
+        self.Vt_all = torch.zeros(self.L, self.D, (cap + 7) // 8 * 8 + 8, dtype=adt(), device=device)      # 16-byte rows
         self.K = [self.K_all[l] for l in range(self.L)]
         self.Vt = [self.Vt_all[l] for l in range(self.L)]
 
@@ -121,9 +121,7 @@ class MUSt3R(HipModule):
         return pk
 
     def _rope(self, pk, n, device):
-        if pk['rope'].get('n', 0) < n:
-            pk['rope'] = dict(n=n, t=hip.rope_table(n, self.embed_dim // self.num_heads, self.rope_base, device))
-        return pk['rope']['t']
+        return grow_table(pk['rope'], n, lambda m: hip.rope_table(m, self.embed_dim // self.num_heads, self.rope_base, device))
 
     def new_bank(self, device, cap_tokens):
         return MemoryBank(self.depth, self.embed_dim, cap_tokens, device)
@@ -139,7 +137,7 @@ class MUSt3R(HipModule):
 
     def _self_and_mlp_pre(self, x, bw, lay, pos, rope):
         H, hd, dev = self.num_heads, self.embed_dim // self.num_heads, x.device
-        xn = empty(lay.rows, self.embed_dim, BF16, dev)
+        xn = empty(lay.rows, self.embed_dim, adt(), dev)
         hip.layernorm(x, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
         o = self_attention(xn, lay, H, hd, bw.qk, bw.v, pos, rope)
         hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, res=x)
@@ -148,13 +146,13 @@ class MUSt3R(HipModule):
     def _cross_q(self, x, bw, xn):
         c = bw.cross
         hip.layernorm(x, c['norm'][0], c['norm'][1], xn, c['norm'][2])
-        q = empty(xn.shape[0], self.embed_dim, BF16, x.device)
+        q = empty(xn.shape[0], self.embed_dim, adt(), x.device)
         hip.gemm(xn, c['q'].w, q, bias=c['q'].b)
         return q
 
     def _mlp(self, x, bw, xn):
         hip.layernorm(x, bw.norm2[0], bw.norm2[1], xn, bw.norm2[2])
-        h = empty(xn.shape[0], bw.fc1.n, BF16, x.device)
+        h = empty(xn.shape[0], bw.fc1.n, adt(), x.device)
         hip.gemm(xn, bw.fc1.w, h, bias=bw.fc1.b, act='gelu')
         hip.gemm(h, bw.fc2.w, x, bias=bw.fc2.b, res=x)
 
@@ -179,14 +177,14 @@ class MUSt3R(HipModule):
         for l, bw in enumerate(pk['blocks']):
             xn = self._self_and_mlp_pre(x, bw, lay, pos, rope)
             q = self._cross_q(x, bw, xn)
-            o = empty(lay.rows, D, BF16, dev)
+            o = empty(lay.rows, D, adt(), dev)
             ldv = bank.Vt[l].stride(0)
             hip.attention(q, bank.K[l], bank.Vt[l], o, 1, H, lay.rows, bank.n, hd,
                           q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
             hip.gemm(o, bw.cross['proj'].w, x, bias=bw.cross['proj'].b, res=x)
             self._mlp(x, bw, xn)
         if feat_out is None:
-            feat_out = empty(V * lay.T, D, BF16, dev)
+            feat_out = empty(V * lay.T, D, adt(), dev)
         hip.layernorm(x, pk['norm'][0], pk['norm'][1], feat_out, pk['norm'][2], rows=V * lay.T, grp=lay.grp)
         pm = self._head(pk, feat_out, V, h, w) if pointmaps else None
         return pm, feat_out
@@ -213,8 +211,8 @@ class MUSt3R(HipModule):
         # hs[l] = tokens entering block l (the candidate memory entries).  No copies: block l reads its residual from
         # hs[l] and the attention-projection GEMM writes the updated stream to a fresh buffer that becomes hs[l+1].
         hs = [x]
-        vt_self = torch.zeros(D, lay.rows + 8, dtype=BF16, device=dev)      # V^T scratch shared by all layers (pad columns stay 0)
-        xn = empty(lay.rows, D, BF16, dev)
+        vt_self = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)      # V^T scratch shared by all layers (pad columns stay 0)
+        xn = empty(lay.rows, D, adt(), dev)
         for l, bw in enumerate(pk['blocks']):
             x_in = hs[l]
             x = hs_all[l + 1]
@@ -224,14 +222,14 @@ class MUSt3R(HipModule):
             o = self_attention(xn, lay, H, hd, bw.qk, bw.v, pos, rope, vt=vt_self)
             hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, res=x_in)
             c = bw.cross
-            o = empty(lay.rows, D, BF16, dev)
+            o = empty(lay.rows, D, adt(), dev)
             if n == 2:
                 # each image attends to the other image's layer input (norm_y + projk / projv on the fly)
-                y = empty(lay.rows, D, BF16, dev)
+                y = empty(lay.rows, D, adt(), dev)
                 hip.layernorm(x_in, c['norm_y'][0], c['norm_y'][1], y, c['norm_y'][2])
-                kk = empty(lay.rows, D, BF16, dev)
+                kk = empty(lay.rows, D, adt(), dev)
                 hip.gemm(y, c['k'].w, kk, bias=c['k'].b)
-                vt = torch.zeros(D, lay.rows + 8, dtype=BF16, device=dev)
+                vt = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)
                 hip.gemm(y, c['v'].w, vt, bias=c['v'].b, trans_out=True)
                 q = self._cross_q(x, bw, xn)
                 ldv = vt.stride(0)
@@ -251,7 +249,7 @@ class MUSt3R(HipModule):
         out = self._append(pk, bank, hs, lay, n, T, hs_all=hs_all)
         if not want_outputs:
             return bank
-        feat = empty(n * T, D, BF16, dev)       # first-pass outputs of the update call (engine/must3r.py:45-46)
+        feat = empty(n * T, D, adt(), dev)       # first-pass outputs of the update call (engine/must3r.py:45-46)
         hip.add_cast(out.view(n, lay.Tp, D)[:, :T].reshape(n * T, D) if lay.Tp == T else
                      out.view(n, lay.Tp, D)[:, :T].contiguous().view(n * T, D), feat)
         return bank, self._head(pk, feat, n, h, w), feat
@@ -279,23 +277,23 @@ class MUSt3R(HipModule):
             kvs = []
             for i in range(2):          # K / V^T of each image's layer input (the other image's context)
                 lay = lays[i]
-                y = empty(lay.rows, D, BF16, dev)
+                y = empty(lay.rows, D, adt(), dev)
                 hip.layernorm(hs[i][l], c['norm_y'][0], c['norm_y'][1], y, c['norm_y'][2])
-                kk = empty(lay.rows, D, BF16, dev)
+                kk = empty(lay.rows, D, adt(), dev)
                 hip.gemm(y, c['k'].w, kk, bias=c['k'].b)
-                vt = torch.zeros(D, lay.rows + 8, dtype=BF16, device=dev)
+                vt = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)
                 hip.gemm(y, c['v'].w, vt, bias=c['v'].b, trans_out=True)
                 kvs.append((kk, vt))
             for i in range(2):
                 lay, x_in = lays[i], hs[i][l]
-                xn = empty(lay.rows, D, BF16, dev)
+                xn = empty(lay.rows, D, adt(), dev)
                 x = empty(lay.rows, D, torch.float32, dev)
                 hip.layernorm(x_in, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
                 o = self_attention(xn, lay, H, hd, bw.qk, bw.v, poss[i], rope)
                 hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, res=x_in)
                 q = self._cross_q(x, bw, xn)
                 kk, vt = kvs[1 - i]
-                o = torch.zeros(lay.rows, D, dtype=BF16, device=dev)
+                o = torch.zeros(lay.rows, D, dtype=adt(), device=dev)
                 ldv = vt.stride(0)
                 hip.attention(q, kk, vt, o, 1, H, lay.T, Ts[1 - i], hd, q_strides=(0, hd, D), k_strides=(0, hd, D),
                               v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
@@ -313,9 +311,9 @@ class MUSt3R(HipModule):
         hip.layernorm(hs[-1], pk['norm'][0], pk['norm'][1], out, pk['norm'][2])
         fb = None
         if self.feedback_type:
-            fbn = empty(lay.rows, D, BF16, dev)
+            fbn = empty(lay.rows, D, adt(), dev)
             hip.layernorm(out, pk['fb_norm'][0], pk['fb_norm'][1], fbn, pk['fb_norm'][2])
-            hh = empty(lay.rows, pk['fb1'].n, BF16, dev)
+            hh = empty(lay.rows, pk['fb1'].n, adt(), dev)
             hip.gemm(fbn, pk['fb1'].w, hh, bias=pk['fb1'].b, act='gelu')
             fb = empty(lay.rows, D, torch.float32, dev)
             hip.gemm(hh, pk['fb2'].w, fb, bias=pk['fb2'].b)
@@ -324,7 +322,7 @@ class MUSt3R(HipModule):
         # the bank as two strided-batch GEMM launches (was 4 launches per layer: 0.3 ms of 2.1 ms per keyframe).
         # (Spreading the 12 independent layer chains over side streams was measured SLOWER inside a captured HIP graph.)
         L, rows = len(pk['blocks']), n * T
-        y = torch.empty(L, rows, D, dtype=BF16, device=dev)
+        y = torch.empty(L, rows, D, dtype=adt(), device=dev)
         if hs_all is not None:                            # all layers' norm_y(h_l + fb) in one strided-batch launch
             hip.layernorm_batch(hs_all[:L], pk['mem_ng'], pk['mem_nb'], y, pk['blocks'][0].cross['norm_y'][2], rows=rows, grp=lay.grp, add=fb)
         else:
@@ -348,7 +346,7 @@ class MUSt3R(HipModule):
         H, W = [int(v) for v in true_shape[0, 0].tolist()]
         h, w = H // self.patch_size, W // self.patch_size
         dev = x.device
-        xe = x.reshape(n * T, -1).to(BF16).contiguous()
+        xe = x.reshape(n * T, -1).to(adt()).contiguous()
         bank = mem[0] if mem is not None else self.new_bank(dev, max(n, 8) * T)
         if render:
             pm, feat = self.render_tokens(xe, n, h, w, bank)

@@ -22,8 +22,8 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .common import (HipModule, Packed, Layout, BF16, empty, vit_block, pack_croco_block, pack_norm, f32, ParamLinear,
-                     grid_pos, ceil_to)
+from .common import (HipModule, Packed, Layout, adt, empty, vit_block, pack_croco_block, pack_norm, f32, ParamLinear,
+                     grid_pos, ceil_to, grow_table)
 from .params import BlockP, MlpP, CrossAttnP, MHAP
 
 VIEW_CHUNK = 16     # views per upscaler pass (bounds the [rows, 22528] / [P, 384] workspaces)
@@ -52,18 +52,17 @@ class InputMixer(HipModule):
         x = torch.zeros(lay.rows, D, dtype=torch.float32, device=dev)
         hip.gemm(cat, pk['inp'].w, x, bias=pk['inp'].b, grp=lay.grp)
         pos = grid_pos(V, h, w, lay.Tp, 0, dev)
-        if pk['rope'].get('n', 0) < max(h, w):
-            pk['rope'] = dict(n=max(h, w), t=hip.rope_table(max(h, w), D // H, 100.0, dev))
+        rope = grow_table(pk['rope'], max(h, w), lambda m: hip.rope_table(m, D // H, 100.0, dev))
         for bw in pk['blocks']:
-            vit_block(x, bw, lay, H, D // H, pos, pk['rope']['t'])
+            vit_block(x, bw, lay, H, D // H, pos, rope)
         hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, :D], pk['norm'][2], rows=V * lay.T, grp=lay.grp)
         return out
 
     def forward(self, x, pos):
         V, T, _ = x.shape
         h = int(pos[0, :, 0].max()) + 1
-        out = torch.empty(V * T, self.hidden_dim, dtype=BF16, device=x.device)
-        self.mix_tokens(x.reshape(V * T, -1).to(BF16).contiguous(), V, h, T // h, out)
+        out = torch.empty(V * T, self.hidden_dim, dtype=adt(), device=x.device)
+        self.mix_tokens(x.reshape(V * T, -1).to(adt()).contiguous(), V, h, T // h, out)
         return out.float().reshape(V, T, -1)
 
 
@@ -105,18 +104,18 @@ class PixelShuffleUpscaler(HipModule):
         for v0 in range(0, V, VIEW_CHUNK):
             n = min(VIEW_CHUNK, V - v0)
             a = cat[v0 * T:(v0 + n) * T]
-            hid = empty(n * T, pk['fc1'].n, BF16, dev)
+            hid = empty(n * T, pk['fc1'].n, adt(), dev)
             hip.gemm(a, pk['fc1'].w, hid, bias=pk['fc1'].b, act='gelu')
             hip.gemm(hid[:, :pk['hid']], pk['p16'].w, fpn_out[v0 * T:(v0 + n) * T], bias=pk['p16'].b)
-            f8 = empty(n * 4 * T, d1, BF16, dev)
+            f8 = empty(n * 4 * T, d1, adt(), dev)
             hip.gemm(hid[:, pk['hid']:], pk['p8'].w, f8, bias=pk['p8'].b, ps=(2, d1, h, w))
             del hid
-            h4 = empty(n * 4 * T, pk['p4a'].n, BF16, dev)
+            h4 = empty(n * 4 * T, pk['p4a'].n, adt(), dev)
             hip.gemm(f8, pk['p4a'].w, h4, bias=pk['p4a'].b, act='gelu')
-            f4 = empty(n * 16 * T, d2, BF16, dev)
+            f4 = empty(n * 16 * T, d2, adt(), dev)
             hip.gemm(h4, pk['p4b'].w, f4, bias=pk['p4b'].b, ps=(2, d2, 2 * h, 2 * w))
             del h4, f8
-            h2 = empty(n * 16 * T, pk['p2a'].n, BF16, dev)
+            h2 = empty(n * 16 * T, pk['p2a'].n, adt(), dev)
             hip.gemm(f4, pk['p2a'].w, h2, bias=pk['p2a'].b, act='gelu')
             hip.gemm(h2, pk['p2b'].w, mask_out[v0:v0 + n], bias=pk['p2b'].b, ps=(2, d3, 4 * h, 4 * w))
             del h2, f4
@@ -128,9 +127,9 @@ class PixelShuffleUpscaler(HipModule):
         V, T, _ = x.shape
         H, W = img_shape
         h, w = H // self.patch_size, W // self.patch_size
-        fpn = torch.empty(V * T, self.fpn_dim, dtype=BF16, device=x.device)
-        mf = torch.empty(V, 8 * h, 8 * w, self.mask_dim, dtype=BF16, device=x.device)
-        self.upscale_tokens(x.reshape(V * T, -1).to(BF16).contiguous(), None, V, h, w, fpn, mf)
+        fpn = torch.empty(V * T, self.fpn_dim, dtype=adt(), device=x.device)
+        mf = torch.empty(V, 8 * h, 8 * w, self.mask_dim, dtype=adt(), device=x.device)
+        self.upscale_tokens(x.reshape(V * T, -1).to(adt()).contiguous(), None, V, h, w, fpn, mf)
         return [fpn.float().reshape(V, h, w, -1).permute(0, 3, 1, 2)], mf.float().permute(0, 3, 1, 2)
 
 
@@ -210,18 +209,18 @@ class LoftUpUpscaler(HipModule):
         V = imgs.shape[0]
         H2, W2 = imgs.shape[2] // 2, imgs.shape[3] // 2
         P = H2 * W2
-        out = empty(V * P, C, BF16, dev)
+        out = empty(V * P, C, adt(), dev)
         for v0 in range(0, V, VIEW_CHUNK):
             n = min(VIEW_CHUNK, V - v0)
             # Fourier features + GroupNorm(1) in two recomputing passes straight to bf16: no [n, P, 203] fp32 feature buffer
             # (pst_loftup_guidance + pst_groupnorm_apply did the same through a 639 MB round trip: 1076 -> 254 us per 16 views)
             st0 = hip.stats_buffer(n, 1, dev)
-            g0 = empty(n * P, pk['c0'], BF16, dev)
+            g0 = empty(n * P, pk['c0'], adt(), dev)
             scratch = torch.empty(n * (3 * P + 6) + 16, dtype=torch.float32, device=dev)
             hip.loftup_guidance_gn(imgs[v0:v0 + n].contiguous(), pk['ff_bias'], pk['gn0'][0], pk['gn0'][1], pk['gn0'][2], scratch, st0, g0,
                                    self.n_freqs)
             del scratch
-            c1 = empty(n * P, C, BF16, dev)
+            c1 = empty(n * P, C, adt(), dev)
             hip.gemm(g0, pk['conv1'].w, c1, bias=pk['conv1'].b, conv=(pk['c0'], H2, W2))
             st = hip.stats_buffer(n, 8, dev)
             hip.groupnorm_stats(c1, st, n, P, C, 8)
@@ -265,14 +264,14 @@ class LoftUpUpscaler(HipModule):
             # The residual stream of these two blocks is kept in bf16: they are HBM-bound over P x C elements per view
             # (fp32 would double the read-modify-write traffic of both residual GEMMs and of every LayerNorm).
             x = guidance[v0 * P:(v0 + n) * P]
-            xn, q, o = empty(n * P, C, BF16, dev), empty(n * P, C, BF16, dev), empty(n * P, C, BF16, dev)
+            xn, q, o = empty(n * P, C, adt(), dev), empty(n * P, C, adt(), dev), empty(n * P, C, adt(), dev)
             rows0, rows1 = v0 * lay.Tp, (v0 + n) * lay.Tp
             for bw in pk['blocks']:
-                y = empty(rows1 - rows0, C, BF16, dev)
+                y = empty(rows1 - rows0, C, adt(), dev)
                 hip.layernorm(kvn[rows0:rows1], bw['norm_y'][0], bw['norm_y'][1], y, bw['norm_y'][2])
-                kk = empty(rows1 - rows0, C, BF16, dev)
+                kk = empty(rows1 - rows0, C, adt(), dev)
                 hip.gemm(y, bw['k'].w, kk, bias=bw['k'].b)
-                vt = torch.zeros(C, rows1 - rows0 + 8, dtype=BF16, device=dev)
+                vt = torch.zeros(C, rows1 - rows0 + 8, dtype=adt(), device=dev)
                 hip.gemm(y, bw['v'].w, vt, bias=bw['v'].b, trans_out=True)
                 hip.layernorm(x, bw['norm2'][0], bw['norm2'][1], xn, bw['norm2'][2])
                 hip.gemm(xn, bw['q'].w, q, bias=bw['q'].b)
@@ -292,10 +291,10 @@ class LoftUpUpscaler(HipModule):
         V, T, _ = tok.shape
         H, W = img_shape
         h, w = H // self.patch_size, W // self.patch_size
-        lr = torch.zeros(V * T, self.lr_width(), dtype=BF16, device=tok.device)
-        lr[:, :self.input_dim] = tok.reshape(V * T, -1).to(BF16)
-        fpn = torch.empty(V * T, self.fpn_dim, dtype=BF16, device=tok.device)
-        mf = torch.empty(V, min(H, W) // 2, max(H, W) // 2, self.dim, dtype=BF16, device=tok.device)   # loftup.py:147-149,184
+        lr = torch.zeros(V * T, self.lr_width(), dtype=adt(), device=tok.device)
+        lr[:, :self.input_dim] = tok.reshape(V * T, -1).to(adt())
+        fpn = torch.empty(V * T, self.fpn_dim, dtype=adt(), device=tok.device)
+        mf = torch.empty(V, min(H, W) // 2, max(H, W) // 2, self.dim, dtype=adt(), device=tok.device)   # loftup.py:147-149,184
         self.upscale_tokens(lr, img.float(), V, h, w, fpn, mf)
         return [fpn.float().reshape(V, h, w, -1).permute(0, 3, 1, 2)], mf.float().permute(0, 3, 1, 2)
 
@@ -402,7 +401,7 @@ class MaskTransformer(HipModule):
     def _embed(self, pk, out):
         dev = out.device
         Q, d = out.shape
-        dn = empty(Q, d, BF16, dev)
+        dn = empty(Q, d, adt(), dev)
         hip.layernorm(out, pk['dn'][0], pk['dn'][1], dn, pk['dn'][2])
         # mask_embed MLP in split precision (x = x_hi + x_lo, W = W_hi + W_lo, fp32 between the layers): its 200 x C result is one
         # factor of the ill-conditioned query x pixel product, where an embedding error of 8e-3 shows up as 1.9e-2 on the mask logits
@@ -410,12 +409,12 @@ class MaskTransformer(HipModule):
         a = empty(Q, d, torch.float32, dev)
         hip.layernorm(out, pk['dn'][0], pk['dn'][1], a, pk['dn'][2])
         for j, (w3, b3) in enumerate(pk['me3']):
-            a3 = empty(Q, w3.shape[1], BF16, dev)
+            a3 = empty(Q, w3.shape[1], adt(), dev)
             hip.split3(a, a3)
             b = empty(Q, w3.shape[0], torch.float32, dev)
             hip.gemm(a3, w3, b, bias=b3, act=None if j == len(pk['me3']) - 1 else 'relu')
             a = b
-        emb = empty(Q, a.shape[1], BF16, dev)
+        emb = empty(Q, a.shape[1], adt(), dev)
         hip.add_cast(a, emb)
         return dn, emb
 
@@ -424,12 +423,13 @@ class MaskTransformer(HipModule):
         Q = dn.shape[0]
         lang = empty(Q, pk['lang'].n, torch.float32, dev)
         hip.gemm(dn, pk['lang'].w, lang, bias=pk['lang'].b)
-        ln = torch.zeros(Q, cls_bf16.shape[1], dtype=BF16, device=dev)
+        ln = torch.zeros(Q, cls_bf16.shape[1], dtype=adt(), device=dev)
         hip.l2norm_rows(lang, ln[:, :lang.shape[1]], 1e-7)
         logits = empty(Q, cls_bf16.shape[0], torch.float32, dev)
-        if pk.get('gam_n') != cls_bf16.shape[0]:
-            pk['gam'], pk['gam_n'] = torch.full((cls_bf16.shape[0],), pk['scale'], dtype=torch.float32, device=dev), cls_bf16.shape[0]
-        gam = pk['gam']
+        gams = pk.setdefault('gam', {})            # keyed by class count, entries never replaced (graph-captured addresses)
+        if cls_bf16.shape[0] not in gams:
+            gams[cls_bf16.shape[0]] = torch.full((cls_bf16.shape[0],), pk['scale'], dtype=torch.float32, device=dev)
+        gam = gams[cls_bf16.shape[0]]
         hip.gemm(ln, cls_bf16, logits, gamma=gam)
         return logits
 
@@ -461,7 +461,7 @@ class MaskTransformer(HipModule):
         masks against the transposed key grid, utils.py:47-49)."""
         n, Hm, Wm, C = mask_feats.shape
         gh, gw = grid if grid is not None else (Hm // 8, Wm // 8)
-        fm = torch.empty(n * gh * gw, C, dtype=BF16, device=mask_feats.device)
+        fm = torch.empty(n * gh * gw, C, dtype=adt(), device=mask_feats.device)
         if (gh * 8, gw * 8) == (Hm, Wm):
             hip.mean4(mask_feats, fm, n, Hm, Wm, C)
         else:
@@ -480,8 +480,8 @@ class MaskTransformer(HipModule):
         portrait = portrait or [False] * len(grids)
         NK = fpn.shape[0]
         assert NK == sum(h * w for h, w in grids) and fm.shape[0] == NK
-        src = empty(NK, d, BF16, dev)           # value input: fpn + level_embed
-        srcpos = empty(NK, d, BF16, dev)        # key input:   ... + sine PE of the view's grid
+        src = empty(NK, d, adt(), dev)           # value input: fpn + level_embed
+        srcpos = empty(NK, d, adt(), dev)        # key input:   ... + sine PE of the view's grid
         hip.add_cast(fpn, src, b=pk['lvl'], b_mod=1)
         if len(set(zip(grids, portrait))) == 1:
             h, w = grids[0]
@@ -505,17 +505,17 @@ class MaskTransformer(HipModule):
         if NKm != NK:
             raise NotImplementedError('total keyframe tokens must be a multiple of 4')
         next_mask(out)
-        qin, ob = empty(Q, d, BF16, dev), empty(Q, d, BF16, dev)
+        qin, ob = empty(Q, d, adt(), dev), empty(Q, d, adt(), dev)
         t32 = empty(Q, d, torch.float32, dev)
         dn = emb = None
         for i, L in enumerate(pk['layers']):
             # masked cross-attention (post-LN): K from src+pos, V from src
-            kc = empty(NK, d, BF16, dev)
+            kc = empty(NK, d, adt(), dev)
             hip.gemm(srcpos, L['ca']['k'].w, kc, bias=L['ca']['k'].b)
-            vt = torch.zeros(d, ceil_to(NK, 8) + 8, dtype=BF16, device=dev)
+            vt = torch.zeros(d, ceil_to(NK, 8) + 8, dtype=adt(), device=dev)
             hip.gemm(src, L['ca']['v'].w, vt, bias=L['ca']['v'].b, trans_out=True)
             hip.add_cast(out, qin, b=qpos)
-            q = empty(Q, d, BF16, dev)
+            q = empty(Q, d, adt(), dev)
             hip.gemm(qin, L['ca']['q'].w, q, bias=L['ca']['q'].b)
             ldv = vt.stride(0)
             hip.attention(q, kc, vt, ob, 1, H, Q, NK, hd, (0, hd, d), (0, hd, d), (0, hd * ldv, ldv), (0, hd, d),
@@ -524,19 +524,19 @@ class MaskTransformer(HipModule):
             hip.layernorm(t32, L['ca_norm'][0], L['ca_norm'][1], out, L['ca_norm'][2])
             # self-attention: q = k = out + query_pos, v = out
             hip.add_cast(out, qin, b=qpos)
-            qk = empty(Q, 2 * d, BF16, dev)
+            qk = empty(Q, 2 * d, adt(), dev)
             hip.gemm(qin, L['sa']['qk'].w, qk, bias=L['sa']['qk'].b)
             hip.add_cast(out, ob)
-            vts = torch.zeros(d, ceil_to(Q, 8) + 8, dtype=BF16, device=dev)
+            vts = torch.zeros(d, ceil_to(Q, 8) + 8, dtype=adt(), device=dev)
             hip.gemm(ob, L['sa']['v'].w, vts, bias=L['sa']['v'].b, trans_out=True)
-            o2 = empty(Q, d, BF16, dev)
+            o2 = empty(Q, d, adt(), dev)
             lds = vts.stride(0)
             hip.attention(qk, qk[:, d:], vts, o2, 1, H, Q, Q, hd, (0, hd, 2 * d), (0, hd, 2 * d), (0, hd * lds, lds), (0, hd, d))
             hip.gemm(o2, L['sa']['o'].w, t32, bias=L['sa']['o'].b, res=out)
             hip.layernorm(t32, L['sa_norm'][0], L['sa_norm'][1], out, L['sa_norm'][2])
             # FFN
             hip.add_cast(out, ob)
-            hmid = empty(Q, L['l1'].n, BF16, dev)
+            hmid = empty(Q, L['l1'].n, adt(), dev)
             hip.gemm(ob, L['l1'].w, hmid, bias=L['l1'].b, act='relu')
             hip.gemm(hmid, L['l2'].w, t32, bias=L['l2'].b, res=out)
             hip.layernorm(t32, L['ff_norm'][0], L['ff_norm'][1], out, L['ff_norm'][2])
@@ -565,9 +565,16 @@ class TextEncoder(nn.Module):
 
     def set_vocab(self, classes, embeddings=None, device=None):
         if embeddings is None:
-            raise NotImplementedError('offline build: pass the pooled SigLIP embeddings explicitly')
+            # reference text_encoder.py:44-47 would run the SigLIP text tower; no HF weights offline: the classes must already be in
+            # the fixed-vocabulary store (class_embeddings), else pass the pooled text embeddings
+            unknown = [c for c in classes if c not in self.class_embeddings]
+            if unknown:
+                raise NotImplementedError('no SigLIP text tower in this build: pass embeddings= (pooled text embeddings [Ncls, %d]) or '
+                                          'fill class_embeddings; unknown classes: %s' % (self.embed_dim, unknown[:5]))
+            return
         self.class_embeddings = {c: e for c, e in zip(classes, embeddings)}
-        self._cls_cache = (None, None)
+        self._cls_gen = getattr(self, '_cls_gen', 0) + 1       # new vocabulary generation: cached device copies of the old one are
+        #                                                        no longer handed out (runners that captured them keep them alive)
 
     def forward(self, classes):
         assert all(c in self.class_embeddings for c in classes), \
@@ -579,13 +586,16 @@ class TextEncoder(nn.Module):
         """unit-norm class embeddings as the bf16 [Ncls, 768] W operand of the class-logit GEMM (normalised on device)."""
         assert all(c in self.class_embeddings for c in classes), \
             "Missing classes in vocabulary. 'set_vocab' must be called if using fixed vocabulary"
-        key = (tuple(classes), str(device))
-        if getattr(self, '_cls_cache', (None, None))[0] != key:
+        key = (tuple(classes), str(device), adt(), getattr(self, '_cls_gen', 0))
+        cache = self.__dict__.setdefault('_cls_cache', {})     # keyed, entries never replaced: a captured graph may hold the address
+        if not isinstance(cache, dict):
+            cache = self.__dict__['_cls_cache'] = {}
+        if key not in cache:
             raw = torch.stack([self.class_embeddings[c] for c in classes]).float().to(device).contiguous()
-            out = torch.zeros(raw.shape[0], ceil_to(raw.shape[1], 64), dtype=BF16, device=device)
+            out = torch.zeros(raw.shape[0], ceil_to(raw.shape[1], 64), dtype=adt(), device=device)
             hip.l2norm_rows(raw, out[:, :raw.shape[1]], 0.0)
-            self._cls_cache = (key, out)
-        return self._cls_cache[1]
+            cache[key] = out
+        return cache[key]
 
 
 class PanopticDecoder(HipModule):
@@ -631,22 +641,22 @@ class PanopticDecoder(HipModule):
         dev = cat.device
         up = self.upscaler
         T = h * w
-        fpn = torch.empty(V * T, up.fpn_dim, dtype=BF16, device=dev)
+        fpn = torch.empty(V * T, up.fpn_dim, dtype=adt(), device=dev)
         if isinstance(up, LoftUpUpscaler):
-            lr = torch.zeros(V * T, up.lr_width(), dtype=BF16, device=dev)
+            lr = torch.zeros(V * T, up.lr_width(), dtype=adt(), device=dev)
             if self.input_mixer is not None:
                 self.input_mixer.mix_tokens(cat, V, h, w, lr)
             else:
                 lr[:, :up.input_dim] = cat
             H2, W2 = imgs.shape[2] // 2, imgs.shape[3] // 2
-            mf = torch.empty(V, min(H2, W2) if h > w else H2, max(H2, W2) if h > w else W2, up.mask_dim, dtype=BF16, device=dev)
+            mf = torch.empty(V, min(H2, W2) if h > w else H2, max(H2, W2) if h > w else W2, up.mask_dim, dtype=adt(), device=dev)
             up.upscale_tokens(lr, imgs, V, h, w, fpn, mf, guidance=guidance)
         else:
             x = cat
             if self.input_mixer is not None:
-                x = torch.empty(V * T, self.input_mixer.hidden_dim, dtype=BF16, device=dev)
+                x = torch.empty(V * T, self.input_mixer.hidden_dim, dtype=adt(), device=dev)
                 self.input_mixer.mix_tokens(cat, V, h, w, x)
-            mf = torch.empty(V, 8 * h, 8 * w, up.mask_dim, dtype=BF16, device=dev)
+            mf = torch.empty(V, 8 * h, 8 * w, up.mask_dim, dtype=adt(), device=dev)
             up.upscale_tokens(x, imgs, V, h, w, fpn, mf)
         if self.fpn_grid(h, w)[1]:
             fpn = fpn.view(V, h, w, -1).transpose(1, 2).reshape(V * T, -1)          # copies (pure data movement)
@@ -654,29 +664,51 @@ class PanopticDecoder(HipModule):
         return fpn, mf
 
     def forward(self, in_feats, in_imgs, pos, true_shape, classes, max_bs=None, outdevice=None, memory_queries=None, multi_ar=False):
-        """Reference signature (panoptic_decoder.py:41) for one scene of same-shape views (images in native orientation):
-        in_feats = (x_enc, y_dec, x_dino) each [1,n,T,*]; returns pred_logits [1,Q,Ncls], pred_masks [1,n,Q,H/2,W/2], out_queries [Q,1,d].
-        MinMaxScaler is applied per view (the demo's max_bs=1 convention)."""
-        if multi_ar:
-            raise NotImplementedError('use PanSt3R.forward_inference_multi_ar (token-level pipeline) for multi-AR scenes')
-        B, n, T = in_feats[0].shape[:3]
-        assert B == 1
-        H, W = [int(v) for v in true_shape[0, 0].tolist()]
-        dev = in_feats[0].device
+        """Reference signature (panoptic_decoder.py:41), images in native orientation.
+        multi_ar=False: in_feats = (x_enc, y_dec, x_dino) each [B,n,T,*], in_imgs [B,n,3,H,W], true_shape [B,n,2]
+            -> pred_logits [B,Q,Ncls], pred_masks [B,n,Q,H/2,W/2], out_queries [Q,B,d]; scenes of a batch are independent.
+        multi_ar=True (panoptic_decoder.py:45-47, panst3r.py:248-249): every argument is a LIST of same-shape stacks ([1,n_i,...]);
+            the queries are decoded against the tokens of ALL stacks, pred_masks is the list of per-stack [1,n_i,Q,h_i,w_i].
+        MinMaxScaler is applied per view (the demo's max_bs=1 convention); `max_bs` only chunks work in the
+        reference and is accepted for signature compatibility."""
+        feats = in_feats if multi_ar else tuple([f] for f in in_feats)
+        imgs = in_imgs if multi_ar else [in_imgs]
+        shapes = true_shape if multi_ar else [true_shape]
+        B = feats[0][0].shape[0]
+        if B != 1:
+            if multi_ar:
+                raise NotImplementedError('multi_ar stacks carry one scene (B == 1), as in the reference call site panst3r.py:248')
+            outs = [self.forward(tuple(f[b:b + 1] for f in in_feats), in_imgs[b:b + 1], None, true_shape[b:b + 1], classes, max_bs, outdevice,
+                                 None if memory_queries is None else memory_queries[:, b:b + 1], False) for b in range(B)]
+            res = {'pred_logits': torch.cat([o['pred_logits'] for o in outs]), 'pred_masks': torch.cat([o['pred_masks'] for o in outs])}
+            if memory_queries is None:
+                res['out_queries'] = torch.cat([o['out_queries'] for o in outs], dim=1)
+                res['aux_outputs'] = []
+            return res
+        dev = feats[0][0].device
         p = self.upscaler.patch_size
-        h, w = H // p, W // p
-        cat = torch.cat([f.reshape(n * T, -1) for f in in_feats], dim=-1).to(BF16).contiguous()
-        fpn, mf = self.features_tokens(cat, in_imgs[0].float().contiguous(), n, h, w)
-        cls = self.text_encoder.normalized_bf16(classes, dev)
         mt = self.mask_transformer
-        grid, portrait = self.fpn_grid(h, w)
+        cls = self.text_encoder.normalized_bf16(classes, dev)
+        fpns, fms, mfs, grids, portraits = [], [], [], [], []
+        for si in range(len(imgs)):
+            n, T = feats[0][si].shape[1:3]
+            H, W = [int(v) for v in shapes[si].reshape(-1, 2)[0].tolist()]
+            h, w = H // p, W // p
+            cat = torch.cat([f[si].reshape(n * T, -1) for f in feats], dim=-1).to(adt()).contiguous()
+            fpn, mf = self.features_tokens(cat, imgs[si][0].float().contiguous(), n, h, w)
+            grid, portrait = self.fpn_grid(h, w)
+            fpns.append(fpn); mfs.append(mf); grids += [grid] * n; portraits += [portrait] * n
+            if memory_queries is None:
+                fms.append(mt.attn_feats(mf, grid))
         if memory_queries is None:
-            outq, hs = mt.decode_tokens(fpn, mt.attn_feats(mf, grid), [grid] * n, cls, [portrait] * n)
+            outq, hs = mt.decode_tokens(torch.cat(fpns) if len(fpns) > 1 else fpns[0], torch.cat(fms) if len(fms) > 1 else fms[0], grids, cls, portraits)
         else:
             outq = memory_queries.reshape(-1, mt.hidden_dim).float().to(dev).contiguous()
             hs = mt.head_state(outq, cls)
-        masks = torch.stack([mt.masks_for(hs.embed, mf[i]) for i in range(n)])[None]
-        res = {'pred_logits': hs.logits[None], 'pred_masks': masks if outdevice is None else masks.to(outdevice)}
+        masks = [torch.stack([mt.masks_for(hs.embed, mf[i]) for i in range(mf.shape[0])])[None] for mf in mfs]
+        if outdevice is not None:
+            masks = [m.to(outdevice) for m in masks]
+        res = {'pred_logits': hs.logits[None], 'pred_masks': masks if multi_ar else masks[0]}
         if memory_queries is None:
             res['out_queries'] = outq[:, None].clone()
             res['aux_outputs'] = []

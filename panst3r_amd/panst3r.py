@@ -11,8 +11,9 @@ Same call signatures and output structure; what changed is HOW the scene is exec
   * decoder_norm -> class logits -> mask_embed of the frozen queries is computed once per scene, each view then costs
     one [Q,C]x[C,P] GEMM (the reference recomputes the heads per chunk, panoptic_decoder.py:71);
   * MinMaxScaler is per view (the demo's max_bs=1 convention), see SURVEY quirk 5.
-`amp` is accepted for signature compatibility: the HIP kernels always compute in bf16 MFMA with fp32 accumulation,
-fp32 residual streams / softmax / normalisation statistics.
+`amp` (False | 'bf16' | 'fp16', reference utils.py:206-215) selects the 16-bit storage / MFMA operand format of the scene:
+'bf16' and 'fp16' as in the reference's autocast; amp=False is the reference's fp32 mode, for which the HIP path (no fp32 MFMA
+variant) runs its most precise format, f16.  Accumulation, residual streams, softmax and normalisation statistics are fp32 always.
 """
 from argparse import Namespace
 import numpy as np
@@ -21,7 +22,7 @@ from torch import nn
 
 from . import hip
 from .model import *            # noqa: F401,F403  (ctor-expression namespace of from_checkpoint, reference panst3r.py:9,14)
-from .model.common import BF16
+from .model.common import adt, precision, amp_dtype
 from .schedule import mem_batches
 
 ENC_CHUNK = 64        # views per encoder / DINOv2 / render pass (M = views*T rows through every GEMM)
@@ -36,13 +37,83 @@ class PanSt3R(nn.Module):
         self.dino_encoder, self.panoptic_decoder = dino_encoder, panoptic_decoder
         self.retrieval, self.preserve_gpu_mem, self.verbose = retrieval, preserve_gpu_mem, verbose
         self.must3r_params = dict(init_num_views=2, batch_num_views=1, render_iterations=1)
+        self.must3r_encoder_requires_grad, self.must3r_decoder_requires_grad = must3r_encoder_requires_grad, must3r_decoder_requires_grad
         self.postprocess_default, self.qubo_enabled = postprocess_default, qubo_enabled
+        self._runners = {}            # scene signature -> [calls, SceneRunner]: repeated same-shape scenes replay captured HIP graphs
+        self.max_cached_runners = 2   # each holds its graph pool (a few GB for a 50-view scene)
 
     def get_must3r_mem_batches(self, n_imgs):
         return mem_batches(n_imgs, self.must3r_params['init_num_views'], self.must3r_params['batch_num_views'])
 
-    def set_vocab(self, class_names, embeddings=None, device=None):
+    def set_vocab(self, class_names, device=None, embeddings=None):
+        """Reference signature set_vocab(class_names, device=None) (panst3r.py:298-299).  The reference runs its SigLIP text tower
+        here; offline there are no SigLIP weights, so the pooled text embeddings [Ncls, 768] are passed as `embeddings=` (keyword)
+        or must already be in `panoptic_decoder.text_encoder.class_embeddings` (the reference's fixed-vocabulary store,
+        text_encoder.py:44-47,94-97), in which case this call only validates that every class is known."""
         self.panoptic_decoder.text_encoder.set_vocab(class_names, embeddings, device=device)
+        self._runners.clear()
+
+    # ------------------------------------------------------------------ reference stage methods (panst3r.py:47-86,127-167)
+    @torch.no_grad()
+    def forward_dino(self, imgs, true_shape, max_bs=None, verbose=None):
+        """DINOv2 forward pass (panst3r.py:47-54; engine/dino.py:8-22 maps the encoder over the flattened (B, n) views):
+        imgs [B,n,3,H,W], true_shape [B,n,2] -> [B,n,T,1024].  `max_bs` chunks the work in the reference; here the views of a call are
+        batched through every GEMM."""
+        B, n = imgs.shape[:2]
+        x = self.dino_encoder(imgs.flatten(0, 1), true_shape.flatten(0, 1))
+        return x.reshape(B, n, *x.shape[1:])
+
+    @torch.no_grad()
+    def forward_must3r_encoder(self, imgs, true_shape, max_bs=None):
+        """MUSt3R encoder (panst3r.py:56-63; engine/must3r.py:8-26): imgs [B,n,3,H,W] -> (x [B,n,T,1024], pos [B,n,T,2]); a LIST of
+        [3,H_i,W_i] images (multi-aspect-ratio input, encoder_multi_ar) -> per-image lists (x[i] [T_i,1024], pos[i] [T_i,2])."""
+        if isinstance(imgs, (list, tuple)):
+            xs, ps = [None] * len(imgs), [None] * len(imgs)
+            groups = {}
+            for i, im in enumerate(imgs):
+                groups.setdefault(tuple(im.shape[-2:]), []).append(i)
+            for idx in groups.values():                      # same-shape images are batched through the encoder
+                x, pos = self.must3r_encoder(torch.stack([imgs[i] for i in idx]), torch.stack([true_shape[i] for i in idx]))
+                for j, i in enumerate(idx):
+                    xs[i], ps[i] = x[j], pos[j]
+            return xs, ps
+        B, n = imgs.shape[:2]
+        x, pos = self.must3r_encoder(imgs.flatten(0, 1), true_shape.flatten(0, 1))
+        return x.reshape(B, n, *x.shape[1:]), pos.reshape(B, n, *pos.shape[1:])
+
+    @torch.no_grad()
+    def forward_must3r_decoder(self, x_must3r, pos_must3r, true_shape, max_bs=None):
+        """MUSt3R decoder (panst3r.py:72-86): sequential memory build over the batches [2,1,1,...] (engine/must3r.py:28-69), then every
+        view is rendered against the accumulated memory (:71-129).  Returns (y_must3r [B,n,T,768], pointmaps [B,n,H,W,7], mem)."""
+        mem, start = None, 0
+        for nb in self.get_must3r_mem_batches(x_must3r.shape[1]):
+            sl = slice(start, start + nb)
+            mem, _, _ = self.must3r_decoder(x_must3r[:, sl].contiguous(), pos_must3r[:, sl].contiguous(), true_shape[:, sl].contiguous(), mem,
+                                            render=False, return_feats=True)
+            start += nb
+        _, pointmaps, feats = self.must3r_decoder(x_must3r, pos_must3r, true_shape, mem, render=True, return_feats=True)
+        return feats[-1], pointmaps, mem
+
+    @torch.no_grad()
+    def _forward_decoder_render(self, imgs, x_must3r, pos_must3r, true_shape, mem_must3r, mem_panst3r, classes, max_bs=None, multi_ar=False,
+                                outdevice=None):
+        """Render-only pass for views that are not keyframes (panst3r.py:127-167): MUSt3R render against the frozen memory, DINOv2,
+        then the panoptic heads with the frozen queries `mem_panst3r`.  multi_ar=False: imgs [B,n,3,H,W] (and matching tensors)
+        -> (pointmaps [B*n,H,W,7], masks [B*n,Q,H/2,W/2]); multi_ar=True: lists of same-shape stacks ([1,n_i,...]) -> lists.  The
+        reference walks the views in slices of max_bs (batched_map); here a stack is one batch through every GEMM."""
+        stacks = list(zip(imgs, x_must3r, pos_must3r, true_shape)) if multi_ar else [(imgs, x_must3r, pos_must3r, true_shape)]
+        pms, mks = [], []
+        for im, x, pos, ts in stacks:
+            B, n = im.shape[:2]
+            if B != 1:
+                raise NotImplementedError('one scene per call on the render-only path (memory and queries belong to one scene)')
+            _, pm, feats = self.must3r_decoder(x, pos, ts, mem_must3r, render=True, return_feats=True)
+            x_dino = self.forward_dino(im, ts, max_bs, verbose=False)
+            pan = self.panoptic_decoder((x, feats[-1], x_dino), im, pos, ts, classes, max_bs=max_bs, outdevice=outdevice, memory_queries=mem_panst3r)
+            pm, mk = pm.flatten(0, 1), pan['pred_masks'].flatten(0, 1)
+            pms.append(pm if outdevice is None else pm.to(outdevice))
+            mks.append(mk)
+        return (pms, mks) if multi_ar else (pms[0], mks[0])
 
     # ------------------------------------------------------------------ scene stages (token level)
     def _cat_width(self):
@@ -105,7 +176,7 @@ class PanSt3R(nn.Module):
     # ------------------------------------------------------------------ reference API
     @torch.no_grad()
     def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=None,
-                                   outdevice=None, amp=False, sim_matrix=None, keyframes=None):
+                                   outdevice=None, amp=False, sim_matrix=None, keyframes=None, check_finite=True):
         """imgs: list[V] of [3,H,W] in [-1,1]; true_shape [V,2]; returns (pointmaps list[V] of [1,H,W,7],
         {'pred_logits' [1,Q,Ncls], 'pred_masks' list[V] of [1,Q,H/2,W/2], 'out_queries' [Q,1,768]}).
         Keyframes: linspace over the views (panst3r.py:183-186) by default.  `use_retrieval=True` (panst3r.py:179-180) takes the
@@ -121,22 +192,48 @@ class PanSt3R(nn.Module):
         dev = imgs[0].device
         shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
         H, W = shapes[0]
-        from .scene import run_scene, HipBackend
-        res, scene = run_scene(HipBackend(self), lambda i: imgs[i], V, H, W, num_keyframes, classes, outdevice=outdevice, shapes=shapes, keyframes=keyframes)
+        # Scene signature: everything the captured graphs depend on.  The FIRST call with a signature runs eagerly (a one-off scene
+        # should not pay a warm-up + capture); from the second call on the scene replays three captured HIP graphs with the new images
+        # copied into the runner's static input buffers.
+        gens = tuple(m.generation for m in (self.must3r_encoder, self.must3r_decoder, self.dino_encoder, self.panoptic_decoder))
+        te = self.panoptic_decoder.text_encoder
+        key = (tuple(shapes), num_keyframes, None if keyframes is None else tuple(int(k) for k in keyframes), tuple(classes), str(dev),
+               amp_dtype(amp), gens, getattr(te, '_cls_gen', 0))
+        ent = self._runners.get(key)
+        if ent is None:
+            from .scene import SceneRunner, HipBackend
+            while len(self._runners) >= max(1, self.max_cached_runners):
+                self._runners.pop(next(iter(self._runners)))
+            runner = SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
+                                 keyframes=keyframes, amp=amp)
+            ent = self._runners[key] = [0, runner]
+        else:
+            ent[1].set_images(imgs)
+            ent[1].use_graphs = True          # captured lazily by run()
+        ent[0] += 1
+        res, scene = ent[1].run(outdevice)
+        if check_finite and amp_dtype(amp) == torch.float16:
+            # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: one reduction over the small scene
+            # outputs + the pointmaps tells; the remedy is amp='bf16' (same speed, 3 fewer mantissa bits)
+            ok = torch.isfinite(scene['out_queries']).all() & torch.isfinite(scene['pred_logits']).all()
+            for i in range(V):
+                ok = ok & torch.isfinite(res[i][0]).all()
+            if not bool(ok):
+                raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16'")
         panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
                   'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
         return [res[i][0] for i in range(V)], panout
 
     @torch.no_grad()
-    def forward_inference_sharded(self, get_image, V, H, W, classes, num_keyframes=None, outdevice=None, group=None):
+    def forward_inference_sharded(self, get_image, V, H, W, classes, num_keyframes=None, outdevice=None, group=None, amp=False):
         """View-sharded scene over the ranks of `group` (one process per GPU, RCCL): returns this rank's
         {view_id: (pointmap, masks)} and the scene-level dict.  See panst3r_amd/scene.py for the plan."""
         import torch.distributed as dist
         from .scene import run_scene, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-        return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice)
+        return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice, amp=amp)
 
-    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None, keyframes=None):
+    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None, keyframes=None, amp=False):
         """Static-shape scene runner (panst3r_amd/scene.py): `images` = {view_id: [3,H,W] device tensor} of the views
         this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True.
         `overlap=True` runs the memory build beside the bulk encoder work on a second stream (faster, NOT reproducible on this
@@ -144,19 +241,20 @@ class PanSt3R(nn.Module):
         import torch.distributed as dist
         from .scene import SceneRunner, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes)
+        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes, amp=amp)
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):
         """Same-shape batch variant (panst3r.py:286-296): imgs [1,n,3,H,W] -> (panout, pointmaps [1,n,H,W,7]);
         every view is a memory view (mem batches [2,1,...]) and every view is rendered."""
         B, n = imgs.shape[:2]
-        if B != 1:
-            raise NotImplementedError('one scene per call on the HIP path')
-        pms, panout = self.forward_inference_multi_ar(list(imgs[0]), true_shape[0], classes, num_keyframes=n, outdevice=outdevice)
-        panout = dict(panout)
-        panout['pred_masks'] = torch.stack([m[0] for m in panout['pred_masks']])[None]
-        return panout, torch.stack([p[0] for p in pms])[None]
+        outs = []
+        for b in range(B):                      # the scenes of a batch are independent (own memory, own queries)
+            pms, panout = self.forward_inference_multi_ar(list(imgs[b]), true_shape[b], classes, num_keyframes=n, outdevice=outdevice)
+            outs.append((torch.stack([m[0] for m in panout['pred_masks']])[None], torch.stack([p[0] for p in pms])[None], panout))
+        panout = {'pred_logits': torch.cat([o[2]['pred_logits'] for o in outs]), 'pred_masks': torch.cat([o[0] for o in outs]),
+                  'out_queries': torch.cat([o[2]['out_queries'] for o in outs], dim=1)}
+        return panout, torch.cat([o[1] for o in outs])
 
     @classmethod
     def from_checkpoint(cls, checkpoint_path, retrieval_path=None):
@@ -171,8 +269,27 @@ class PanSt3R(nn.Module):
         model = cls(must3r_encoder=must3r_encoder, must3r_decoder=must3r_decoder, dino_encoder=dino_encoder,
                     panoptic_decoder=panoptic_decoder, retrieval=ckpt.get('retrieval'),
                     postprocess_default=getattr(a, 'postprocess_default', 'standard_v2'), qubo_enabled=getattr(a, 'qubo_enabled', True))
-        model.load_state_dict(ckpt['weights'], strict=False)
+        # strict=False as in the reference (panst3r.py:323) - but the result is CHECKED: the encoder / decoder key names of this build are
+        # restated from memory, so a checkpoint whose keys differ must not run silently on random weights.
+        check_checkpoint_keys(model.load_state_dict(ckpt['weights'], strict=False))
         return model
+
+
+# state-dict keys a released checkpoint may carry / lack without consequence for the inference path
+IGNORABLE_MISSING = ()            # nothing on the path may keep its random init
+IGNORABLE_UNEXPECTED = ('panoptic_decoder.text_encoder.',        # SigLIP text tower: class embeddings are injected (fixed vocabulary)
+                        'dino_encoder.dinov2.embeddings.mask_token',      # unused at inference (HF Dinov2)
+                        'criterion.', 'matcher.')                # training-only modules
+
+
+def check_checkpoint_keys(result):
+    """Raise unless every parameter of the inference path was loaded and every checkpoint entry was consumed (modulo the whitelist)."""
+    missing = [k for k in result.missing_keys if not k.startswith(IGNORABLE_MISSING or ('\0',))]
+    unexpected = [k for k in result.unexpected_keys if not k.startswith(IGNORABLE_UNEXPECTED)]
+    if missing or unexpected:
+        show = lambda ks: ', '.join(ks[:8]) + (' ... (%d in all)' % len(ks) if len(ks) > 8 else '')
+        raise RuntimeError('checkpoint does not match this build - it would run on partly random weights.\n  missing (%d): %s\n  unexpected (%d): %s'
+                           % (len(missing), show(missing), len(unexpected), show(unexpected)))
 
 
 # ---------------------------------------------------------------------- released configurations (configs/base.yaml, base_v2.yaml)

@@ -96,8 +96,11 @@ class SceneRunner:
     Views may have different shapes (landscape or portrait, native orientation): they are batched per shape group
     (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
-    def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None):
+    def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None,
+                 amp=None):
         self.b, self.V, self.classes = backend, V, classes
+        self.amp = amp                # False | 'bf16' | 'fp16' (reference utils.py:206-215): 16-bit format of this runner, fixed for its lifetime
+        self._refs = None             # packed weights / tables the captured graphs point into (kept alive with the runner)
         self.rank, self.world, self.group = rank, world, group
         if V < 2:
             # the memory build starts from a PAIR of views (schedule [2,1,1,...], panst3r.py:35-39,65-70; the reference's helper
@@ -236,6 +239,17 @@ class SceneRunner:
     def _eager(self):
         self.stage1(); self.gather1(); self.stage2(); self.gather2(); self.stage3()
 
+    def set_images(self, images):
+        """Load a new scene of the SAME shapes / schedule into the static input buffers (the captured graphs read them in place).
+        images: {view_id: [3,H,W] tensor} or a list indexed by view id; only this rank's views are read."""
+        for g in self.groups:
+            for r, j in enumerate(g.idx):
+                vid = self.order[self.mine[j]]
+                im = images[vid]
+                if tuple(im.shape[-2:]) != (g.H, g.W):
+                    raise ValueError('view %d: shape %s does not match the runner (%d, %d)' % (vid, tuple(im.shape[-2:]), g.H, g.W))
+                g.imgs[r].copy_(im, non_blocking=True)
+
     def _capture(self):
         self._eager()                              # warm-up: packs weights, builds tables, fills allocator pools
         torch.cuda.synchronize()
@@ -251,40 +265,48 @@ class SceneRunner:
             if gather is not None:
                 gather()
         torch.cuda.synchronize()
+        if hasattr(self.b, 'pack_refs'):
+            self._refs = self.b.pack_refs()      # the graphs hold raw pointers into these packs: they must outlive a later load_state_dict
 
     @torch.no_grad()
-    def run(self, outdevice=None, eager=False, serial=None):
+    def run(self, outdevice=None, eager=False, serial=None, copy=True):
+        """Execute the scene.  copy=True (default) returns outputs the caller owns; copy=False returns VIEWS into the runner's
+        graph-pool buffers, valid only until the next run() (bench.py, which consumes nothing, uses that)."""
         if serial is not None:
             assert eager or not self.use_graphs or self.graphs is None, 'overlap mode is fixed once the graphs are captured'
             prev, self.serial = self.serial, serial
             try:
-                return self.run(outdevice, eager)
+                return self.run(outdevice, eager, copy=copy)
             finally:
                 self.serial = prev
-        if self.use_graphs and not eager:
-            if self.graphs is None:
-                self._capture()
+        with self.b.precision(self.amp):
+            if self.use_graphs and not eager:
+                if self.graphs is None:
+                    self._capture()
+                else:
+                    self.graphs[0].replay(); self.gather1(); self.graphs[1].replay(); self.gather2(); self.graphs[2].replay()
             else:
-                self.graphs[0].replay(); self.gather1(); self.graphs[1].replay(); self.gather2(); self.graphs[2].replay()
-        else:
-            self._eager()
-        return self.results(outdevice)
+                self._eager()
+        return self.results(outdevice, copy=copy)
 
-    def results(self, outdevice=None):
-        """({view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} of this rank's views, scene dict) after stage 3."""
+    def results(self, outdevice=None, copy=True):
+        """({view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} of this rank's views, scene dict) after stage 3.
+        With captured graphs the outputs live in buffers the next run() overwrites in place: copy=True clones them (moving them to
+        `outdevice` is a copy already)."""
         outq, logits, masks = self.out
+        own = (lambda t: t.clone()) if (copy and self.use_graphs and outdevice is None) else (lambda t: t)
         res = {}
         for j, i in enumerate(self.mine):
             g, r = self.where[j]
             m, pm = masks[j][None], g.pointmaps[r][None]
             if outdevice is not None:
                 m, pm = m.to(outdevice), pm.to(outdevice)
-            res[self.order[i]] = (pm, m)
-        return res, {'pred_logits': logits[None], 'out_queries': outq[:, None]}
+            res[self.order[i]] = (own(pm), own(m))
+        return res, {'pred_logits': own(logits[None]), 'out_queries': own(outq[:, None])}
 
 
 @torch.no_grad()
-def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None, keyframes=None):
+def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None, keyframes=None, amp=None):
     """Run one scene eagerly.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
     Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
     {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W);
@@ -292,7 +314,7 @@ def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=No
     Kc = V if (K is None or K > V) else max(int(K), 2)
     _, order, owner = assign_views(V, Kc, world, keyframes)
     images = {order[i]: get_image(order[i]) for i in range(V) if owner[i] == rank}
-    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes).run(outdevice)
+    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes, amp=amp).run(outdevice)
 
 
 class HipBackend:
@@ -304,8 +326,21 @@ class HipBackend:
         self.mask_dim = model.panoptic_decoder.mask_transformer.mask_dim
         self.De = model.must3r_encoder.embed_dim
 
+    def precision(self, amp):
+        from .model.common import precision
+        return precision(amp)
+
+    def pack_refs(self):
+        from .model.common import HipModule
+        refs = []
+        for m in self.m.children():
+            if isinstance(m, HipModule):
+                refs.extend(m.pack_refs())
+        return refs
+
     def alloc_cat(self, rows, device):
-        return torch.empty(rows, self.m._cat_width(), dtype=torch.bfloat16, device=device)
+        from .model.common import adt
+        return torch.empty(rows, self.m._cat_width(), dtype=adt(), device=device)
 
     def encode_enc(self, imgs, cat_rows):
         self.m.encode_views(imgs, cat_rows, dino=False)
@@ -339,7 +374,7 @@ class HipBackend:
     def attn_feats(self, mf, k_local, grid):
         mt = self.m.panoptic_decoder.mask_transformer
         if k_local == 0:
-            return torch.zeros(0, mt.mask_dim, dtype=torch.bfloat16, device=mf.device)
+            return torch.zeros(0, mt.mask_dim, dtype=mf.dtype, device=mf.device)
         return mt.attn_feats(mf[:k_local], grid)
 
     def decode(self, fpn_kf, fm_kf, K, grids, classes, portrait):

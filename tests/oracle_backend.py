@@ -10,6 +10,10 @@ import torch.nn.functional as F
 
 
 class OracleBackend:
+    def precision(self, amp):
+        import contextlib
+        return contextlib.nullcontext()
+
     def __init__(self, model):
         self.m = model
         self.patch_size = model.must3r_encoder.patch_size

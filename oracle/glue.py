@@ -1,4 +1,7 @@
-"""Host-side glue mirroring the reference's `panst3r/utils.py` interface (same names, argument meaning, errors).
+"""TEST INFRASTRUCTURE (oracle/): restatement of the reference's host-side glue `panst3r/utils.py` (same names, argument meaning, errors).
+The product does not import this: the scene runner (panst3r_amd/scene.py) batches views per shape group itself; these functions pin the
+reference semantics the runner must reproduce (chunking, portrait transposes, unstacking) against reference-generated goldens.
+
 
   batched_map            reference utils.py:90-196   chunk along a flattened dim, call fn, concatenate, unflatten
   transpose_to_landscape reference utils.py:8-61     run a head per orientation, swap portrait results back

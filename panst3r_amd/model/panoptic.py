@@ -386,7 +386,7 @@ class MaskTransformer(HipModule):
                     lang=Packed(self.lang_embed.weight, self.lang_embed.bias, device),
                     me=[Packed(l.weight, l.bias, device) for l in self.mask_embed.layers],
                     # the same MLP for split-precision evaluation: weights [W_hi | W_lo | W_hi] bf16, fp32 bias
-                    me3=[(hip.pack_split3(l.weight).to(device), f32(l.bias, device)) for l in self.mask_embed.layers],
+                    me3=[(hip.pack_split3(l.weight, adt()).to(device), f32(l.bias, device)) for l in self.mask_embed.layers],
                     scale=float(self.cls_logit_scale.detach().exp()), pe={})
 
     def _pe(self, pk, h, w, portrait, device):

@@ -9,6 +9,7 @@ import torch
 
 from conftest import rel_l2
 import tiny
+from panst3r_amd.model.common import adt
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -76,7 +77,7 @@ def test_panoptic_decoder(pair):
         # per-module: features (mixer + upscaler) in the reference layouts
         cat = torch.cat(feats, -1)
         fo, mo = o.panoptic_decoder.features(cat, imgs, pos, ts, max_bs=1)
-        fh, mh = h.panoptic_decoder.features_tokens(cat.reshape(n * T, -1).to(torch.bfloat16).to(DEV), imgs[0].to(DEV), n, 4, 6)
+        fh, mh = h.panoptic_decoder.features_tokens(cat.reshape(n * T, -1).to(adt()).to(DEV), imgs[0].to(DEV), n, 4, 6)
     assert rel_l2(fh.float().cpu().reshape(n, 4, 6, -1).permute(0, 3, 1, 2), fo[0]) < 2e-2
     assert rel_l2(mh.float().cpu().permute(0, 3, 1, 2), mo[0]) < 2.5e-2
     assert rel_l2(rh['out_queries'].cpu(), ro['out_queries']) < 3e-2

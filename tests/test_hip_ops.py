@@ -564,7 +564,7 @@ def test_split3_gemm_is_near_fp32():
     hi, hi2, lo = x3[:, :K].float().cpu(), x3[:, K:2 * K].float().cpu(), x3[:, 2 * K:].float().cpu()
     assert torch.equal(hi, hi2) and torch.equal(hi, x.to(d16()).float())
     assert rel_l2(hi + lo, x) < 2e-5
-    w3 = hip.pack_split3(w).to(dev())
+    w3 = hip.pack_split3(w, d16()).to(dev())
     out = torch.empty(M, N, dtype=torch.float32, device=dev())
     hip.gemm(x3, w3, out, bias=b.to(dev()))
     ref = x.double() @ w.double().T + b.double()

@@ -6,7 +6,7 @@ import pytest
 
 from conftest import rel_l2
 from panst3r_amd.synthetic import fill_module_
-from panst3r_amd import utils as U
+from oracle import glue as U
 from oracle import panoptic as OP
 from oracle import dino as OD
 

@@ -3,6 +3,7 @@
 
 Run:  python tests/golden/make_golden.py          (needs /root/reference; never runs on the GPU box)
       python tests/golden/make_golden.py retrieval   (G8, keyframes by retrieval: separate invocation, different stubs)
+      python tests/golden/make_golden.py g2          (G2, FULL-DIM MaskTransformer: strided output samples + norms; inputs by seed)
 
 Recipe: `import panst3r` fails because must3r/croco/dust3r are not installed, so the
 reference-owned files are imported through bare package stubs, and the five croco/must3r symbols they need
@@ -209,6 +210,51 @@ def main():
     golden_postprocess(R)
 
 
+G2_CASES = {   # tag -> (weight seed, sharp, views, token grid, classes); shared with tests/test_hip_fullsize.py
+    'plain': dict(seed=12, sharp=1.0, n=3, h=6, w=8, ncls=20),
+    'sharp': dict(seed=15, sharp=8.0, n=2, h=6, w=8, ncls=20),
+}
+
+
+def g2_inputs(c):
+    """Inputs of a G2 case from seeds (nothing but the seeds is stored): FPN tokens [1,n,768,h,w], mask features [1,n,384,8h,8w],
+    true shapes, unit-norm class embeddings, and one extra view for the heads-only path."""
+    n, h, w = c['n'], c['h'], c['w']
+    fpn = rnd(200 + c['seed'], 1, n, 768, h, w)
+    mf = rnd(210 + c['seed'], 1, n, 384, 8 * h, 8 * w)
+    ts = torch.tensor([[[16 * h, 16 * w]] * n])
+    cls = torch.nn.functional.normalize(rnd(220 + c['seed'], c['ncls'], 768), dim=-1)
+    mf_extra = rnd(230 + c['seed'], 1, 1, 384, 8 * h, 8 * w)
+    return fpn, mf, ts, cls, mf_extra
+
+
+G2_QSTRIDE, G2_PSTRIDE = 7, 5
+
+
+@torch.no_grad()
+def golden_g2():
+    """G2: the reference's full-dimension MaskTransformer (hidden 768, 200 queries, mask_dim 384, 8 heads, 6 layers,
+    ff 2048: configs/base_v2.yaml:17-23) run by its OWN code (mask_transformer.py:121-288) on seeded inputs; strided samples of the
+    mask logits + norms, all class logits and queries are kept.  Pins the full-size masked cross-attention / einsum path
+    independently of the oracle restatement; weights by panst3r_amd.synthetic.fill_module_ (plain and the 'sharp' set)."""
+    from panst3r_amd.synthetic import fill_module_
+    R = import_reference()
+    MT = R['mask_transformer']
+    for tag, c in G2_CASES.items():
+        m = MT.MaskTransformer([768], 768, 2048, 384, 200, 8, 6, lang_dim=768, num_feature_levels=1, landscape_only=True).eval()
+        fill_module_(m, seed=c['seed'], sharp=c['sharp'])
+        fpn, mf, ts, cls, mf_extra = g2_inputs(c)
+        out = m([fpn], mf, ts, cls)
+        heads = m.forward_prediction_heads(out['out_queries'], mf_extra, cls)
+        pm = out['pred_masks'][0]                          # [n, Q, H/2, W/2]
+        flat = pm.flatten(2)
+        save('mask_transformer_full_%s' % tag, pred_logits=npy(out['pred_logits']), out_queries=npy(out['out_queries']),
+             mask_samples=npy(flat[:, ::G2_QSTRIDE, ::G2_PSTRIDE]), mask_norm=npy(flat.norm(dim=-1)),
+             mask_pos_frac=npy((flat > 0).float().mean(-1)),
+             heads_logits=npy(heads[0]), heads_samples=npy(heads[1][0].flatten(2)[:, ::G2_QSTRIDE, ::G2_PSTRIDE]),
+             heads_norm=npy(heads[1][0].flatten(2).norm(dim=-1)))
+
+
 def golden_postprocess(R):
     """G6: panoptic_inference_v2 (engine/postprocess.py:14-130) on fixed logits.  The function
     overwrites its mask list in place (:19-21), so the inputs are saved from clones taken before the call."""
@@ -306,6 +352,10 @@ def golden_retrieval():
         print(tag, 'anchors', state['anchors'].tolist(), '-> keyframes', [int(k) for k in kf])
     save('keyframes_retrieval', **out)
 
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'g2':
+    golden_g2()
+    sys.exit(0)
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'retrieval':         # G8 only (separate process: it replaces the package stubs)

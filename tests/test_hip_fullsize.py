@@ -1,39 +1,128 @@
-"""FULL-SIZE parity of the HIP path (ViT-L/16 encoder, DINOv2-L, 12-layer MUSt3R decoder, v2 mixer + LoftUp, 200 queries) against
-the fp32 CPU oracle with the same synthetic weights: 2 views / 2 keyframes at 384x512 -- the sample bench.py's cpu_baseline
-leg times, reused here through the same helpers.  The other -m gpu tests use tiny configurations.
+"""FULL-SIZE parity of the HIP path (ViT-L/16 encoder, DINOv2-L, 12-layer MUSt3R decoder, v1 pixel-shuffle / v2 mixer + LoftUp,
+200 queries) against the fp32 CPU oracle with the same synthetic weights at 384x512, through the helpers bench.py's cpu_baseline leg
+uses.  The other -m gpu tests use tiny configurations.
 
-Tolerances are the ones SURVEY 8(d) states for bf16 MFMA vs the fp32 oracle.  Four of the five hold; the mask sign agreement
-(>= 99.5 %) does not at full size (99.3 % measured) and is kept as an explicit xfail, not relaxed."""
+Tolerances: the five SURVEY 8(d) states for the 16-bit MFMA path vs the fp32 oracle (bench.TOLERANCE): pointmaps rel-L2 <= 2e-2, mask
+logits rel-L2 <= 3e-2 AND sign agreement >= 99.5 %, class logits abs <= 0.05, out_queries rel-L2 <= 2e-2.  They are asserted, unrelaxed,
+for the shipped default format (f16 operands, amp='fp16' / amp=False) on
+  * 2 views / 2 keyframes (v2)                       -- the bench.py parity sample,
+  * 5 views / 3 keyframes, v1 AND v2                 -- heads-only (non-keyframe) views, a real memory bank, split-K attention,
+  * 3 views / 2 keyframes with the "sharp" weight set -- QK weights x8, softmax far from uniform,
+and against reference-GENERATED goldens for the full-dimension MaskTransformer (G2).
+amp='bf16' (the range-safe fallback: same speed, 3 fewer mantissa bits) meets four of the five; its sign agreement is 99.3 % on the
+zero-centred random-init logits (rel-L2 2.1e-2 -> ~0.7 % flips), asserted at the level it holds so a regression shows."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def build_full(variant, sharp=1.0):
+    from panst3r_amd import hip
+    from panst3r_amd.panst3r import CONFIG_V1, CONFIG_V2, build_from_config
+    from panst3r_amd.synthetic import fill_module_, synth_class_embeddings
+    hip.lib()
+    model = build_from_config(CONFIG_V2 if variant == 'v2' else CONFIG_V1).eval()
+    fill_module_(model, seed=1, sharp=sharp)
+    names, emb = synth_class_embeddings(100)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
+    model.to(torch.device(DEV))
+    return model, state, names, emb
 
 
 @pytest.fixture(scope='module')
 def full():
     """(model on the GPU, CPU copy of its weights, class names, class embeddings): full-size v2 with the synthetic fill."""
-    from panst3r_amd import hip
-    from panst3r_amd.panst3r import CONFIG_V2, build_from_config
-    from panst3r_amd.synthetic import fill_module_, synth_class_embeddings
-    hip.lib()
-    model = build_from_config(CONFIG_V2).eval()
-    fill_module_(model, seed=1)
-    names, emb = synth_class_embeddings(100)
-    state = {k: v.clone() for k, v in model.state_dict().items()}
-    model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
-    model.to(torch.device('cuda:0'))
-    return model, state, names, emb
+    return build_full('v2')
 
 
-@pytest.fixture(scope='module')
-def parity(full):
+def scene_parity(built, variant, V, K, amps=('fp16',)):
     import bench
-    model, state, names, emb = full
-    dev = torch.device('cuda:0')
-    _, ref, imgs, ts = bench.cpu_baseline('v2', 384, 512, state, names, emb, bench.usable_cores())
-    with torch.no_grad():
-        return bench.full_size_parity(model, dev, ref, imgs, ts, names)
+    model, state, names, emb = built
+    _, ref, imgs, ts = bench.cpu_baseline(variant, 384, 512, state, names, emb, bench.usable_cores(), V=V, K=K)
+    return {amp: bench.full_size_parity(model, torch.device(DEV), ref, imgs, ts, names, amp=amp, K=K) for amp in amps}
+
+
+def assert_within(par):
+    t = par['tolerance']
+    assert par['pointmaps_rel_l2'] <= t['pointmaps_rel_l2'], par
+    assert par['mask_logits_rel_l2'] <= t['mask_logits_rel_l2'], par
+    assert par['mask_sign_agreement'] >= t['mask_sign_agreement'], par
+    assert par['class_logits_max_abs'] <= t['class_logits_max_abs'], par
+    assert par['out_queries_rel_l2'] <= t['out_queries_rel_l2'], par
+    assert par['within_tolerance']
+
+
+def test_full_size_outputs_within_stated_tolerance(full):
+    """bench.py's parity sample (2 views / 2 keyframes, v2) in both formats."""
+    par = scene_parity(full, 'v2', 2, 2, amps=('fp16', 'bf16'))
+    assert_within(par['fp16'])
+    b, t = par['bf16'], par['bf16']['tolerance']
+    assert b['pointmaps_rel_l2'] <= t['pointmaps_rel_l2'] and b['mask_logits_rel_l2'] <= t['mask_logits_rel_l2'], b
+    assert b['class_logits_max_abs'] <= t['class_logits_max_abs'] and b['out_queries_rel_l2'] <= t['out_queries_rel_l2'], b
+    assert b['mask_sign_agreement'] >= 0.992, b          # bf16 fallback: measured 99.30 %, i.e. BELOW the 99.5 % the default format meets
+
+
+@pytest.mark.parametrize('variant', ['v1', 'v2'])
+def test_full_size_5_views_3_keyframes(variant, full):
+    """V > K: two views are rendered heads-only against a 3-keyframe memory bank (split-K cross-attention in the build,
+    12 x 2304-key memory attention in the render), v1 = BASELINE configs[1]'s variant, v2 = configs[2..4]'s."""
+    built = full if variant == 'v2' else build_full('v1')
+    assert_within(scene_parity(built, variant, 5, 3)['fp16'])
+
+
+def test_full_size_sharp_weight_set():
+    """SURVEY 8(d) second weight set: QK weights x8 so that softmax is far from uniform (errors in the scores are amplified)."""
+    built = build_full('v2', sharp=8.0)
+    assert_within(scene_parity(built, 'v2', 3, 2)['fp16'])
+
+
+@pytest.mark.parametrize('tag', ['plain', 'sharp'])
+def test_full_dim_mask_transformer_vs_reference_golden(tag):
+    """G2: the HIP query decoder + prediction heads at FULL dimension (hidden 768, 200 queries, mask_dim 384, 8 heads of 96,
+    6 layers) against outputs of the reference's own MaskTransformer code (tests/golden/make_golden.py g2): all class logits and
+    queries, strided samples + norms of the mask logits, and the heads-only path -- independent of the oracle restatement."""
+    import importlib.util
+    from panst3r_amd.model import MaskTransformer
+    from panst3r_amd.model.common import adt, precision
+    from panst3r_amd.synthetic import fill_module_
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location('make_golden', os.path.join(here, 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)                      # top level only defines functions / constants; nothing reads /root/reference here
+    c = mg.G2_CASES[tag]
+    z = np.load(os.path.join(here, 'golden', 'mask_transformer_full_%s.npz' % tag))
+    fpn, mf, ts, cls, mf_extra = mg.g2_inputs(c)
+    n, h, w = c['n'], c['h'], c['w']
+    m = MaskTransformer([768], 768, 2048, 384, 200, 8, 6, lang_dim=768, num_feature_levels=1, landscape_only=True).eval()
+    fill_module_(m, seed=c['seed'], sharp=c['sharp'])
+    m.to(DEV)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    with torch.no_grad(), precision('fp16'):
+        tok = fpn[0].flatten(2).permute(0, 2, 1).reshape(n * h * w, 768).to(adt()).to(DEV).contiguous()        # [n*T, d] token-major
+        mfp = mf[0].permute(0, 2, 3, 1).to(adt()).to(DEV).contiguous()                                           # [n, Hm, Wm, C] pixel-major
+        cls16 = cls.to(adt()).to(DEV).contiguous()
+        outq, hs = m.decode_tokens(tok, m.attn_feats(mfp, (h, w)), [(h, w)] * n, cls16, [False] * n)
+        masks = torch.stack([m.masks_for(hs.embed, mfp[i]) for i in range(n)]).flatten(2).cpu()
+        hs2 = m.head_state(torch.from_numpy(z['out_queries']).reshape(200, 768).to(DEV), cls16)
+        hm = m.masks_for(hs2.embed, mf_extra[0, 0].permute(1, 2, 0).to(adt()).to(DEV).contiguous()).flatten(1)[None].cpu()
+    assert rel(outq.cpu(), torch.from_numpy(z['out_queries']).reshape(200, 768)) <= 2e-2
+    assert float((hs.logits.cpu() - torch.from_numpy(z['pred_logits'])[0]).abs().max()) <= 0.05
+    ref_s = torch.from_numpy(z['mask_samples'])
+    got_s = masks[:, ::mg.G2_QSTRIDE, ::mg.G2_PSTRIDE]
+    assert rel(got_s, ref_s) <= 3e-2
+    assert float(((got_s > 0) == (ref_s > 0)).float().mean()) >= 0.995
+    assert rel(masks.norm(dim=-1), torch.from_numpy(z['mask_norm'])) <= 1e-2
+    assert float(((masks > 0).float().mean(-1) - torch.from_numpy(z['mask_pos_frac'])).abs().max()) <= 0.01
+    assert float((hs2.logits.cpu() - torch.from_numpy(z['heads_logits'])[0]).abs().max()) <= 0.05
+    ref_h = torch.from_numpy(z['heads_samples'])
+    got_h = hm[:, ::mg.G2_QSTRIDE, ::mg.G2_PSTRIDE]
+    assert rel(got_h, ref_h) <= 3e-2 and float(((got_h > 0) == (ref_h > 0)).float().mean()) >= 0.995
 
 
 def test_full_size_graph_replay_equals_eager(full):
@@ -57,21 +146,6 @@ def test_full_size_graph_replay_equals_eager(full):
         assert torch.equal(s['out_queries'], q), kw
         for k in range(V):
             assert torch.equal(r[k][0], ref[k][0]) and torch.equal(r[k][1], ref[k][1]), (kw, k)
-
-
-def test_full_size_outputs_within_stated_tolerance(parity):
-    t = parity['tolerance']
-    assert parity['pointmaps_rel_l2'] <= t['pointmaps_rel_l2'], parity
-    assert parity['mask_logits_rel_l2'] <= t['mask_logits_rel_l2'], parity
-    assert parity['class_logits_max_abs'] <= t['class_logits_max_abs'], parity
-    assert parity['out_queries_rel_l2'] <= t['out_queries_rel_l2'], parity
-    assert parity['mask_sign_agreement'] >= 0.985, parity          # floor actually held; the stated 99.5 % is the xfail below
-
-
-@pytest.mark.xfail(reason='known gap: 99.3 % measured vs the 99.5 % of SURVEY 8(d); follows from the ~2e-2 rel-L2 of zero-centred '
-                          'random-init mask logits (DESIGN.md section 6)', strict=False)
-def test_full_size_mask_sign_agreement_meets_survey_criterion(parity):
-    assert parity['mask_sign_agreement'] >= parity['tolerance']['mask_sign_agreement'], parity
 
 
 def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, keyframes=None):

@@ -1,7 +1,7 @@
 """Module-level and end-to-end parity of the HIP path against the fp32 CPU oracle (same seeded weights and inputs).
 
-Tolerances (bf16 MFMA / fp32 accumulate vs fp32 oracle): rel-L2 <= 2e-2 on tokens / pointmaps / queries,
-<= 3e-2 on mask logits with >= 99 % sign agreement, class logits abs <= 0.05.
+Tolerances = SURVEY 8(d) for the 16-bit MFMA path (default format f16, fp32 accumulate) vs the fp32 oracle: rel-L2 <= 2e-2 on tokens /
+pointmaps / queries, <= 3e-2 on mask logits with >= 99.5 % sign agreement, class logits abs <= 0.05.
 """
 import pytest
 import numpy as np
@@ -79,12 +79,12 @@ def test_panoptic_decoder(pair):
         fo, mo = o.panoptic_decoder.features(cat, imgs, pos, ts, max_bs=1)
         fh, mh = h.panoptic_decoder.features_tokens(cat.reshape(n * T, -1).to(adt()).to(DEV), imgs[0].to(DEV), n, 4, 6)
     assert rel_l2(fh.float().cpu().reshape(n, 4, 6, -1).permute(0, 3, 1, 2), fo[0]) < 2e-2
-    assert rel_l2(mh.float().cpu().permute(0, 3, 1, 2), mo[0]) < 2.5e-2
-    assert rel_l2(rh['out_queries'].cpu(), ro['out_queries']) < 3e-2
+    assert rel_l2(mh.float().cpu().permute(0, 3, 1, 2), mo[0]) < 2e-2
+    assert rel_l2(rh['out_queries'].cpu(), ro['out_queries']) < 2e-2
     assert float((rh['pred_logits'].cpu() - ro['pred_logits']).abs().max()) < 0.05
     mk_h, mk_o = rh['pred_masks'].cpu(), ro['pred_masks']
-    assert rel_l2(mk_h, mk_o) < 4e-2
-    assert float(((mk_h > 0) == (mk_o > 0)).float().mean()) > 0.99
+    assert rel_l2(mk_h, mk_o) < 3e-2
+    assert float(((mk_h > 0) == (mk_o > 0)).float().mean()) >= 0.995
     # heads-only path with the oracle's queries
     with torch.no_grad():
         r2o = o.panoptic_decoder(feats, imgs, pos, ts, tiny.NAMES, max_bs=1, memory_queries=ro['out_queries'])
@@ -105,13 +105,13 @@ def test_scene_end_to_end(pair, V, K):
     assert pan_h['pred_masks'][0].shape == (1, 24, H // 2, W // 2)
     for a, b in zip(pm_h, pm_o):
         assert rel_l2(a.cpu(), b) < 2e-2
-    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 4e-2
-    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.08
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 2e-2
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.05
     agree = []
     for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
-        assert rel_l2(a.cpu(), b) < 6e-2
+        assert rel_l2(a.cpu(), b) < 3e-2
         agree.append(float(((a.cpu() > 0) == (b > 0)).float().mean()))
-    assert min(agree) > 0.985
+    assert min(agree) >= 0.995
 
 
 def test_scene_keyframes_by_retrieval(pair):
@@ -136,9 +136,9 @@ def test_scene_keyframes_by_retrieval(pair):
     pm_h, pan_h = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K, use_retrieval=True, sim_matrix=sim)
     for a, b in zip(pm_h, pm_o):
         assert rel_l2(a.cpu(), b) < 2e-2
-    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 4e-2
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 2e-2
     for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
-        assert rel_l2(a.cpu(), b) < 6e-2
+        assert rel_l2(a.cpu(), b) < 3e-2
     runner = h.scene_runner({i: im.to(DEV) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, keyframes=kf, use_graphs=True)
     assert runner.keyframes == kf and runner.order[:K] == kf
     runner.run()
@@ -197,8 +197,8 @@ def test_scene_224_padded_token_layout(pair):
     assert pm_h.shape == (1, V, H, W, 7) and pan_h['pred_masks'].shape == (1, V, 24, H // 2, W // 2)
     for i in range(V):
         assert rel_l2(pm_h[0, i].cpu(), pm_o[i][0]) < 2e-2
-        assert rel_l2(pan_h['pred_masks'][0, i].cpu(), pan_o['pred_masks'][i][0]) < 6e-2
-    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.08
+        assert rel_l2(pan_h['pred_masks'][0, i].cpu(), pan_o['pred_masks'][i][0]) < 3e-2
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.05
 
 
 @pytest.mark.parametrize('K', [3, 5])
@@ -214,8 +214,8 @@ def test_scene_multi_aspect_ratio(pair, K):
     for i, (a, b) in enumerate(shapes):
         assert pm_h[i].shape == (1, a, b, 7) and pan_h['pred_masks'][i].shape == (1, 24, a // 2, b // 2)
         assert rel_l2(pm_h[i].cpu(), pm_o[i]) < 2e-2
-        assert rel_l2(pan_h['pred_masks'][i].cpu(), pan_o['pred_masks'][i]) < 6e-2
-    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 4e-2
+        assert rel_l2(pan_h['pred_masks'][i].cpu(), pan_o['pred_masks'][i]) < 3e-2
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 2e-2
 
 
 @pytest.mark.parametrize('K', [2, 5])
@@ -232,9 +232,9 @@ def test_scene_portrait_views(pair, K):
         assert pm_h[i].shape == pm_o[i].shape == (1, a, b, 7)
         assert pan_h['pred_masks'][i].shape == pan_o['pred_masks'][i].shape
         assert rel_l2(pm_h[i].cpu(), pm_o[i]) < 2e-2
-        assert rel_l2(pan_h['pred_masks'][i].cpu(), pan_o['pred_masks'][i]) < 6e-2
-    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 4e-2
-    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.08
+        assert rel_l2(pan_h['pred_masks'][i].cpu(), pan_o['pred_masks'][i]) < 3e-2
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 2e-2
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.05
 
 
 def test_panoptic_decoder_portrait(pair):
@@ -250,5 +250,5 @@ def test_panoptic_decoder_portrait(pair):
         ro = o.panoptic_decoder(feats, imgs, pos, ts, tiny.NAMES, max_bs=1)
         rh = h.panoptic_decoder(tuple(f.to(DEV) for f in feats), imgs.to(DEV), pos.to(DEV), ts, tiny.NAMES, max_bs=1)
     assert rh['pred_masks'].shape == ro['pred_masks'].shape
-    assert rel_l2(rh['out_queries'].cpu(), ro['out_queries']) < 3e-2
-    assert rel_l2(rh['pred_masks'].cpu(), ro['pred_masks']) < 4e-2
+    assert rel_l2(rh['out_queries'].cpu(), ro['out_queries']) < 2e-2
+    assert rel_l2(rh['pred_masks'].cpu(), ro['pred_masks']) < 3e-2

@@ -179,3 +179,29 @@ def test_postprocess_v2(golden, tag):
         assert torch.equal(a, b)
     for a, b in zip(res['conf'], g.lst('conf')):
         assert float((a - b).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('tag', ['plain', 'sharp'])
+@torch.no_grad()
+def test_mask_transformer_full_dim(tag):
+    """G2: the oracle's MaskTransformer at FULL dimension (hidden 768, 200 queries, mask_dim 384, 6 layers, plain and sharp weights)
+    against strided samples / norms produced by the reference's own code (make_golden.py g2; inputs regenerated from seeds)."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location('make_golden', os.path.join(here, 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    c = mg.G2_CASES[tag]
+    z = np.load(os.path.join(here, 'golden', 'mask_transformer_full_%s.npz' % tag))
+    fpn, mf, ts, cls, mf_extra = mg.g2_inputs(c)
+    m = OP.MaskTransformer([768], 768, 2048, 384, 200, 8, 6, lang_dim=768, num_feature_levels=1, landscape_only=True).eval()
+    fill_module_(m, seed=c['seed'], sharp=c['sharp'])
+    out = m([fpn], mf, ts, cls)
+    close(out['pred_logits'], torch.from_numpy(z['pred_logits']), 5e-5)
+    close(out['out_queries'], torch.from_numpy(z['out_queries']), 5e-5)
+    flat = out['pred_masks'][0].flatten(2)
+    close(flat[:, ::mg.G2_QSTRIDE, ::mg.G2_PSTRIDE], torch.from_numpy(z['mask_samples']), 5e-5)
+    close(flat.norm(dim=-1), torch.from_numpy(z['mask_norm']), 5e-5)
+    heads = m.forward_prediction_heads(torch.from_numpy(z['out_queries']), mf_extra, cls)
+    close(heads[1][0].flatten(2)[:, ::mg.G2_QSTRIDE, ::mg.G2_PSTRIDE], torch.from_numpy(z['heads_samples']), 5e-5)

@@ -72,6 +72,17 @@ typedef struct pst_gemm_params {
   int32_t batch;
   int64_t a_bs, w_bs, c_bs, bias_bs;
   int32_t dtype16;                   /* PST_BF16 / PST_F16: format of A, W, a 16-bit C and a 16-bit residual */
+  /* ---- LayerNorm folded into the GEMMs around it (pre-LN blocks: x += f(LN(x)) ; no stand-alone LayerNorm pass).
+     PRODUCER side (the GEMM that writes the residual stream; plain row-major store, N % 64 == 0):
+       xcopy      16-bit copy of the stored C values [M, N] with leading dim ldxc (C fp32 only; the consumer's A operand), or NULL
+       stats_out  fp32 [M][stats_ld][2]: (sum, sum of squares) of the stored values of row m over the 64 columns [64 g, 64 g + 64),
+                  written at [m][g]; stats_ld >= N / 64.  Deterministic (fixed-order lane reduction, no atomics).  NULL = off.
+     CONSUMER side (ln_stats != NULL): A holds the RAW rows x (the producer's xcopy), W = W0 diag(ln_gamma) and bias = W0 beta + b0
+     were folded at pack time, ln_colsum[n] = sum_k W[n,k] (fp32 sum of the 16-bit-rounded W).  With mean / rstd of row m from the
+     ln_groups partials of ln_stats[m] over K elements:   C[m,n] = epi'( rstd (acc[m,n] - mean ln_colsum[n]) + bias[n] ). */
+  void* xcopy; int64_t ldxc;
+  float* stats_out; int32_t stats_ld;
+  const float* ln_stats; int32_t ln_groups; const float* ln_colsum; float ln_eps;
 } pst_gemm_params;
 
 int pst_gemm(const pst_gemm_params* p, void* stream);
@@ -121,7 +132,11 @@ int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const float* add,
                       int out_fp32, const float* gamma, const float* beta, int rows, int D, float eps,
                       int grp_in, int grp_out, int grp_off, void* stream);
 
-/* strided batch of the above: problem i uses x + i*x_bs, y + i*y_bs, gamma/beta + i*w_bs (elements); `add` (optional) is shared.
+/* rowstats: the producer-side outputs of the LayerNorm fold for a stream that no GEMM produced (first block of a stack): x fp32 [rows, D]
+ * (D % 64 == 0) -> xcopy 16-bit [rows, D] and stats fp32 [rows][stats_ld][2] = per-row (sum, sum of squares) over each 64-column group. */
+int pst_rowstats(const float* x, int64_t ldx, void* xcopy, int64_t ldxc, float* stats, int stats_ld, int rows, int D, int dtype16, void* stream);
+
+/* strided batch of pst_layernorm_add: problem i uses x + i*x_bs, y + i*y_bs, gamma/beta + i*w_bs (elements); `add` (optional) is shared.
  * One launch for the 12 per-layer `norm_y(h_l + feedback)` of a MUSt3R memory append. */
 int pst_layernorm_add_batch(const void* x, int64_t ldx, int in_fp32, const float* add, int64_t ld_add, void* y, int64_t ldy,
                             int out_fp32, const float* gamma, const float* beta, int rows, int D, float eps,

@@ -140,6 +140,30 @@ __device__ __forceinline__ uint4 rope_chunk(const pst_gemm_params& p, uint4 own,
   return rope_rotate<F16>(own, partner, cs, n);
 }
 
+// ---------------------------------------------------------------- LayerNorm fold (see pst_gemm_params)
+// Consumer prologue: thread t < BM turns the `ln_groups` partial (sum, sumsq) of A row m0 + t into (rstd, -mean * rstd) in LDS.
+__device__ __forceinline__ void ln_fold_prologue(const pst_gemm_params& p, float2* lnst, int tid, int m0, int BM) {
+  if (tid < BM) {
+    const int m = min(m0 + tid, p.M - 1);
+    const float2* st = (const float2*)p.ln_stats + (int64_t)m * p.ln_groups;
+    float s = 0.f, q = 0.f;
+    for (int g = 0; g < p.ln_groups; ++g) { const float2 v = st[g]; s += v.x; q += v.y; }
+    const float inv_d = 1.0f / (float)p.K;
+    const float mean = s * inv_d;
+    const float rstd = rsqrtf(fmaxf(q * inv_d - mean * mean, 0.f) + p.ln_eps);
+    lnst[tid] = make_float2(rstd, -mean * rstd);
+  }
+}
+
+// Producer: (sum, sumsq) of `cnt` fp32 values reduced over the LANES-lane group that holds one row's 64-column group; the group's
+// first lane writes stats_out[row][grp].  Fixed xor-shuffle tree: deterministic.
+template <int LANES>
+__device__ __forceinline__ void ln_fold_stats(const pst_gemm_params& p, float s, float q, int lane_in_row, int64_t orow, int n) {
+#pragma unroll
+  for (int o = 1; o < LANES; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if ((lane_in_row & (LANES - 1)) == 0) *((float2*)p.stats_out + orow * p.stats_ld + (n >> 6)) = make_float2(s, q);
+}
+
 // Bijective XCD-aware remap: hardware places block b on XCD b%8; give each XCD a contiguous chunk of tiles.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;

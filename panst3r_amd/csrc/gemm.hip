@@ -100,14 +100,29 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
         f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
         val = *(uint4*)&f;
       }
+      float ssum = 0.f, ssq = 0.f;                          // LayerNorm fold: statistics of the values as stored
       if (!F32 && resb) {                                   // add in fp32, one rounding
         uint32_t* w32 = (uint32_t*)&val;
         const uint32_t* q32 = (const uint32_t*)&rq[F32 ? 0 : it];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          w32[q] = H16<F16>::pack(H16<F16>::lo(w32[q]) + H16<F16>::lo(q32[q]), H16<F16>::hi(w32[q]) + H16<F16>::hi(q32[q]));
+        for (int q = 0; q < 4; ++q) {
+          const float lo = H16<F16>::lo(w32[q]) + H16<F16>::lo(q32[q]), hi = H16<F16>::hi(w32[q]) + H16<F16>::hi(q32[q]);
+          ssum += lo + hi; ssq += lo * lo + hi * hi;
+          w32[q] = H16<F16>::pack(lo, hi);
+        }
+      } else if (!F32 && p.stats_out) {
+        const uint32_t* w32 = (const uint32_t*)&val;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float lo = H16<F16>::lo(w32[q]), hi = H16<F16>::hi(w32[q]); ssum += lo + hi; ssq += lo * lo + hi * hi; }
       }
       *(uint4*)((char*)p.C + ((int64_t)orow[it] * p.ldc + n) * (F32 ? 4 : 2)) = val;
+      if (F32) {
+        const float4 f = *(const float4*)&val;
+        if (p.xcopy) *(uint2*)((bf16_t*)p.xcopy + (int64_t)orow[it] * p.ldxc + n) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
+        if (p.stats_out) ln_fold_stats<16>(p, f.x + f.y + f.z + f.w, f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w, c, orow[it], n);
+      } else if (p.stats_out) {
+        ln_fold_stats<8>(p, ssum, ssq, c, orow[it], n);
+      }
     }
     return;
   }
@@ -137,20 +152,19 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
     const float* rp = (p.res && !p.res_bf16) ? p.res + roff : nullptr;
     const bf16_t* rpb = (p.res && p.res_bf16) ? (const bf16_t*)p.res + roff : nullptr;
     if (F32) {
+      float4 f = *(float4*)&val;
       if (rp) {
         const float4 q = pre ? resv[it] : *(const float4*)rp;
-        float4 f = *(float4*)&val;
         f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
-        *(float4*)((float*)p.C + off) = f;
       } else if (rpb) {
         const uint2 q = *(const uint2*)rpb;
-        float4 f = *(float4*)&val;
         f.x += H16<F16>::lo(q.x); f.y += H16<F16>::hi(q.x);
         f.z += H16<F16>::lo(q.y); f.w += H16<F16>::hi(q.y);
-        *(float4*)((float*)p.C + off) = f;
-      } else {
-        *(uint4*)((float*)p.C + off) = val;
       }
+      *(float4*)((float*)p.C + off) = f;
+      // LayerNorm fold (plain row-major stores only, N % 64 == 0: a 16-lane group = one 64-column group, wholly inside or outside)
+      if (p.xcopy) *(uint2*)((bf16_t*)p.xcopy + (int64_t)orow * p.ldxc + n) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
+      if (p.stats_out) ln_fold_stats<16>(p, f.x + f.y + f.z + f.w, f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w, c, orow, n);
       continue;
     }
     if (rpb) {             // bf16 residual stream (LoftUp blocks): 16-byte load, add in fp32, one rounding
@@ -170,6 +184,13 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
         const float hi = H16<F16>::hi(w32[q]) + ((n + 2 * q + 1 < p.N) ? rp[2 * q + 1] : 0.f);
         w32[q] = H16<F16>::pack(lo, hi);
       }
+    }
+    if (p.stats_out) {        // LayerNorm fold on a 16-bit stream (LoftUp blocks): 8 lanes = one 64-column group
+      const uint32_t* w32 = (const uint32_t*)&val;
+      float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float lo = H16<F16>::lo(w32[q]), hi = H16<F16>::hi(w32[q]); ssum += lo + hi; ssq += lo * lo + hi * hi; }
+      ln_fold_stats<8>(p, ssum, ssq, c, orow, n);
     }
     bf16_t* dst = (bf16_t*)p.C + off;
     // a chunk is 8 columns; N % 4 == 0, so the last chunk of a row may hold only 4 valid columns, and a pixel-shuffle
@@ -289,6 +310,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // LayerNorm fold, consumer side: (rstd, -mean rstd) of the tile's A rows, behind the operand slabs (the C staging of the
+  // epilogue ends exactly there); made visible to every wave by the barriers of the main loop
+  float2* lnst = (float2*)(smem + NST * (BM + BN) * 128);
+  if (p.ln_stats) ln_fold_prologue(p, lnst, tid, m0, BM);
+
   // LDS read offsets: fragment i of a wave lives 16 rows further (same swizzle key), K-half kk flips chunk bit 2
   const int a_row = wr * (16 * FM) + l16, b_row = wc * (16 * FN) + l16;
   const int a_off = a_row * 128 + ((g ^ ((a_row >> 1) & 7)) << 4);
@@ -361,12 +387,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
       const float b = p.bias ? p.bias[n] : 0.f;
       const int mb = m0 + wr * (16 * FM) + g * (4 * FM);
       bf16_t* dst = Ct + (int64_t)n * p.ldc + mb;
+      const float cs = p.ln_stats ? p.ln_colsum[n] : 0.f;
       float v[4 * FM];
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float x = acc[i][j][r] + b;
+          float x = acc[i][j][r];
+          if (p.ln_stats) { const float2 st = lnst[wr * (16 * FM) + g * (4 * FM) + 4 * i + r]; x = x * st.x + st.y * cs; }
+          x += b;
           if (p.act == 1) x = gelu_erf(x); else if (p.act == 2) x = fmaxf(x, 0.f);
           v[4 * i + r] = x;
         }
@@ -398,13 +427,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
   __syncthreads();                                          // every wave is done with its MFMA operand reads
   {
     const int cb = wc * (16 * FN) + g * (4 * FN);           // tile-local first column of the lane's run
-    float4 bias4[FN], gam4[FN];
+    float4 bias4[FN], gam4[FN], cs4[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = min(n0 + cb + 4 * j, p.N - 4);
       bias4[j] = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       gam4[j] = p.gamma ? *(const float4*)(p.gamma + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+      cs4[j] = p.ln_stats ? *(const float4*)(p.ln_colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float2 lns[FM];                                         // read before the C staging below reuses the operand slabs (lnst lies behind them)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) lns[i] = p.ln_stats ? lnst[wr * (16 * FM) + i * 16 + l16] : make_float2(1.f, 0.f);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int r = wr * (16 * FM) + i * 16 + l16;          // tile-local row of this lane
@@ -412,7 +445,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
       const int key = r & (nch - 1);
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+        float v[4] = {fmaf(acc[i][j][0], lns[i].x, fmaf(lns[i].y, cs4[j].x, bias4[j].x)), fmaf(acc[i][j][1], lns[i].x, fmaf(lns[i].y, cs4[j].y, bias4[j].y)),
+                      fmaf(acc[i][j][2], lns[i].x, fmaf(lns[i].y, cs4[j].z, bias4[j].z)), fmaf(acc[i][j][3], lns[i].x, fmaf(lns[i].y, cs4[j].w, bias4[j].w))};
         if (p.act == 1) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
@@ -448,7 +482,7 @@ static int launch_t(const pst_gemm_params& p, hipStream_t s) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
-  const size_t lds = NST * (BM + BN) * 128;
+  const size_t lds = NST * (BM + BN) * 128 + BM * sizeof(float2);      // operand slabs + the LayerNorm-fold row table
   hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS, NST, F16>), dim3(tiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, tiles, tiles_m, tiles_n);
   return check_launch("gemm");
 }
@@ -489,6 +523,13 @@ static int gemm_validate(const pst_gemm_params* pp) {
   }
   if (p.res && (p.ldr % (p.res_bf16 ? 8 : 4))) { set_error("gemm: ldr must be a multiple of 4 (fp32) / 8 (bf16)"); return PST_EINVAL; }
   if (p.res && p.res_bf16 && ((uintptr_t)p.res & 15)) { set_error("gemm: bf16 residual must be 16-byte aligned"); return PST_EINVAL; }
+  if ((p.stats_out || p.xcopy) && (p.N % 64 || p.ps_p || p.trans_out || p.res_mod || p.batch > 1 || (p.stats_out && p.stats_ld < p.N / 64) ||
+                                   (p.xcopy && (!p.out_fp32 || p.ldxc % 4 || ((uintptr_t)p.xcopy & 7))))) {
+    set_error("gemm: LayerNorm-fold producer outputs need a plain row-major store with N%%64==0 (xcopy: fp32 C only)"); return PST_EINVAL;
+  }
+  if (p.ln_stats && (!p.ln_colsum || p.ln_groups <= 0 || p.conv_c || p.batch > 1 || !(p.ln_eps > 0.f))) {
+    set_error("gemm: LayerNorm-fold consumer needs ln_colsum, ln_groups > 0, ln_eps > 0 (no conv / batch mode)"); return PST_EINVAL;
+  }
   if (p.batch > 1 && (p.gamma || p.res || p.conv_c || p.rope_hd || p.ps_p || p.grp_in || p.kernel == 256 || p.batch > 65535 ||
                       (p.a_bs | p.w_bs | p.c_bs) % 8 || p.bias_bs % 4)) {
     set_error("gemm: strided batch supports bias/act/trans_out only, strides multiples of 8 elements (batch=%d)", p.batch); return PST_EINVAL;

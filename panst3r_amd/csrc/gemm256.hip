@@ -85,6 +85,10 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // LayerNorm fold, consumer side: (rstd, -mean rstd) of the 256 A rows of the tile, behind the operand buffers
+  float2* lnst = (float2*)(smem + 2 * BUF_BYTES);
+  if (p.ln_stats) ln_fold_prologue(p, lnst, tid, m0, 256);
+
   bf16x8 af[4][2];        // current A sub-tile: 4 row fragments x 2 K halves
   bf16x8 bfr[2][2][2];    // both B sub-tiles: [n sub-tile][fragment][K half]
 
@@ -154,13 +158,17 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
         const int nn = min(n0 + cb + 4 * j, p.N - 4);
         const float4 bias4 = p.bias ? *(const float4*)(p.bias + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 gam4 = p.gamma ? *(const float4*)(p.gamma + nn) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 cs4 = p.ln_stats ? *(const float4*)(p.ln_colsum + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int r = wm * 128 + i * 16 + l16;             // tile-local row
           const int rr = r - pass * rows_pass;
           char* rowp = smem + rr * pitch;
           const int rkey = rr & (nch - 1);
-          float v[4] = {acc[i][j][0] + bias4.x, acc[i][j][1] + bias4.y, acc[i][j][2] + bias4.z, acc[i][j][3] + bias4.w};
+          // (the row table lies behind the operand buffers, beyond the C staging area: it stays valid through every pass)
+          const float2 st = p.ln_stats ? lnst[r] : make_float2(1.f, 0.f);
+          float v[4] = {fmaf(acc[i][j][0], st.x, fmaf(st.y, cs4.x, bias4.x)), fmaf(acc[i][j][1], st.x, fmaf(st.y, cs4.y, bias4.y)),
+                        fmaf(acc[i][j][2], st.x, fmaf(st.y, cs4.z, bias4.z)), fmaf(acc[i][j][3], st.x, fmaf(st.y, cs4.w, bias4.w))};
           if (p.act == 1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
     const int n = n0 + c * epc;
     // ---- fast path (interior tile, row-major bf16 store without residual: fc1 / fused-RoPE q,k): compile-time
     // chunking, padded-view row remap carried incrementally (one division per thread instead of one per row)
-    if (!f32o && p.ps_p == 0 && p.res_mod == 0 && !p.res && m0 + 256 <= p.M && n0 + 256 <= p.N && (p.ldc & 7) == 0 &&
+    if (!f32o && !p.stats_out && p.ps_p == 0 && p.res_mod == 0 && !p.res && m0 + 256 <= p.M && n0 + 256 <= p.N && (p.ldc & 7) == 0 &&
         ((uintptr_t)p.C & 15) == 0) {
       const int cc = tid & 31, r0 = tid >> 5;                  // 32 chunks per 512-B row, 16 rows per sweep
       const int nn = n0 + cc * 8;
@@ -243,20 +251,19 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
       const float* rp = (p.res && !p.res_bf16) ? p.res + roff : nullptr;
       const bf16_t* rpb = (p.res && p.res_bf16) ? (const bf16_t*)p.res + roff : nullptr;
       if (f32o) {
+        float4 f = *(float4*)&val;
         if (rp) {
           const float4 q = *(const float4*)rp;
-          float4 f = *(float4*)&val;
           f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
-          *(float4*)((float*)p.C + off) = f;
         } else if (rpb) {
           const uint2 q = *(const uint2*)rpb;
-          float4 f = *(float4*)&val;
           f.x += H16<F16>::lo(q.x); f.y += H16<F16>::hi(q.x);
           f.z += H16<F16>::lo(q.y); f.w += H16<F16>::hi(q.y);
-          *(float4*)((float*)p.C + off) = f;
-        } else {
-          *(uint4*)((float*)p.C + off) = val;
         }
+        *(float4*)((float*)p.C + off) = f;
+        // LayerNorm fold, producer side: a row is one wave here (64 chunks of 4 columns), a 64-column group = 16 lanes
+        if (p.xcopy) *(uint2*)((bf16_t*)p.xcopy + (int64_t)orow * p.ldxc + n) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
+        if (p.stats_out) ln_fold_stats<16>(p, f.x + f.y + f.z + f.w, f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w, c, orow, n);
         continue;
       }
       if (rpb) {             // bf16 residual stream (LoftUp blocks): 16-byte load, add in fp32, one rounding
@@ -277,6 +284,13 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
           w32[q] = H16<F16>::pack(lo, hi);
         }
       }
+      if (p.stats_out) {      // LayerNorm fold on a 16-bit stream: 8 lanes = one 64-column group
+        const uint32_t* w32 = (const uint32_t*)&val;
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float lo = H16<F16>::lo(w32[q]), hi = H16<F16>::hi(w32[q]); ssum += lo + hi; ssq += lo * lo + hi * hi; }
+        ln_fold_stats<8>(p, ssum, ssq, c, orow, n);
+      }
       bf16_t* dst = (bf16_t*)p.C + off;
       const bool full = (n + 8 <= p.N) && (p.ps_p == 0 || ((n % seg) + 8 <= seg));
       if (full && ((((uintptr_t)dst) & 15) == 0)) {
@@ -296,17 +310,19 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
   }
 }
 
+constexpr int LDS256 = 2 * BUF_BYTES + 256 * (int)sizeof(float2);      // operand buffers + the LayerNorm-fold row table
+
 int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const int tiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
     attr_set = true;
   }
-  if (p.dtype16 == DT_F16) hipLaunchKernelGGL(gemm256_kernel<true>, dim3(tiles), dim3(512), 2 * BUF_BYTES, s, p, tiles, tiles_m, tiles_n);
-  else hipLaunchKernelGGL(gemm256_kernel<false>, dim3(tiles), dim3(512), 2 * BUF_BYTES, s, p, tiles, tiles_m, tiles_n);
+  if (p.dtype16 == DT_F16) hipLaunchKernelGGL(gemm256_kernel<true>, dim3(tiles), dim3(512), LDS256, s, p, tiles, tiles_m, tiles_n);
+  else hipLaunchKernelGGL(gemm256_kernel<false>, dim3(tiles), dim3(512), LDS256, s, p, tiles, tiles_m, tiles_n);
   return check_launch("gemm256");
 }
 

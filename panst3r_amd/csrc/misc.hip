@@ -106,6 +106,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t l
   }
 }
 
+// ------------------------------------------------------------------ LayerNorm-fold producer outputs of an fp32 stream
+// One 16-lane group per (row, 64-column group): lane = 4 columns.  16-bit copy + (sum, sumsq) of the group (fixed shuffle tree).
+__global__ __launch_bounds__(256) void rowstats_kernel(const float* x, int64_t ldx, bf16_t* xc, int64_t ldxc, float2* stats, int stats_ld,
+                                                       int rows, int D, int tc) {
+  const int groups = D >> 6;
+  const int64_t total = (int64_t)rows * groups * 16;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {   // total % 16 == 0: groups stay whole
+    const int sub = (int)(i & 15);
+    const int64_t rg = i >> 4;
+    const int g = (int)(rg % groups);
+    const int64_t row = rg / groups;
+    const int c = g * 64 + sub * 4;
+    const float4 v = *(const float4*)(x + row * ldx + c);
+    *(uint2*)(xc + row * ldxc + c) = make_uint2(pack2(v.x, v.y, tc), pack2(v.z, v.w, tc));
+    float s = v.x + v.y + v.z + v.w, q = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (sub == 0) stats[row * stats_ld + g] = make_float2(s, q);
+  }
+}
+
 // ------------------------------------------------------------------ split-precision operand: fp32 x -> [x_hi | x_hi | x_lo] bf16
 // x = x_hi + x_lo with x_hi = bf16(x), x_lo = bf16(x - x_hi).  Against weights packed as [W_hi | W_lo | W_hi] one bf16 MFMA GEMM over
 // 3K computes x_hi W_hi + x_hi W_lo + x_lo W_hi ~ x W with ~16 mantissa bits (the lo x lo term is dropped).  Used for the 200-row mask
@@ -362,6 +383,19 @@ extern "C" int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const 
                                  int grp_out, int grp_off, void* stream) {
   if (!add) { set_error("layernorm_add: null addend"); return PST_EINVAL; }
   return launch_layernorm(x, ldx, in_fp32, add, ld_add, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, stream);
+}
+
+extern "C" int pst_rowstats(const float* x, int64_t ldx, void* xcopy, int64_t ldxc, float* stats, int stats_ld, int rows, int D, int dtype16,
+                            void* stream) {
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !x || !xcopy || !stats || rows <= 0 || D <= 0 || D % 64 || ldx % 4 || ldxc % 4 || stats_ld < D / 64 ||
+      ((uintptr_t)x & 15) || ((uintptr_t)xcopy & 7)) {
+    set_error("rowstats: bad argument (D=%d must be a multiple of 64)", D); return PST_EINVAL;
+  }
+  const int64_t total = (int64_t)rows * (D / 64) * 16;
+  int64_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(rowstats_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)xcopy, ldxc, (float2*)stats, stats_ld, rows, D, dtype16);
+  return check_launch("rowstats");
 }
 
 static inline bool bad16(int tc) { return tc != DT_BF16 && tc != DT_F16; }

@@ -25,7 +25,8 @@ class GemmParams(C.Structure):
                 ('grp_in', i32), ('grp_out', i32), ('grp_off', i32),
                 ('ps_p', i32), ('ps_c', i32), ('ps_h', i32), ('ps_w', i32),
                 ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('rope_pos', vp), ('rope_cs', vp), ('rope_hd', i32), ('res_bf16', i32), ('kernel', i32),
-                ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('c_bs', i64), ('bias_bs', i64), ('dtype16', i32)]
+                ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('c_bs', i64), ('bias_bs', i64), ('dtype16', i32),
+                ('xcopy', vp), ('ldxc', i64), ('stats_out', vp), ('stats_ld', i32), ('ln_stats', vp), ('ln_groups', i32), ('ln_colsum', vp), ('ln_eps', f32)]
 
 
 class AttnParams(C.Structure):
@@ -39,7 +40,7 @@ class AttnParams(C.Structure):
 
 
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
-           'pst_layernorm_add_batch', 'pst_split3', 'pst_rope2d',
+           'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize']
@@ -161,8 +162,10 @@ ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 
 
 def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
-         M=None, kernel=0, rope=None, batch=None):
-    """out = epi(a @ w.T).  a [M,K] bf16 (row-major view), w [N,K] bf16, out bf16/fp32 2-D view (or raw buffer for ps)."""
+         M=None, kernel=0, rope=None, batch=None, xcopy=None, stats_out=None, ln=None):
+    """out = epi(a @ w.T).  a [M,K] 16-bit (row-major view), w [N,K] 16-bit, out 16-bit / fp32 2-D view (or raw buffer for ps).
+    LayerNorm fold (include/panst3r_hip.h): producer side `xcopy` (16-bit copy of an fp32 out) and `stats_out` (fp32 [M, N/64, 2]);
+    consumer side `ln` = (stats [M, groups, 2], colsum [N], eps) with `a` the raw rows and `w` / `bias` folded at pack time."""
     _dev(a, *H16); _dev(w, *H16); _dev(out, torch.bfloat16, torch.float16, torch.float32)
     p = GemmParams()
     p.dtype16 = _same16(a, w, out, res)
@@ -203,6 +206,16 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
         p.rope_pos, p.rope_cs, p.rope_hd = _ptr(_dev(rope[0], torch.int32)), _ptr(_dev(rope[1], torch.float32)), 64
     if grp is not None:
         p.grp_in, p.grp_out, p.grp_off = grp
+    if xcopy is not None:
+        p.xcopy, p.ldxc = _ptr(_dev(xcopy, a.dtype)), _rowmajor(xcopy)
+    if stats_out is not None:
+        assert stats_out.dtype == torch.float32 and stats_out.dim() == 3 and stats_out.shape[2] == 2 and stats_out.is_contiguous()
+        p.stats_out, p.stats_ld = _ptr(_dev(stats_out)), stats_out.shape[1]
+    if ln is not None:
+        st, cs, eps = ln
+        assert st.dtype == torch.float32 and st.dim() == 3 and st.shape[2] == 2 and st.is_contiguous() and st.shape[1] * 64 >= K
+        p.ln_stats, p.ln_groups, p.ln_colsum, p.ln_eps = _ptr(_dev(st)), K // 64, _ptr(_dev(cs, torch.float32)), float(eps)
+        assert K % 64 == 0 and st.shape[1] == K // 64, 'LayerNorm fold: the statistics must cover exactly the K columns of A'
     if TIMER is not None:
         name = lib().pst_gemm_variant(C.byref(p))          # the C side names the kernel it dispatches to (no re-derived rule here)
         ev = TIMER.bracket(name.decode() if name else 'gemm?', 2.0 * Mv * N * K * (batch[0] if batch else 1),
@@ -297,6 +310,16 @@ def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None):
                                _tc(out), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)),
                                rows, D, f32(eps), g[0], g[1], g[2], _stream()), 'pst_layernorm')
     return out
+
+
+def rowstats(x, xcopy, stats):
+    """LayerNorm-fold producer outputs for an fp32 stream no GEMM wrote: 16-bit copy + per-row (sum, sumsq) per 64-column group."""
+    _dev(x, torch.float32); _dev(xcopy, *H16); _dev(stats, torch.float32)
+    rows, D = x.shape
+    assert stats.dim() == 3 and stats.shape[2] == 2 and stats.is_contiguous() and stats.shape[1] * 64 >= D
+    _check(lib().pst_rowstats(_ptr(x), i64(_rowmajor(x)), _ptr(xcopy), i64(_rowmajor(xcopy)), _ptr(stats), stats.shape[1], rows, D, _tc(xcopy), _stream()),
+           'pst_rowstats')
+    return xcopy, stats
 
 
 def split3(x, out):

@@ -3,8 +3,8 @@
 uses.  The other -m gpu tests use tiny configurations.
 
 Tolerances: the five SURVEY 8(d) states for the 16-bit MFMA path vs the fp32 oracle (bench.TOLERANCE): pointmaps rel-L2 <= 2e-2, mask
-logits rel-L2 <= 3e-2 AND sign agreement >= 99.5 %, class logits abs <= 0.05, out_queries rel-L2 <= 2e-2.  They are asserted, unrelaxed,
-for the shipped default format (f16 operands, amp='fp16' / amp=False) on
+logits rel-L2 <= 3e-2 AND sign agreement >= 99.5 % of the pixels (all views of the scene pooled), class logits abs <= 0.05, out_queries
+rel-L2 <= 2e-2.  They are asserted, unrelaxed, for the shipped default format (f16 operands, amp='fp16' / amp=False) on
   * 2 views / 2 keyframes (v2)                       -- the bench.py parity sample,
   * 5 views / 3 keyframes, v1 AND v2                 -- heads-only (non-keyframe) views, a real memory bank, split-K attention,
   * 3 views / 2 keyframes with the "sharp" weight set -- QK weights x8, softmax far from uniform,
@@ -41,11 +41,37 @@ def full():
     return build_full('v2')
 
 
-def scene_parity(built, variant, V, K, amps=('fp16',)):
+def scene_parity(built, variant, V, K, amps=('fp16',), want_ref=False):
     import bench
     model, state, names, emb = built
     _, ref, imgs, ts = bench.cpu_baseline(variant, 384, 512, state, names, emb, bench.usable_cores(), V=V, K=K)
-    return {amp: bench.full_size_parity(model, torch.device(DEV), ref, imgs, ts, names, amp=amp, K=K) for amp in amps}
+    par = {amp: bench.full_size_parity(model, torch.device(DEV), ref, imgs, ts, names, amp=amp, K=K) for amp in amps}
+    return (par, ref) if want_ref else par
+
+
+def heads_only_parity(built, V, K, ref, amp='fp16'):
+    """Mask logits of every view computed by the HIP path from ITS mask features but the ORACLE's frozen queries (the reference's
+    heads-only path, panoptic_decoder.py:71 with memory_queries): per-view (rel-L2, sign agreement) against the oracle's masks.  This
+    takes the query decoder - whose thresholded attention masks make a few queries discontinuous functions of their inputs - out of
+    the comparison, so the stated tolerances must hold for EVERY view."""
+    from panst3r_amd.model.common import precision
+    from panst3r_amd.synthetic import synth_image
+    model, _, names, _ = built
+    pm_o, pan_o = ref
+    dev = torch.device(DEV)
+    runner = model.scene_runner({i: synth_image(i, 384, 512).to(dev) for i in range(V)}, V, 384, 512, names, num_keyframes=K, use_graphs=False, amp=amp)
+    with torch.no_grad():
+        runner.run()
+        mt = model.panoptic_decoder.mask_transformer
+        with precision(amp):
+            cls = model.panoptic_decoder.text_encoder.normalized_bf16(names, dev)
+            hs = mt.head_state(pan_o['out_queries'].reshape(-1, mt.hidden_dim).float().to(dev).contiguous(), cls)
+            out = []
+            for j, i in enumerate(runner.mine):
+                g, r = runner.where[j]
+                a, b = mt.masks_for(hs.embed, g.mf[r]).cpu(), pan_o['pred_masks'][runner.order[i]][0]
+                out.append((float((a.double() - b.double()).norm() / b.double().norm()), float(((a > 0) == (b > 0)).float().mean())))
+    return out
 
 
 def assert_within(par):
@@ -73,7 +99,12 @@ def test_full_size_5_views_3_keyframes(variant, full):
     """V > K: two views are rendered heads-only against a 3-keyframe memory bank (split-K cross-attention in the build,
     12 x 2304-key memory attention in the render), v1 = BASELINE configs[1]'s variant, v2 = configs[2..4]'s."""
     built = full if variant == 'v2' else build_full('v1')
-    assert_within(scene_parity(built, variant, 5, 3)['fp16'])
+    par, ref = scene_parity(built, variant, 5, 3, want_ref=True)
+    assert_within(par['fp16'])                                             # scene-level (all views pooled), as stated
+    w = par['fp16']['worst_view']                                          # worst single view: bounded, reported in bench.py's parity object
+    assert w['mask_logits_rel_l2'] <= 4e-2 and w['mask_sign_agreement'] >= 0.992, par
+    for e, agree in heads_only_parity(built, 5, 3, ref):                   # with the query decoder factored out: EVERY view, as stated
+        assert e <= 3e-2 and agree >= 0.995, (e, agree)
 
 
 def test_full_size_sharp_weight_set():

@@ -572,3 +572,64 @@ def test_split3_gemm_is_near_fp32():
     hip.gemm(bf(x).to(dev()), bf(w).to(dev()), plain, bias=b.to(dev()))
     e_split, e_plain = rel_l2(out.cpu(), ref), rel_l2(plain.cpu(), ref)
     assert e_split < 5e-5 and e_plain > 20 * e_split, (e_split, e_plain)
+
+
+@pytest.mark.parametrize('M,N,D,kern', [(300, 256, 128, 0), (768, 1024, 1024, 0), (2000, 2048, 1024, 256), (200, 192, 192, 0), (1000, 768, 384, 128)])
+def test_gemm_layernorm_fold_consumer(M, N, D, kern):
+    """LayerNorm folded into the consuming GEMM: raw 16-bit rows + per-row statistics in, gamma / beta folded into W / bias at pack
+    time, rstd (acc - mean colsum) + bias in the epilogue == LN(x) W^T + b (plain, GELU and transposed stores)."""
+    from panst3r_amd import hip
+    x = rn(800, M, D) * 1.7 + 0.4
+    x[:, 5] += 6.0                                             # an outlier channel, as ViT residual streams have
+    gamma, beta = 1 + 0.2 * rn(801, D), 0.1 * rn(802, D)
+    w, b = rn(803, N, D, scale=D ** -0.5), 0.1 * rn(804, N)
+    eps = 1e-6
+    ref = F.layer_norm(x, (D,), gamma, beta, eps) @ w.T + b
+    xc = torch.empty(M, D, dtype=d16(), device=dev())
+    st = torch.empty(M, D // 64, 2, device=dev())
+    hip.rowstats(x.to(dev()), xc, st)
+    assert torch.equal(xc.cpu(), x.to(d16()))
+    g = x.reshape(M, D // 64, 64)
+    assert rel_l2(st[..., 0].cpu(), g.sum(-1)) < 1e-5 and rel_l2(st[..., 1].cpu(), (g * g).sum(-1)) < 1e-5
+    wf = (w * gamma[None]).to(d16())
+    bfold = (w @ beta + b).to(dev())
+    cs = wf.float().sum(1).to(dev())
+    tol = 1.2e-2 if d16() == torch.bfloat16 else 2e-3
+    out = torch.full((M, N), float('nan'), dtype=torch.float32, device=dev())
+    hip.gemm(xc, wf.to(dev()), out, bias=bfold, ln=(st, cs, eps), kernel=kern)
+    assert rel_l2(out.cpu(), ref) < tol, rel_l2(out.cpu(), ref)
+    out16 = torch.full((M, N), float('nan'), dtype=d16(), device=dev())
+    hip.gemm(xc, wf.to(dev()), out16, bias=bfold, ln=(st, cs, eps), act='gelu', kernel=kern)
+    assert rel_l2(out16.float().cpu(), F.gelu(ref)) < tol + 4e-3
+    if kern != 256:
+        outt = torch.zeros(N, (M + 7) // 8 * 8 + 8, dtype=d16(), device=dev())
+        hip.gemm(xc, wf.to(dev()), outt, bias=bfold, ln=(st, cs, eps), trans_out=True, kernel=kern)
+        assert rel_l2(outt[:, :M].float().cpu().T, ref) < tol + 4e-3
+
+
+@pytest.mark.parametrize('M,N,K,kern', [(300, 256, 128, 0), (768, 1024, 1024, 0), (1500, 1024, 4096, 256), (130, 192, 64, 0), (5000, 384, 384, 128)])
+def test_gemm_layernorm_fold_producer(M, N, K, kern):
+    """The residual-writing GEMM also emits the 16-bit copy of the new stream and the per-row / per-64-column-group (sum, sumsq) the
+    next block's consumer GEMMs normalise with -- bit-identical to rowstats run on its fp32 output."""
+    from panst3r_amd import hip
+    a, w, b = bf(rn(810, M, K)).to(dev()), bf(rn(811, N, K, scale=K ** -0.5)).to(dev()), rn(812, N).to(dev())
+    res = rn(813, M, N).to(dev())
+    y = res.clone()
+    xc = torch.full((M, N), float('nan'), dtype=d16(), device=dev())
+    st = torch.full((M, N // 64, 2), float('nan'), device=dev())
+    hip.gemm(a, w, y, bias=b, res=y, xcopy=xc, stats_out=st, kernel=kern)
+    plain = res.clone()
+    hip.gemm(a, w, plain, bias=b, res=plain, kernel=kern)
+    assert torch.equal(y, plain)                                               # the extra outputs do not change the stream
+    xc2 = torch.empty_like(xc)
+    st2 = torch.empty_like(st)
+    hip.rowstats(y, xc2, st2)
+    assert torch.equal(xc, xc2)
+    assert rel_l2(st.cpu(), st2.cpu()) < 1e-6 and bool(torch.isfinite(st).all())
+    # 16-bit residual stream (LoftUp blocks): statistics of the stored (rounded) values
+    r16 = bf(rn(814, M, N)).to(dev())
+    o16 = r16.clone()
+    st3 = torch.full((M, N // 64, 2), float('nan'), device=dev())
+    hip.gemm(a, w, o16, bias=b, res=o16, stats_out=st3, kernel=kern)
+    g = o16.float().reshape(M, N // 64, 64)
+    assert rel_l2(st3[..., 0].cpu(), g.sum(-1).cpu()) < 1e-4 and rel_l2(st3[..., 1].cpu(), (g * g).sum(-1).cpu()) < 1e-4

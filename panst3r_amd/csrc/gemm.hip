@@ -106,9 +106,8 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
         const uint32_t* q32 = (const uint32_t*)&rq[F32 ? 0 : it];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float lo = H16<F16>::lo(w32[q]) + H16<F16>::lo(q32[q]), hi = H16<F16>::hi(w32[q]) + H16<F16>::hi(q32[q]);
-          ssum += lo + hi; ssq += lo * lo + hi * hi;
-          w32[q] = H16<F16>::pack(lo, hi);
+          w32[q] = H16<F16>::pack(H16<F16>::lo(w32[q]) + H16<F16>::lo(q32[q]), H16<F16>::hi(w32[q]) + H16<F16>::hi(q32[q]));
+          if (p.stats_out) { const float lo = H16<F16>::lo(w32[q]), hi = H16<F16>::hi(w32[q]); ssum += lo + hi; ssq += lo * lo + hi * hi; }   // of the STORED values
         }
       } else if (!F32 && p.stats_out) {
         const uint32_t* w32 = (const uint32_t*)&val;

@@ -58,7 +58,7 @@ def ceil_to(x, m):
 
 class Packed:
     """bf16 weight [N, Kpad] (K zero-padded to a multiple of 64) + fp32 bias."""
-    __slots__ = ('w', 'b', 'n', 'k')
+    __slots__ = ('w', 'b', 'n', 'k', 'cs', 'eps')
 
     def __init__(self, weight, bias=None, device=None, row_perm=None):
         w = weight.detach().reshape(weight.shape[0], -1).float()
@@ -79,7 +79,27 @@ class Packed:
         out = Packed.__new__(Packed)
         out.w, out.n, out.k = self.w[a:b], b - a, self.k
         out.b = None if self.b is None else self.b[a:b]
+        if getattr(self, 'cs', None) is not None:
+            out.cs, out.eps = self.cs[a:b], self.eps
         return out
+
+
+def fold_ln(weight, bias, ln, device):
+    """LayerNorm folded into the Linear that consumes it (pack time): LN(x) W^T + b = rstd (x W'^T - mean colsum) + b' with
+    W' = W diag(gamma), b' = W beta + b, colsum[n] = sum_k W'[n,k] -- summed from the 16-bit-ROUNDED W', the values the MFMA multiplies.
+    The GEMM then reads the raw 16-bit rows and applies (rstd, mean) per row in its epilogue (pst_gemm_params: ln_stats)."""
+    w = weight.detach().reshape(weight.shape[0], -1).float()
+    g, bt = ln.weight.detach().float(), ln.bias.detach().float()
+    assert w.shape[1] == g.numel() and g.numel() % 64 == 0, 'LayerNorm fold needs the normalised dim to be a multiple of 64'
+    pk = Packed(w * g[None], w @ bt + (0 if bias is None else bias.detach().float()), device)
+    pk.cs = pk.w.float().sum(1).contiguous()
+    pk.eps = float(ln.eps)
+    return pk
+
+
+def ln_of(pk, st):
+    """the `ln=` argument of hip.gemm for a folded Packed"""
+    return (st, pk.cs, pk.eps)
 
 
 def f32(t, device):
@@ -161,21 +181,23 @@ def empty(rows, cols, dtype, device):
     return torch.empty(rows, cols, dtype=dtype, device=device)
 
 
-def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
-    """q,k projection (+RoPE) / transposed v projection / flash attention on a [lay.rows, D] bf16 buffer.
-    `vt`: optional caller-owned V^T scratch [D, >= lay.rows + 8] (saves an allocation per layer)."""
+def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None, st=None):
+    """q,k projection (+RoPE) / transposed v projection / flash attention on a [lay.rows, D] 16-bit buffer.
+    `vt`: optional caller-owned V^T scratch [D, >= lay.rows + 8] (saves an allocation per layer).
+    `st`: LayerNorm-fold statistics of the rows of `xn` - then xn holds the RAW stream and w_qk / w_v are folded (fold_ln)."""
     dev = xn.device
     D = H * hd
     qk = empty(lay.rows, 2 * D, adt(), dev)
+    lq = None if st is None else ln_of(w_qk, st)
     if rope is not None and hd == 64:
-        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, rope=(pos, rope))      # RoPE-2D applied in the GEMM's store phase
+        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, rope=(pos, rope), ln=lq)      # RoPE-2D applied in the GEMM's store phase
     else:
-        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b)
+        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, ln=lq)
         if rope is not None:
             hip.rope2d_(qk, pos, rope, 2 * H, hd)
     if vt is None:
         vt = torch.empty(D, lay.rows + 8, dtype=adt(), device=dev)
-    hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True)
+    hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True, ln=None if st is None else ln_of(w_v, st))
     o = empty(lay.rows, D, adt(), dev)
     if lay.Tp != lay.N:
         o.view(lay.V, lay.Tp, D)[:, lay.N:].zero_()      # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
@@ -198,27 +220,48 @@ def pack_norm(ln, device):
     return (f32(ln.weight, device), f32(ln.bias, device), float(ln.eps))
 
 
-def pack_croco_block(blk, device):
+def pack_croco_block(blk, device, norm_mlp=None):
+    """Pre-LN block with norm1 folded into qkv and the MLP's pre-norm (norm2; `norm_mlp` = norm3 for a decoder block) into fc1."""
     D = blk.attn.qkv.weight.shape[1]
-    qkv = Packed(blk.attn.qkv.weight, blk.attn.qkv.bias, device)
+    qkv = fold_ln(blk.attn.qkv.weight, blk.attn.qkv.bias, blk.norm1, device)
+    nm = blk.norm2 if norm_mlp is None else norm_mlp
     return BlockW(pack_norm(blk.norm1, device), qkv.rows(0, 2 * D), qkv.rows(2 * D, 3 * D),
-                  Packed(blk.attn.proj.weight, blk.attn.proj.bias, device), pack_norm(blk.norm2, device),
-                  Packed(blk.mlp.fc1.weight, blk.mlp.fc1.bias, device), Packed(blk.mlp.fc2.weight, blk.mlp.fc2.bias, device))
+                  Packed(blk.attn.proj.weight, blk.attn.proj.bias, device), pack_norm(nm, device),
+                  fold_ln(blk.mlp.fc1.weight, blk.mlp.fc1.bias, nm, device), Packed(blk.mlp.fc2.weight, blk.mlp.fc2.bias, device))
 
 
-def vit_block(x, bw, lay, H, hd, pos=None, rope=None):
-    """x fp32 [lay.rows, D] residual stream, updated in place."""
-    dev = x.device
-    D = H * hd
-    xn = empty(lay.rows, D, adt(), dev)
-    hip.layernorm(x, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
-    o = self_attention(xn, lay, H, hd, bw.qk, bw.v, pos, rope)
-    hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, gamma=bw.ls1, res=x)
-    hip.layernorm(x, bw.norm2[0], bw.norm2[1], xn, bw.norm2[2])
+class Stream:
+    """A pre-LN residual stream and its LayerNorm-fold companions: x fp32 [rows, D] (the stream), xb = 16-bit copy of x (the A operand of
+    the GEMMs that consume LN(x)), st = per-row (sum, sumsq) per 64-column group [rows, D/64, 2].  Every GEMM that writes x refreshes xb
+    and st from its epilogue (hip.gemm xcopy= / stats_out=); `refresh()` does it for a stream no GEMM produced."""
+    __slots__ = ('x', 'xb', 'st')
+
+    def __init__(self, x, xb=None, st=None):
+        rows, D = x.shape
+        assert D % 64 == 0, 'LayerNorm fold needs D %% 64 == 0 (got %d)' % D
+        self.x = x
+        self.xb = empty(rows, D, adt(), x.device) if xb is None else xb
+        self.st = torch.empty(rows, D // 64, 2, dtype=torch.float32, device=x.device) if st is None else st
+
+    def refresh(self):
+        hip.rowstats(self.x, self.xb, self.st)
+        return self
+
+    def residual(self, a, w, gamma=None, res=None):
+        """x = (res or x) + gamma * (a W^T + b), refreshing xb / st"""
+        hip.gemm(a, w.w, self.x, bias=w.b, gamma=gamma, res=self.x if res is None else res, xcopy=self.xb, stats_out=self.st)
+
+
+def vit_block(s, bw, lay, H, hd, pos=None, rope=None):
+    """s: Stream over the fp32 residual [lay.rows, D], updated in place.  No stand-alone LayerNorm: norm1 / norm2 are folded into the
+    qkv / fc1 GEMMs, whose row statistics come out of the epilogues of the two residual GEMMs."""
+    dev = s.x.device
+    o = self_attention(s.xb, lay, H, hd, bw.qk, bw.v, pos, rope, st=s.st)
+    s.residual(o, bw.proj, gamma=bw.ls1)
     h = empty(lay.rows, bw.fc1.n, adt(), dev)
-    hip.gemm(xn, bw.fc1.w, h, bias=bw.fc1.b, act='gelu')
-    hip.gemm(h, bw.fc2.w, x, bias=bw.fc2.b, gamma=bw.ls2, res=x)
-    return x
+    hip.gemm(s.xb, bw.fc1.w, h, bias=bw.fc1.b, act='gelu', ln=ln_of(bw.fc1, s.st))
+    s.residual(h, bw.fc2, gamma=bw.ls2)
+    return s
 
 
 class ParamLinear(nn.Linear):

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
-from .common import HipModule, Packed, Layout, adt, BlockW, empty, vit_block, pack_norm, f32, ParamLinear
+from .common import HipModule, Packed, Layout, adt, BlockW, empty, vit_block, pack_norm, f32, ParamLinear, fold_ln, Stream
 
 
 class _Proj(nn.Module):
@@ -101,10 +101,10 @@ class DinoV2Encoder(HipModule):
         blocks = []
         for L in d.encoder.layer:
             a = L.attention.attention
-            qk = Packed(torch.cat([a.query.weight, a.key.weight]), torch.cat([a.query.bias, a.key.bias]), device)
-            blocks.append(BlockW(pack_norm(L.norm1, device), qk, Packed(a.value.weight, a.value.bias, device),
+            qk = fold_ln(torch.cat([a.query.weight, a.key.weight]), torch.cat([a.query.bias, a.key.bias]), L.norm1, device)
+            blocks.append(BlockW(pack_norm(L.norm1, device), qk, fold_ln(a.value.weight, a.value.bias, L.norm1, device),
                                  Packed(L.attention.output.dense.weight, L.attention.output.dense.bias, device),
-                                 pack_norm(L.norm2, device), Packed(L.mlp.fc1.weight, L.mlp.fc1.bias, device),
+                                 pack_norm(L.norm2, device), fold_ln(L.mlp.fc1.weight, L.mlp.fc1.bias, L.norm2, device),
                                  Packed(L.mlp.fc2.weight, L.mlp.fc2.bias, device),
                                  f32(L.layer_scale1.lambda1, device), f32(L.layer_scale2.lambda1, device)))
         pe = d.embeddings.patch_embeddings.projection
@@ -147,8 +147,9 @@ class DinoV2Encoder(HipModule):
         hip.gemm(patches, pk['patch'].w, x, bias=pk['patch'].b, res=pospatch, res_mod=lay.T, grp=lay.grp)
         if TAPS is not None:
             TAPS.append(('pre', pre.clone())); TAPS.append(('patches', patches.clone())); TAPS.append(('embed', x.clone()))
+        s = Stream(x).refresh()
         for i, bw in enumerate(pk['blocks']):
-            vit_block(x, bw, lay, Hh, D // Hh)
+            vit_block(s, bw, lay, Hh, D // Hh)
             if TAPS is not None:
                 TAPS.append(('block %d' % i, x.clone()))
         hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, col0:col0 + D], pk['norm'][2], rows=V * lay.T, grp=lay.grp)

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .common import (HipModule, Packed, Layout, adt, empty, vit_block, pack_croco_block, pack_norm, grid_pos, grow_table)
+from .common import (HipModule, Packed, Layout, adt, empty, vit_block, pack_croco_block, pack_norm, grid_pos, grow_table, Stream)
 from .params import BlockP
 
 
@@ -53,8 +53,9 @@ class Dust3rEncoder(HipModule):
         hip.gemm(patches, pk['patch'].w, x, bias=pk['patch'].b, grp=lay.grp)
         pos = grid_pos(V, gh, gw, lay.Tp, 0, dev)
         rope = self.rope_table(pk, max(gh, gw), D // Hh, dev)
+        s = Stream(x).refresh()
         for bw in pk['blocks']:
-            vit_block(x, bw, lay, Hh, D // Hh, pos, rope)
+            vit_block(s, bw, lay, Hh, D // Hh, pos, rope)
         if out is None:
             out = empty(V * lay.T, D, adt(), dev)
         hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, :D] if out.shape[1] != D else out, pk['norm'][2],

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import hip
 from .common import (HipModule, Packed, Layout, adt, BlockW, empty, pack_norm, pack_croco_block, self_attention, f32,
-                     ParamLinear, grid_pos, grow_table)
+                     ParamLinear, grid_pos, grow_table, Stream, fold_ln, ln_of)
 from .params import BlockP, CrossAttnP, MlpP, AttnP
 
 
@@ -96,12 +96,15 @@ class MUSt3R(HipModule):
         e2d = Packed(self.feat_embed_enc_to_dec.weight, self.feat_embed_enc_to_dec.bias, device)
         blocks = []
         for b in self.blocks_dec:
-            bw = pack_croco_block(b, device)
+            bw = pack_croco_block(b, device, norm_mlp=b.norm3)          # the MLP's pre-norm in a decoder block is norm3
             c = b.cross_attn
-            bw.cross = dict(norm=pack_norm(b.norm2, device), q=Packed(c.projq.weight, c.projq.bias, device),
+            # LayerNorm fold: norm2 into the cross-attention query projection; norm_y into projk / projv for the first update call, where
+            # the two images attend to each other's layer INPUT (whose row statistics exist).  The append path normalises h_l + feedback,
+            # a sum no GEMM has produced, and keeps the plain projk / projv behind one batched LayerNorm launch.
+            bw.cross = dict(norm=pack_norm(b.norm2, device), q=fold_ln(c.projq.weight, c.projq.bias, b.norm2, device),
                             k=Packed(c.projk.weight, c.projk.bias, device), v=Packed(c.projv.weight, c.projv.bias, device),
+                            k_f=fold_ln(c.projk.weight, c.projk.bias, b.norm_y, device), v_f=fold_ln(c.projv.weight, c.projv.bias, b.norm_y, device),
                             proj=Packed(c.proj.weight, c.proj.bias, device), norm_y=pack_norm(b.norm_y, device))
-            bw.norm2 = pack_norm(b.norm3, device)           # the MLP's pre-norm in a decoder block is norm3
             blocks.append(bw)
         perm = torch.arange(ch * p * p).reshape(ch, p, p).permute(1, 2, 0).reshape(-1)
         pk = dict(e2d=e2d, bias_ref=e2d.b, bias_other=(e2d.b + f32(self.image2_embed, device).reshape(-1)).contiguous(),
@@ -135,26 +138,17 @@ class MUSt3R(HipModule):
             hip.gemm(x_enc[:lay.T], pk['e2d'].w, x[:lay.Tp], bias=pk['bias_ref'])
         return x
 
-    def _self_and_mlp_pre(self, x, bw, lay, pos, rope):
-        H, hd, dev = self.num_heads, self.embed_dim // self.num_heads, x.device
-        xn = empty(lay.rows, self.embed_dim, adt(), dev)
-        hip.layernorm(x, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
-        o = self_attention(xn, lay, H, hd, bw.qk, bw.v, pos, rope)
-        hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, res=x)
-        return xn
-
-    def _cross_q(self, x, bw, xn):
+    def _cross_q(self, s, bw):
+        """cross-attention queries of stream s: norm2 folded into projq"""
         c = bw.cross
-        hip.layernorm(x, c['norm'][0], c['norm'][1], xn, c['norm'][2])
-        q = empty(xn.shape[0], self.embed_dim, adt(), x.device)
-        hip.gemm(xn, c['q'].w, q, bias=c['q'].b)
+        q = empty(s.x.shape[0], self.embed_dim, adt(), s.x.device)
+        hip.gemm(s.xb, c['q'].w, q, bias=c['q'].b, ln=ln_of(c['q'], s.st))
         return q
 
-    def _mlp(self, x, bw, xn):
-        hip.layernorm(x, bw.norm2[0], bw.norm2[1], xn, bw.norm2[2])
-        h = empty(xn.shape[0], bw.fc1.n, adt(), x.device)
-        hip.gemm(xn, bw.fc1.w, h, bias=bw.fc1.b, act='gelu')
-        hip.gemm(h, bw.fc2.w, x, bias=bw.fc2.b, res=x)
+    def _mlp(self, s, bw):
+        h = empty(s.x.shape[0], bw.fc1.n, adt(), s.x.device)
+        hip.gemm(s.xb, bw.fc1.w, h, bias=bw.fc1.b, act='gelu', ln=ln_of(bw.fc1, s.st))
+        s.residual(h, bw.fc2)
 
     def _head(self, pk, feat, V, h, w):
         """feat bf16 [V*T, D] (row-major view) -> pointmaps fp32 [V, H, W, 7] through the fused pixel-shuffle store."""
@@ -172,17 +166,19 @@ class MUSt3R(HipModule):
         hd = D // H
         lay = Layout(V, h * w)
         x = self._embed(pk, x_enc, lay, first_is_ref=False)
+        s = Stream(x).refresh()
         pos = grid_pos(V, h, w, lay.Tp, 0, dev)
         rope = self._rope(pk, max(h, w), dev)
         for l, bw in enumerate(pk['blocks']):
-            xn = self._self_and_mlp_pre(x, bw, lay, pos, rope)
-            q = self._cross_q(x, bw, xn)
+            o = self_attention(s.xb, lay, H, hd, bw.qk, bw.v, pos, rope, st=s.st)
+            s.residual(o, bw.proj)
+            q = self._cross_q(s, bw)
             o = empty(lay.rows, D, adt(), dev)
             ldv = bank.Vt[l].stride(0)
             hip.attention(q, bank.K[l], bank.Vt[l], o, 1, H, lay.rows, bank.n, hd,
                           q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
-            hip.gemm(o, bw.cross['proj'].w, x, bias=bw.cross['proj'].b, res=x)
-            self._mlp(x, bw, xn)
+            s.residual(o, bw.cross['proj'])
+            self._mlp(s, bw)
         if feat_out is None:
             feat_out = empty(V * lay.T, D, adt(), dev)
         hip.layernorm(x, pk['norm'][0], pk['norm'][1], feat_out, pk['norm'][2], rows=V * lay.T, grp=lay.grp)
@@ -205,33 +201,32 @@ class MUSt3R(HipModule):
         lay = Layout(n, T)
         # hs_all[l] = tokens entering block l, hs_all[L] = final stream: ONE tensor, so the append normalises all layers in one launch
         hs_all = torch.empty(L + 1, lay.rows, D, dtype=torch.float32, device=dev)
-        x = self._embed(pk, x_enc, lay, first_is_ref=(bank.nimgs == 0), out=hs_all[0])
+        xb_all = torch.empty(L + 1, lay.rows, D, dtype=adt(), device=dev)              # LayerNorm-fold companions of the L + 1 streams
+        st_all = torch.empty(L + 1, lay.rows, D // 64, 2, dtype=torch.float32, device=dev)
+        S = [Stream(hs_all[l], xb_all[l], st_all[l]) for l in range(L + 1)]
+        self._embed(pk, x_enc, lay, first_is_ref=(bank.nimgs == 0), out=hs_all[0])
+        S[0].refresh()
         pos = grid_pos(n, h, w, lay.Tp, 0, dev)
         rope = self._rope(pk, max(h, w), dev)
         # hs[l] = tokens entering block l (the candidate memory entries).  No copies: block l reads its residual from
         # hs[l] and the attention-projection GEMM writes the updated stream to a fresh buffer that becomes hs[l+1].
-        hs = [x]
+        hs = [hs_all[0]]
         vt_self = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)      # V^T scratch shared by all layers (pad columns stay 0)
-        xn = empty(lay.rows, D, adt(), dev)
         for l, bw in enumerate(pk['blocks']):
-            x_in = hs[l]
-            x = hs_all[l + 1]
+            s_in, s = S[l], S[l + 1]
             if lay.Tp != lay.T:
-                x.zero_()
-            hip.layernorm(x_in, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
-            o = self_attention(xn, lay, H, hd, bw.qk, bw.v, pos, rope, vt=vt_self)
-            hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, res=x_in)
+                s.x.zero_()
+            o = self_attention(s_in.xb, lay, H, hd, bw.qk, bw.v, pos, rope, vt=vt_self, st=s_in.st)
+            s.residual(o, bw.proj, res=s_in.x)
             c = bw.cross
             o = empty(lay.rows, D, adt(), dev)
             if n == 2:
-                # each image attends to the other image's layer input (norm_y + projk / projv on the fly)
-                y = empty(lay.rows, D, adt(), dev)
-                hip.layernorm(x_in, c['norm_y'][0], c['norm_y'][1], y, c['norm_y'][2])
+                # each image attends to the other image's layer input (norm_y folded into projk / projv, on the fly)
                 kk = empty(lay.rows, D, adt(), dev)
-                hip.gemm(y, c['k'].w, kk, bias=c['k'].b)
+                hip.gemm(s_in.xb, c['k_f'].w, kk, bias=c['k_f'].b, ln=ln_of(c['k_f'], s_in.st))
                 vt = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)
-                hip.gemm(y, c['v'].w, vt, bias=c['v'].b, trans_out=True)
-                q = self._cross_q(x, bw, xn)
+                hip.gemm(s_in.xb, c['v_f'].w, vt, bias=c['v_f'].b, trans_out=True, ln=ln_of(c['v_f'], s_in.st))
+                q = self._cross_q(s, bw)
                 ldv = vt.stride(0)
                 hip.attention(q, kk[lay.Tp:], vt[:, lay.Tp:], o, 2, H, T, T, hd,
                               q_strides=(lay.Tp * D, hd, D), k_strides=(-lay.Tp * D, hd, D),
@@ -239,13 +234,13 @@ class MUSt3R(HipModule):
                 if lay.Tp != T:
                     o.view(2, lay.Tp, D)[:, T:] = 0
             else:
-                q = self._cross_q(x, bw, xn)
+                q = self._cross_q(s, bw)
                 ldv = bank.Vt[l].stride(0)
                 hip.attention(q, bank.K[l], bank.Vt[l], o, 1, H, lay.rows, bank.n, hd,
                               q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
-            hip.gemm(o, c['proj'].w, x, bias=c['proj'].b, res=x)
-            self._mlp(x, bw, xn)
-            hs.append(x)
+            s.residual(o, c['proj'])
+            self._mlp(s, bw)
+            hs.append(s.x)
         out = self._append(pk, bank, hs, lay, n, T, hs_all=hs_all)
         if not want_outputs:
             return bank
@@ -271,35 +266,32 @@ class MUSt3R(HipModule):
         xs = [self._embed(pk, x_enc[i], lays[i], first_is_ref=(i == 0)) for i in range(2)]
         poss = [grid_pos(1, h, w, lay.Tp, 0, dev) for (h, w), lay in zip(grids, lays)]
         rope = self._rope(pk, max(max(g) for g in grids), dev)
-        hs = [[xs[0]], [xs[1]]]
+        S = [[Stream(xs[0]).refresh()], [Stream(xs[1]).refresh()]]           # S[i][l] = stream of image i entering block l
         for l, bw in enumerate(pk['blocks']):
             c = bw.cross
             kvs = []
-            for i in range(2):          # K / V^T of each image's layer input (the other image's context)
-                lay = lays[i]
-                y = empty(lay.rows, D, adt(), dev)
-                hip.layernorm(hs[i][l], c['norm_y'][0], c['norm_y'][1], y, c['norm_y'][2])
+            for i in range(2):          # K / V^T of each image's layer input (the other image's context), norm_y folded
+                lay, s_in = lays[i], S[i][l]
                 kk = empty(lay.rows, D, adt(), dev)
-                hip.gemm(y, c['k'].w, kk, bias=c['k'].b)
+                hip.gemm(s_in.xb, c['k_f'].w, kk, bias=c['k_f'].b, ln=ln_of(c['k_f'], s_in.st))
                 vt = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)
-                hip.gemm(y, c['v'].w, vt, bias=c['v'].b, trans_out=True)
+                hip.gemm(s_in.xb, c['v_f'].w, vt, bias=c['v_f'].b, trans_out=True, ln=ln_of(c['v_f'], s_in.st))
                 kvs.append((kk, vt))
             for i in range(2):
-                lay, x_in = lays[i], hs[i][l]
-                xn = empty(lay.rows, D, adt(), dev)
-                x = empty(lay.rows, D, torch.float32, dev)
-                hip.layernorm(x_in, bw.norm1[0], bw.norm1[1], xn, bw.norm1[2])
-                o = self_attention(xn, lay, H, hd, bw.qk, bw.v, poss[i], rope)
-                hip.gemm(o, bw.proj.w, x, bias=bw.proj.b, res=x_in)
-                q = self._cross_q(x, bw, xn)
+                lay, s_in = lays[i], S[i][l]
+                s = Stream(empty(lay.rows, D, torch.float32, dev))
+                o = self_attention(s_in.xb, lay, H, hd, bw.qk, bw.v, poss[i], rope, st=s_in.st)
+                s.residual(o, bw.proj, res=s_in.x)
+                q = self._cross_q(s, bw)
                 kk, vt = kvs[1 - i]
                 o = torch.zeros(lay.rows, D, dtype=adt(), device=dev)
                 ldv = vt.stride(0)
                 hip.attention(q, kk, vt, o, 1, H, lay.T, Ts[1 - i], hd, q_strides=(0, hd, D), k_strides=(0, hd, D),
                               v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
-                hip.gemm(o, c['proj'].w, x, bias=c['proj'].b, res=x)
-                self._mlp(x, bw, xn)
-                hs[i].append(x)
+                s.residual(o, c['proj'])
+                self._mlp(s, bw)
+                S[i].append(s)
+        hs = [[s.x for s in S[0]], [s.x for s in S[1]]]
         for i in range(2):
             self._append(pk, bank, hs[i], lays[i], 1, Ts[i])
         return bank

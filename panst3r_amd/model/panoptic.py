@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from .. import hip
 from .common import (HipModule, Packed, Layout, adt, empty, vit_block, pack_croco_block, pack_norm, f32, ParamLinear,
-                     grid_pos, ceil_to, grow_table)
+                     grid_pos, ceil_to, grow_table, Stream, fold_ln, ln_of)
 from .params import BlockP, MlpP, CrossAttnP, MHAP
 
 VIEW_CHUNK = 16     # views per upscaler pass (bounds the [rows, 22528] / [P, 384] workspaces)
@@ -53,8 +53,9 @@ class InputMixer(HipModule):
         hip.gemm(cat, pk['inp'].w, x, bias=pk['inp'].b, grp=lay.grp)
         pos = grid_pos(V, h, w, lay.Tp, 0, dev)
         rope = grow_table(pk['rope'], max(h, w), lambda m: hip.rope_table(m, D // H, 100.0, dev))
+        st = Stream(x).refresh()
         for bw in pk['blocks']:
-            vit_block(x, bw, lay, H, D // H, pos, rope)
+            vit_block(st, bw, lay, H, D // H, pos, rope)
         hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, :D], pk['norm'][2], rows=V * lay.T, grp=lay.grp)
         return out
 

@@ -107,9 +107,15 @@ def test_full_size_5_views_3_keyframes(variant, full):
         assert e <= 3e-2 and agree >= 0.995, (e, agree)
 
 
+SHARP = 8.0 ** 0.5      # q and k projection rows x sqrt(8) each => every QK^T attention logit x8 (synthetic.fill_value scales both)
+
+
 def test_full_size_sharp_weight_set():
-    """SURVEY 8(d) second weight set: QK weights x8 so that softmax is far from uniform (errors in the scores are amplified)."""
-    built = build_full('v2', sharp=8.0)
+    """SURVEY 8(d) second weight set ("QK weights x8 so that softmax is not near-uniform"): every attention logit of the model is 8x
+    the plain set's, so the softmax is peaked and score errors are amplified.  (Scaling q AND k rows by 8 each - logits x64 - turns
+    every attention into an arg-max whose winner flips on 1e-3 score differences: after 36 layers the fp32 oracle and ANY 16-bit
+    evaluation are uncorrelated, rel-L2 > 1; measured, profiles/r2_parity_notes.md.)"""
+    built = build_full('v2', sharp=SHARP)
     assert_within(scene_parity(built, 'v2', 3, 2)['fp16'])
 
 

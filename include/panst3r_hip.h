@@ -132,9 +132,11 @@ int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const float* add,
                       int out_fp32, const float* gamma, const float* beta, int rows, int D, float eps,
                       int grp_in, int grp_out, int grp_off, void* stream);
 
-/* rowstats: the producer-side outputs of the LayerNorm fold for a stream that no GEMM produced (first block of a stack): x fp32 [rows, D]
- * (D % 64 == 0) -> xcopy 16-bit [rows, D] and stats fp32 [rows][stats_ld][2] = per-row (sum, sum of squares) over each 64-column group. */
-int pst_rowstats(const float* x, int64_t ldx, void* xcopy, int64_t ldxc, float* stats, int stats_ld, int rows, int D, int dtype16, void* stream);
+/* rowstats: the producer-side outputs of the LayerNorm fold for a stream that no GEMM produced (first block of a stack): x [rows, D] of
+ * element type x_type (PST_F32, or the 16-bit format itself), D % 64 == 0 -> xcopy 16-bit [rows, D] (optional: NULL when x already is
+ * the 16-bit stream) and stats fp32 [rows][stats_ld][2] = per-row (sum, sum of squares) over each 64-column group. */
+int pst_rowstats(const void* x, int64_t ldx, int x_type, void* xcopy, int64_t ldxc, float* stats, int stats_ld, int rows, int D, int dtype16,
+                 void* stream);
 
 /* strided batch of pst_layernorm_add: problem i uses x + i*x_bs, y + i*y_bs, gamma/beta + i*w_bs (elements); `add` (optional) is shared.
  * One launch for the 12 per-layer `norm_y(h_l + feedback)` of a MUSt3R memory append. */

@@ -392,9 +392,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float x = acc[i][j][r];
-          if (p.ln_stats) { const float2 st = lnst[wr * (16 * FM) + g * (4 * FM) + 4 * i + r]; x = x * st.x + st.y * cs; }
-          x += b;
+          // explicit fmaf chain, the same as the row-major epilogue: every instantiation (tile size) rounds identically
+          const float2 st = p.ln_stats ? lnst[wr * (16 * FM) + g * (4 * FM) + 4 * i + r] : make_float2(1.f, 0.f);
+          float x = fmaf(acc[i][j][r], st.x, fmaf(st.y, cs, b));
           if (p.act == 1) x = gelu_erf(x); else if (p.act == 2) x = fmaxf(x, 0.f);
           v[4 * i + r] = x;
         }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t l
 
 // ------------------------------------------------------------------ LayerNorm-fold producer outputs of an fp32 stream
 // One 16-lane group per (row, 64-column group): lane = 4 columns.  16-bit copy + (sum, sumsq) of the group (fixed shuffle tree).
-__global__ __launch_bounds__(256) void rowstats_kernel(const float* x, int64_t ldx, bf16_t* xc, int64_t ldxc, float2* stats, int stats_ld,
+__global__ __launch_bounds__(256) void rowstats_kernel(const void* x, int64_t ldx, int x_tc, bf16_t* xc, int64_t ldxc, float2* stats, int stats_ld,
                                                        int rows, int D, int tc) {
   const int groups = D >> 6;
   const int64_t total = (int64_t)rows * groups * 16;
@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* x, int64_t l
     const int g = (int)(rg % groups);
     const int64_t row = rg / groups;
     const int c = g * 64 + sub * 4;
-    const float4 v = *(const float4*)(x + row * ldx + c);
-    *(uint2*)(xc + row * ldxc + c) = make_uint2(pack2(v.x, v.y, tc), pack2(v.z, v.w, tc));
-    float s = v.x + v.y + v.z + v.w, q = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    float v[4];
+    load4(x, row * ldx + c, x_tc, v);
+    if (xc) *(uint2*)(xc + row * ldxc + c) = make_uint2(pack2(v[0], v[1], tc), pack2(v[2], v[3], tc));
+    float s = v[0] + v[1] + v[2] + v[3], q = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
     if (sub == 0) stats[row * stats_ld + g] = make_float2(s, q);
@@ -385,16 +386,16 @@ extern "C" int pst_layernorm_add(const void* x, int64_t ldx, int in_fp32, const 
   return launch_layernorm(x, ldx, in_fp32, add, ld_add, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, stream);
 }
 
-extern "C" int pst_rowstats(const float* x, int64_t ldx, void* xcopy, int64_t ldxc, float* stats, int stats_ld, int rows, int D, int dtype16,
+extern "C" int pst_rowstats(const void* x, int64_t ldx, int x_type, void* xcopy, int64_t ldxc, float* stats, int stats_ld, int rows, int D, int dtype16,
                             void* stream) {
-  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !x || !xcopy || !stats || rows <= 0 || D <= 0 || D % 64 || ldx % 4 || ldxc % 4 || stats_ld < D / 64 ||
-      ((uintptr_t)x & 15) || ((uintptr_t)xcopy & 7)) {
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || (x_type != DT_F32 && x_type != dtype16) || !x || !stats || rows <= 0 || D <= 0 || D % 64 || ldx % 4 ||
+      (xcopy && (ldxc % 4 || ((uintptr_t)xcopy & 7))) || stats_ld < D / 64 || ((uintptr_t)x & (x_type == DT_F32 ? 15 : 7))) {
     set_error("rowstats: bad argument (D=%d must be a multiple of 64)", D); return PST_EINVAL;
   }
   const int64_t total = (int64_t)rows * (D / 64) * 16;
   int64_t g = (total + 255) / 256;
   if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(rowstats_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)xcopy, ldxc, (float2*)stats, stats_ld, rows, D, dtype16);
+  hipLaunchKernelGGL(rowstats_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_type, (bf16_t*)xcopy, ldxc, (float2*)stats, stats_ld, rows, D, dtype16);
   return check_launch("rowstats");
 }
 

@@ -313,12 +313,18 @@ def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None):
 
 
 def rowstats(x, xcopy, stats):
-    """LayerNorm-fold producer outputs for an fp32 stream no GEMM wrote: 16-bit copy + per-row (sum, sumsq) per 64-column group."""
-    _dev(x, torch.float32); _dev(xcopy, *H16); _dev(stats, torch.float32)
+    """LayerNorm-fold producer outputs for a stream no GEMM wrote: per-row (sum, sumsq) per 64-column group, plus the 16-bit copy of an
+    fp32 stream (xcopy=None when x already is the 16-bit stream)."""
+    _dev(x, torch.float32, *H16); _dev(stats, torch.float32)
     rows, D = x.shape
     assert stats.dim() == 3 and stats.shape[2] == 2 and stats.is_contiguous() and stats.shape[1] * 64 >= D
-    _check(lib().pst_rowstats(_ptr(x), i64(_rowmajor(x)), _ptr(xcopy), i64(_rowmajor(xcopy)), _ptr(stats), stats.shape[1], rows, D, _tc(xcopy), _stream()),
-           'pst_rowstats')
+    if xcopy is None:
+        assert x.dtype in H16
+        d16 = _tc(x)
+    else:
+        d16 = _tc(_dev(xcopy, *H16))
+    _check(lib().pst_rowstats(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(xcopy), i64(_rowmajor(xcopy) if xcopy is not None else 0), _ptr(stats),
+                              stats.shape[1], rows, D, d16, _stream()), 'pst_rowstats')
     return xcopy, stats
 
 

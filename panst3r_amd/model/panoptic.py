@@ -182,9 +182,9 @@ class LoftUpUpscaler(HipModule):
         for b in self.ca_transformer_blocks:
             c = b.cross_attn
             blocks.append(dict(norm2=pack_norm(b.norm2, device), norm3=pack_norm(b.norm3, device), norm_y=pack_norm(b.norm_y, device),
-                               q=Packed(c.projq.weight, c.projq.bias, device), k=Packed(c.projk.weight, c.projk.bias, device),
+                               q=fold_ln(c.projq.weight, c.projq.bias, b.norm2, device), k=Packed(c.projk.weight, c.projk.bias, device),
                                v=Packed(c.projv.weight, c.projv.bias, device), proj=Packed(c.proj.weight, c.proj.bias, device),
-                               fc1=Packed(b.mlp.fc1.weight, b.mlp.fc1.bias, device), fc2=Packed(b.mlp.fc2.weight, b.mlp.fc2.bias, device)))
+                               fc1=fold_ln(b.mlp.fc1.weight, b.mlp.fc1.bias, b.norm3, device), fc2=Packed(b.mlp.fc2.weight, b.mlp.fc2.bias, device)))
         gn = lambda g: (f32(g.weight, device), f32(g.bias, device), float(g.eps))
         return dict(pe=Packed(self.patch_embed.weight, self.patch_embed.bias, device), c0=c0,
                     lr_bias=f32(self.lr_pe.biases, device), ff_bias=f32(self.fourier_feat[1].biases, device),
@@ -265,7 +265,11 @@ class LoftUpUpscaler(HipModule):
             # The residual stream of these two blocks is kept in bf16: they are HBM-bound over P x C elements per view
             # (fp32 would double the read-modify-write traffic of both residual GEMMs and of every LayerNorm).
             x = guidance[v0 * P:(v0 + n) * P]
-            xn, q, o = empty(n * P, C, adt(), dev), empty(n * P, C, adt(), dev), empty(n * P, C, adt(), dev)
+            q, o = empty(n * P, C, adt(), dev), empty(n * P, C, adt(), dev)
+            # LayerNorm fold on the 16-bit stream: norm2 / norm3 live in projq / fc1, their row statistics come out of the epilogues of
+            # the two residual GEMMs (no stand-alone pass over the [n*P, C] tensor: 4 of the 16 passes per chunk gone)
+            st = torch.empty(n * P, C // 64, 2, dtype=torch.float32, device=dev)
+            hip.rowstats(x, None, st)
             rows0, rows1 = v0 * lay.Tp, (v0 + n) * lay.Tp
             for bw in pk['blocks']:
                 y = empty(rows1 - rows0, C, adt(), dev)
@@ -274,17 +278,15 @@ class LoftUpUpscaler(HipModule):
                 hip.gemm(y, bw['k'].w, kk, bias=bw['k'].b)
                 vt = torch.zeros(C, rows1 - rows0 + 8, dtype=adt(), device=dev)
                 hip.gemm(y, bw['v'].w, vt, bias=bw['v'].b, trans_out=True)
-                hip.layernorm(x, bw['norm2'][0], bw['norm2'][1], xn, bw['norm2'][2])
-                hip.gemm(xn, bw['q'].w, q, bias=bw['q'].b)
+                hip.gemm(x, bw['q'].w, q, bias=bw['q'].b, ln=ln_of(bw['q'], st))
                 ldv = vt.stride(0)
                 hip.attention(q, kk, vt, o, n, Hh, P, T, hd, q_strides=(P * C, hd, C), k_strides=(lay.Tp * C, hd, C),
                               v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(P * C, hd, C))
-                hip.gemm(o, bw['proj'].w, x, bias=bw['proj'].b, res=x)
-                hip.layernorm(x, bw['norm3'][0], bw['norm3'][1], xn, bw['norm3'][2])
-                hip.gemm(xn, bw['fc1'].w, q, bias=bw['fc1'].b, act='gelu')
-                hip.gemm(q, bw['fc2'].w, x, bias=bw['fc2'].b, res=x)
+                hip.gemm(o, bw['proj'].w, x, bias=bw['proj'].b, res=x, stats_out=st)
+                hip.gemm(x, bw['fc1'].w, q, bias=bw['fc1'].b, act='gelu', ln=ln_of(bw['fc1'], st))
+                hip.gemm(q, bw['fc2'].w, x, bias=bw['fc2'].b, res=x, stats_out=st)
             hip.layernorm(x, pk['norm'][0], pk['norm'][1], mask_out[v0:v0 + n].view(n * P, C), pk['norm'][2])
-            del x, xn, q, o
+            del x, q, o, st
         return fpn_out, mask_out
 
     def forward(self, inputs, img_shape):

@@ -157,10 +157,25 @@ __device__ __forceinline__ void ln_fold_prologue(const pst_gemm_params& p, float
 
 // Producer: (sum, sumsq) of `cnt` fp32 values reduced over the LANES-lane group that holds one row's 64-column group; the group's
 // first lane writes stats_out[row][grp].  Fixed xor-shuffle tree: deterministic.
+// DPP butterfly over LANES (8 or 16) consecutive lanes of a 16-lane DPP row: quad xor 1, quad xor 2, row_half_mirror, (row_mirror).
+// VALU only -- __shfl_xor lowers to ds_bpermute, i.e. LDS crossbar traffic next to the co-resident block's ds_read-bound main loop
+// (measured: +9 us on a 108 us residual GEMM).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int LANES>
+__device__ __forceinline__ float row_sum(float v) {
+  v = dpp_add<0xB1>(v);            // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);            // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);           // row_half_mirror: 8 lanes
+  if constexpr (LANES == 16) v = dpp_add<0x140>(v);      // row_mirror: 16 lanes
+  return v;
+}
 template <int LANES>
 __device__ __forceinline__ void ln_fold_stats(const pst_gemm_params& p, float s, float q, int lane_in_row, int64_t orow, int n) {
-#pragma unroll
-  for (int o = 1; o < LANES; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  s = row_sum<LANES>(s);
+  q = row_sum<LANES>(q);
   if ((lane_in_row & (LANES - 1)) == 0) *((float2*)p.stats_out + orow * p.stats_ld + (n >> 6)) = make_float2(s, q);
 }
 

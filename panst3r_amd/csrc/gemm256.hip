@@ -85,9 +85,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // LayerNorm fold, consumer side: (rstd, -mean rstd) of the 256 A rows of the tile, behind the operand buffers
-  float2* lnst = (float2*)(smem + 2 * BUF_BYTES);
-  if (p.ln_stats) ln_fold_prologue(p, lnst, tid, m0, 256);
+  float2* lnst = (float2*)(smem + 2 * BUF_BYTES);       // LayerNorm-fold row table, behind the operand buffers
 
   bf16x8 af[4][2];        // current A sub-tile: 4 row fragments x 2 K halves
   bf16x8 bfr[2][2][2];    // both B sub-tiles: [n sub-tile][fragment][K half]
@@ -119,6 +117,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
   // ---- prologue: tile 0 (4 half-tiles) + B of tile 1; wait for tile 0 only
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
   stage(2, 1); stage(3, 1);
+  // LayerNorm fold, consumer side: (rstd, -mean rstd) of the 256 A rows; after the prologue DMA issue (its loads wait in the shadow of tile 0)
+  if (p.ln_stats) ln_fold_prologue(p, lnst, tid, m0, 256);
   if (nk > 1) PST_VMCNT(4); else PST_VMCNT(0);
   __builtin_amdgcn_s_barrier();
 

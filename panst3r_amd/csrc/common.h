@@ -157,6 +157,11 @@ __device__ __forceinline__ void ln_fold_prologue(const pst_gemm_params& p, float
 
 // Producer: (sum, sumsq) of `cnt` fp32 values reduced over the LANES-lane group that holds one row's 64-column group; the group's
 // first lane writes stats_out[row][grp].  Fixed xor-shuffle tree: deterministic.
+// per-thread part of the statistics: strictly sequential, explicit fmaf -- every call site (fast / edge epilogue paths of every tile
+// size, rowstats) must round identically, and `a*a + b*b` is contracted into FMAs in a site-dependent association otherwise.
+__device__ __forceinline__ void ln_acc(float a, float& s, float& q) { s += a; q = fmaf(a, a, q); }
+__device__ __forceinline__ void ln_acc4(const float4& f, float& s, float& q) { s = 0.f; q = 0.f; ln_acc(f.x, s, q); ln_acc(f.y, s, q); ln_acc(f.z, s, q); ln_acc(f.w, s, q); }
+
 // DPP butterfly over LANES (8 or 16) consecutive lanes of a 16-lane DPP row: quad xor 1, quad xor 2, row_half_mirror, (row_mirror).
 // VALU only -- __shfl_xor lowers to ds_bpermute, i.e. LDS crossbar traffic next to the co-resident block's ds_read-bound main loop
 // (measured: +9 us on a 108 us residual GEMM).

@@ -107,18 +107,18 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           w32[q] = H16<F16>::pack(H16<F16>::lo(w32[q]) + H16<F16>::lo(q32[q]), H16<F16>::hi(w32[q]) + H16<F16>::hi(q32[q]));
-          if (p.stats_out) { const float lo = H16<F16>::lo(w32[q]), hi = H16<F16>::hi(w32[q]); ssum += lo + hi; ssq += lo * lo + hi * hi; }   // of the STORED values
+          if (p.stats_out) { ln_acc(H16<F16>::lo(w32[q]), ssum, ssq); ln_acc(H16<F16>::hi(w32[q]), ssum, ssq); }   // of the STORED values
         }
       } else if (!F32 && p.stats_out) {
         const uint32_t* w32 = (const uint32_t*)&val;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const float lo = H16<F16>::lo(w32[q]), hi = H16<F16>::hi(w32[q]); ssum += lo + hi; ssq += lo * lo + hi * hi; }
+        for (int q = 0; q < 4; ++q) { ln_acc(H16<F16>::lo(w32[q]), ssum, ssq); ln_acc(H16<F16>::hi(w32[q]), ssum, ssq); }
       }
       *(uint4*)((char*)p.C + ((int64_t)orow[it] * p.ldc + n) * (F32 ? 4 : 2)) = val;
       if (F32) {
         const float4 f = *(const float4*)&val;
         if (p.xcopy) *(uint2*)((bf16_t*)p.xcopy + (int64_t)orow[it] * p.ldxc + n) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
-        if (p.stats_out) ln_fold_stats<16>(p, f.x + f.y + f.z + f.w, f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w, c, orow[it], n);
+        if (p.stats_out) { float ss, sq; ln_acc4(f, ss, sq); ln_fold_stats<16>(p, ss, sq, c, orow[it], n); }
       } else if (p.stats_out) {
         ln_fold_stats<8>(p, ssum, ssq, c, orow[it], n);
       }
@@ -163,7 +163,7 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
       *(float4*)((float*)p.C + off) = f;
       // LayerNorm fold (plain row-major stores only, N % 64 == 0: a 16-lane group = one 64-column group, wholly inside or outside)
       if (p.xcopy) *(uint2*)((bf16_t*)p.xcopy + (int64_t)orow * p.ldxc + n) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
-      if (p.stats_out) ln_fold_stats<16>(p, f.x + f.y + f.z + f.w, f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w, c, orow, n);
+      if (p.stats_out) { float ss, sq; ln_acc4(f, ss, sq); ln_fold_stats<16>(p, ss, sq, c, orow, n); }
       continue;
     }
     if (rpb) {             // bf16 residual stream (LoftUp blocks): 16-byte load, add in fp32, one rounding
@@ -188,7 +188,7 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
       const uint32_t* w32 = (const uint32_t*)&val;
       float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const float lo = H16<F16>::lo(w32[q]), hi = H16<F16>::hi(w32[q]); ssum += lo + hi; ssq += lo * lo + hi * hi; }
+      for (int q = 0; q < 4; ++q) { ln_acc(H16<F16>::lo(w32[q]), ssum, ssq); ln_acc(H16<F16>::hi(w32[q]), ssum, ssq); }
       ln_fold_stats<8>(p, ssum, ssq, c, orow, n);
     }
     bf16_t* dst = (bf16_t*)p.C + off;

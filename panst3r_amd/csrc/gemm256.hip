@@ -263,7 +263,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
         *(float4*)((float*)p.C + off) = f;
         // LayerNorm fold, producer side: a row is one wave here (64 chunks of 4 columns), a 64-column group = 16 lanes
         if (p.xcopy) *(uint2*)((bf16_t*)p.xcopy + (int64_t)orow * p.ldxc + n) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
-        if (p.stats_out) ln_fold_stats<16>(p, f.x + f.y + f.z + f.w, f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w, c, orow, n);
+        if (p.stats_out) { float ss, sq; ln_acc4(f, ss, sq); ln_fold_stats<16>(p, ss, sq, c, orow, n); }
         continue;
       }
       if (rpb) {             // bf16 residual stream (LoftUp blocks): 16-byte load, add in fp32, one rounding
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
         const uint32_t* w32 = (const uint32_t*)&val;
         float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const float lo = H16<F16>::lo(w32[q]), hi = H16<F16>::hi(w32[q]); ssum += lo + hi; ssq += lo * lo + hi * hi; }
+        for (int q = 0; q < 4; ++q) { ln_acc(H16<F16>::lo(w32[q]), ssum, ssq); ln_acc(H16<F16>::hi(w32[q]), ssum, ssq); }
         ln_fold_stats<8>(p, ssum, ssq, c, orow, n);
       }
       bf16_t* dst = (bf16_t*)p.C + off;

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const void* x, int64_t ld
     float v[4];
     load4(x, row * ldx + c, x_tc, v);
     if (xc) *(uint2*)(xc + row * ldxc + c) = make_uint2(pack2(v[0], v[1], tc), pack2(v[2], v[3], tc));
-    float s = v[0] + v[1] + v[2] + v[3], q = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    float s, q;
+    ln_acc4(make_float4(v[0], v[1], v[2], v[3]), s, q);
     s = row_sum<16>(s);           // the same reduction tree as the GEMM epilogues (ln_fold_stats): bit-identical statistics
     q = row_sum<16>(q);
     if (sub == 0) stats[row * stats_ld + g] = make_float2(s, q);

@@ -47,3 +47,16 @@ with torch.no_grad():
         return y[:72].clone(), xb[:72].clone(), st[:72].clone()
     p5, p3 = prod(120), prod(72)
     print('producer equal (y, xcopy, stats):', [torch.equal(u, v) for u, v in zip(p5, p3)])
+    # ---- decoder render / mixer / upscaler row independence, and run-to-run determinism of the memory build
+    for variant in ('v1', 'v2'):
+        hm = tiny.build(tiny.hip_ns(), variant).to(DEV)
+        c5 = torch.zeros(5 * T, hm._cat_width(), dtype=adt(), device=DEV); hm.encode_views(imgs, c5)
+        b1 = hm.build_memory(c5[:3 * T, :De].contiguous(), 3, 4, 6)
+        b2 = hm.build_memory(c5[:3 * T, :De].contiguous(), 3, 4, 6)
+        print(variant, 'memory build deterministic:', torch.equal(b1.K_all[:, :b1.n], b2.K_all[:, :b2.n]), torch.equal(b1.Vt_all[:, :, :b1.n], b2.Vt_all[:, :, :b2.n]))
+        c3 = c5[:3 * T].clone()
+        pm5 = hm.render_views(c5, 5, 4, 6, b1); pm3 = hm.render_views(c3, 3, 4, 6, b1)
+        print(variant, 'render: pointmaps equal', torch.equal(pm5[:3], pm3), 'feats equal', torch.equal(c5[:3 * T, De:De + Dd], c3[:, De:De + Dd]))
+        f5, m5 = hm.panoptic_decoder.features_tokens(c5, imgs, 5, 4, 6)
+        f3, m3 = hm.panoptic_decoder.features_tokens(c3, imgs[:3].contiguous(), 3, 4, 6)
+        print(variant, 'features: fpn equal', torch.equal(f5[:3 * T], f3), 'mask feats equal', torch.equal(m5[:3], m3))

@@ -147,7 +147,13 @@ __device__ __forceinline__ void ln_fold_prologue(const pst_gemm_params& p, float
     const int m = min(m0 + tid, p.M - 1);
     const float2* st = (const float2*)p.ln_stats + (int64_t)m * p.ln_groups;
     float s = 0.f, q = 0.f;
-    for (int g = 0; g < p.ln_groups; ++g) { const float2 v = st[g]; s += v.x; q += v.y; }
+    // all partials of the row requested at once (one load round trip instead of ln_groups dependent ones), summed in index order
+    float2 v[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] = g < p.ln_groups ? st[g] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { s += v[g].x; q += v[g].y; }
+    for (int g = 16; g < p.ln_groups; ++g) { const float2 t = st[g]; s += t.x; q += t.y; }
     const float inv_d = 1.0f / (float)p.K;
     const float mean = s * inv_d;
     const float rstd = rsqrtf(fmaxf(q * inv_d - mean * mean, 0.f) + p.ln_eps);

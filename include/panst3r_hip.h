@@ -168,6 +168,20 @@ int pst_rope2d(void* x, int64_t ld, const int32_t* pos, const float* cs, int row
 int pst_patchify(const float* img, void* out, int64_t ld, int nimg, int C, int H, int W, int p, int dtype16, void* stream);
 int pst_dino_preprocess(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, void* stream);
 
+/* ---------------------------------------------------------------- input side
+ * image_prepare: the reference's `load_images` transform on the device (tools/demo_panst3r.py:94-114): decoded uint8 RGB [Hs, Ws, 3]
+ *   -> ImgNorm (ToTensor + Normalize(0.5, 0.5): [-1, 1]) -> resize to (Hr, Wr), bilinear with antialiasing (what
+ *   torchvision.transforms.Resize does to a tensor) -> crop [top, top+H) x [left, left+W) -> fp32 [3, H, W].
+ *   (`get_resize_function` itself is un-vendored must3r code: the (Hr, Wr, top, left) recipe is restated on the host, parity unpinned.)
+ * patch_rows: fp32 images [nimg, 3, H, W] in [-1, 1] -> the patch-row operands of BOTH patch-embed GEMMs in one launch (either may be
+ *   NULL):  enc  16-bit [nimg*T, ld_enc]: p_enc x p_enc patches, column (c*p + dy)*p + dx, zero padded    (== pst_patchify)
+ *           dino 16-bit [nimg*T, ld_dino]: p_dino x p_dino patches of the image ImageNet-normalised and bilinearly resized to
+ *                (H/p_enc*p_dino, W/p_enc*p_dino), bit-identical to pst_dino_preprocess + pst_patchify without the fp32 intermediate
+ *                (model/dino.py:61-66).  dino_transposed: DINOv2 takes the transposed image (portrait views, model/dino.py:15-47). */
+int pst_image_prepare(const uint8_t* src, int Hs, int Ws, float* dst, int Hr, int Wr, int top, int left, int H, int W, void* stream);
+int pst_patch_rows(const float* img, void* enc, int64_t ld_enc, void* dino, int64_t ld_dino, int nimg, int H, int W, int p_enc, int p_dino,
+                   int dino_transposed, int dtype16, void* stream);
+
 /* ---------------------------------------------------------------- elementwise helpers
  * add_cast: y = a + (b ? b[row % b_mod] : 0); a_fp32 / b_fp32 / y_fp32 are element type codes; [rows, D] with leading dims. */
 int pst_add_cast(const void* a, int64_t lda, int a_fp32, const void* b, int64_t ldb, int b_fp32, int b_mod,

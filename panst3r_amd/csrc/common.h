@@ -142,18 +142,28 @@ __device__ __forceinline__ uint4 rope_chunk(const pst_gemm_params& p, uint4 own,
 
 // ---------------------------------------------------------------- LayerNorm fold (see pst_gemm_params)
 // Consumer prologue: thread t < BM turns the `ln_groups` partial (sum, sumsq) of A row m0 + t into (rstd, -mean * rstd) in LDS.
+// The partials of a row are contiguous: for the usual group counts they are fetched by unconditional 16-byte loads issued back to
+// back (one load round trip; a predicated per-group loop made hipcc wait after the first load - two round trips per tile).
+template <int NG>
+__device__ __forceinline__ void ln_row_sums(const float2* st, float& s, float& q) {
+  static_assert(NG % 2 == 0, "pairs of groups per 16-byte load");
+  float4 v[NG / 2];
+#pragma unroll
+  for (int g = 0; g < NG / 2; ++g) v[g] = ((const float4*)st)[g];
+  s = 0.f; q = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG / 2; ++g) { s += v[g].x; q += v[g].y; s += v[g].z; q += v[g].w; }     // index order, as the generic loop
+}
 __device__ __forceinline__ void ln_fold_prologue(const pst_gemm_params& p, float2* lnst, int tid, int m0, int BM) {
   if (tid < BM) {
     const int m = min(m0 + tid, p.M - 1);
     const float2* st = (const float2*)p.ln_stats + (int64_t)m * p.ln_groups;
     float s = 0.f, q = 0.f;
-    // all partials of the row requested at once (one load round trip instead of ln_groups dependent ones), summed in index order
-    float2 v[16];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) v[g] = g < p.ln_groups ? st[g] : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) { s += v[g].x; q += v[g].y; }
-    for (int g = 16; g < p.ln_groups; ++g) { const float2 t = st[g]; s += t.x; q += t.y; }
+    if (p.ln_groups == 16) ln_row_sums<16>(st, s, q);            // D = 1024 (encoder, DINOv2)
+    else if (p.ln_groups == 12) ln_row_sums<12>(st, s, q);       // D = 768 (decoder, mixer)
+    else if (p.ln_groups == 6) ln_row_sums<6>(st, s, q);         // D = 384 (LoftUp)
+    else if (p.ln_groups == 2) ln_row_sums<2>(st, s, q);
+    else for (int g = 0; g < p.ln_groups; ++g) { const float2 t = st[g]; s += t.x; q += t.y; }
     const float inv_d = 1.0f / (float)p.K;
     const float mean = s * inv_d;
     const float rstd = rsqrtf(fmaxf(q * inv_d - mean * mean, 0.f) + p.ln_eps);
@@ -161,8 +171,6 @@ __device__ __forceinline__ void ln_fold_prologue(const pst_gemm_params& p, float
   }
 }
 
-// Producer: (sum, sumsq) of `cnt` fp32 values reduced over the LANES-lane group that holds one row's 64-column group; the group's
-// first lane writes stats_out[row][grp].  Fixed xor-shuffle tree: deterministic.
 // per-thread part of the statistics: strictly sequential, explicit fmaf -- every call site (fast / edge epilogue paths of every tile
 // size, rowstats) must round identically, and `a*a + b*b` is contracted into FMAs in a site-dependent association otherwise.
 __device__ __forceinline__ void ln_acc(float a, float& s, float& q) { s += a; q = fmaf(a, a, q); }

@@ -41,7 +41,7 @@ class AttnParams(C.Structure):
 
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
            'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
-           'pst_patchify', 'pst_dino_preprocess', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
+           'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize']
 
@@ -374,6 +374,29 @@ def dino_preprocess(img, out):
     assert img.is_contiguous() and out.is_contiguous()
     _check(lib().pst_dino_preprocess(_ptr(img), _ptr(out), n, h, w, out.shape[-2], out.shape[-1], _stream()), 'pst_dino_preprocess')
     return out
+
+
+def image_prepare(src_u8, out, resized, crop_origin):
+    """decoded uint8 [Hs, Ws, 3] (device) -> fp32 `out` [3, H, W] in [-1, 1]: ImgNorm, antialiased bilinear resize to `resized` = (Hr, Wr),
+    crop of out's size at `crop_origin` = (top, left)."""
+    _dev(src_u8, torch.uint8); _dev(out, torch.float32)
+    assert src_u8.dim() == 3 and src_u8.shape[2] == 3 and src_u8.is_contiguous() and out.is_contiguous() and out.shape[0] == 3
+    Hs, Ws = src_u8.shape[:2]
+    _check(lib().pst_image_prepare(_ptr(src_u8), Hs, Ws, _ptr(out), int(resized[0]), int(resized[1]), int(crop_origin[0]), int(crop_origin[1]),
+                                   out.shape[1], out.shape[2], _stream()), 'pst_image_prepare')
+    return out
+
+
+def patch_rows(img, enc=None, dino=None, p_enc=16, p_dino=14, dino_transposed=False):
+    """fp32 images [n, 3, H, W] -> patch rows of the encoder (`enc` 16-bit [n*T, >= 3 p^2]) and / or DINOv2 (`dino`) in one launch."""
+    _dev(img, torch.float32)
+    assert img.is_contiguous() and (enc is not None or dino is not None)
+    n, _, H, W = img.shape
+    d16 = _same16(enc, dino)
+    _check(lib().pst_patch_rows(_ptr(img), _ptr(enc), i64(_rowmajor(enc) if enc is not None else 0), _ptr(dino),
+                                i64(_rowmajor(dino) if dino is not None else 0), n, H, W, p_enc, p_dino, int(dino_transposed), d16, _stream()),
+           'pst_patch_rows')
+    return enc, dino
 
 
 def add_cast(a, out, b=None, b_mod=0):

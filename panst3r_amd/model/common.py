@@ -181,14 +181,13 @@ def empty(rows, cols, dtype, device):
     return torch.empty(rows, cols, dtype=dtype, device=device)
 
 
-def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None, st=None):
-    """q,k projection (+RoPE) / transposed v projection / flash attention on a [lay.rows, D] 16-bit buffer.
-    `vt`: optional caller-owned V^T scratch [D, >= lay.rows + 8] (saves an allocation per layer).
-    `st`: LayerNorm-fold statistics of the rows of `xn` - then xn holds the RAW stream and w_qk / w_v are folded (fold_ln)."""
-    dev = xn.device
+def self_attention(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
+    """q,k projection (+RoPE) / transposed v projection / flash attention of LN(stream s) with the folded weights w_qk / w_v.
+    `vt`: optional caller-owned V^T scratch [D, >= lay.rows + 8] (saves an allocation per layer)."""
+    dev = s.x.device
     D = H * hd
     qk = empty(lay.rows, 2 * D, adt(), dev)
-    lq = None if st is None else ln_of(w_qk, st)
+    xn, lq = s.operand(w_qk)
     if rope is not None and hd == 64:
         hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, rope=(pos, rope), ln=lq)      # RoPE-2D applied in the GEMM's store phase
     else:
@@ -197,7 +196,8 @@ def self_attention(xn, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None, st=N
             hip.rope2d_(qk, pos, rope, 2 * H, hd)
     if vt is None:
         vt = torch.empty(D, lay.rows + 8, dtype=adt(), device=dev)
-    hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True, ln=None if st is None else ln_of(w_v, st))
+    xn, lv = s.operand(w_v)
+    hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True, ln=lv)
     o = empty(lay.rows, D, adt(), dev)
     if lay.Tp != lay.N:
         o.view(lay.V, lay.Tp, D)[:, lay.N:].zero_()      # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
@@ -230,36 +230,80 @@ def pack_croco_block(blk, device, norm_mlp=None):
                   fold_ln(blk.mlp.fc1.weight, blk.mlp.fc1.bias, nm, device), Packed(blk.mlp.fc2.weight, blk.mlp.fc2.bias, device))
 
 
+_UNIT = {}
+
+
+def unit_affine(D, device):
+    """(ones, zeros) fp32 [D]: affine parameters of a LayerNorm whose gamma / beta were folded into the consuming weights"""
+    key = (D, str(device))
+    if key not in _UNIT:
+        _UNIT[key] = (torch.ones(D, dtype=torch.float32, device=device), torch.zeros(D, dtype=torch.float32, device=device))
+    return _UNIT[key]
+
+
+def fold_in_epilogue():
+    """LayerNorm statistics applied in the consumer GEMM's epilogue (raw 16-bit rows in) - the f16 default.  In bf16 the raw stream
+    would be rounded to 8 mantissa bits BEFORE its mean is subtracted (measured at full size: mask logits rel-L2 2.1e-2 -> 3.6e-2), so
+    the bf16 fallback normalises first: one (x - mean) rstd pass per LayerNorm, gamma / beta still folded into the weights."""
+    return adt() == F16
+
+
 class Stream:
-    """A pre-LN residual stream and its LayerNorm-fold companions: x fp32 [rows, D] (the stream), xb = 16-bit copy of x (the A operand of
-    the GEMMs that consume LN(x)), st = per-row (sum, sumsq) per 64-column group [rows, D/64, 2].  Every GEMM that writes x refreshes xb
-    and st from its epilogue (hip.gemm xcopy= / stats_out=); `refresh()` does it for a stream no GEMM produced."""
-    __slots__ = ('x', 'xb', 'st')
+    """A pre-LN residual stream and its LayerNorm-fold companions: x (fp32 [rows, D], or the 16-bit stream itself), xb = 16-bit operand
+    of the GEMMs that consume LN(x), st = per-row (sum, sumsq) per 64-column group [rows, D/64, 2].
+    f16: xb is the raw 16-bit copy of x; every GEMM that writes x refreshes xb and st from its epilogue (hip.gemm xcopy= / stats_out=),
+         `refresh()` does it for a stream no GEMM produced, and consumers pass ln=(st, colsum, eps).
+    bf16: xb = (x - mean) rstd, produced by one LayerNorm pass per version of x (`operand()` runs it lazily); consumers take it as is.
+    Either way the consumers use the SAME folded weights (fold_ln): W diag(gamma), W beta + b."""
+    __slots__ = ('x', 'xb', 'st', 'fold', 'dirty', 'eps')
 
     def __init__(self, x, xb=None, st=None):
         rows, D = x.shape
         assert D % 64 == 0, 'LayerNorm fold needs D %% 64 == 0 (got %d)' % D
-        self.x = x
-        self.xb = empty(rows, D, adt(), x.device) if xb is None else xb
-        self.st = torch.empty(rows, D // 64, 2, dtype=torch.float32, device=x.device) if st is None else st
+        self.x, self.fold, self.dirty, self.eps = x, fold_in_epilogue(), True, None
+        if x.dtype != torch.float32 and self.fold:
+            self.xb = x                               # a 16-bit stream is its own raw operand
+        else:
+            self.xb = empty(rows, D, adt(), x.device) if xb is None else xb
+        self.st = None
+        if self.fold:
+            self.st = torch.empty(rows, D // 64, 2, dtype=torch.float32, device=x.device) if st is None else st
 
     def refresh(self):
-        hip.rowstats(self.x, self.xb, self.st)
+        if self.fold:
+            hip.rowstats(self.x, None if self.xb is self.x else self.xb, self.st)
+            self.dirty = False
         return self
 
+    def operand(self, pk):
+        """(A operand, ln= argument) for a GEMM with the folded weights `pk` consuming LN(x)"""
+        if self.fold:
+            return self.xb, (self.st, pk.cs, pk.eps)
+        if self.dirty or self.eps != pk.eps:          # one pass per version of x (and per eps): norm1 / norm_y ... share it
+            ones, zeros = unit_affine(self.x.shape[1], self.x.device)
+            hip.layernorm(self.x, ones, zeros, self.xb, pk.eps)
+            self.dirty, self.eps = False, pk.eps
+        return self.xb, None
+
     def residual(self, a, w, gamma=None, res=None):
-        """x = (res or x) + gamma * (a W^T + b), refreshing xb / st"""
-        hip.gemm(a, w.w, self.x, bias=w.b, gamma=gamma, res=self.x if res is None else res, xcopy=self.xb, stats_out=self.st)
+        """x = (res or x) + gamma * (a W^T + b); in fold mode the epilogue also refreshes xb / st"""
+        r = self.x if res is None else res
+        if self.fold:
+            hip.gemm(a, w.w, self.x, bias=w.b, gamma=gamma, res=r, xcopy=None if self.xb is self.x else self.xb, stats_out=self.st)
+        else:
+            hip.gemm(a, w.w, self.x, bias=w.b, gamma=gamma, res=r)
+            self.dirty = True
 
 
 def vit_block(s, bw, lay, H, hd, pos=None, rope=None):
-    """s: Stream over the fp32 residual [lay.rows, D], updated in place.  No stand-alone LayerNorm: norm1 / norm2 are folded into the
-    qkv / fc1 GEMMs, whose row statistics come out of the epilogues of the two residual GEMMs."""
+    """s: Stream over the fp32 residual [lay.rows, D], updated in place.  norm1 / norm2 are folded into the qkv / fc1 weights; in f16
+    their row statistics come out of the epilogues of the two residual GEMMs (no stand-alone LayerNorm pass)."""
     dev = s.x.device
-    o = self_attention(s.xb, lay, H, hd, bw.qk, bw.v, pos, rope, st=s.st)
+    o = self_attention(s, lay, H, hd, bw.qk, bw.v, pos, rope)
     s.residual(o, bw.proj, gamma=bw.ls1)
     h = empty(lay.rows, bw.fc1.n, adt(), dev)
-    hip.gemm(s.xb, bw.fc1.w, h, bias=bw.fc1.b, act='gelu', ln=ln_of(bw.fc1, s.st))
+    a, ln = s.operand(bw.fc1)
+    hip.gemm(a, bw.fc1.w, h, bias=bw.fc1.b, act='gelu', ln=ln)
     s.residual(h, bw.fc2, gamma=bw.ls2)
     return s
 

@@ -129,24 +129,31 @@ class DinoV2Encoder(HipModule):
         return pk['pos'][key]
 
     @torch.no_grad()
-    def encode_tokens(self, img, out, col0=0):
-        """img fp32 [V,3,H,W] in [-1,1] (landscape or native orientation) -> bf16 tokens written to out[:, col0:col0+D]."""
+    def patch_width(self, device):
+        return self.packed(device)['patch'].k
+
+    def encode_tokens(self, img, out, col0=0, patches=None, transposed=False):
+        """img fp32 [V,3,H,W] in [-1,1] -> 16-bit tokens written to out[:, col0:col0+D].  `transposed`: DINOv2 runs on the TRANSPOSED image
+        (portrait views with landscape_only, model/dino.py:15-47) - sampled with swapped axes, no transposed copy.  ImageNet
+        normalisation + bilinear resize to the 14-pixel grid + 14x14 patch rows are one kernel (hip.patch_rows); `patches` when the
+        caller already produced them together with the encoder's."""
         dev = img.device
         pk = self.packed(dev)
         V, _, H, W = img.shape
+        if transposed:
+            H, W = W, H
         p, D, Hh = self.patch_size, self.embed_dim, self.num_heads
         gh, gw = H // self.output_stride, W // self.output_stride
-        pre = torch.empty(V, 3, gh * p, gw * p, dtype=torch.float32, device=dev)
-        hip.dino_preprocess(img.contiguous(), pre)
         lay = Layout(V, gh * gw, extra=1)
-        patches = empty(V * lay.T, pk['patch'].k, adt(), dev)
-        hip.patchify(pre, patches, p)
+        if patches is None:
+            patches = empty(V * lay.T, pk['patch'].k, adt(), dev)
+            hip.patch_rows(img.contiguous(), dino=patches, p_enc=self.output_stride, p_dino=p, dino_transposed=transposed)
         cls, pospatch = self._pos(pk, gh, gw, dev)
         x = torch.zeros(lay.rows, D, dtype=torch.float32, device=dev)
         x.view(V, lay.Tp, D)[:, 0] = cls
         hip.gemm(patches, pk['patch'].w, x, bias=pk['patch'].b, res=pospatch, res_mod=lay.T, grp=lay.grp)
         if TAPS is not None:
-            TAPS.append(('pre', pre.clone())); TAPS.append(('patches', patches.clone())); TAPS.append(('embed', x.clone()))
+            TAPS.append(('patches', patches.clone())); TAPS.append(('embed', x.clone()))
         s = Stream(x).refresh()
         for i, bw in enumerate(pk['blocks']):
             vit_block(s, bw, lay, Hh, D // Hh)
@@ -160,12 +167,13 @@ class DinoV2Encoder(HipModule):
         V = image.shape[0]
         hh, ww = true_shape.T
         land = (ww >= hh)
-        x = image.float()
+        x = image.float().contiguous()
+        tr = False
         if self.landscape_only and not bool(land.all()):
             if not bool((~land).all()):
                 raise NotImplementedError('mixed-orientation batches: call once per orientation')
-            x = x.transpose(2, 3).contiguous()      # dinov2_transpose (model/dino.py:15-47): portrait views run transposed
+            tr = True                                # dinov2_transpose (model/dino.py:15-47): portrait views run transposed
         out = torch.empty(V * (x.shape[2] // self.output_stride) * (x.shape[3] // self.output_stride), self.embed_dim,
                           dtype=adt(), device=x.device)
-        self.encode_tokens(x, out)
+        self.encode_tokens(x, out, transposed=tr)
         return out.float().reshape(V, -1, self.embed_dim)

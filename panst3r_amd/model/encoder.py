@@ -38,17 +38,19 @@ class Dust3rEncoder(HipModule):
         return grow_table(pk['rope'], n, lambda m: hip.rope_table(m, hd, self.rope_base, device))
 
     @torch.no_grad()
-    def encode_tokens(self, img, out=None):
-        """img fp32 [V,3,H,W] (one shape) -> bf16 tokens [V*T, out_ld] written into `out[:, :D]` (or a new buffer),
-        plus int32 positions [V*T, 2]."""
+    def encode_tokens(self, img, out=None, patches=None):
+        """img fp32 [V,3,H,W] (one shape) -> 16-bit tokens [V*T, out_ld] written into `out[:, :D]` (or a new buffer),
+        plus int32 positions [V*T, 2].  `patches`: the 16x16 patch rows when the caller already produced them (hip.patch_rows makes the
+        rows of both ViTs in one launch)."""
         dev = img.device
         pk = self.packed(dev)
         V, _, H, W = img.shape
         p, D, Hh = self.patch_size, self.embed_dim, self.num_heads
         gh, gw = H // p, W // p
         lay = Layout(V, gh * gw)
-        patches = empty(V * lay.T, pk['patch'].k, adt(), dev)
-        hip.patchify(img.contiguous(), patches, p)
+        if patches is None:
+            patches = empty(V * lay.T, pk['patch'].k, adt(), dev)
+            hip.patch_rows(img.contiguous(), enc=patches, p_enc=p)
         x = torch.zeros(lay.rows, D, dtype=torch.float32, device=dev)
         hip.gemm(patches, pk['patch'].w, x, bias=pk['patch'].b, grp=lay.grp)
         pos = grid_pos(V, gh, gw, lay.Tp, 0, dev)

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import hip
 from .common import (HipModule, Packed, Layout, adt, BlockW, empty, pack_norm, pack_croco_block, self_attention, f32,
-                     ParamLinear, grid_pos, grow_table, Stream, fold_ln, ln_of)
+                     ParamLinear, grid_pos, grow_table, Stream, fold_ln, ln_of, fold_in_epilogue)
 from .params import BlockP, CrossAttnP, MlpP, AttnP
 
 
@@ -142,12 +142,14 @@ class MUSt3R(HipModule):
         """cross-attention queries of stream s: norm2 folded into projq"""
         c = bw.cross
         q = empty(s.x.shape[0], self.embed_dim, adt(), s.x.device)
-        hip.gemm(s.xb, c['q'].w, q, bias=c['q'].b, ln=ln_of(c['q'], s.st))
+        a, ln = s.operand(c['q'])
+        hip.gemm(a, c['q'].w, q, bias=c['q'].b, ln=ln)
         return q
 
     def _mlp(self, s, bw):
         h = empty(s.x.shape[0], bw.fc1.n, adt(), s.x.device)
-        hip.gemm(s.xb, bw.fc1.w, h, bias=bw.fc1.b, act='gelu', ln=ln_of(bw.fc1, s.st))
+        a, ln = s.operand(bw.fc1)
+        hip.gemm(a, bw.fc1.w, h, bias=bw.fc1.b, act='gelu', ln=ln)
         s.residual(h, bw.fc2)
 
     def _head(self, pk, feat, V, h, w):
@@ -170,7 +172,7 @@ class MUSt3R(HipModule):
         pos = grid_pos(V, h, w, lay.Tp, 0, dev)
         rope = self._rope(pk, max(h, w), dev)
         for l, bw in enumerate(pk['blocks']):
-            o = self_attention(s.xb, lay, H, hd, bw.qk, bw.v, pos, rope, st=s.st)
+            o = self_attention(s, lay, H, hd, bw.qk, bw.v, pos, rope)
             s.residual(o, bw.proj)
             q = self._cross_q(s, bw)
             o = empty(lay.rows, D, adt(), dev)
@@ -202,7 +204,7 @@ class MUSt3R(HipModule):
         # hs_all[l] = tokens entering block l, hs_all[L] = final stream: ONE tensor, so the append normalises all layers in one launch
         hs_all = torch.empty(L + 1, lay.rows, D, dtype=torch.float32, device=dev)
         xb_all = torch.empty(L + 1, lay.rows, D, dtype=adt(), device=dev)              # LayerNorm-fold companions of the L + 1 streams
-        st_all = torch.empty(L + 1, lay.rows, D // 64, 2, dtype=torch.float32, device=dev)
+        st_all = torch.empty(L + 1, lay.rows, D // 64, 2, dtype=torch.float32, device=dev) if fold_in_epilogue() else [None] * (L + 1)
         S = [Stream(hs_all[l], xb_all[l], st_all[l]) for l in range(L + 1)]
         self._embed(pk, x_enc, lay, first_is_ref=(bank.nimgs == 0), out=hs_all[0])
         S[0].refresh()
@@ -216,16 +218,17 @@ class MUSt3R(HipModule):
             s_in, s = S[l], S[l + 1]
             if lay.Tp != lay.T:
                 s.x.zero_()
-            o = self_attention(s_in.xb, lay, H, hd, bw.qk, bw.v, pos, rope, vt=vt_self, st=s_in.st)
+            o = self_attention(s_in, lay, H, hd, bw.qk, bw.v, pos, rope, vt=vt_self)
             s.residual(o, bw.proj, res=s_in.x)
             c = bw.cross
             o = empty(lay.rows, D, adt(), dev)
             if n == 2:
                 # each image attends to the other image's layer input (norm_y folded into projk / projv, on the fly)
                 kk = empty(lay.rows, D, adt(), dev)
-                hip.gemm(s_in.xb, c['k_f'].w, kk, bias=c['k_f'].b, ln=ln_of(c['k_f'], s_in.st))
+                a, ln = s_in.operand(c['k_f'])
+                hip.gemm(a, c['k_f'].w, kk, bias=c['k_f'].b, ln=ln)
                 vt = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)
-                hip.gemm(s_in.xb, c['v_f'].w, vt, bias=c['v_f'].b, trans_out=True, ln=ln_of(c['v_f'], s_in.st))
+                hip.gemm(a, c['v_f'].w, vt, bias=c['v_f'].b, trans_out=True, ln=ln if ln is None else ln_of(c['v_f'], s_in.st))
                 q = self._cross_q(s, bw)
                 ldv = vt.stride(0)
                 hip.attention(q, kk[lay.Tp:], vt[:, lay.Tp:], o, 2, H, T, T, hd,
@@ -273,14 +276,15 @@ class MUSt3R(HipModule):
             for i in range(2):          # K / V^T of each image's layer input (the other image's context), norm_y folded
                 lay, s_in = lays[i], S[i][l]
                 kk = empty(lay.rows, D, adt(), dev)
-                hip.gemm(s_in.xb, c['k_f'].w, kk, bias=c['k_f'].b, ln=ln_of(c['k_f'], s_in.st))
+                a, ln = s_in.operand(c['k_f'])
+                hip.gemm(a, c['k_f'].w, kk, bias=c['k_f'].b, ln=ln)
                 vt = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)
-                hip.gemm(s_in.xb, c['v_f'].w, vt, bias=c['v_f'].b, trans_out=True, ln=ln_of(c['v_f'], s_in.st))
+                hip.gemm(a, c['v_f'].w, vt, bias=c['v_f'].b, trans_out=True, ln=ln if ln is None else ln_of(c['v_f'], s_in.st))
                 kvs.append((kk, vt))
             for i in range(2):
                 lay, s_in = lays[i], S[i][l]
                 s = Stream(empty(lay.rows, D, torch.float32, dev))
-                o = self_attention(s_in.xb, lay, H, hd, bw.qk, bw.v, poss[i], rope, st=s_in.st)
+                o = self_attention(s_in, lay, H, hd, bw.qk, bw.v, poss[i], rope)
                 s.residual(o, bw.proj, res=s_in.x)
                 q = self._cross_q(s, bw)
                 kk, vt = kvs[1 - i]

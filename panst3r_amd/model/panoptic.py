@@ -266,10 +266,9 @@ class LoftUpUpscaler(HipModule):
             # (fp32 would double the read-modify-write traffic of both residual GEMMs and of every LayerNorm).
             x = guidance[v0 * P:(v0 + n) * P]
             q, o = empty(n * P, C, adt(), dev), empty(n * P, C, adt(), dev)
-            # LayerNorm fold on the 16-bit stream: norm2 / norm3 live in projq / fc1, their row statistics come out of the epilogues of
-            # the two residual GEMMs (no stand-alone pass over the [n*P, C] tensor: 4 of the 16 passes per chunk gone)
-            st = torch.empty(n * P, C // 64, 2, dtype=torch.float32, device=dev)
-            hip.rowstats(x, None, st)
+            # LayerNorm fold on the 16-bit stream: norm2 / norm3 live in projq / fc1; in f16 their row statistics come out of the epilogues
+            # of the two residual GEMMs (no stand-alone pass over the [n*P, C] tensor: 4 of the 16 passes per chunk gone)
+            s = Stream(x).refresh()
             rows0, rows1 = v0 * lay.Tp, (v0 + n) * lay.Tp
             for bw in pk['blocks']:
                 y = empty(rows1 - rows0, C, adt(), dev)
@@ -278,15 +277,17 @@ class LoftUpUpscaler(HipModule):
                 hip.gemm(y, bw['k'].w, kk, bias=bw['k'].b)
                 vt = torch.zeros(C, rows1 - rows0 + 8, dtype=adt(), device=dev)
                 hip.gemm(y, bw['v'].w, vt, bias=bw['v'].b, trans_out=True)
-                hip.gemm(x, bw['q'].w, q, bias=bw['q'].b, ln=ln_of(bw['q'], st))
+                a, ln = s.operand(bw['q'])
+                hip.gemm(a, bw['q'].w, q, bias=bw['q'].b, ln=ln)
                 ldv = vt.stride(0)
                 hip.attention(q, kk, vt, o, n, Hh, P, T, hd, q_strides=(P * C, hd, C), k_strides=(lay.Tp * C, hd, C),
                               v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(P * C, hd, C))
-                hip.gemm(o, bw['proj'].w, x, bias=bw['proj'].b, res=x, stats_out=st)
-                hip.gemm(x, bw['fc1'].w, q, bias=bw['fc1'].b, act='gelu', ln=ln_of(bw['fc1'], st))
-                hip.gemm(q, bw['fc2'].w, x, bias=bw['fc2'].b, res=x, stats_out=st)
+                s.residual(o, bw['proj'])
+                a, ln = s.operand(bw['fc1'])
+                hip.gemm(a, bw['fc1'].w, q, bias=bw['fc1'].b, act='gelu', ln=ln)
+                s.residual(q, bw['fc2'])
             hip.layernorm(x, pk['norm'][0], pk['norm'][1], mask_out[v0:v0 + n].view(n * P, C), pk['norm'][2])
-            del x, q, o, st
+            del x, q, o, s
         return fpn_out, mask_out
 
     def forward(self, inputs, img_shape):

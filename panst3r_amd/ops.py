@@ -40,12 +40,15 @@ def _t3(v):
 
 
 # ---------------------------------------------------------------------------------------------------- registered ops
-@_op('gemm', ('out',))
+@_op('gemm', ('out', 'xcopy', 'stats_out'))
 def gemm(a: Tensor, w: Tensor, out: Tensor, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None, res: Optional[Tensor] = None,
          res_mod: int = 0, act: str = 'none', trans_out: bool = False, grp: Optional[List[int]] = None, ps: Optional[List[int]] = None,
-         conv: Optional[List[int]] = None, rope_pos: Optional[Tensor] = None, rope_table: Optional[Tensor] = None, kernel: int = 0) -> None:
+         conv: Optional[List[int]] = None, rope_pos: Optional[Tensor] = None, rope_table: Optional[Tensor] = None, kernel: int = 0,
+         xcopy: Optional[Tensor] = None, stats_out: Optional[Tensor] = None, ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None,
+         ln_eps: float = 0.0) -> None:
     hip.gemm(a, w, out, bias=bias, gamma=gamma, res=res, res_mod=res_mod, act=act, trans_out=trans_out, grp=_t3(grp), ps=_t3(ps), conv=_t3(conv),
-             rope=None if rope_pos is None else (rope_pos, rope_table), kernel=kernel)
+             rope=None if rope_pos is None else (rope_pos, rope_table), kernel=kernel, xcopy=xcopy, stats_out=stats_out,
+             ln=None if ln_stats is None else (ln_stats, ln_colsum, ln_eps))
 
 
 @_op('attention', ('out',))
@@ -75,6 +78,22 @@ def patchify(img: Tensor, out: Tensor, p: int) -> None:
 @_op('dino_preprocess', ('out',))
 def dino_preprocess(img: Tensor, out: Tensor) -> None:
     hip.dino_preprocess(img, out)
+
+
+@_op('image_prepare', ('out',))
+def image_prepare(src_u8: Tensor, out: Tensor, resized: List[int], crop_origin: List[int]) -> None:
+    hip.image_prepare(src_u8, out, tuple(resized), tuple(crop_origin))
+
+
+@_op('patch_rows', ('enc', 'dino'))
+def patch_rows(img: Tensor, enc: Optional[Tensor] = None, dino: Optional[Tensor] = None, p_enc: int = 16, p_dino: int = 14,
+               dino_transposed: bool = False) -> None:
+    hip.patch_rows(img, enc=enc, dino=dino, p_enc=p_enc, p_dino=p_dino, dino_transposed=dino_transposed)
+
+
+@_op('rowstats', ('xcopy', 'stats'))
+def rowstats(x: Tensor, xcopy: Optional[Tensor], stats: Tensor) -> None:
+    hip.rowstats(x, xcopy, stats)
 
 
 @_op('add_cast', ('out',))

@@ -126,15 +126,20 @@ class PanSt3R(nn.Module):
         p = self.must3r_encoder.patch_size
         T = (H // p) * (W // p)
         De, Dd = self.must3r_encoder.embed_dim, self.must3r_decoder.embed_dim
+        tr = bool(H > W and self.dino_encoder.landscape_only)   # dinov2_transpose (model/dino.py:15-47): portrait views run transposed
         for v0 in range(0, V, ENC_CHUNK):
             sl = slice(v0 * T, min(V, v0 + ENC_CHUNK) * T)
-            im = imgs[v0:v0 + ENC_CHUNK]
+            im = imgs[v0:v0 + ENC_CHUNK].contiguous()
+            pe = pdn = None
+            if enc and dino:                                      # the patch rows of both ViTs in ONE launch
+                n = im.shape[0]
+                pe = torch.empty(n * T, self.must3r_encoder.packed(im.device)['patch'].k, dtype=adt(), device=im.device)
+                pdn = torch.empty(n * T, self.dino_encoder.patch_width(im.device), dtype=adt(), device=im.device)
+                hip.patch_rows(im, enc=pe, dino=pdn, p_enc=p, p_dino=self.dino_encoder.patch_size, dino_transposed=tr)
             if enc:
-                self.must3r_encoder.encode_tokens(im, out=cat[sl])
+                self.must3r_encoder.encode_tokens(im, out=cat[sl], patches=pe)
             if dino:
-                if H > W and self.dino_encoder.landscape_only:
-                    im = im.transpose(2, 3).contiguous()         # dinov2_transpose (model/dino.py:15-47): portrait views run transposed
-                self.dino_encoder.encode_tokens(im, cat[sl], col0=De + Dd)
+                self.dino_encoder.encode_tokens(im, cat[sl], col0=De + Dd, patches=pdn, transposed=tr)
 
     @torch.no_grad()
     def build_memory(self, enc_kf, K, h=None, w=None, grids=None):

@@ -14,7 +14,8 @@ model.must3r_decoder.to(dev)
 dec = model.must3r_decoder
 h, w = 24, 32
 T = h * w
-enc = (torch.randn(K * T, 1024, device=dev) * 0.5).to(torch.bfloat16)
+from panst3r_amd.model.common import adt
+enc = (torch.randn(K * T, 1024, device=dev) * 0.5).to(adt())
 def run():
     return model.build_memory(enc, K, h, w)
 run(); torch.cuda.synchronize()

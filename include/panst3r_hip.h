@@ -260,6 +260,20 @@ int pst_pp_select(const int* keep, int* cnt_orig, int* cnt_mask, int Q, double o
 int pst_pp_finalize(const int* best_q, const float* best_m, const int* seg_id, int n, float mask_threshold,
                     float void_confidence, int* pan, float* conf, void* stream);
 
+/* ---------------------------------------------------------------- pointmap post-processing
+ * The demo's camera recovery (tools/demo_panst3r.py:220-221,246-277) on the device, per scene instead of per view on the host:
+ *   pointmap_activate  raw decoder output fp32 [npix, 7] -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]
+ *                      (must3r.engine.inference.postprocess, [3P]: mode 0 = 'norm_exp' xyz expm1(|xyz|)/|xyz|, 1 = linear; conf = 1 + exp(c))
+ *   focal_weiszfeld    dust3r.post_process.estimate_focal_knowing_depth(focal_mode='weiszfeld'): pts3d_local [V, H*W, 3], principal points
+ *                      pp [V, 2] (x, y) -> focal [V]; closed-form L2 start + `iters` (reference: 10) re-weighted least-squares steps
+ *   rigid_moments      the sums roma.rigid_points_registration(x, y, weights=conf-1) needs: per view 16 doubles = sum w, sum w x (3),
+ *                      sum w y (3), sum w y x^T (9); x = pts3d_local, y = pts3d, w = conf + weight_offset (reference: -1).  The 3x3
+ *                      special-Procrustes SVD of the centred moment matrix is host work on 9 numbers.
+ * One block per view, fixed-order double-precision reductions (bit-reproducible). */
+int pst_pointmap_activate(const float* raw, float* pts3d, float* pts3d_local, float* conf, int64_t npix, int mode, void* stream);
+int pst_focal_weiszfeld(const float* pts3d_local, const float* pp, float* focal, int nviews, int H, int W, int iters, void* stream);
+int pst_rigid_moments(const float* x, const float* y, const float* conf, double* out, int nviews, int npix, float weight_offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

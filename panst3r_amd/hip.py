@@ -43,7 +43,7 @@ EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 
            'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
-           'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize']
+           'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize', 'pst_pointmap_activate', 'pst_focal_weiszfeld', 'pst_rigid_moments']
 
 
 def lib():
@@ -519,3 +519,27 @@ def pp_finalize(best_q, best_m, seg_id, n, mask_threshold, void_confidence, pan,
     _dev(best_q, torch.int32); _dev(best_m, torch.float32); _dev(seg_id, torch.int32); _dev(pan, torch.int32); _dev(conf, torch.float32)
     _check(lib().pst_pp_finalize(_ptr(best_q), _ptr(best_m), _ptr(seg_id), n, C.c_float(mask_threshold), C.c_float(void_confidence), _ptr(pan),
                                  _ptr(conf), _stream()), 'pst_pp_finalize')
+
+
+# ------------------------------------------------------------------ pointmap post-processing
+def pointmap_activate(raw, pts3d, pts3d_local, conf, mode=0):
+    for t in (raw, pts3d, pts3d_local, conf):
+        _dev(t, torch.float32)
+        assert t.is_contiguous()
+    npix = raw.numel() // 7
+    _check(lib().pst_pointmap_activate(_ptr(raw), _ptr(pts3d), _ptr(pts3d_local), _ptr(conf), i64(npix), int(mode), _stream()), 'pst_pointmap_activate')
+
+
+def focal_weiszfeld(pts3d_local, pp, focal, H, W, iters=10):
+    _dev(pts3d_local, torch.float32); _dev(pp, torch.float32); _dev(focal, torch.float32)
+    assert pts3d_local.is_contiguous() and pp.is_contiguous() and focal.numel() * H * W * 3 == pts3d_local.numel()
+    _check(lib().pst_focal_weiszfeld(_ptr(pts3d_local), _ptr(pp), _ptr(focal), focal.numel(), H, W, iters, _stream()), 'pst_focal_weiszfeld')
+    return focal
+
+
+def rigid_moments(x, y, conf, out, weight_offset=-1.0):
+    _dev(x, torch.float32); _dev(y, torch.float32); _dev(conf, torch.float32); _dev(out, torch.float64)
+    V = out.shape[0]
+    assert x.is_contiguous() and y.is_contiguous() and conf.is_contiguous() and out.is_contiguous() and out.shape[1] == 16
+    _check(lib().pst_rigid_moments(_ptr(x), _ptr(y), _ptr(conf), _ptr(out), V, conf.numel() // V, C.c_float(weight_offset), _stream()), 'pst_rigid_moments')
+    return out

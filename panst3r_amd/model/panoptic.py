@@ -501,10 +501,19 @@ class MaskTransformer(HipModule):
         mask = torch.zeros(Q, NKm, dtype=torch.uint8, device=dev)
         logits_attn = empty(Q, NK, torch.float32, dev)
 
+        forced, log = getattr(self, 'forced_masks', None), getattr(self, 'mask_log', None)
+        step = [0]
+
         def next_mask(o):
             dn, emb = self._embed(pk, o)
-            hip.gemm(emb, fm, logits_attn)
-            hip.attn_mask_from_logits(logits_attn, mask[:, :NK] if NKm == NK else mask)
+            if forced is not None:           # parity instrumentation (tests / bench.py): take the attention-mask BITS of this decoder layer from
+                mask.copy_(forced[step[0]])  # outside, so that the hard threshold at logit 0 cannot amplify a 1e-3 difference into another query
+            else:
+                hip.gemm(emb, fm, logits_attn)
+                hip.attn_mask_from_logits(logits_attn, mask[:, :NK] if NKm == NK else mask)
+            if log is not None:
+                log.append(mask.clone())
+            step[0] += 1
             return dn, emb
         if NKm != NK:
             raise NotImplementedError('total keyframe tokens must be a multiple of 4')

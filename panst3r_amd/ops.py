@@ -40,15 +40,27 @@ def _t3(v):
 
 
 # ---------------------------------------------------------------------------------------------------- registered ops
-@_op('gemm', ('out', 'xcopy', 'stats_out'))
+@_op('gemm', ('out',))
 def gemm(a: Tensor, w: Tensor, out: Tensor, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None, res: Optional[Tensor] = None,
          res_mod: int = 0, act: str = 'none', trans_out: bool = False, grp: Optional[List[int]] = None, ps: Optional[List[int]] = None,
          conv: Optional[List[int]] = None, rope_pos: Optional[Tensor] = None, rope_table: Optional[Tensor] = None, kernel: int = 0,
-         xcopy: Optional[Tensor] = None, stats_out: Optional[Tensor] = None, ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None,
-         ln_eps: float = 0.0) -> None:
+         ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None, ln_eps: float = 0.0) -> None:
+    """C = epi(A W^T); with ln_stats the LayerNorm of the rows of A is applied in the epilogue (folded weights, include/panst3r_hip.h)."""
     hip.gemm(a, w, out, bias=bias, gamma=gamma, res=res, res_mod=res_mod, act=act, trans_out=trans_out, grp=_t3(grp), ps=_t3(ps), conv=_t3(conv),
-             rope=None if rope_pos is None else (rope_pos, rope_table), kernel=kernel, xcopy=xcopy, stats_out=stats_out,
-             ln=None if ln_stats is None else (ln_stats, ln_colsum, ln_eps))
+             rope=None if rope_pos is None else (rope_pos, rope_table), kernel=kernel, ln=None if ln_stats is None else (ln_stats, ln_colsum, ln_eps))
+
+
+@_op('gemm_stream', ('out', 'xcopy', 'stats_out'))
+def gemm_stream(a: Tensor, w: Tensor, out: Tensor, xcopy: Tensor, stats_out: Tensor, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
+                res: Optional[Tensor] = None, kernel: int = 0) -> None:
+    """residual GEMM that writes the fp32 stream `out`, its 16-bit copy and the per-row LayerNorm statistics (fold producer)"""
+    hip.gemm(a, w, out, bias=bias, gamma=gamma, res=res, kernel=kernel, xcopy=xcopy, stats_out=stats_out)
+
+
+@_op('gemm_stream16', ('out', 'stats_out'))
+def gemm_stream16(a: Tensor, w: Tensor, out: Tensor, stats_out: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None, kernel: int = 0) -> None:
+    """the same for a 16-bit residual stream (LoftUp blocks): `out` is its own operand copy"""
+    hip.gemm(a, w, out, bias=bias, res=res, kernel=kernel, stats_out=stats_out)
 
 
 @_op('attention', ('out',))
@@ -86,13 +98,12 @@ def image_prepare(src_u8: Tensor, out: Tensor, resized: List[int], crop_origin: 
 
 
 @_op('patch_rows', ('enc', 'dino'))
-def patch_rows(img: Tensor, enc: Optional[Tensor] = None, dino: Optional[Tensor] = None, p_enc: int = 16, p_dino: int = 14,
-               dino_transposed: bool = False) -> None:
+def patch_rows(img: Tensor, enc: Tensor, dino: Tensor, p_enc: int = 16, p_dino: int = 14, dino_transposed: bool = False) -> None:
     hip.patch_rows(img, enc=enc, dino=dino, p_enc=p_enc, p_dino=p_dino, dino_transposed=dino_transposed)
 
 
 @_op('rowstats', ('xcopy', 'stats'))
-def rowstats(x: Tensor, xcopy: Optional[Tensor], stats: Tensor) -> None:
+def rowstats(x: Tensor, xcopy: Tensor, stats: Tensor) -> None:
     hip.rowstats(x, xcopy, stats)
 
 

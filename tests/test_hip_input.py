@@ -68,4 +68,4 @@ def test_load_images_pair_and_shapes(tmp_path):
     assert len(views) == 2 and views[0]['img'].shape == (3, 384, 512) and list(views[0]['true_shape']) == [384, 512]
     again = load_images([arr, arr[:, ::-1].copy()], size=224, verbose=False, device=DEV)
     assert again[0]['img'].shape == (3, 160, 224)
-    assert float((again[0]['img'].flip(-1) - again[1]['img']).abs().max()) < 1e-5          # the filter is symmetric: mirrored input, mirrored output
+    assert float((again[0]['img'].flip(-1) - again[1]['img']).abs().max()) < 1e-4          # the filter is symmetric: mirrored input, mirrored output

@@ -148,11 +148,56 @@ def full_size_parity(model, dev, ref, imgs, ts, names, amp='fp16', K=2):
 REAL_STDOUT = 1
 
 
+def cpu_c1(threads):
+    """BASELINE configs[0] (the reference's own CPU-runnable case): 2 views at 224x224, fp32, v1 model, PanSt3R.forward style."""
+    from oracle.pipeline import build
+    from panst3r_amd.synthetic import fill_module_, synth_image, synth_class_embeddings
+    torch.set_num_threads(threads)
+    model = fill_module_(build('v1'), seed=1)
+    names, emb = synth_class_embeddings(100)
+    model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
+    imgs = torch.stack([synth_image(i, 224, 224, 7) for i in range(2)])[None]
+    ts = torch.tensor([[[224, 224]] * 2])
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        model(imgs, ts, names)
+    dt = time.perf_counter() - t0
+    return {'config': 'C1: 2 views / 2 keyframes, 224x224, v1, fp32 torch', 'frames_per_s': round(2 / dt, 4), 'seconds': round(dt, 2)}
+
+
+def hbm_stage_table(timer, V, H, W, variant):
+    """Per-stage HBM GB/s of the sub-stages SURVEY 8(d) lists as HBM-bound, from the instrumented step's HIP events: ALGORITHMIC bytes
+    (what the stage must move once) / event time, against the 8 TB/s peak."""
+    from panst3r_amd import flops as F
+    out = {}
+    by = timer.by_tag()
+    Q, C, P = 200, (384 if variant == 'v2' else 256), (H // 2) * (W // 2)
+
+    def add(key, pred, nbytes):
+        ms = sum(d['ms'] for (n, t), d in by.items() if pred(n, t))
+        cnt = sum(d['launches'] for (n, t), d in by.items() if pred(n, t))
+        if cnt:
+            out[key] = {'launches': cnt, 'bytes_per_launch': int(nbytes), 'avg_us': round(1e3 * ms / cnt, 2),
+                        'GBps': round(nbytes * cnt / (ms * 1e-3) / 1e9, 1), 'frac_of_8TBps': round(nbytes * cnt / (ms * 1e-3) / 8e12, 4)}
+    add('mask_head (query x pixel einsum, per view)', lambda n, t: n.startswith('gemm') and t[:3] == (Q, P, C), C * P * 2 + Q * P * 4)
+    T = (H // 16) * (W // 16)
+    pm = [(n, t) for (n, t) in by if n.startswith('gemm') and len(t) > 9 and t[9] == 'ps' and t[1] == 1792]
+    for n, t in pm:
+        add('pointmap head + pixel-shuffle store (M=%d)' % t[0], lambda nn, tt, t=t: nn == n and tt == t, t[0] * 768 * 2 + t[0] * 1792 * 4)
+    summ = timer.summary()
+    for k in ('layernorm', 'rowstats', 'groupnorm_stats', 'groupnorm_apply', 'loftup_guidance_gn', 'mean4', 'patch_rows'):
+        d = summ.get(k)
+        if d and d['launches']:
+            out[k] = {'launches': d['launches'], 'bytes_per_launch': int(d['bytes'] / d['launches']), 'avg_us': round(1e3 * d['ms'] / d['launches'], 2),
+                      'GBps': round(d['bytes'] / (d['ms'] * 1e-3) / 1e9, 1), 'frac_of_8TBps': round(d['bytes'] / (d['ms'] * 1e-3) / 8e12, 4)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--variant', default='v2', choices=['v1', 'v2'])
     ap.add_argument('--views', type=int, default=50)
     ap.add_argument('--keyframes', type=int, default=16)
@@ -160,6 +205,8 @@ def main():
     ap.add_argument('--width', type=int, default=512)
     ap.add_argument('--amp', default='fp16', choices=['fp16', 'bf16'], help="16-bit MFMA operand format (reference --amp, tools/demo_panst3r.py:88)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-c2', action='store_true', help='also time the reduced C2 sample (v1, 8 views / 8 keyframes) on the host: ~1 min')
+    ap.add_argument('--no-alt-dtype', action='store_true', help='skip the short measurement of the other 16-bit format')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--overlap', action='store_true', help='MEASUREMENT ONLY: run the memory build beside the independent encoder/DINOv2 work on a second stream '
                     '(+8 %% frames/s; was not reproducible until one kernel was fixed, mechanism not understood: DESIGN.md section 4); default: back to back')
@@ -190,7 +237,8 @@ def main():
     model = build_from_config(CONFIG_V2 if args.variant == 'v2' else CONFIG_V1).eval()
     fill_module_(model, seed=1)
     names, emb = synth_class_embeddings(100)
-    state = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    host_legs = rank == 0 and world == 1 and not args.no_cpu_baseline
+    state = {k: v.clone() for k, v in model.state_dict().items()} if host_legs else None
     model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
     model.to(dev)
 
@@ -199,38 +247,43 @@ def main():
     mine = {order[i] for i in range(V) if owner[i] == rank}
     images = {i: synth_image(i, H, W).to(dev) for i in sorted(mine)}        # inputs resident in HBM before timing
 
-    runner = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager, overlap=args.overlap and not args.no_overlap, amp=args.amp)
-
-    def step(eager=False):
-        # the instrumented eager step always runs the two branches of stage 2 back-to-back (also under --overlap): per-kernel
-        # HIP-event durations are then not inflated by kernels of the other branch sharing the CUs
-        return runner.run(eager=eager, serial=True, copy=False) if eager else runner.run(copy=False)
-
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):      # the first run also captures the three HIP graphs of the scene
-        step()
-    timer = None
-    fence()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        if s == args.steps - 1 and not args.no_kernel_timing:
-            # the LAST timed step runs eagerly (not as a graph replay) with HIP events around every MFMA-kernel launch
-            timer = hip.KernelTimer()
-            hip.TIMER = timer
-            step(eager=True)
-        else:
-            step()
-    hip.TIMER = None
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    def measure(amp, steps, warmup, instrument):
+        """W untimed warm-up steps (the first also captures the three HIP graphs), then EXACTLY `steps` timed steps between two fences."""
+        runner = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager, overlap=args.overlap and not args.no_overlap, amp=amp)
+        for _ in range(max(warmup, 1)):
+            runner.run(copy=False)
+        timer = None
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        fence()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            marks[s].record()
+            if s == steps - 1 and instrument:
+                # the LAST timed step runs eagerly (not as a graph replay) with HIP events around every MFMA-kernel and HBM-stage launch; it
+                # runs the two branches of stage 2 back-to-back also under --overlap (event durations not inflated by the other branch)
+                timer = hip.KernelTimer()
+                hip.TIMER = timer
+                runner.run(eager=True, serial=True, copy=False)
+            else:
+                runner.run(copy=False)
+        marks[steps].record()
+        hip.TIMER = None
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+        per = sorted(marks[s].elapsed_time(marks[s + 1]) for s in range(steps - (1 if instrument else 0)))      # graph-replay steps only
+        del runner
+        return elapsed, (per[len(per) // 2] if per else None), timer
+
+    elapsed, median_ms, timer = measure(args.amp, args.steps, args.warmup, not args.no_kernel_timing)
 
     if rank == 0:
         fps = V * args.steps / elapsed
@@ -243,40 +296,72 @@ def main():
                                    % (args.variant, V, K, H, W),
                        'variant': args.variant, 'views': V, 'keyframes': K, 'resolution': [H, W],
                        'parallelism': 'views sharded over %d rank(s)' % world,
+                       'operands': "%s MFMA operands, fp32 accumulate / residual streams / softmax / statistics (reference --amp %s, tools/demo_panst3r.py:88)"
+                                   % ('f16' if args.amp == 'fp16' else 'bf16', args.amp),
                        'launch': 'eager' if args.eager else 'HIP-graph replay (3 graphs per scene; last timed step eager + HIP-event instrumented)',
                        'overlap': 'memory build || non-keyframe encoder + DINOv2 (2 streams; opt-in, DESIGN.md section 4)' if (args.overlap and not args.no_overlap)
                                   else 'off (one stream; the two-stream variant is opt-in, DESIGN.md section 4)',
+                       'median_ms_per_graph_step': None if median_ms is None else round(median_ms, 3),
+                       'median_frames_per_s': None if median_ms is None else round(V / (median_ms * 1e-3), 2),
                        'scene_algorithmic_tflop': round(scene_flops / 1e12, 2),
                        'scene_mfma_frac': round(scene_flops / (elapsed / args.steps) / world / (PEAK_BF16_TFLOPS * 1e12), 4)},
         }
         if timer is not None and os.environ.get('PST_SHAPE_PROFILE') == '1':      # per-shape table of the instrumented step (stderr)
             rows = sorted(timer.by_tag().items(), key=lambda kv: -kv[1]['ms'])
-            for (name, tag), d in rows[:40]:
+            for (name, tag), d in rows[:48]:
                 print('%-24s %-62s x%-4d %8.2f ms %7.1f TF' % (name, tag, d['launches'], d['ms'], d['flops'] / (d['ms'] * 1e-3) / 1e12), file=sys.stderr)
         if timer is not None:
-            summ = timer.summary()
+            summ = {k: v for k, v in timer.summary().items() if v['flops'] > 0}
             dom = max(summ, key=lambda k: summ[k]['ms'])
             d = summ[dom]
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
-            # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r1_pmc_summary.json: FETCH_SIZE and
-            # WRITE_SIZE in separate rocprofv3 --pmc runs of this same workload, FETCH_SIZE doubled per the gfx950 note)
-            traffic = None
+            # HBM bytes per launch of that kernel from PMC passes of THIS kernel source (tools/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate
+            # rocprofv3 --pmc runs of this workload, FETCH_SIZE doubled per the gfx950 note); null when the committed summary is of other sources
+            traffic, traffic_note = None, 'no PMC summary for these kernel sources'
             try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_summary.json')))
-                key = dom.replace(',', ', ')
-                e = pmc.get(key) or next((v for k, v in pmc.items() if k.startswith(key[:-1] + ',')), None)   # PMC names carry every template argument
-                if e and args.views == 50 and args.keyframes == 16 and args.variant == 'v2':
-                    traffic = int(e['hbm_read_bytes_per_launch'] + e['hbm_write_bytes_per_launch'])
+                from panst3r_amd.build import source_hash
+                for fn in sorted(os.listdir(os.path.join(ROOT, 'profiles')), reverse=True):
+                    if not fn.endswith('_pmc_summary.json'):
+                        continue
+                    pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+                    if pmc.get('_source_hash') != source_hash():
+                        continue
+                    key = dom.replace(',', ', ')
+                    e = pmc.get(key) or next((v for k, v in pmc.items() if k.startswith(key[:-1] + ',')), None)   # PMC names carry every template argument
+                    if e and V == 50 and K == 16 and args.variant == 'v2':
+                        traffic = int(e['hbm_read_bytes_per_launch'] + e['hbm_write_bytes_per_launch'])
+                        traffic_note = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same kernel sources: %s)' % (fn, pmc['_source_hash'])
+                    break
             except Exception:
                 pass
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic, 'launches': d['launches'],
+                               'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_note, 'launches': d['launches'],
                                'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
                                'avg_launch_gflop': round(d['flops'] / d['launches'] / 1e9, 3)}
             out['kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 2),
                                   'tflops': round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1)} for k, v in sorted(summ.items())}
-        if state is not None:
-            out['cpu_baseline'], ref, ref_imgs, ref_ts = cpu_baseline(args.variant, H, W, state, names, emb, usable_cores())
+            out['hbm_stages'] = hbm_stage_table(timer, V, H, W, args.variant)
+        if host_legs and not args.no_alt_dtype:
+            alt = 'bf16' if args.amp == 'fp16' else 'fp16'
+            e2, m2, _ = measure(alt, max(3, args.steps // 4), 1, False)
+            out['alt_dtype'] = {'dtype': 'bf16' if alt == 'bf16' else 'f16', 'value': round(V * max(3, args.steps // 4) / e2, 3),
+                                'note': 'the other 16-bit format of the reference (--amp %s), same scene, %d timed steps' % (alt, max(3, args.steps // 4))}
+        if host_legs:
+            threads = usable_cores()
+            out['cpu_baseline'], ref, ref_imgs, ref_ts = cpu_baseline(args.variant, H, W, state, names, emb, threads)
+            samples = {'C1': cpu_c1(threads)}
+            if args.cpu_baseline_c2:
+                m1 = build_from_config(CONFIG_V1).eval()
+                fill_module_(m1, seed=1)
+                rec, _, _, _ = cpu_baseline('v1', H, W, {k: v.clone() for k, v in m1.state_dict().items()}, names, emb, threads, V=8, K=8)
+                samples['C2_reduced'] = {'config': 'C2 reduced: v1, 8 views / 8 keyframes, %dx%d' % (H, W), 'frames_per_s': rec['value']}
+                del m1
+            # C4 extrapolated from the measured sample by algorithmic FLOPs (labelled as such)
+            sample_flops = F.scene_flops(H, W, 2, 2, args.variant)
+            cpu_tflops = sample_flops / (2 / out['cpu_baseline']['value']) / 1e12
+            samples['C4_extrapolated'] = {'config': 'C4: %s, %d views / %d keyframes (EXTRAPOLATED by algorithmic FLOPs from the measured sample, not run)' % (args.variant, V, K),
+                                          'frames_per_s': round(V / (scene_flops / 1e12 / cpu_tflops), 4), 'host_tflops_fp32': round(cpu_tflops, 3)}
+            out['cpu_baseline']['other_configs'] = samples
             out['parity'] = full_size_parity(model, dev, ref, ref_imgs, ref_ts, names, args.amp)
             if not out['parity']['within_tolerance']:
                 print('WARNING: full-size parity outside the stated tolerance: %s' % out['parity'], file=sys.stderr)

@@ -32,6 +32,18 @@ def _hipcc():
 PER_FILE_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
+def source_hash():
+    """sha256 over the kernel sources + the C ABI header: stamps profiles (tools/pmc_profile.sh) so that bench.py only quotes PMC-derived
+    numbers that were measured on the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))) + [os.path.join(os.path.dirname(HERE), 'include', 'panst3r_hip.h')]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 

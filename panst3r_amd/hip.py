@@ -131,15 +131,38 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, a, b, _tag in self.records:
-            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+        for name, flops, a, b, tag in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d['launches'] += 1
             d['ms'] += a.elapsed_time(b)
             d['flops'] += flops
+            if tag and tag[0] == 'bytes':
+                d['bytes'] += tag[1]
         return out
 
 
 TIMER = None      # set to a KernelTimer to time launches
+
+
+def _esz(t):
+    return t.element_size()
+
+
+def hbm_timed(name, nbytes):
+    """Decorator for the HBM-bound streaming ops: with a KernelTimer installed the launch is bracketed by HIP events on the launch stream
+    and recorded with its ALGORITHMIC byte count nbytes(*args) (bench.py reports GB/s per stage against the 8 TB/s HBM peak)."""
+    def deco(fn):
+        def wrapped(*a, **k):
+            if TIMER is None:
+                return fn(*a, **k)
+            ev = TIMER.bracket(name, 0.0, ('bytes', float(nbytes(*a, **k))))
+            ev[0].record()
+            r = fn(*a, **k)
+            ev[1].record()
+            return r
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+    return deco
 
 _ZERO = {}
 
@@ -220,7 +243,7 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
         name = lib().pst_gemm_variant(C.byref(p))          # the C side names the kernel it dispatches to (no re-derived rule here)
         ev = TIMER.bracket(name.decode() if name else 'gemm?', 2.0 * Mv * N * K * (batch[0] if batch else 1),
                            (Mv, N, K, 'f32' if out.dtype == torch.float32 else '16', act or '', 'res' if res is not None else '',
-                            'grp' if grp is not None else '', 'rope' if rope is not None else '', 'conv' if conv is not None else ''))
+                            'grp' if grp is not None else '', 'rope' if rope is not None else '', 'conv' if conv is not None else '', 'ps' if ps is not None else ''))
         ev[0].record()
         _check(lib().pst_gemm(C.byref(p), _stream()), 'pst_gemm')
         ev[1].record()
@@ -294,6 +317,7 @@ def layernorm_batch(x_all, gamma_all, beta_all, out_all, eps, rows=None, grp=Non
     return out_all
 
 
+@hbm_timed('layernorm', lambda x, gamma, beta, out, eps, rows=None, grp=None, add=None: (out.shape[0] if rows is None else rows) * gamma.numel() * (_esz(x) + _esz(out) + (4 if add is not None else 0)))
 def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None):
     """out = LN(x [+ add]); `add`: optional fp32 rows indexed like x (fused residual-style addend)."""
     _dev(x, torch.float32, *H16); _dev(out, torch.float32, *H16)
@@ -312,6 +336,7 @@ def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None):
     return out
 
 
+@hbm_timed('rowstats', lambda x, xcopy, stats: x.numel() * (_esz(x) + (2 if xcopy is not None else 0)))
 def rowstats(x, xcopy, stats):
     """LayerNorm-fold producer outputs for a stream no GEMM wrote: per-row (sum, sumsq) per 64-column group, plus the 16-bit copy of an
     fp32 stream (xcopy=None when x already is the 16-bit stream)."""
@@ -387,6 +412,7 @@ def image_prepare(src_u8, out, resized, crop_origin):
     return out
 
 
+@hbm_timed('patch_rows', lambda img, enc=None, dino=None, **k: img.numel() * 4 + (enc.numel() * 2 if enc is not None else 0) + (dino.numel() * 2 if dino is not None else 0))
 def patch_rows(img, enc=None, dino=None, p_enc=16, p_dino=14, dino_transposed=False):
     """fp32 images [n, 3, H, W] -> patch rows of the encoder (`enc` 16-bit [n*T, >= 3 p^2]) and / or DINOv2 (`dino`) in one launch."""
     _dev(img, torch.float32)
@@ -416,6 +442,7 @@ def l2norm_rows(x, out, eps):
     return out
 
 
+@hbm_timed('mean4', lambda F, Fm, nimg, Hm, Wm, Cc: Fm.numel() * 2 * 5)
 def mean4(F, Fm, nimg, Hm, Wm, Cc):
     _dev(F, *H16); _dev(Fm, *H16)
     _check(lib().pst_mean4(_ptr(F), _ptr(Fm), nimg, Hm, Wm, Cc, _same16(F, Fm), _stream()), 'pst_mean4')
@@ -441,6 +468,7 @@ def stats_buffer(nimg, G, device):
     return torch.empty(nimg * G * 2 * (1 + STATS_BLOCKS), dtype=torch.float32, device=device)
 
 
+@hbm_timed('loftup_guidance_gn', lambda img, biases, gamma, beta, eps, scratch, stats, out, nf: img.numel() * 4 + out.numel() * 2)
 def loftup_guidance_gn(img, biases, gamma, beta, eps, scratch, stats, out, nf):
     """Fourier guidance features + GroupNorm(1) straight to bf16 `out` [nimg*P, ld] (zero-padded columns); no fp32 feature buffer."""
     _dev(img, torch.float32); _dev(biases, torch.float32); _dev(scratch, torch.float32); _dev(stats, torch.float32); _dev(out, *H16)
@@ -452,12 +480,14 @@ def loftup_guidance_gn(img, biases, gamma, beta, eps, scratch, stats, out, nf):
     return out
 
 
+@hbm_timed('groupnorm_stats', lambda x, stats, nimg, P, Cc, G: nimg * P * Cc * _esz(x))
 def groupnorm_stats(x, stats, nimg, P, Cc, G):
     _dev(x); _dev(stats, torch.float32)
     _check(lib().pst_groupnorm_stats(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(stats), nimg, P, Cc, G, _stream()),
            'pst_groupnorm_stats')
 
 
+@hbm_timed('groupnorm_apply', lambda x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu: nimg * P * (Cc * _esz(x) + out.shape[1] * 2))
 def groupnorm_apply(x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu):
     _dev(x); _dev(out, *H16)
     _check(lib().pst_groupnorm_apply(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(stats), _ptr(gamma), _ptr(beta),

@@ -58,7 +58,7 @@ def ceil_to(x, m):
 
 class Packed:
     """bf16 weight [N, Kpad] (K zero-padded to a multiple of 64) + fp32 bias."""
-    __slots__ = ('w', 'b', 'n', 'k', 'cs', 'eps')
+    __slots__ = ('w', 'b', 'n', 'k', 'cs', 'eps', 'ln')
 
     def __init__(self, weight, bias=None, device=None, row_perm=None):
         w = weight.detach().reshape(weight.shape[0], -1).float()
@@ -79,21 +79,37 @@ class Packed:
         out = Packed.__new__(Packed)
         out.w, out.n, out.k = self.w[a:b], b - a, self.k
         out.b = None if self.b is None else self.b[a:b]
-        if getattr(self, 'cs', None) is not None:
-            out.cs, out.eps = self.cs[a:b], self.eps
+        if getattr(self, 'eps', None) is not None:
+            out.cs, out.eps, out.ln = (None if self.cs is None else self.cs[a:b]), self.eps, self.ln
         return out
 
 
+def fold_in_epilogue():
+    """LayerNorm statistics applied in the consumer GEMM's epilogue (raw 16-bit rows in, gamma / beta folded into the weights) - the f16
+    default.  In bf16 the raw stream would be rounded to 8 mantissa bits BEFORE its mean is subtracted and the mask-feature error doubles
+    (full size: mask logits rel-L2 2.1e-2 -> 3.6e-2), so the bf16 fallback keeps the separate LayerNorm pass and the plain weights."""
+    return adt() == F16
+
+
 def fold_ln(weight, bias, ln, device):
-    """LayerNorm folded into the Linear that consumes it (pack time): LN(x) W^T + b = rstd (x W'^T - mean colsum) + b' with
-    W' = W diag(gamma), b' = W beta + b, colsum[n] = sum_k W'[n,k] -- summed from the 16-bit-ROUNDED W', the values the MFMA multiplies.
-    The GEMM then reads the raw 16-bit rows and applies (rstd, mean) per row in its epilogue (pst_gemm_params: ln_stats)."""
+    """Weights of a Linear that consumes LN(x).
+    f16 (LayerNorm folded into the GEMM, pack time): LN(x) W^T + b = rstd (x W'^T - mean colsum) + b' with W' = W diag(gamma),
+      b' = W beta + b, colsum[n] = sum_k W'[n,k] -- summed from the 16-bit-ROUNDED W', the values the MFMA multiplies.  The GEMM then
+      reads the raw 16-bit rows and applies (rstd, mean) per row in its epilogue (pst_gemm_params: ln_stats).
+    bf16 (range-safe fallback): plain weights; the LayerNorm (with its gamma / beta, kept in `pk.ln`) runs as its own pass before the
+      GEMM, exactly the round-1 arithmetic -- 8 mantissa bits leave no room for rounding the raw stream before its mean is removed."""
     w = weight.detach().reshape(weight.shape[0], -1).float()
     g, bt = ln.weight.detach().float(), ln.bias.detach().float()
     assert w.shape[1] == g.numel() and g.numel() % 64 == 0, 'LayerNorm fold needs the normalised dim to be a multiple of 64'
+    if not fold_in_epilogue():
+        pk = Packed(w, None if bias is None else bias.detach().float(), device)
+        pk.cs, pk.eps = None, float(ln.eps)
+        pk.ln = (g.to(device).contiguous(), bt.to(device).contiguous(), id(ln))
+        return pk
     pk = Packed(w * g[None], w @ bt + (0 if bias is None else bias.detach().float()), device)
     pk.cs = pk.w.float().sum(1).contiguous()
     pk.eps = float(ln.eps)
+    pk.ln = None
     return pk
 
 
@@ -241,20 +257,13 @@ def unit_affine(D, device):
     return _UNIT[key]
 
 
-def fold_in_epilogue():
-    """LayerNorm statistics applied in the consumer GEMM's epilogue (raw 16-bit rows in) - the f16 default.  In bf16 the raw stream
-    would be rounded to 8 mantissa bits BEFORE its mean is subtracted (measured at full size: mask logits rel-L2 2.1e-2 -> 3.6e-2), so
-    the bf16 fallback normalises first: one (x - mean) rstd pass per LayerNorm, gamma / beta still folded into the weights."""
-    return adt() == F16
-
-
 class Stream:
     """A pre-LN residual stream and its LayerNorm-fold companions: x (fp32 [rows, D], or the 16-bit stream itself), xb = 16-bit operand
     of the GEMMs that consume LN(x), st = per-row (sum, sumsq) per 64-column group [rows, D/64, 2].
     f16: xb is the raw 16-bit copy of x; every GEMM that writes x refreshes xb and st from its epilogue (hip.gemm xcopy= / stats_out=),
          `refresh()` does it for a stream no GEMM produced, and consumers pass ln=(st, colsum, eps).
-    bf16: xb = (x - mean) rstd, produced by one LayerNorm pass per version of x (`operand()` runs it lazily); consumers take it as is.
-    Either way the consumers use the SAME folded weights (fold_ln): W diag(gamma), W beta + b."""
+    bf16: xb = LN(x) with the consumer's gamma / beta, one LayerNorm pass per version of x and per LayerNorm (`operand()` runs it lazily);
+          consumers are plain GEMMs with the unfolded weights (the round-1 arithmetic)."""
     __slots__ = ('x', 'xb', 'st', 'fold', 'dirty', 'eps')
 
     def __init__(self, x, xb=None, st=None):
@@ -279,10 +288,10 @@ class Stream:
         """(A operand, ln= argument) for a GEMM with the folded weights `pk` consuming LN(x)"""
         if self.fold:
             return self.xb, (self.st, pk.cs, pk.eps)
-        if self.dirty or self.eps != pk.eps:          # one pass per version of x (and per eps): norm1 / norm_y ... share it
-            ones, zeros = unit_affine(self.x.shape[1], self.x.device)
-            hip.layernorm(self.x, ones, zeros, self.xb, pk.eps)
-            self.dirty, self.eps = False, pk.eps
+        g, bt, lid = pk.ln
+        if self.dirty or self.eps != lid:             # one pass per version of x and per LayerNorm (qk / v share norm1's)
+            hip.layernorm(self.x, g, bt, self.xb, pk.eps)
+            self.dirty, self.eps = False, lid
         return self.xb, None
 
     def residual(self, a, w, gamma=None, res=None):

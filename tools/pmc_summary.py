@@ -61,6 +61,10 @@ with open(out_md, 'w') as f:
     f.write('| kernel | launches | avg us (under PMC) | MFMA busy / (active cycles x 1024 SIMDs) | HBM read MB/launch (FETCH_SIZE x2) | HBM write MB/launch | HBM GB/s (of 8000 spec / 6300 achievable) |\n|---|---|---|---|---|---|---|\n')
     for _, k, n, us, mu, rd, wr, gbs in rows[:24]:
         f.write('| `%s` | %d | %.1f | %.1f %% | %.2f | %.2f | %.0f |\n' % (k, n, us, 100 * mu, rd, wr, gbs))
-json.dump({k: {'launches': n, 'mfma_util': round(mu, 4), 'hbm_read_bytes_per_launch': rd * 1e6, 'hbm_write_bytes_per_launch': wr * 1e6,
-               'hbm_gbps': round(gbs, 1)} for _, k, n, us, mu, rd, wr, gbs in rows}, open(out_json, 'w'), indent=1)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from panst3r_amd.build import source_hash
+summary = {'_source_hash': source_hash(), '_command': 'tools/pmc_profile.sh (rocprofv3 --pmc, 3 passes of bench.py --no-cpu-baseline --steps 1 --eager --no-kernel-timing)'}
+summary.update({k: {'launches': n, 'mfma_util': round(mu, 4), 'hbm_read_bytes_per_launch': rd * 1e6, 'hbm_write_bytes_per_launch': wr * 1e6,
+               'hbm_gbps': round(gbs, 1)} for _, k, n, us, mu, rd, wr, gbs in rows})
+json.dump(summary, open(out_json, 'w'), indent=1)
 print(open(out_md).read())

@@ -68,3 +68,8 @@ def panoptic_inference_v2(mask_cls, mask_pred, true_shape, label_mode='sigmoid',
         cur_prob, cur_classes, cur_idx, cur_masks = cur_prob[sel], cur_classes[sel], cur_idx[sel], cur_masks[sel]   # :115-119
     return [{'pan': [pan[i, :h, :w].contiguous() for i, (h, w) in enumerate(shapes)], 'segments_info': segments,
              'conf': [conf[i, :h, :w].contiguous() for i, (h, w) in enumerate(shapes)]}]
+
+
+def panoptic_inference_v1(*args, mask_threshold=0.5, overlap_threshold=0.8, **kwargs):
+    """reference engine/postprocess.py:9-11: one round with the Mask2Former thresholds"""
+    return panoptic_inference_v2(*args, mask_threshold=mask_threshold, overlap_threshold=overlap_threshold, niters=1, **kwargs)

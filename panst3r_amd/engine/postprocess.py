@@ -10,6 +10,11 @@ import torch
 from .. import hip
 
 
+def panoptic_inference_v1(*args, mask_threshold=0.5, overlap_threshold=0.8, **kwargs):
+    """reference engine/postprocess.py:9-11: the Mask2Former-style single round (niters=1) with its own thresholds"""
+    return panoptic_inference_v2(*args, mask_threshold=mask_threshold, overlap_threshold=overlap_threshold, niters=1, **kwargs)
+
+
 @torch.no_grad()
 def panoptic_inference_v2(mask_cls, mask_pred, true_shape, label_mode='sigmoid', cls_threshold=0.1, temperature=None,
                           mask_threshold=0.25, overlap_threshold=0.5, niters=2, void_confidence=0.1, device=None, multi_ar=False):

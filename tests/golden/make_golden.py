@@ -278,6 +278,10 @@ def golden_postprocess(R):
         info = np.array([[d['id'], d['query_id'], d['category_id']] for d in res['segments_info']], dtype=np.int64).reshape(-1, 3)
         save('postprocess_v2' + tag, logits=npy(logits), masks=npy(masks), size=size, info=info,
              pan=[np.asarray(p) for p in npy(res['pan'])], conf=[np.asarray(c) for c in npy(res['conf'])])
+        if not kw:      # G6 "v1/v2": panoptic_inference_v1 (postprocess.py:9-11) = one round, mask_threshold 0.5, overlap_threshold 0.8, same inputs
+            r1 = PP.panoptic_inference_v1(logits.clone(), [m.clone() for m in masks], size, label_mode='sigmoid', device='cpu', multi_ar=True)[0]
+            info1 = np.array([[d['id'], d['query_id'], d['category_id']] for d in r1['segments_info']], dtype=np.int64).reshape(-1, 3)
+            save('postprocess_v1' + tag, info=info1, pan=[np.asarray(p) for p in npy(r1['pan'])], conf=[np.asarray(c) for c in npy(r1['conf'])])
 
     case('', 60, 16, 5, [(16, 24)] * 3, [[32, 48]] * 3)
     case('_multiar', 70, 24, 7, [(16, 24), (12, 24), (24, 16)], [[32, 48], [24, 48], [48, 32]])

@@ -248,3 +248,26 @@ def test_full_size_sharded_equals_unsharded_on_one_gpu(full, monkeypatch, V, K, 
     for i in range(V):
         assert torch.equal(res[i][0], ref[i][0]), ('pointmap', i)
         assert torch.equal(res[i][1], ref[i][1]), ('masks', i)
+
+
+def test_full_size_c5_200_views_32_keyframes(full):
+    """BASELINE configs[4] on one GPU: 200 views, 32 keyframes, fp16 operands (the reference's `--amp fp16`) - the memory-bank stress case:
+    Nmem = 24 576 tokens per layer (432 MiB of K / V^T caches), 31 sequential memory updates, 168 heads-only views.  Size-independent
+    properties: every output finite, the three captured HIP graphs replay to the same bits as the eager launch, keyframe order kept."""
+    from panst3r_amd.synthetic import synth_image
+    model, _, names, _ = full
+    dev = torch.device(DEV)
+    V, K, H, W = 200, 32, 384, 512
+    imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
+    runner = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=True, amp='fp16')
+    assert len(runner.keyframes) == K and runner.keyframes == sorted(runner.keyframes)
+    r1, s1 = runner.run()                                   # eager warm-up + capture
+    assert torch.isfinite(s1['out_queries']).all() and torch.isfinite(s1['pred_logits']).all()
+    for k in range(0, V, 7):
+        assert torch.isfinite(r1[k][0]).all() and torch.isfinite(r1[k][1]).all(), k
+    assert r1[0][1].shape == (1, 200, H // 2, W // 2) and r1[0][0].shape == (1, H, W, 7)
+    r2, s2 = runner.run()                                   # graph replay
+    r3, s3 = runner.run(eager=True)
+    assert torch.equal(s1['out_queries'], s2['out_queries']) and torch.equal(s1['out_queries'], s3['out_queries'])
+    for k in (0, 1, 99, 199):
+        assert torch.equal(r1[k][0], r2[k][0]) and torch.equal(r1[k][1], r2[k][1]) and torch.equal(r1[k][0], r3[k][0]) and torch.equal(r1[k][1], r3[k][1]), k

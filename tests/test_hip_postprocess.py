@@ -51,6 +51,17 @@ def test_postprocess_golden(golden, tag, kw):
     _compare(res, ref, frac=0.0)
 
 
+@pytest.mark.parametrize('tag', ['', '_multiar'])
+def test_postprocess_v1_golden(golden, tag):
+    """panoptic_inference_v1 (reference engine/postprocess.py:9-11) on the GPU against the reference-generated golden."""
+    from panst3r_amd.engine import panoptic_inference_v1
+    g, g1 = golden('postprocess_v2' + tag), golden('postprocess_v1' + tag)
+    res = panoptic_inference_v1(g.t('logits').to(DEV), [m.to(DEV) for m in g.lst('masks')], g.z['size'], multi_ar=True)[0]
+    ref = {'segments_info': [{'id': int(a), 'query_id': int(b), 'category_id': int(c)} for a, b, c in g1.z['info'].tolist()],
+           'pan': g1.lst('pan'), 'conf': g1.lst('conf')}
+    _compare(res, ref, frac=0.0)
+
+
 @pytest.mark.parametrize('kw', [{}, dict(niters=1), dict(niters=3, overlap_threshold=0.3), dict(cls_threshold=2.0),
                                 dict(mask_threshold=0.4, void_confidence=0.0)])
 def test_postprocess_vs_oracle(kw):

@@ -181,6 +181,19 @@ def test_postprocess_v2(golden, tag):
         assert float((a - b).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize('tag', ['', '_multiar'])
+def test_postprocess_v1(golden, tag):
+    """G6 "v1/v2": oracle panoptic_inference_v1 == the reference's (engine/postprocess.py:9-11) on the inputs of the v2 goldens."""
+    from oracle.postprocess import panoptic_inference_v1
+    g, g1 = golden('postprocess_v2' + tag), golden('postprocess_v1' + tag)
+    res = panoptic_inference_v1(g.t('logits'), g.lst('masks'), g.z['size'])[0]
+    assert [[d['id'], d['query_id'], d['category_id']] for d in res['segments_info']] == g1.z['info'].tolist()
+    for a, b in zip(res['pan'], g1.lst('pan')):
+        assert torch.equal(a, b)
+    for a, b in zip(res['conf'], g1.lst('conf')):
+        assert float((a - b).abs().max()) < 1e-6
+
+
 @pytest.mark.parametrize('tag', ['plain', 'sharp'])
 @torch.no_grad()
 def test_mask_transformer_full_dim(tag):

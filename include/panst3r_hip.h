@@ -260,6 +260,20 @@ int pst_pp_select(const int* keep, int* cnt_orig, int* cnt_mask, int Q, double o
 int pst_pp_finalize(const int* best_q, const float* best_m, const int* seg_id, int n, float mask_threshold,
                     float void_confidence, int* pan, float* conf, void* stream);
 
+/* ---------------------------------------------------------------- QUBO post-processing (engine/postprocess.py:135-336)
+ * The O(Q^2 x pixels) part of `panoptic_inference_qubo` on the device; the simulated annealing over the Q x Q matrix stays on the
+ * host, as in the reference (:176-183 "Optimization done on CPU").
+ *   qubo_upsample  mask logits fp32 [Q,hm,wm] of one view -> sigmoid -> bilinear (align_corners=False) to [Q,H,W] probabilities (:138-142)
+ *   qubo_overlap   Wacc[Q][Q] (double, accumulated over the views of the scene) += sum_p min(m_i[p], m_j[p]) -- the overlaps AND, on the
+ *                  diagonal, the mask areas of `weight_from_masks` (:243-254).  ws: >= pst_qubo_workspace_floats(Q, P) floats.
+ *                  Deterministic: per-block partial sums, reduced over pixel chunks in index order.
+ *   qubo_argmax    per pixel (max, first arg-max) over the probabilities of the selected queries `sel` (int32, ascending): conf and
+ *                  instance index maps (:188). */
+int pst_qubo_upsample(const float* logits, float* probs, int Q, int hm, int wm, int H, int W, void* stream);
+int64_t pst_qubo_workspace_floats(int Q, int64_t P);
+int pst_qubo_overlap(const float* probs, int Q, int64_t P, float* ws, double* Wacc, void* stream);
+int pst_qubo_argmax(const float* probs, const int* sel, int nsel, int64_t P, float* conf, int* inst, void* stream);
+
 /* ---------------------------------------------------------------- pointmap post-processing
  * The demo's camera recovery (tools/demo_panst3r.py:220-221,246-277) on the device, per scene instead of per view on the host:
  *   pointmap_activate  raw decoder output fp32 [npix, 7] -> pts3d [npix,3], pts3d_local [npix,3], conf [npix]

@@ -11,6 +11,7 @@ The selection of a query in one round does not depend on the other queries' sele
 taken once per round, before the loop), so the per-query Python loop of the reference is restated as vector ops.
 Only 'sigmoid' label mode is restated (the released configs, configs/base.yaml:24).
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -73,3 +74,50 @@ def panoptic_inference_v2(mask_cls, mask_pred, true_shape, label_mode='sigmoid',
 def panoptic_inference_v1(*args, mask_threshold=0.5, overlap_threshold=0.8, **kwargs):
     """reference engine/postprocess.py:9-11: one round with the Mask2Former thresholds"""
     return panoptic_inference_v2(*args, mask_threshold=mask_threshold, overlap_threshold=overlap_threshold, niters=1, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------------ QUBO (engine/postprocess.py:135-336)
+def qubo_weights(mask_pred, true_shape, penalty=1):
+    """-W of `weight_from_masks` (:229-259) for a list of mask logits [1,Q,h,w]: sigmoid, bilinear to the true shapes, zero-padded to the
+    largest; W_ii = mask area, W_ij = -(1 + penalty) sum min(m_i, m_j) / 2, normalised by padded image size and view count (float32)."""
+    up = [F.interpolate(m.float().sigmoid(), size=[int(v) for v in ts], mode='bilinear', align_corners=False)[0] for m, ts in zip(mask_pred, true_shape)]
+    Hm, Wm = max(u.shape[-2] for u in up), max(u.shape[-1] for u in up)
+    Q = up[0].shape[0]
+    S = torch.zeros(Q, Q, dtype=torch.float64)
+    for u in up:
+        f = u.flatten(1).double()
+        for i in range(Q):
+            S[i] += torch.minimum(f[i][None], f).sum(1)
+    W = -(1 + penalty) * S / 2
+    W[torch.arange(Q), torch.arange(Q)] = torch.diagonal(S)
+    W = W / (Hm * Wm) / len(up)
+    return (-W).float().numpy(), up, (Hm, Wm)
+
+
+def panoptic_inference_qubo(mask_cls, mask_pred, true_shape, num_redo=20, prob_threshold=0.01, temperature=None):
+    """CPU restatement of the reference's QUBO post-processing (multi_ar call, sigmoid labels): weights, the product's annealer (host code,
+    shared: it IS the reference's algorithm step for step), per-pixel arg-max among the selected queries, per-instance filtering."""
+    from panst3r_amd.engine.postprocess import solve_qubo_simulated_annealing
+    Wneg, up, (Hm, Wm) = qubo_weights(mask_pred, true_shape)
+    cls = mask_cls[0].float().sigmoid()
+    if temperature is not None:
+        cls = torch.softmax(cls.sigmoid() / temperature, dim=-1)
+    sol, _ = solve_qubo_simulated_annealing(Wneg, redo=num_redo, silent=True)
+    sel = torch.from_numpy(np.flatnonzero(np.asarray(sol).astype(bool)))
+    cls_probs, cls_ids = cls[sel].max(dim=1)
+    pad = torch.zeros(len(up), len(sel), Hm, Wm)
+    for v, u in enumerate(up):
+        pad[v, :, :u.shape[-2], :u.shape[-1]] = u[sel]
+    conf, inst = pad.max(dim=1)                         # [V,Hm,Wm]
+    pan = torch.zeros_like(inst)
+    segs, new_id = [], 1
+    for k in torch.unique(inst).tolist():
+        m = inst == k
+        mask_conf = float(conf[m].mean())
+        if float(cls_probs[k]) * mask_conf < prob_threshold:
+            continue
+        pan[m] = new_id
+        segs.append({'id': new_id, 'query_id': int(k), 'class_prob': float(cls_probs[k]), 'mask_conf': mask_conf, 'category_id': int(cls_ids[k]), 'area': int(m.sum())})
+        new_id += 1
+    shapes = [u.shape[-2:] for u in up]
+    return [{'pan': [pan[i, :h, :w] for i, (h, w) in enumerate(shapes)], 'segments_info': segs, 'conf': [conf[i, :h, :w] for i, (h, w) in enumerate(shapes)]}], Wneg

@@ -355,3 +355,107 @@ extern "C" int pst_pp_finalize(const int* best_q, const float* best_m, const int
                      void_confidence, pan, conf);
   return check_launch("pp_finalize");
 }
+
+// ------------------------------------------------------------------ QUBO post-processing (reference engine/postprocess.py:135-336)
+// The reference's `weight_from_masks` (:229-259) builds W[i][j] = sum over all pixels of all views of min(m_i, m_j) (diagonal = mask area) with a
+// Python loop over queries on the CPU: O(Q^2 P) = 4e11 min-adds for 200 queries x 50 views.  Here: qubo_upsample (sigmoid + bilinear to the
+// true shape, as :138-142) and qubo_overlap (one block = 16 x 16 query pairs x one chunk of pixels, both query tiles staged in LDS, partial sums
+// per block, fixed-order reduction over chunks in double) -- deterministic, no atomics.
+namespace pst {
+
+__global__ __launch_bounds__(256) void qubo_upsample_kernel(const float* logits, float* probs, int Q, int hm, int wm, int H, int W) {
+  const float sy = (float)hm / (float)H, sx = (float)wm / (float)W;
+  const int64_t total = (int64_t)Q * H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), q = (int)(i / ((int64_t)W * H));
+    const float fy = fmaxf((y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf((x + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = min((int)fy, hm - 1), x0 = min((int)fx, wm - 1);
+    const int y1 = min(y0 + 1, hm - 1), x1 = min(x0 + 1, wm - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const float* m = logits + (int64_t)q * hm * wm;
+    auto sg = [](float v) { return 1.0f / (1.0f + expf(-v)); };
+    const float a = sg(m[y0 * wm + x0]), b = sg(m[y0 * wm + x1]), c = sg(m[y1 * wm + x0]), d = sg(m[y1 * wm + x1]);
+    probs[i] = (1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * c + wx * d);
+  }
+}
+
+constexpr int QT = 16, QCH = 256;       // query tile, pixels per chunk
+__global__ __launch_bounds__(256) void qubo_overlap_kernel(const float* probs, int Q, int64_t P, float* part) {
+  __shared__ float A[QT][QCH + 1], B[QT][QCH + 1];
+  const int ti = blockIdx.y, tj = blockIdx.z, chunk = blockIdx.x;
+  const int64_t p0 = (int64_t)chunk * QCH;
+  for (int k = threadIdx.x; k < QT * QCH; k += 256) {
+    const int r = k / QCH, c = k - r * QCH;
+    const int qi = ti * QT + r, qj = tj * QT + r;
+    const int64_t p = p0 + c;
+    A[r][c] = (qi < Q && p < P) ? probs[(int64_t)qi * P + p] : 0.f;
+    B[r][c] = (qj < Q && p < P) ? probs[(int64_t)qj * P + p] : 0.f;
+  }
+  __syncthreads();
+  const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+  float s = 0.f;
+#pragma unroll 8
+  for (int c = 0; c < QCH; ++c) s += fminf(A[i][c], B[j][c]);
+  part[(((int64_t)chunk * gridDim.y + ti) * gridDim.z + tj) * (QT * QT) + threadIdx.x] = s;
+}
+
+// W[i][j] += sum over chunks (index order) of the partials; one thread per (i, j)
+__global__ void qubo_reduce_kernel(const float* part, double* Wacc, int Q, int nchunk, int nt) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Q * Q) return;
+  const int i = idx / Q, j = idx - i * Q;
+  const int ti = i / QT, tj = j / QT, l = (i % QT) * QT + (j % QT);
+  double s = 0.0;
+  for (int c = 0; c < nchunk; ++c) s += (double)part[(((int64_t)c * nt + ti) * nt + tj) * (QT * QT) + l];
+  Wacc[idx] += s;
+}
+
+// per pixel: (max, first arg-max) of the probabilities of the SELECTED queries (`sel` ascending query ids): conf / instance ids (:188)
+__global__ void qubo_argmax_kernel(const float* probs, const int* sel, int nsel, int64_t P, float* conf, int* inst) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    float best = -1.f;
+    int bi = 0;
+    for (int k = 0; k < nsel; ++k) {
+      const float v = probs[(int64_t)sel[k] * P + p];
+      if (v > best) { best = v; bi = k; }
+    }
+    conf[p] = best;
+    inst[p] = bi;
+  }
+}
+
+}  // namespace pst
+
+extern "C" int pst_qubo_upsample(const float* logits, float* probs, int Q, int hm, int wm, int H, int W, void* stream) {
+  using namespace pst;
+  if (!logits || !probs || Q <= 0 || hm <= 0 || wm <= 0 || H <= 0 || W <= 0) { set_error("qubo_upsample: bad argument"); return PST_EINVAL; }
+  int64_t g = ((int64_t)Q * H * W + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(qubo_upsample_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, logits, probs, Q, hm, wm, H, W);
+  return check_launch("qubo_upsample");
+}
+
+extern "C" int64_t pst_qubo_workspace_floats(int Q, int64_t P) {
+  const int64_t nt = (Q + pst::QT - 1) / pst::QT, nchunk = (P + pst::QCH - 1) / pst::QCH;
+  return nchunk * nt * nt * pst::QT * pst::QT;
+}
+
+extern "C" int pst_qubo_overlap(const float* probs, int Q, int64_t P, float* ws, double* Wacc, void* stream) {
+  using namespace pst;
+  if (!probs || !ws || !Wacc || Q <= 0 || P <= 0 || Q > 1024) { set_error("qubo_overlap: bad argument"); return PST_EINVAL; }
+  const int nt = (Q + QT - 1) / QT;
+  const int64_t nchunk = (P + QCH - 1) / QCH;
+  if (nchunk > 2147483647ll) { set_error("qubo_overlap: too many pixels"); return PST_EINVAL; }
+  hipLaunchKernelGGL(qubo_overlap_kernel, dim3((unsigned)nchunk, nt, nt), dim3(256), 0, (hipStream_t)stream, probs, Q, P, ws);
+  hipLaunchKernelGGL(qubo_reduce_kernel, dim3((Q * Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, Wacc, Q, (int)nchunk, nt);
+  return check_launch("qubo_overlap");
+}
+
+extern "C" int pst_qubo_argmax(const float* probs, const int* sel, int nsel, int64_t P, float* conf, int* inst, void* stream) {
+  using namespace pst;
+  if (!probs || !sel || !conf || !inst || nsel <= 0 || P <= 0) { set_error("qubo_argmax: bad argument"); return PST_EINVAL; }
+  int64_t g = (P + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(qubo_argmax_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, probs, sel, nsel, P, conf, inst);
+  return check_launch("qubo_argmax");
+}

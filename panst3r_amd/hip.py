@@ -43,7 +43,8 @@ EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 
            'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
-           'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize', 'pst_pointmap_activate', 'pst_focal_weiszfeld', 'pst_rigid_moments']
+           'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize', 'pst_pointmap_activate', 'pst_focal_weiszfeld', 'pst_rigid_moments',
+           'pst_qubo_upsample', 'pst_qubo_workspace_floats', 'pst_qubo_overlap', 'pst_qubo_argmax']
 
 
 def lib():
@@ -59,6 +60,8 @@ def lib():
     L.pst_gemm_variant.restype = C.c_char_p
     L.pst_attn_variant.restype = C.c_char_p
     L.pst_attn_workspace_bytes.restype = C.c_int64
+    L.pst_qubo_workspace_floats.restype = C.c_int64
+    L.pst_qubo_workspace_floats.argtypes = [C.c_int, C.c_int64]
     L.pst_abi_version.restype = C.c_int
     if L.pst_abi_version() != ABI_VERSION:
         raise RuntimeError('libpanst3r_hip.so ABI %d != expected %d; rebuild' % (L.pst_abi_version(), ABI_VERSION))
@@ -573,3 +576,20 @@ def rigid_moments(x, y, conf, out, weight_offset=-1.0):
     assert x.is_contiguous() and y.is_contiguous() and conf.is_contiguous() and out.is_contiguous() and out.shape[1] == 16
     _check(lib().pst_rigid_moments(_ptr(x), _ptr(y), _ptr(conf), _ptr(out), V, conf.numel() // V, C.c_float(weight_offset), _stream()), 'pst_rigid_moments')
     return out
+
+
+# ------------------------------------------------------------------ QUBO post-processing (engine/postprocess.py:135-336)
+def qubo_upsample(logits, probs, Q, hm, wm, H, W):
+    _dev(logits, torch.float32); _dev(probs, torch.float32)
+    _check(lib().pst_qubo_upsample(_ptr(logits), _ptr(probs), Q, hm, wm, H, W, _stream()), 'pst_qubo_upsample')
+
+
+def qubo_overlap(probs, Q, P, Wacc):
+    _dev(probs, torch.float32); _dev(Wacc, torch.float64)
+    ws = torch.empty(int(lib().pst_qubo_workspace_floats(Q, P)), dtype=torch.float32, device=probs.device)
+    _check(lib().pst_qubo_overlap(_ptr(probs), Q, i64(P), _ptr(ws), _ptr(Wacc), _stream()), 'pst_qubo_overlap')
+
+
+def qubo_argmax(probs, sel, P, conf, inst):
+    _dev(probs, torch.float32); _dev(sel, torch.int32); _dev(conf, torch.float32); _dev(inst, torch.int32)
+    _check(lib().pst_qubo_argmax(_ptr(probs), _ptr(sel), sel.numel(), i64(P), _ptr(conf), _ptr(inst), _stream()), 'pst_qubo_argmax')

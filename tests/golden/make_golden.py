@@ -212,7 +212,7 @@ def main():
 
 G2_CASES = {   # tag -> (weight seed, sharp, views, token grid, classes); shared with tests/test_hip_fullsize.py
     'plain': dict(seed=12, sharp=1.0, n=3, h=6, w=8, ncls=20),
-    'sharp': dict(seed=15, sharp=8.0, n=2, h=6, w=8, ncls=20),
+    'sharp': dict(seed=15, sharp=2.0 ** 0.5, n=2, h=6, w=8, ncls=20),     # q and k rows x sqrt(2): every attention logit x2
 }
 
 
@@ -244,7 +244,18 @@ def golden_g2():
         m = MT.MaskTransformer([768], 768, 2048, 384, 200, 8, 6, lang_dim=768, num_feature_levels=1, landscape_only=True).eval()
         fill_module_(m, seed=c['seed'], sharp=c['sharp'])
         fpn, mf, ts, cls, mf_extra = g2_inputs(c)
+        amasks, fph = [], m.forward_prediction_heads
+
+        def rec(*a, **k):                                  # the attention-mask bits of every decoder layer (mask_transformer.py:264-272)
+            o = fph(*a, **k)
+            if o[2] is not None:
+                am = o[2][0].clone()
+                am[am.all(-1)] = False                     # fully blocked rows attend everywhere (:172)
+                amasks.append(am.numpy())
+            return o
+        m.forward_prediction_heads = rec
         out = m([fpn], mf, ts, cls)
+        m.forward_prediction_heads = fph
         heads = m.forward_prediction_heads(out['out_queries'], mf_extra, cls)
         pm = out['pred_masks'][0]                          # [n, Q, H/2, W/2]
         flat = pm.flatten(2)
@@ -252,7 +263,8 @@ def golden_g2():
              mask_samples=npy(flat[:, ::G2_QSTRIDE, ::G2_PSTRIDE]), mask_norm=npy(flat.norm(dim=-1)),
              mask_pos_frac=npy((flat > 0).float().mean(-1)),
              heads_logits=npy(heads[0]), heads_samples=npy(heads[1][0].flatten(2)[:, ::G2_QSTRIDE, ::G2_PSTRIDE]),
-             heads_norm=npy(heads[1][0].flatten(2).norm(dim=-1)))
+             heads_norm=npy(heads[1][0].flatten(2).norm(dim=-1)),
+             attn_masks=np.packbits(np.stack(amasks[:6]).astype(np.uint8), axis=-1), attn_mask_keys=np.int64(amasks[0].shape[-1]))
 
 
 def golden_postprocess(R):
@@ -286,6 +298,35 @@ def golden_postprocess(R):
     case('', 60, 16, 5, [(16, 24)] * 3, [[32, 48]] * 3)
     case('_multiar', 70, 24, 7, [(16, 24), (12, 24), (24, 16)], [[32, 48], [24, 48], [48, 32]])
     case('_temp', 80, 12, 4, [(8, 12)] * 2, [[16, 24]] * 2, temperature=0.1, cls_threshold=0.3, overlap_threshold=0.6)
+
+
+def golden_qubo(R):
+    """G6b: panoptic_inference_qubo (engine/postprocess.py:135-336) with a fixed numpy seed: the weight matrix of `weight_from_masks`, the
+    annealer's solution on it, and the function's final maps / segments.  np.random is seeded identically before every call."""
+    PP = R['postprocess']
+    for tag, seed, Q, ncls, lowres, sizes in (('', 90, 12, 5, [(12, 16)] * 2, [[24, 32]] * 2), ('_multiar', 95, 10, 4, [(8, 12), (12, 8)], [[16, 24], [24, 16]])):
+        g = np.random.Generator(np.random.PCG64(seed))
+        logits = rnd(seed, 1, Q, ncls) * 2
+        masks = []
+        for i, (h, w) in enumerate(lowres):
+            m = rnd(seed + 1 + i, 1, Q, h, w) * 1.5 - 3.0
+            for q in range(Q):
+                y0, x0 = int(g.integers(0, h - 2)), int(g.integers(0, w - 2))
+                y1, x1 = int(g.integers(y0 + 2, h + 1)), int(g.integers(x0 + 2, w + 1))
+                m[0, q, y0:y1, x0:x1] += 6.0
+            masks.append(m)
+        size = np.array(sizes)
+        up = [torch.nn.functional.interpolate(m.sigmoid(), size=list(map(int, s)), mode='bilinear', align_corners=False) for m, s in zip(masks, size)]
+        padded = torch.nested.nested_tensor(up).to_padded_tensor(0.).transpose(0, 1)[0].transpose(0, 1)     # [Q,V,Hm,Wm] as :141-153
+        _, Wneg = PP.weight_from_masks(padded.clone(), logits[0].sigmoid(), silent=True)
+        np.random.seed(1234)
+        sol, en = PP.solve_qubo_simulated_annealing(Wneg, redo=3, silent=True)
+        np.random.seed(1234)
+        res = PP.panoptic_inference_qubo(logits.clone(), [m.clone() for m in masks], size, label_mode='sigmoid', device='cpu', num_redo=3, silent=True, multi_ar=True)[0]
+        info = np.array([[d['id'], d['query_id'], int(d['category_id']), d['area']] for d in res['segments_info']], dtype=np.int64).reshape(-1, 4)
+        probs = np.array([[d['class_prob'], d['mask_conf']] for d in res['segments_info']], dtype=np.float64).reshape(-1, 2)
+        save('postprocess_qubo' + tag, logits=npy(logits), masks=npy(masks), size=size, Wneg=Wneg, solution=np.asarray(sol), energy=np.float64(en),
+             info=info, probs=probs, pan=[np.asarray(p) for p in npy(res['pan'])], conf=[np.asarray(c) for c in npy(res['conf'])])
 
 
 def golden_retrieval():
@@ -364,6 +405,9 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'g2':
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'retrieval':         # G8 only (separate process: it replaces the package stubs)
         golden_retrieval()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'qubo':             # G6b only
+        with torch.no_grad():
+            golden_qubo(import_reference())
     elif len(sys.argv) > 1 and sys.argv[1] == 'postprocess':      # regenerate G6 only
         with torch.no_grad():
             golden_postprocess(import_reference())

@@ -663,3 +663,28 @@ def test_gemm_layernorm_fold_row_independent():
         else:
             for k, v in res.items():
                 assert torch.equal(v, ref[k]), (M, k)
+
+
+@pytest.mark.parametrize('H,Nq,Nk,hd,gain', [(4, 300, 2500, 64, 8.0), (2, 200, 1000, 96, 8.0), (4, 768, 768, 64, 2.83)])
+def test_attention_peaked_softmax(H, Nq, Nk, hd, gain):
+    """The 'sharp' regime of SURVEY 8(d) at the op level: q and k scaled so that every logit is gain^2 times the usual one (x64: the softmax
+    is an arg-max with a few runners-up; many lazy-rescale events, exp arguments down to -1000).  Against a float64 softmax of the SAME
+    16-bit inputs the kernel's error stays at output-rounding level -- the network-level sensitivity to sharp attention
+    (tests/diag/sharp_probe.py) is not an attention-kernel property."""
+    from panst3r_amd import hip
+    q, k, v = bf(rn(950, 1, H, Nq, hd) * gain), bf(rn(951, 1, H, Nk, hd) * gain), bf(rn(952, 1, H, Nk, hd))
+    s = (q.double() @ k.double().transpose(-1, -2)) * hd ** -0.5
+    ref = torch.softmax(s, dim=-1) @ v.double()
+    assert float(torch.softmax(s, dim=-1).max(-1).values.median()) > (0.9 if gain > 4 else 0.15)         # really peaked
+    D = H * hd
+    qd = q[0].permute(1, 0, 2).reshape(Nq, D).contiguous().to(dev())
+    kd = k[0].permute(1, 0, 2).reshape(Nk, D).contiguous().to(dev())
+    vt = torch.zeros(D, (Nk + 7) // 8 * 8 + 8, dtype=d16())
+    vt[:, :Nk] = v[0].permute(0, 2, 1).reshape(D, Nk)
+    vt = vt.to(dev())
+    for ns in (1, 4):
+        od = torch.full((Nq, D), float('nan'), dtype=d16(), device=dev())
+        hip.attention(qd, kd, vt, od, 1, H, Nq, Nk, hd, (0, hd, D), (0, hd, D), (0, hd * vt.stride(0), vt.stride(0)), (0, hd, D), nsplit=ns)
+        got = od.float().cpu().reshape(Nq, H, hd).permute(1, 0, 2)[None]
+        assert torch.isfinite(got).all()
+        assert rel_l2(got, ref) < (6e-3 if d16() == torch.bfloat16 else 1.5e-3), (ns, rel_l2(got, ref))

@@ -105,3 +105,27 @@ def test_postprocess_downsampling_fallback():
     ref = ref_fn(logits, [m.clone() for m in masks], size)[0]
     res = panoptic_inference_v2(logits.to(DEV), [m.to(DEV) for m in masks], size, multi_ar=True)[0]
     _compare(res, ref, frac=2e-3)
+
+
+@pytest.mark.parametrize('tag', ['', '_multiar'])
+def test_postprocess_qubo_golden(golden, tag):
+    """panoptic_inference_qubo with the O(Q^2 x pixels) sums on the GPU against the reference-generated golden (numpy seed 1234): the weight
+    matrix to 1e-5 of its scale, then - same seed - the reference's segments and maps."""
+    import numpy as np
+    from panst3r_amd.engine.postprocess import panoptic_inference_qubo, qubo_weights
+    g = golden('postprocess_qubo' + tag)
+    masks = [m.to(DEV) for m in g.lst('masks')]
+    shapes = [tuple(int(v) for v in s) for s in g.z['size']]
+    Wneg = qubo_weights([m[0].contiguous() for m in masks], shapes, torch.device(DEV))
+    assert float(np.abs(Wneg - g.z['Wneg']).max()) < 1e-5 * float(np.abs(g.z['Wneg']).max())
+    np.random.seed(1234)
+    res = panoptic_inference_qubo(g.t('logits'), masks, g.z['size'], device=DEV, num_redo=3, silent=True, multi_ar=True)[0]
+    assert [[d['id'], d['query_id'], int(d['category_id']), d['area']] for d in res['segments_info']] == g.z['info'].tolist()
+    for d, (cp, mc) in zip(res['segments_info'], g.z['probs'].tolist()):
+        assert abs(d['class_prob'] - cp) < 1e-6 and abs(d['mask_conf'] - mc) < 1e-5
+    same = tot = 0
+    for a, b, ca, cb in zip(res['pan'], g.lst('pan'), res['conf'], g.lst('conf')):
+        eq = a.cpu() == b
+        same += int(eq.sum()); tot += eq.numel()
+        assert float((ca.cpu() - cb)[eq].abs().max()) < 1e-5
+    assert same == tot, (same, tot)

@@ -218,3 +218,26 @@ def test_mask_transformer_full_dim(tag):
     close(flat.norm(dim=-1), torch.from_numpy(z['mask_norm']), 5e-5)
     heads = m.forward_prediction_heads(torch.from_numpy(z['out_queries']), mf_extra, cls)
     close(heads[1][0].flatten(2)[:, ::mg.G2_QSTRIDE, ::mg.G2_PSTRIDE], torch.from_numpy(z['heads_samples']), 5e-5)
+
+
+@pytest.mark.parametrize('tag', ['', '_multiar'])
+def test_postprocess_qubo(golden, tag):
+    """G6b: QUBO post-processing (engine/postprocess.py:135-336).  Reference-generated, numpy seed 1234: the weight matrix of
+    `weight_from_masks`, the annealer's solution / energy on it (the product's host annealer must reproduce the reference's draw
+    sequence), and the final maps / segments."""
+    from oracle.postprocess import qubo_weights, panoptic_inference_qubo
+    from panst3r_amd.engine.postprocess import solve_qubo_simulated_annealing
+    g = golden('postprocess_qubo' + tag)
+    Wneg, _, _ = qubo_weights(g.lst('masks'), g.z['size'])
+    assert float(np.abs(Wneg - g.z['Wneg']).max()) < 1e-6 * float(np.abs(g.z['Wneg']).max())
+    np.random.seed(1234)
+    sol, en = solve_qubo_simulated_annealing(g.z['Wneg'], redo=3, silent=True)
+    assert np.array_equal(np.asarray(sol), g.z['solution']) and abs(en - float(g.z['energy'])) < 1e-12
+    np.random.seed(1234)
+    res, _ = panoptic_inference_qubo(g.t('logits'), g.lst('masks'), g.z['size'], num_redo=3)
+    res = res[0]
+    assert [[d['id'], d['query_id'], d['category_id'], d['area']] for d in res['segments_info']] == g.z['info'].tolist()
+    for a, b in zip(res['pan'], g.lst('pan')):
+        assert torch.equal(a, b)
+    for a, b in zip(res['conf'], g.lst('conf')):
+        assert float((a - b).abs().max()) < 1e-6

@@ -26,7 +26,7 @@ def resize_recipe(size, patch_size, H, W):
 
 def prepare_image(rgb_u8, size, patch_size=16, device='cuda'):
     """decoded image uint8 [H, W, 3] (numpy or tensor) -> fp32 [3, Hc, Wc] in [-1, 1] on `device` (the model's input format)."""
-    t = torch.as_tensor(np.ascontiguousarray(rgb_u8) if isinstance(rgb_u8, np.ndarray) else rgb_u8)
+    t = torch.from_numpy(np.array(rgb_u8, copy=True)) if isinstance(rgb_u8, np.ndarray) else torch.as_tensor(rgb_u8)
     assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3, 'expected a decoded RGB image, uint8 [H, W, 3]'
     t = t.to(device).contiguous()
     (Hr, Wr), (top, left), (Hc, Wc) = resize_recipe(size, patch_size, t.shape[0], t.shape[1])

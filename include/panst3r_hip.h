@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 12
+#define PST_ABI_VERSION 13
 
 /* element type codes: every `*_type` / `dtype16` argument below (and the former `*_fp32` flags: 0 and 1 keep their meaning) */
 #define PST_BF16 0   /* bfloat16, raw uint16 */
@@ -111,6 +111,9 @@ typedef struct pst_attn_params {
   int32_t nsplit;
   void* ws; int64_t ws_bytes;
   int32_t dtype16;                             /* PST_BF16 / PST_F16: format of Q, K, Vt, O */
+  /* 1: Q already carries scale * log2(e) (the model path folds it into the q projection's epilogue, pst_gemm_params.gamma, so it is
+     applied in fp32 before q is rounded): the kernel computes p = exp2(q.k - m) with no per-score multiply and ignores `scale`. */
+  int32_t prescaled;
 } pst_attn_params;
 
 int64_t pst_attn_workspace_bytes(int B, int H, int Nq, int hd, int nsplit);

@@ -37,7 +37,7 @@ struct AttnCfg {
   __device__ static __forceinline__ int kswz(int row) { return (HD == 64) ? ((row >> 1) & 7) : (row & 15); }
 };
 
-template <int HD, int QF, bool F16>
+template <int HD, int QF, bool F16, bool PRE>
 __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   using C = AttnCfg<HD>;
   constexpr int NKK = HD / 32;      // K-steps of the QK^T contraction
@@ -114,11 +114,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   for (int hf = 0; hf < NHF; ++hf)
 #pragma unroll
     for (int a = 0; a < QF; ++a) o[hf][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[QF], l_run[QF];
+  // Online-softmax state of the lane's query column(s).  The score accumulators START at -reference (negm), so the MFMA itself
+  // delivers s - m; the row sum l comes out of the PV MFMA as one more output row with V^T == 1 (lsum: every register of the
+  // fragment holds the full 64-key sum of the 16-bit P values the numerator uses) -- no per-score subtract, no per-score add.
+  // m_run == NEG marks a row that has not seen an unmasked key yet ("virgin": reference 0, o == l == 0 exactly).
+  f32x4 negm[QF], lsum[QF];
+  float m_run[QF];
 #pragma unroll
-  for (int a = 0; a < QF; ++a) { m_run[a] = NEG; l_run[a] = 0.f; }
+  for (int a = 0; a < QF; ++a) { m_run[a] = NEG; negm[a] = f32x4{0.f, 0.f, 0.f, 0.f}; lsum[a] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  bf16x8 ones;
+  {
+    union { bf16x8 v; uint32_t u[4]; } t;
+    t.u[0] = t.u[1] = t.u[2] = t.u[3] = F16 ? 0x3c003c00u : 0x3f803f80u;
+    ones = t.v;
+  }
 
-  const float c_exp = p.scale * 1.4426950408889634f;
+  // PRE: Q already carries scale * log2(e) (folded into the q projection's epilogue): p = exp2(s - m) with no multiply at all
+  const float c_exp = PRE ? 1.0f : p.scale * 1.4426950408889634f;
   const float lazy_thr = 8.0f / c_exp;               // 2^8 in the exp2 domain, in score units
   const int tiles_all = (p.Nk + KT - 1) / KT;
   const int tps = (tiles_all + nsplit - 1) / nsplit;
@@ -138,12 +150,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
     const char* vb_ = kb_ + C::K_BYTES;
     const int k0 = kt * KT;
 
-    // ---- S^T = K Q^T
+    // ---- S^T - m = K Q^T - m
     f32x4 s[4][QF];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
 #pragma unroll
-      for (int a = 0; a < QF; ++a) s[f][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < QF; ++a) s[f][a] = negm[a];
       const int row = f * 16 + l16;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
           if (mrow && key < p.Nk) mb = *(const uint32_t*)(mrow + key);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (key + r >= p.Nk || ((mb >> (8 * r)) & 0xff)) s[f][a][r] = NEG;
+            if (key + r >= p.Nk || ((mb >> (8 * r)) & 0xff)) s[f][a][r] = NEG;       // exp2 of it is exactly 0
         }
       }
       float mx = NEG;
@@ -179,50 +191,39 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][a][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      // Lazy rescaling: the running reference m_run only moves when a score exceeds it by more than 2^8 in the exp2
-      // domain (softmax is invariant to the reference; exp values stay <= 256, exact enough in fp32 / bf16), and the
-      // O / l rescale is skipped for the whole wave unless some query column needs it.  Sentinel rows (m_run == NEG)
-      // always take the update when a real key arrives, which wipes their garbage with alpha == 0.
-      const float m_old = m_run[a];
-      const bool need = mx > m_old + lazy_thr;
+      // Lazy rescaling: the reference only moves when a score exceeds it by more than 2^8 in the exp2 domain (softmax is
+      // invariant to the reference; exp values stay <= 256, exact enough in fp32 / 16 bit), and the whole update is skipped
+      // wave-wide unless some query column needs it.  A virgin row takes the first real score it meets as its reference.
+      const bool virgin = m_run[a] == NEG;
+      const bool need = virgin ? (mx > 0.5f * NEG) : (mx > lazy_thr);
       if (__any(need)) {
-        const float m_new = need ? mx : m_old;
-        const float alpha = __builtin_amdgcn_exp2f((m_old - m_new) * c_exp);
+        const float shift = need ? mx : 0.f;                      // new reference = old + shift
+        const float alpha = virgin ? 1.0f : __builtin_amdgcn_exp2f(-shift * c_exp);
+        const float m_new = need ? (virgin ? 0.f : m_run[a]) + mx : m_run[a];
         m_run[a] = m_new;
-        l_run[a] *= alpha;
+        if (need) negm[a] = f32x4{-m_new, -m_new, -m_new, -m_new};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lsum[a][r] *= alpha;
 #pragma unroll
         for (int hf = 0; hf < NHF; ++hf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[hf][a][r] *= alpha;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[f][a][r] -= shift;
       }
-      const float m_ref = m_run[a];
-      float ps = 0.f;
       float pv[4][4];
-      if (Mp || tail) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f((s[f][a][r] - m_ref) * c_exp);   // subtract first: sentinel - sentinel == 0 exactly
-            pv[f][r] = e;
-            ps += e;
-          }
-      } else {                                   // every score is finite, so is m_ref: one FMA per score
-        const float mc = -m_ref * c_exp;
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
 #ifndef PST_ABL_NOEXP
-            const float e = __builtin_amdgcn_exp2f(fmaf(s[f][a][r], c_exp, mc));
+          pv[f][r] = __builtin_amdgcn_exp2f(PRE ? s[f][a][r] : s[f][a][r] * c_exp);
 #else
-            const float e = fmaf(s[f][a][r], c_exp, mc);
+          pv[f][r] = s[f][a][r];
 #endif
-            pv[f][r] = e;
-            ps += e;
-          }
-      }
-      l_run[a] += ps;
+        }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         union { bf16x8 v; uint32_t u[4]; } pk;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
       }
     }
 
-    // ---- O^T += V^T P^T
+    // ---- O^T += V^T P^T, l += 1^T P^T
 #pragma unroll
     for (int hf = 0; hf < NHF; ++hf) {
       const int row = hf * 16 + l16;
@@ -246,6 +247,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
         for (int a = 0; a < QF; ++a) o[hf][a] = H16<F16>::mfma(vf, pb[a][kb], o[hf][a]);
       }
     }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int a = 0; a < QF; ++a) lsum[a] = H16<F16>::mfma(ones, pb[a][kb], lsum[a]);
   }
 
   // ---- split-K: unnormalised partial O plus (running max, sum) go to the fp32 workspace; attn_combine_kernel merges
@@ -255,9 +260,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
     float* ws_ml = ws_o + (int64_t)nsplit * rows * HD;
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
-      float l = l_run[a];
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
+      const float l = lsum[a][0];
       const int q = q_wave0 + a * 16 + l16;
       if (q < p.Nq) {
         const int64_t row = ((int64_t)b * p.H + h) * p.Nq + q;
@@ -273,10 +276,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   // ---- normalise and store: lane owns q = l16, head-dim rows 16*hf + 4*g + r
 #pragma unroll
   for (int a = 0; a < QF; ++a) {
-    float l = l_run[a];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float inv = 1.0f / l;
+    const float l = lsum[a][0];
+    const float inv = l > 0.f ? 1.0f / l : 0.f;           // a row with every key masked: zeros
     const int q = q_wave0 + a * 16 + l16;
     if (q < p.Nq) {
       bf16_t* dst = Op + (int64_t)q * p.o_rs + 4 * g;
@@ -293,7 +294,7 @@ __global__ void attn_combine_kernel(const pst_attn_params p, int hd) {
   const int64_t rows = (int64_t)p.B * p.H * p.Nq;
   const int per_row = hd / 4;
   const int64_t total = rows * per_row;
-  const float c_exp = p.scale * 1.4426950408889634f;
+  const float c_exp = p.prescaled ? 1.0f : p.scale * 1.4426950408889634f;
   const float* ws_o = (const float*)p.ws;
   const float* ws_ml = ws_o + (int64_t)p.nsplit * rows * hd;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -309,7 +310,7 @@ __global__ void attn_combine_kernel(const pst_attn_params p, int hd) {
       l += ml.y * wgt;
       acc[0] += v.x * wgt; acc[1] += v.y * wgt; acc[2] += v.z * wgt; acc[3] += v.w * wgt;
     }
-    const float inv = 1.0f / l;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
     const int q = (int)(row % p.Nq);
     const int bh = (int)(row / p.Nq), h = bh % p.H, b = bh / p.H;
     bf16_t* dst = (bf16_t*)p.O + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)q * p.o_rs + d;
@@ -317,12 +318,12 @@ __global__ void attn_combine_kernel(const pst_attn_params p, int hd) {
   }
 }
 
-template <int HD, int QF, bool F16>
-static int launch_attn(const pst_attn_params& p, hipStream_t s) {
+template <int HD, int QF, bool F16, bool PRE>
+static int launch_attn4(const pst_attn_params& p, hipStream_t s) {
   const int qblocks = (p.Nq + 64 * QF - 1) / (64 * QF);
   const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
   const long grid = (long)qblocks * p.H * p.B * nsplit;
-  hipLaunchKernelGGL((attn_kernel<HD, QF, F16>), dim3((unsigned)grid), dim3(256), 2 * AttnCfg<HD>::BUF, s, p);
+  hipLaunchKernelGGL((attn_kernel<HD, QF, F16, PRE>), dim3((unsigned)grid), dim3(256), 2 * AttnCfg<HD>::BUF, s, p);
   if (nsplit > 1) {
     const int64_t total = (int64_t)p.B * p.H * p.Nq * (HD / 4);
     int64_t g = (total + 255) / 256;
@@ -332,6 +333,11 @@ static int launch_attn(const pst_attn_params& p, hipStream_t s) {
   return check_launch("attn_fwd");
 }
 
+template <int HD, int QF, bool F16>
+static int launch_attn(const pst_attn_params& p, hipStream_t s) {
+  return p.prescaled ? launch_attn4<HD, QF, F16, true>(p, s) : launch_attn4<HD, QF, F16, false>(p, s);
+}
+
 }  // namespace pst
 
 static int attn_validate(const pst_attn_params* pp) {
@@ -339,6 +345,8 @@ static int attn_validate(const pst_attn_params* pp) {
   if (!pp) { set_error("attn: null params"); return PST_EINVAL; }
   const pst_attn_params& p = *pp;
   if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("attn: dtype16 must be PST_BF16 or PST_F16"); return PST_EINVAL; }
+  if (p.prescaled != 0 && p.prescaled != 1) { set_error("attn: prescaled must be 0 or 1"); return PST_EINVAL; }
+  if (!p.prescaled && !(p.scale > 0.f)) { set_error("attn: scale must be positive"); return PST_EINVAL; }
   if (p.hd != 64 && p.hd != 96) { set_error("attn: head dim %d unsupported (64 or 96)", p.hd); return PST_EINVAL; }
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) { set_error("attn: bad shape"); return PST_EINVAL; }
   if (!p.Q || !p.K || !p.Vt || !p.O || !p.zeros) { set_error("attn: null operand"); return PST_EINVAL; }

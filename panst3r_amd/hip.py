@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -36,7 +36,7 @@ class AttnParams(C.Structure):
                 ('O', vp), ('o_bs', i64), ('o_hs', i64), ('o_rs', i64),
                 ('mask', vp), ('m_bs', i64), ('m_rs', i64),
                 ('B', i32), ('H', i32), ('Nq', i32), ('Nk', i32), ('hd', i32),
-                ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64), ('dtype16', i32)]
+                ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64), ('dtype16', i32), ('prescaled', i32)]
 
 
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
@@ -264,9 +264,13 @@ def auto_nsplit(B, H, Nq, Nk):
     return max(1, min(512 // blocks, Nk // 512, 32))
 
 
+LOG2E = 1.4426950408889634
+
+
 def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale=None, mask=None,
-              mask_strides=(0, 0), nsplit=None, ws=None):
-    """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row)."""
+              mask_strides=(0, 0), nsplit=None, ws=None, prescaled=False):
+    """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row).
+    prescaled: q was produced with scale * LOG2E folded in (see `qscale`): softmax in the exp2 domain without a per-score multiply."""
     _dev(q, *H16); _dev(k, *H16); _dev(vt, *H16); _dev(out, *H16)
     p = AttnParams()
     p.dtype16 = _same16(q, k, vt, out)
@@ -279,6 +283,7 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
         p.mask, (p.m_bs, p.m_rs) = _ptr(mask), mask_strides
     p.B, p.H, p.Nq, p.Nk, p.hd = B, H, Nq, Nk, hd
     p.scale = float(hd ** -0.5 if scale is None else scale)
+    p.prescaled = 1 if prescaled else 0
     p.zeros = _ptr(zeros_page(q.device))
     ns = auto_nsplit(B, H, Nq, Nk) if nsplit is None else nsplit
     if ns > 1:

@@ -204,10 +204,11 @@ def self_attention(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
     D = H * hd
     qk = empty(lay.rows, 2 * D, adt(), dev)
     xn, lq = s.operand(w_qk)
+    qs = qscale(D, 2 * D, hd, dev)                                          # softmax scale * log2(e) folded into q (linear: commutes with RoPE)
     if rope is not None and hd == 64:
-        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, rope=(pos, rope), ln=lq)      # RoPE-2D applied in the GEMM's store phase
+        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, gamma=qs, rope=(pos, rope), ln=lq)      # RoPE-2D applied in the GEMM's store phase
     else:
-        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, ln=lq)
+        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, gamma=qs, ln=lq)
         if rope is not None:
             hip.rope2d_(qk, pos, rope, 2 * H, hd)
     if vt is None:
@@ -220,7 +221,7 @@ def self_attention(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
     ldq, ldv = qk.stride(0), vt.stride(0)
     hip.attention(qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd,
                   q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq),
-                  v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D))
+                  v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D), prescaled=True)
     return o
 
 
@@ -247,6 +248,19 @@ def pack_croco_block(blk, device, norm_mlp=None):
 
 
 _UNIT = {}
+_QSCALE = {}
+
+
+def qscale(n_q, n, hd, device):
+    """per-column epilogue multiplier (hip.gemm `gamma`) of a q (or fused q|k) projection: the first n_q columns carry
+    hd^-0.5 * log2(e), the rest 1 -- applied in fp32 before q is rounded to 16 bit, so the attention kernel runs its softmax in the exp2
+    domain without a per-score multiply (hip.attention prescaled=True).  Cached for the life of the process (captured graphs hold it)."""
+    key = (n_q, n, hd, str(device))
+    if key not in _QSCALE:
+        g = torch.ones(n, dtype=torch.float32, device=device)
+        g[:n_q] = hd ** -0.5 * hip.LOG2E
+        _QSCALE[key] = g
+    return _QSCALE[key]
 
 
 def unit_affine(D, device):

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .common import (HipModule, Packed, Layout, adt, BlockW, empty, pack_norm, pack_croco_block, self_attention, f32,
+from .common import (HipModule, qscale, Packed, Layout, adt, BlockW, empty, pack_norm, pack_croco_block, self_attention, f32,
                      ParamLinear, grid_pos, grow_table, Stream, fold_ln, ln_of, fold_in_epilogue)
 from .params import BlockP, CrossAttnP, MlpP, AttnP
 
@@ -143,7 +143,7 @@ class MUSt3R(HipModule):
         c = bw.cross
         q = empty(s.x.shape[0], self.embed_dim, adt(), s.x.device)
         a, ln = s.operand(c['q'])
-        hip.gemm(a, c['q'].w, q, bias=c['q'].b, ln=ln)
+        hip.gemm(a, c['q'].w, q, bias=c['q'].b, gamma=qscale(self.embed_dim, self.embed_dim, self.embed_dim // self.num_heads, s.x.device), ln=ln)
         return q
 
     def _mlp(self, s, bw):
@@ -178,7 +178,7 @@ class MUSt3R(HipModule):
             o = empty(lay.rows, D, adt(), dev)
             ldv = bank.Vt[l].stride(0)
             hip.attention(q, bank.K[l], bank.Vt[l], o, 1, H, lay.rows, bank.n, hd,
-                          q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
+                          q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D), prescaled=True)
             s.residual(o, bw.cross['proj'])
             self._mlp(s, bw)
         if feat_out is None:
@@ -233,14 +233,14 @@ class MUSt3R(HipModule):
                 ldv = vt.stride(0)
                 hip.attention(q, kk[lay.Tp:], vt[:, lay.Tp:], o, 2, H, T, T, hd,
                               q_strides=(lay.Tp * D, hd, D), k_strides=(-lay.Tp * D, hd, D),
-                              v_strides=(-lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D))
+                              v_strides=(-lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D), prescaled=True)
                 if lay.Tp != T:
                     o.view(2, lay.Tp, D)[:, T:] = 0
             else:
                 q = self._cross_q(s, bw)
                 ldv = bank.Vt[l].stride(0)
                 hip.attention(q, bank.K[l], bank.Vt[l], o, 1, H, lay.rows, bank.n, hd,
-                              q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
+                              q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D), prescaled=True)
             s.residual(o, c['proj'])
             self._mlp(s, bw)
             hs.append(s.x)
@@ -291,7 +291,7 @@ class MUSt3R(HipModule):
                 o = torch.zeros(lay.rows, D, dtype=adt(), device=dev)
                 ldv = vt.stride(0)
                 hip.attention(q, kk, vt, o, 1, H, lay.T, Ts[1 - i], hd, q_strides=(0, hd, D), k_strides=(0, hd, D),
-                              v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D))
+                              v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D), prescaled=True)
                 s.residual(o, c['proj'])
                 self._mlp(s, bw)
                 S[i].append(s)

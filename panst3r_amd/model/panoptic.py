@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .common import (HipModule, Packed, Layout, adt, empty, vit_block, pack_croco_block, pack_norm, f32, ParamLinear,
+from .common import (HipModule, qscale, Packed, Layout, adt, empty, vit_block, pack_croco_block, pack_norm, f32, ParamLinear,
                      grid_pos, ceil_to, grow_table, Stream, fold_ln, ln_of)
 from .params import BlockP, MlpP, CrossAttnP, MHAP
 
@@ -278,10 +278,10 @@ class LoftUpUpscaler(HipModule):
                 vt = torch.zeros(C, rows1 - rows0 + 8, dtype=adt(), device=dev)
                 hip.gemm(y, bw['v'].w, vt, bias=bw['v'].b, trans_out=True)
                 a, ln = s.operand(bw['q'])
-                hip.gemm(a, bw['q'].w, q, bias=bw['q'].b, ln=ln)
+                hip.gemm(a, bw['q'].w, q, bias=bw['q'].b, gamma=qscale(C, C, hd, dev), ln=ln)
                 ldv = vt.stride(0)
                 hip.attention(q, kk, vt, o, n, Hh, P, T, hd, q_strides=(P * C, hd, C), k_strides=(lay.Tp * C, hd, C),
-                              v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(P * C, hd, C))
+                              v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(P * C, hd, C), prescaled=True)
                 s.residual(o, bw['proj'])
                 a, ln = s.operand(bw['fc1'])
                 hip.gemm(a, bw['fc1'].w, q, bias=bw['fc1'].b, act='gelu', ln=ln)
@@ -529,22 +529,22 @@ class MaskTransformer(HipModule):
             hip.gemm(src, L['ca']['v'].w, vt, bias=L['ca']['v'].b, trans_out=True)
             hip.add_cast(out, qin, b=qpos)
             q = empty(Q, d, adt(), dev)
-            hip.gemm(qin, L['ca']['q'].w, q, bias=L['ca']['q'].b)
+            hip.gemm(qin, L['ca']['q'].w, q, bias=L['ca']['q'].b, gamma=qscale(d, d, hd, dev))
             ldv = vt.stride(0)
             hip.attention(q, kc, vt, ob, 1, H, Q, NK, hd, (0, hd, d), (0, hd, d), (0, hd * ldv, ldv), (0, hd, d),
-                          mask=mask, mask_strides=(0, NKm))
+                          mask=mask, mask_strides=(0, NKm), prescaled=True)
             hip.gemm(ob, L['ca']['o'].w, t32, bias=L['ca']['o'].b, res=out)
             hip.layernorm(t32, L['ca_norm'][0], L['ca_norm'][1], out, L['ca_norm'][2])
             # self-attention: q = k = out + query_pos, v = out
             hip.add_cast(out, qin, b=qpos)
             qk = empty(Q, 2 * d, adt(), dev)
-            hip.gemm(qin, L['sa']['qk'].w, qk, bias=L['sa']['qk'].b)
+            hip.gemm(qin, L['sa']['qk'].w, qk, bias=L['sa']['qk'].b, gamma=qscale(d, 2 * d, hd, dev))
             hip.add_cast(out, ob)
             vts = torch.zeros(d, ceil_to(Q, 8) + 8, dtype=adt(), device=dev)
             hip.gemm(ob, L['sa']['v'].w, vts, bias=L['sa']['v'].b, trans_out=True)
             o2 = empty(Q, d, adt(), dev)
             lds = vts.stride(0)
-            hip.attention(qk, qk[:, d:], vts, o2, 1, H, Q, Q, hd, (0, hd, 2 * d), (0, hd, 2 * d), (0, hd * lds, lds), (0, hd, d))
+            hip.attention(qk, qk[:, d:], vts, o2, 1, H, Q, Q, hd, (0, hd, 2 * d), (0, hd, 2 * d), (0, hd * lds, lds), (0, hd, d), prescaled=True)
             hip.gemm(o2, L['sa']['o'].w, t32, bias=L['sa']['o'].b, res=out)
             hip.layernorm(t32, L['sa_norm'][0], L['sa_norm'][1], out, L['sa_norm'][2])
             # FFN

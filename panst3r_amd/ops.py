@@ -66,9 +66,9 @@ def gemm_stream16(a: Tensor, w: Tensor, out: Tensor, stats_out: Tensor, bias: Op
 @_op('attention', ('out',))
 def attention(q: Tensor, k: Tensor, vt: Tensor, out: Tensor, B: int, H: int, Nq: int, Nk: int, hd: int, q_strides: List[int], k_strides: List[int],
               v_strides: List[int], o_strides: List[int], scale: Optional[float] = None, mask: Optional[Tensor] = None,
-              mask_strides: Optional[List[int]] = None, nsplit: Optional[int] = None, ws: Optional[Tensor] = None) -> None:
+              mask_strides: Optional[List[int]] = None, nsplit: Optional[int] = None, ws: Optional[Tensor] = None, prescaled: bool = False) -> None:
     hip.attention(q, k, vt, out, B, H, Nq, Nk, hd, tuple(q_strides), tuple(k_strides), tuple(v_strides), tuple(o_strides), scale=scale, mask=mask,
-                  mask_strides=tuple(mask_strides) if mask_strides else (0, 0), nsplit=nsplit, ws=ws)
+                  mask_strides=tuple(mask_strides) if mask_strides else (0, 0), nsplit=nsplit, ws=ws, prescaled=prescaled)
 
 
 @_op('layernorm', ('out',))

@@ -187,8 +187,12 @@ def test_gemm_implicit_conv3x3(Cin, Cout, H, W):
     assert rel_l2(out.cpu(), ref) < 2e-3
 
 
-def _attn_ref(q, k, v, mask=None):
-    s = (q @ k.transpose(-1, -2)) * q.shape[-1] ** -0.5
+LN2 = 0.6931471805599453
+
+
+def _attn_ref(q, k, v, mask=None, pre=False):
+    """pre: q already carries hd^-0.5 * log2(e) (the model path's prescaled mode): softmax of q.k * ln 2"""
+    s = (q @ k.transpose(-1, -2)) * (LN2 if pre else q.shape[-1] ** -0.5)
     if mask is not None:
         s = s.masked_fill(mask[:, None], float('-inf'))
     return s.softmax(-1) @ v
@@ -197,9 +201,10 @@ def _attn_ref(q, k, v, mask=None):
 @pytest.mark.parametrize('B,H,Nq,Nk,hd', [(1, 2, 64, 64, 64), (2, 3, 200, 333, 64), (1, 16, 769, 769, 64), (1, 4, 768, 1536, 96),
                                           (3, 2, 50, 70, 96), (1, 12, 2304, 768, 64)])
 @pytest.mark.parametrize('masked', [False, True])
-def test_attention(B, H, Nq, Nk, hd, masked):
+@pytest.mark.parametrize('pre', [False, True])
+def test_attention(B, H, Nq, Nk, hd, masked, pre):
     from panst3r_amd import hip
-    q, k, v = bf(rn(20, B, H, Nq, hd)), bf(rn(21, B, H, Nk, hd)), bf(rn(22, B, H, Nk, hd))
+    q, k, v = bf(rn(20, B, H, Nq, hd) * (hd ** -0.5 * hip.LOG2E if pre else 1.0)), bf(rn(21, B, H, Nk, hd)), bf(rn(22, B, H, Nk, hd))
     mask = None
     if masked:
         g = np.random.Generator(np.random.PCG64(5))
@@ -208,7 +213,7 @@ def test_attention(B, H, Nq, Nk, hd, masked):
         mask[:, 0, 64:] = True                                   # a row whose later tiles are fully blocked
         mask[:, 1, :Nk - 1] = True                               # a row whose only open key is the last one
         mask[:, 1, Nk - 1] = False
-    ref = _attn_ref(q.float(), k.float(), v.float(), mask)
+    ref = _attn_ref(q.float(), k.float(), v.float(), mask, pre)
     # device layouts: q/k/o token-major [B, N, H*hd]; V transposed [H*hd, B*Nkp] (key contiguous, views side by side)
     Nkp = (Nk + 7) // 8 * 8
     qd = q.permute(0, 2, 1, 3).reshape(B, Nq, H * hd).contiguous().to(dev())
@@ -228,24 +233,25 @@ def test_attention(B, H, Nq, Nk, hd, masked):
     hip.attention(qd, kd, vt, od, B, H, Nq, Nk, hd,
                   q_strides=(Nq * H * hd, hd, H * hd), k_strides=(Nk * H * hd, hd, H * hd),
                   v_strides=(Nkp, hd * vt.stride(0), vt.stride(0)), o_strides=(Nq * H * hd, hd, H * hd),
-                  mask=md, mask_strides=ms)
+                  mask=md, mask_strides=ms, prescaled=pre)
     got = od.float().cpu().reshape(B, Nq, H, hd).permute(0, 2, 1, 3)
     assert torch.isfinite(got).all()
     assert rel_l2(got, ref) < 1.2e-2
 
 
 @pytest.mark.parametrize('H,Nq,Nk,hd,ns,masked', [(12, 768, 6144, 64, 4, False), (8, 200, 3000, 96, 7, True), (2, 70, 1100, 64, 32, False)])
-def test_attention_split_k(H, Nq, Nk, hd, ns, masked):
+@pytest.mark.parametrize('pre', [False, True])
+def test_attention_split_k(H, Nq, Nk, hd, ns, masked, pre):
     """flash-decoding split over the key range + combine == unsplit softmax (incl. empty / tail splits and masks)."""
     from panst3r_amd import hip
-    q, k, v = bf(rn(23, 1, H, Nq, hd)), bf(rn(24, 1, H, Nk, hd)), bf(rn(25, 1, H, Nk, hd))
+    q, k, v = bf(rn(23, 1, H, Nq, hd) * (hd ** -0.5 * hip.LOG2E if pre else 1.0)), bf(rn(24, 1, H, Nk, hd)), bf(rn(25, 1, H, Nk, hd))
     mask = None
     if masked:
         g = np.random.Generator(np.random.PCG64(6))
         mask = torch.from_numpy(g.uniform(size=(1, Nq, Nk)) < 0.7)
         mask[:, :, 5] = False
         mask[:, 3, :2048] = True           # a row whose first splits are fully blocked
-    ref = _attn_ref(q.float(), k.float(), v.float(), mask)
+    ref = _attn_ref(q.float(), k.float(), v.float(), mask, pre)
     D = H * hd
     qd = q[0].permute(1, 0, 2).reshape(Nq, D).contiguous().to(dev())
     kd = k[0].permute(1, 0, 2).reshape(Nk, D).contiguous().to(dev())
@@ -258,26 +264,57 @@ def test_attention_split_k(H, Nq, Nk, hd, ns, masked):
     for nsplit in (ns, None):
         od = torch.full((Nq, D), float('nan'), dtype=d16(), device=dev())
         hip.attention(qd, kd, vt, od, 1, H, Nq, Nk, hd, (0, hd, D), (0, hd, D), (0, hd * vt.stride(0), vt.stride(0)), (0, hd, D),
-                      mask=md, mask_strides=ms, nsplit=nsplit)
+                      mask=md, mask_strides=ms, nsplit=nsplit, prescaled=pre)
         got = od.float().cpu().reshape(Nq, H, hd).permute(1, 0, 2)
         assert torch.isfinite(got).all()
         assert rel_l2(got, ref[0]) < 1.2e-2
 
 
-def test_attention_softmax_rescale_spike():
-    """Force the online-softmax rescale branch: one key in a late tile dominates one query row (guide rule 26)."""
+@pytest.mark.parametrize('pre', [False, True])
+def test_attention_softmax_rescale_spike(pre):
+    """Force the online-softmax rescale branch: one key in a late tile dominates one query row (guide rule 26); and a first tile
+    whose scores are all far BELOW zero (the reference must come from the data, not from the accumulator's initial 0)."""
     from panst3r_amd import hip
     H, Nq, Nk, hd = 1, 32, 256, 64
-    q, k, v = bf(rn(30, 1, H, Nq, hd)), bf(rn(31, 1, H, Nk, hd)), bf(rn(32, 1, H, Nk, hd))
+    c = hd ** -0.5 * hip.LOG2E if pre else 1.0
+    q, k, v = rn(30, 1, H, Nq, hd), rn(31, 1, H, Nk, hd), bf(rn(32, 1, H, Nk, hd))
     k[0, 0, 200] = q[0, 0, 5] * 6.0
-    ref = _attn_ref(q.double(), k.double(), v.double()).float()
+    k[0, 0, :64] -= q[0, 0, 7] * 8.0                  # row 7: every key of the first tile scores about -60 (x 8 before the scale)
+    q, k = bf(q * c), bf(k)
+    ref = _attn_ref(q.double(), k.double(), v.double(), None, pre).float()
     qd, kd = q[0, 0].contiguous().to(dev()), k[0, 0].contiguous().to(dev())
     vt = torch.zeros(hd, Nk + 8, dtype=d16())
     vt[:, :Nk] = v[0, 0].T
     vt = vt.to(dev())
     od = torch.zeros(Nq, hd, dtype=d16(), device=dev())
-    hip.attention(qd, kd, vt, od, 1, 1, Nq, Nk, hd, (0, 0, hd), (0, 0, hd), (0, 0, vt.stride(0)), (0, 0, hd))
+    hip.attention(qd, kd, vt, od, 1, 1, Nq, Nk, hd, (0, 0, hd), (0, 0, hd), (0, 0, vt.stride(0)), (0, 0, hd), prescaled=pre)
     assert rel_l2(od.float().cpu(), ref[0, 0]) < 1.2e-2
+    assert rel_l2(od.float().cpu()[7], ref[0, 0, 7]) < 1.2e-2
+
+
+def test_attention_fully_masked_rows_are_zero():
+    """a query row whose every key is blocked: finite zeros (l == 0 guard), with and without split-K; its neighbours are unaffected"""
+    from panst3r_amd import hip
+    H, Nq, Nk, hd = 2, 40, 300, 64
+    q, k, v = bf(rn(33, 1, H, Nq, hd)), bf(rn(34, 1, H, Nk, hd)), bf(rn(35, 1, H, Nk, hd))
+    mask = torch.zeros(1, Nq, Nk, dtype=torch.bool)
+    mask[0, 3] = True
+    mask[0, 20, 10:] = True
+    ref = _attn_ref(q.float(), k.float(), v.float(), mask)
+    D = H * hd
+    qd = q[0].permute(1, 0, 2).reshape(Nq, D).contiguous().to(dev())
+    kd = k[0].permute(1, 0, 2).reshape(Nk, D).contiguous().to(dev())
+    vt = torch.zeros(D, (Nk + 7) // 8 * 8 + 8, dtype=d16())
+    vt[:, :Nk] = v[0].permute(0, 2, 1).reshape(D, Nk)
+    vt = vt.to(dev())
+    md = mask[0].to(torch.uint8).contiguous().to(dev())
+    for ns in (1, 3):
+        od = torch.full((Nq, D), float('nan'), dtype=d16(), device=dev())
+        hip.attention(qd, kd, vt, od, 1, H, Nq, Nk, hd, (0, hd, D), (0, hd, D), (0, hd * vt.stride(0), vt.stride(0)), (0, hd, D), mask=md, mask_strides=(0, Nk), nsplit=ns)
+        got = od.float().cpu().reshape(Nq, H, hd).permute(1, 0, 2)
+        assert torch.isfinite(got).all() and float(got[:, 3].abs().max()) == 0.0
+        keep = [i for i in range(Nq) if i != 3]
+        assert rel_l2(got[:, keep], ref[0][:, keep]) < 1.2e-2
 
 
 @pytest.mark.parametrize('D,eps', [(1024, 1e-6), (768, 1e-6), (384, 1e-5), (48, 1e-5), (2816, 1e-5)])

@@ -37,6 +37,19 @@ struct AttnCfg {
   __device__ static __forceinline__ int kswz(int row) { return (HD == 64) ? ((row >> 1) & 7) : (row & 15); }
 };
 
+// max over lanes {l, l^16, l^32, l^48}: v_permlane16_swap / v_permlane32_swap exchange whole 16- / 32-lane rows between two
+// registers (here twice the same one), so x = {r0, r0, r2, r2}, y = {r1, r1, r3, r3} and max(x, y) is the pairwise row max.
+__device__ __forceinline__ float max_rows(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a[0]), "v"(a[1]));
+  const unsigned w = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(b[0]), "v"(b[1]));
+  return m;
+}
+
 template <int HD, int QF, bool F16, bool PRE>
 __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   using C = AttnCfg<HD>;
@@ -90,10 +103,27 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
     v_chunk[j] = pos ^ ((row >> 1) & 7);
   }
 
+  // full tiles: per-thread 32-bit byte offsets inside the tile + a wave-uniform (scalar) tile base -- no per-tile vector address
+  // arithmetic (the kernel is VALU-issue bound: SQ anatomy in profiles/).  The last, ragged tile clamps keys / substitutes zeros.
+  uint32_t k_off[K_PER_THR], v_off[V_PER_THR];
+#pragma unroll
+  for (int j = 0; j < K_PER_THR; ++j) k_off[j] = (uint32_t)(k_key[j] * (int)p.k_rs + k_chunk[j] * 8) * 2u;
+#pragma unroll
+  for (int j = 0; j < V_PER_THR; ++j) v_off[j] = (uint32_t)(v_row[j] * (int)p.v_ds + v_chunk[j] * 8) * 2u;
   auto stage = [&](int kt, int buf) {
     const int k0 = kt * KT;
     char* kd = smem + buf * C::BUF + wave * 1024;
     char* vd = smem + buf * C::BUF + C::K_BYTES + wave * 1024;
+    if (k0 + KT <= p.Nk) {
+      const char* kbase = (const char*)Kp + (int64_t)k0 * p.k_rs * 2;
+      const char* vbase = (const char*)Vp + (int64_t)k0 * 2;
+#pragma unroll
+      for (int j = 0; j < K_PER_THR; ++j)
+        if (C::KSLOTS == C::KCHUNKS || k_chunk[j] < C::KCHUNKS) glds16(kbase + k_off[j], kd + j * 4096);
+#pragma unroll
+      for (int j = 0; j < V_PER_THR; ++j) glds16(vbase + v_off[j], vd + j * 4096);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < K_PER_THR; ++j) {
       if (C::KSLOTS == C::KCHUNKS || k_chunk[j] < C::KCHUNKS) {
@@ -168,6 +198,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
 
     // ---- mask, online softmax; P stays in the lane
     bf16x8 pb[QF][2];
+    float mx[QF];
     const bool tail = (k0 + KT > p.Nk);
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
@@ -184,24 +215,34 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
             if (key + r >= p.Nk || ((mb >> (8 * r)) & 0xff)) s[f][a][r] = NEG;       // exp2 of it is exactly 0
         }
       }
-      float mx = NEG;
+      // two independent v_max3 chains (a dependent VALU chain issues at ~0.6 of the independent rate): 8 instructions, depth 5
+      auto max3 = [](float x, float y, float z) { return fmaxf(fmaxf(x, y), z); };
+      float m0 = max3(s[0][a][0], s[0][a][1], s[0][a][2]), m1 = max3(s[2][a][0], s[2][a][1], s[2][a][2]);
+      m0 = max3(m0, s[0][a][3], s[1][a][0]); m1 = max3(m1, s[2][a][3], s[3][a][0]);
+      m0 = max3(m0, s[1][a][1], s[1][a][2]); m1 = max3(m1, s[3][a][1], s[3][a][2]);
+      mx[a] = fmaxf(max3(m0, m1, s[1][a][3]), s[3][a][3]);
+    }
+    // max over the 4 lanes that share a query column (lane bits 4, 5): two cross-row swaps on the VALU, no LDS round trip
+    bool virgin[QF], need[QF];
+    bool some = false;
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][a][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+    for (int a = 0; a < QF; ++a) {
+      mx[a] = max_rows(mx[a]);
       // Lazy rescaling: the reference only moves when a score exceeds it by more than 2^8 in the exp2 domain (softmax is
       // invariant to the reference; exp values stay <= 256, exact enough in fp32 / 16 bit), and the whole update is skipped
       // wave-wide unless some query column needs it.  A virgin row takes the first real score it meets as its reference.
-      const bool virgin = m_run[a] == NEG;
-      const bool need = virgin ? (mx > 0.5f * NEG) : (mx > lazy_thr);
-      if (__any(need)) {
-        const float shift = need ? mx : 0.f;                      // new reference = old + shift
-        const float alpha = virgin ? 1.0f : __builtin_amdgcn_exp2f(-shift * c_exp);
-        const float m_new = need ? (virgin ? 0.f : m_run[a]) + mx : m_run[a];
+      virgin[a] = m_run[a] == NEG;
+      need[a] = virgin[a] ? (mx[a] > 0.5f * NEG) : (mx[a] > lazy_thr);
+      some = some || need[a];
+    }
+    if (__any(some)) {
+#pragma unroll
+      for (int a = 0; a < QF; ++a) {
+        const float shift = need[a] ? mx[a] : 0.f;                      // new reference = old + shift
+        const float alpha = virgin[a] ? 1.0f : __builtin_amdgcn_exp2f(-shift * c_exp);
+        const float m_new = need[a] ? (virgin[a] ? 0.f : m_run[a]) + mx[a] : m_run[a];
         m_run[a] = m_new;
-        if (need) negm[a] = f32x4{-m_new, -m_new, -m_new, -m_new};
+        if (need[a]) negm[a] = f32x4{-m_new, -m_new, -m_new, -m_new};
 #pragma unroll
         for (int r = 0; r < 4; ++r) lsum[a][r] *= alpha;
 #pragma unroll
@@ -213,6 +254,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[f][a][r] -= shift;
       }
+    }
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
       float pv[4][4];
 #pragma unroll
       for (int f = 0; f < 4; ++f)
@@ -357,6 +401,7 @@ static int attn_validate(const pst_attn_params* pp) {
   if (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.Vt) & 15 || ((uintptr_t)p.O & 7)) {
     set_error("attn: operands must be 16-byte aligned"); return PST_EINVAL;
   }
+  if (p.k_rs * 64 * 2 >= (1ll << 31) || p.v_ds * (int64_t)p.hd * 2 >= (1ll << 31)) { set_error("attn: K row / V^T row stride too large"); return PST_EINVAL; }
   if (p.mask && ((p.m_rs | p.m_bs) % 4 || ((uintptr_t)p.mask & 3))) { set_error("attn: mask rows must be 4-byte aligned"); return PST_EINVAL; }
   if (p.nsplit > 1) {
     const int64_t need = (int64_t)p.nsplit * p.B * p.H * p.Nq * (p.hd + 2) * 4;

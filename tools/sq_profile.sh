@@ -6,13 +6,14 @@
 set -e
 TAG=$1; shift
 ROOT=$(pwd)
+SCRIPT=$ROOT/$1; shift
 OUT=$ROOT/gpurun_out/sq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES \
-  --output-format csv -d $OUT/p1 -o p1 -- python "$@" > $OUT/p1.log 2>&1 || true
+  --output-format csv -d $OUT/p1 -o p1 -- python $SCRIPT "$@" > $OUT/p1.log 2>&1 || true
 rocprofv3 --kernel-trace --pmc SQ_INST_CYCLES_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_COEXEC_CYCLES \
-  --output-format csv -d $OUT/p2 -o p2 -- python "$@" > $OUT/p2.log 2>&1 || true
+  --output-format csv -d $OUT/p2 -o p2 -- python $SCRIPT "$@" > $OUT/p2.log 2>&1 || true
 cd $ROOT
 python - $OUT $ROOT/gpurun_out/${TAG}_sq.md <<'PY'
 import csv, glob, sys, collections, re

@@ -88,14 +88,30 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// exact-GELU 0.5 x (1 + erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 output
-// resolution): one v_exp_f32 + one v_rcp_f32 + 7 FMAs instead of libm erff's ~25-instruction polynomial.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erf(|x|/sqrt2)
-  return 0.5f * x * (1.0f + copysignf(e, x));
+// exact-GELU 0.5 x (1 + erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the 16-bit output
+// resolution), on PAIRS of values: the GEMM epilogues are VALU-issue bound (SQ anatomy, profiles/), and v_pk_fma_f32 / v_pk_mul_f32
+// run two lanes' worth per issue -- 2 v_rcp + 2 v_exp + 2 v_bfi + 13 packed / integer ops per pair instead of ~16 per value.
+// Every operation is an explicit fma / mul (no contraction left to the compiler): identical bits in every kernel that inlines it.
+__device__ __forceinline__ f32x2_t splat2(float a) { return f32x2_t{a, a}; }
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+  const f32x2_t z = __builtin_elementwise_abs(x) * splat2(0.70710678118654752f);
+  const f32x2_t d = __builtin_elementwise_fma(splat2(0.3275911f), z, splat2(1.0f));
+  const f32x2_t t = f32x2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2_t p = __builtin_elementwise_fma(t, splat2(1.061405429f), splat2(-1.453152027f));
+  p = __builtin_elementwise_fma(t, p, splat2(1.421413741f));
+  p = __builtin_elementwise_fma(t, p, splat2(-0.284496736f));
+  p = __builtin_elementwise_fma(t, p, splat2(0.254829592f));
+  p = p * t;
+  const f32x2_t a = (z * z) * splat2(-1.4426950408889634f);
+  const f32x2_t ex = f32x2_t{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  const f32x2_t e = __builtin_elementwise_fma(-p, ex, splat2(1.0f));            // erf(|x| / sqrt2)
+  const f32x2_t es = f32x2_t{__builtin_copysignf(e.x, x.x), __builtin_copysignf(e.y, x.y)};
+  const f32x2_t hx = x * splat2(0.5f);
+  return __builtin_elementwise_fma(hx, es, hx);
+}
+__device__ __forceinline__ void gelu_erf4(float (&v)[4]) {
+  const f32x2_t a = gelu_erf2(f32x2_t{v[0], v[1]}), b = gelu_erf2(f32x2_t{v[2], v[3]});
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
 }  // namespace pst

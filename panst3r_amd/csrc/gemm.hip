@@ -21,6 +21,8 @@
 namespace pst {
 
 int launch_gemm256(const pst_gemm_params& p, hipStream_t s);   // gemm256.hip
+int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus);
+bool gemm256_persistent_ok(const pst_gemm_params& p);
 
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
@@ -397,9 +399,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
           // explicit fmaf chain, the same as the row-major epilogue: every instantiation (tile size) rounds identically
           const float2 st = p.ln_stats ? lnst[wr * (16 * FM) + g * (4 * FM) + 4 * i + r] : make_float2(1.f, 0.f);
           float x = fmaf(acc[i][j][r], st.x, fmaf(st.y, cs, b));
-          if (p.act == 1) x = gelu_erf(x); else if (p.act == 2) x = fmaxf(x, 0.f);
+          if (p.act == 2) x = fmaxf(x, 0.f);
           v[4 * i + r] = x;
         }
+      if (p.act == 1) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) gelu_erf4(*(float (*)[4])(v + 4 * i));
+      }
       if (mb + 4 * FM <= p.M && (((uintptr_t)dst) & 15) == 0) {
 #pragma unroll
         for (int q = 0; q < FM / 2; ++q)
@@ -449,8 +455,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
         float v[4] = {fmaf(acc[i][j][0], lns[i].x, fmaf(lns[i].y, cs4[j].x, bias4[j].x)), fmaf(acc[i][j][1], lns[i].x, fmaf(lns[i].y, cs4[j].y, bias4[j].y)),
                       fmaf(acc[i][j][2], lns[i].x, fmaf(lns[i].y, cs4[j].z, bias4[j].z)), fmaf(acc[i][j][3], lns[i].x, fmaf(lns[i].y, cs4[j].w, bias4[j].w))};
         if (p.act == 1) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+          gelu_erf4(v);
         } else if (p.act == 2) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -563,7 +568,7 @@ extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
   const int c = gemm_choice(p);
   // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
   if (p.trans_out) return c == 0 ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
-  if (c == 2) return launch_gemm256(p, s);
+  if (c == 2) return gemm256_persistent_ok(p) ? launch_gemm256p(p, s, num_cus()) : launch_gemm256(p, s);
   return c == 0 ? launch<2, 2, false, 4>(p, s) : launch<4, 4, false, 2>(p, s);
 }
 
@@ -571,5 +576,5 @@ extern "C" const char* pst_gemm_variant(const pst_gemm_params* pp) {
   if (gemm_validate(pp)) return nullptr;
   const int c = gemm_choice(*pp);
   if (pp->trans_out) return c == 0 ? "gemm_kernel<2,2,true>" : "gemm_kernel<4,4,true>";
-  return c == 2 ? "gemm256_kernel" : (c == 0 ? "gemm_kernel<2,2,false>" : "gemm_kernel<4,4,false>");
+  return c == 2 ? (pst::gemm256_persistent_ok(*pp) ? "gemm256p_kernel" : "gemm256_kernel") : (c == 0 ? "gemm_kernel<2,2,false>" : "gemm_kernel<4,4,false>");
 }

@@ -170,8 +170,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
           float v[4] = {fmaf(acc[i][j][0], st.x, fmaf(st.y, cs4.x, bias4.x)), fmaf(acc[i][j][1], st.x, fmaf(st.y, cs4.y, bias4.y)),
                         fmaf(acc[i][j][2], st.x, fmaf(st.y, cs4.z, bias4.z)), fmaf(acc[i][j][3], st.x, fmaf(st.y, cs4.w, bias4.w))};
           if (p.act == 1) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+            gelu_erf4(v);
           } else if (p.act == 2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -310,7 +309,203 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
   }
 }
 
+
+// ---------------------------------------------------------------- persistent variant: one workgroup per CU walks the tile list
+// For the plain 16-bit row-major GEMMs (fc1 + GELU, q|k projections without RoPE).  The non-persistent kernel above spends ~15 us of
+// every 256x256 tile outside its main loop (K-sweep at M = 38800, N = 4096: 424 us at K = 1024, +256..294 us per further 1024 of K):
+// a whole round of workgroups retires together, so the chip alternates between a burst of 32 MB of stores with idle matrix cores and
+// a prologue in which every CU waits for its first operand tile.  Here
+//   * the operand tiles of the NEXT output tile are requested by LDS-DMA BEFORE the epilogue of the current one (the operand buffers
+//     are free after the last K step, and this epilogue does not touch LDS), so the prologue latency hides behind the epilogue;
+//   * C goes straight from the accumulators to global memory: W rows are staged so that a lane owns two 8-column runs (perm_row8) and
+//     the 4 lanes of a row write 64 contiguous bytes per store instruction; stores are fire-and-forget -- nothing waits for them but
+//     the in-order vmcnt of the next tile's first wait, by which time the operand tiles (requested earlier) had to land anyway;
+//   * workgroups drift apart, so the store bursts of different CUs no longer coincide.
+// Per-element K order is the same as in every other tile size: bit-identical results.
+__device__ __forceinline__ int perm_row8(int row) {       // LDS row (fragment f, fragment row 4g + r) -> tile column it holds
+  const int sub = row >> 6, rho = row & 63;
+  const int f = rho >> 4, g = (rho >> 2) & 3, r = rho & 3;
+  return (sub << 6) + (f >> 1) * 32 + g * 8 + (f & 1) * 4 + r;
+}
+
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int g = lane >> 4, l16 = lane & 15;
+  const bf16_t* Ab = (const bf16_t*)p.A;
+  const bf16_t* Wb = (const bf16_t*)p.W;
+  const int nk = p.K / 64;
+
+  auto tile_origin = [&](int t, int& m0, int& n0) {        // grouped order: GROUP_M row-tiles share their W column-tile in L2
+    const int grp = t / (G256_GROUP_M * tiles_n);
+    const int first_m = grp * G256_GROUP_M;
+    const int gm = min(G256_GROUP_M, tiles_m - first_m);
+    const int tl = t - grp * G256_GROUP_M * tiles_n;
+    m0 = (first_m + tl % gm) * 256;
+    n0 = (tl / gm) * 256;
+  };
+  // block b of the launch walks tiles xcd_remap(b), xcd_remap(b + gridDim.x), ...: consecutive blocks of one XCD stay on neighbouring tiles
+  int a_src[2][2], b_src[2][2];
+  auto describe = [&](int m0, int n0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = j * 512 + tid, lrow = c >> 3, pos = c & 7;
+      const int sw = ((pos ^ ((lrow >> 1) & 7)) << 3);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        a_src[h][j] = min(m0 + h * 128 + lrow, p.M - 1) * (int)p.lda + sw;
+        b_src[h][j] = (n0 + h * 128 + perm_row8(lrow)) * (int)p.ldw + sw;
+      }
+    }
+  };
+  auto stage = [&](int which, int kt) {
+    if (kt >= nk) return;
+    char* dst = smem + (kt & 1) * BUF_BYTES + which * HALF_BYTES + wave * 1024;
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16_t* s = which < 2 ? Ab + (a_src[which & 1][j] + k0) : Wb + (b_src[which & 1][j] + k0);
+      glds16(s, dst + j * 8192);
+    }
+  };
+
+  const int key = (l16 >> 1) & 7;
+  const int a_off = wm * HALF_BYTES + l16 * 128 + ((g ^ key) << 4);
+  const int b_off = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + ((wn & 1) * 64 + l16) * 128 + ((g ^ key) << 4);
+  // per-tile tables behind the operand buffers, double buffered by tile parity (a fast wave may already fill the next tile's
+  // tables while a slow one still reads this tile's in its epilogue): LayerNorm-fold rows (rstd, -mean rstd) and the column
+  // constants (bias, LayerScale / q-scale, fold column sum).  The epilogue reads them from LDS: a global load there would sit
+  // BEHIND the next tile's operand DMA in the in-order vmcnt queue and stall the epilogue for a full HBM round trip.
+  float2* lnst_all = (float2*)(smem + 2 * BUF_BYTES);                     // [2][256]
+  float* coltab_all = (float*)(smem + 2 * BUF_BYTES + 2 * 256 * 8);       // [2][3][256]
+  int par = 0;
+
+  f32x4 acc[8][4];
+  bf16x8 af[4][2];
+  bf16x8 bfr[2][2][2];
+  auto read_a = [&](const char* buf, int mi) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) af[i][kk] = *(const bf16x8*)(buf + ((a_off ^ (kk << 6)) + (mi * 64 + i * 16) * 128));
+  };
+  auto read_b = [&](const char* buf, int ni) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) bfr[ni][j][kk] = *(const bf16x8*)(buf + ((b_off ^ (kk << 6)) + (ni * 32 + j * 16) * 128));
+  };
+  auto mma = [&](int mi, int ni) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[mi * 4 + i][ni * 2 + j] = H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  int slot = blockIdx.x;
+  int m0, n0;
+  tile_origin(xcd_remap(slot, ntiles), m0, n0);
+  describe(m0, n0);
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  for (;;) {
+    float2* lnst = lnst_all + par * 256;
+    float* coltab = coltab_all + par * 768;
+    if (p.ln_stats) ln_fold_prologue(p, lnst, tid, m0, 256);
+    if (tid < 256) {
+      coltab[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+      coltab[256 + tid] = p.gamma ? p.gamma[n0 + tid] : 1.f;
+      coltab[512 + tid] = p.ln_stats ? p.ln_colsum[n0 + tid] : 0.f;
+    }
+    // ---- B of K tile 1 last: with the in-order vmcnt, "all but the 4 newest" = everything of K tile 0 (and every older store)
+    stage(2, 1); stage(3, 1);
+    if (nk > 1) PST_VMCNT(4); else PST_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* buf = smem + (kt & 1) * BUF_BYTES;
+      read_a(buf, 0);
+      read_b(buf, 0);
+      stage(0, kt + 1);
+      read_b(buf, 1);
+      mma(0, 0);
+      stage(1, kt + 1);
+      mma(0, 1);
+      __builtin_amdgcn_s_barrier();
+      read_a(buf, 1);
+      stage(2, kt + 2);
+      mma(1, 1);
+      stage(3, kt + 2);
+      mma(1, 0);
+      if (kt + 2 < nk) PST_VMCNT(4); else PST_VMCNT(0);
+      __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- request the next tile's first operand tiles: the buffers are free, and nothing below issues a global LOAD
+    const int cm0 = m0, cn0 = n0;
+    slot += gridDim.x;
+    const bool more = slot < ntiles;
+    if (more) {
+      tile_origin(xcd_remap(slot, ntiles), m0, n0);
+      describe(m0, n0);
+      stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+    }
+
+    // ---- epilogue from the accumulators: lane (g, l16) owns row l16 of each row fragment and, per 32-column half, columns g*8 .. g*8+7
+    const bool fold = p.ln_stats != nullptr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int cl = wn * 64 + h * 32 + g * 8;               // tile-local first column
+      const int nn = cn0 + cl;
+      float4 bias4[2], gam4[2], cs4[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bias4[u] = *(const float4*)(coltab + cl + 4 * u);
+        gam4[u] = *(const float4*)(coltab + 256 + cl + 4 * u);
+        cs4[u] = *(const float4*)(coltab + 512 + cl + 4 * u);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = wm * 128 + i * 16 + l16;
+        const int m = cm0 + r;
+        const float2 st = fold ? lnst[r] : make_float2(1.f, 0.f);
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 a = acc[i][2 * h + u];
+          float v[4] = {fmaf(a[0], st.x, fmaf(st.y, cs4[u].x, bias4[u].x)), fmaf(a[1], st.x, fmaf(st.y, cs4[u].y, bias4[u].y)),
+                        fmaf(a[2], st.x, fmaf(st.y, cs4[u].z, bias4[u].z)), fmaf(a[3], st.x, fmaf(st.y, cs4[u].w, bias4[u].w))};
+          if (p.act == 1) {
+            gelu_erf4(v);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          }
+          v[0] *= gam4[u].x; v[1] *= gam4[u].y; v[2] *= gam4[u].z; v[3] *= gam4[u].w;
+          w[2 * u] = H16<F16>::pack(v[0], v[1]);
+          w[2 * u + 1] = H16<F16>::pack(v[2], v[3]);
+        }
+        if (m < p.M) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    par ^= 1;
+    if (!more) break;
+  }
+}
+
 constexpr int LDS256 = 2 * BUF_BYTES + 256 * (int)sizeof(float2);      // operand buffers + the LayerNorm-fold row table
+constexpr int LDS256P = 2 * BUF_BYTES + 2 * 256 * (int)sizeof(float2) + 2 * 3 * 256 * (int)sizeof(float);      // persistent kernel: two sets of per-tile tables
 
 int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
@@ -324,6 +519,28 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
   if (p.dtype16 == DT_F16) hipLaunchKernelGGL(gemm256_kernel<true>, dim3(tiles), dim3(512), LDS256, s, p, tiles, tiles_m, tiles_n);
   else hipLaunchKernelGGL(gemm256_kernel<false>, dim3(tiles), dim3(512), LDS256, s, p, tiles, tiles_m, tiles_n);
   return check_launch("gemm256");
+}
+
+// plain 16-bit row-major output (bias / activation / LayerScale / LayerNorm-fold consumer): the persistent kernel's class
+bool gemm256_persistent_ok(const pst_gemm_params& p) {
+  return !p.out_fp32 && !p.res && !p.rope_hd && !p.ps_p && !p.grp_in && !p.res_mod && !p.stats_out && !p.xcopy && p.N % 256 == 0 && (p.ldc & 7) == 0 &&
+         ((uintptr_t)p.C & 15) == 0 && (p.ln_stats == nullptr || p.ln_groups == 16 || p.ln_groups == 12 || p.ln_groups == 6 || p.ln_groups == 2) &&
+         (int64_t)p.M * p.ldc < (1ll << 31);
+}
+
+int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus) {
+  const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / 256;
+  const int tiles = tiles_m * tiles_n;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    attr_set = true;
+  }
+  const int grid = tiles < cus ? tiles : cus;
+  if (p.dtype16 == DT_F16) hipLaunchKernelGGL(gemm256p_kernel<true>, dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+  else hipLaunchKernelGGL(gemm256p_kernel<false>, dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+  return check_launch("gemm256p");
 }
 
 }  // namespace pst

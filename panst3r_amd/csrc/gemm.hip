@@ -23,6 +23,7 @@ namespace pst {
 int launch_gemm256(const pst_gemm_params& p, hipStream_t s);   // gemm256.hip
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus);
 bool gemm256_persistent_ok(const pst_gemm_params& p);
+int gemm256_persistent_class(const pst_gemm_params& p);
 
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
@@ -556,7 +557,13 @@ static int gemm_choice(const pst_gemm_params& p) {
   const bool fits32 = (int64_t)p.M * p.lda < (1ll << 31) && (int64_t)p.N * p.ldw < (1ll << 31);
   // measured on MI355X: the 256^2 kernel wins for deep K / wide N (v1 MLPs +10 %, 8192^3 +20 %), loses for K < 1024 or ragged N
   const bool shape256 = p.N % 256 == 0 && p.K >= 1024 && (p.N >= 2048 || p.K >= 2048) && tiles256 >= 3 * 256 - 64;
-  if (p.conv_c == 0 && fits32 && p.batch <= 1 && (p.kernel == 256 || (p.kernel == 0 && shape256))) return 2;
+  // the persistent variant (plain 16-bit row-major outputs) has no per-round fixed cost and wins from 1.5 rounds of tiles and K >= 512 on
+  // (measured, M = 38400: N = K = 768 58 vs 74 us, 1536 x 768 118 vs 151, 3072 x 768 + GELU 314 vs 356, 1024 x 1024 103 vs 127 us)
+  // its residual-stream class (fp32 out + residual + fold producer) pays the epilogue's HBM burst with every CU at once: it only wins
+  // for deep K (1024 x 4096: 480 vs 497 us, 768 x 3072: 277 vs 308; 1024 x 1024: 202 vs 185 -- stays on the 128x128 kernel)
+  const int pclass = pst::gemm256_persistent_class(p);
+  const bool shape256p = tiles256 >= 384 && ((pclass == 1 && p.K >= 512) || (pclass == 2 && p.K >= 2048));
+  if (p.conv_c == 0 && fits32 && p.batch <= 1 && (p.kernel == 256 || (p.kernel == 0 && (shape256 || shape256p)))) return 2;
   return small ? 0 : 1;
 }
 

@@ -328,7 +328,29 @@ __device__ __forceinline__ int perm_row8(int row) {       // LDS row (fragment f
   return (sub << 6) + (f >> 1) * 32 + g * 8 + (f & 1) * 4 + r;
 }
 
-template <bool F16>
+// sums over the 4 lanes that share a fragment row (lane bits 4 and 5): x + (lane ^ 16), then + (lane ^ 32); VALU row swaps, no LDS
+__device__ __forceinline__ float add_lane16(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_lane32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// a * b, rounded, then + c, rounded (HIP's __fmul_rn / __fadd_rn are plain operators, i.e. contractable into one fma)
+__device__ __forceinline__ float mul_add_2r(float a, float b, float c) {
+#pragma clang fp contract(off)
+  const float t = a * b;
+  return t + c;
+}
+
+// RES: fp32 output = fp32 residual + ..., with the LayerNorm-fold producer outputs (16-bit copy, per-row (sum, sumsq) of each 64-column
+// group) -- the residual-stream GEMMs (proj, fc2).  The statistics reproduce the summation tree of the row-phase epilogues bit for bit:
+// 4-column chunks summed in order, chunk pairs, quads, octets, halves.
+template <bool F16, bool RES>
 __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -452,18 +474,92 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
       __builtin_amdgcn_s_barrier();
     }
 
-    // ---- request the next tile's first operand tiles: the buffers are free, and nothing below issues a global LOAD
     const int cm0 = m0, cn0 = n0;
     slot += gridDim.x;
     const bool more = slot < ntiles;
-    if (more) {
-      tile_origin(xcd_remap(slot, ntiles), m0, n0);
-      describe(m0, n0);
-      stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+    // request the next tile's first operand tiles: the buffers are free.  Loads issued after this point queue BEHIND that DMA in the
+    // in-order vmcnt, so the plain epilogue issues none at all and the residual epilogue requests its first half before it.
+    auto request_next = [&]() {
+      if (more) {
+        tile_origin(xcd_remap(slot, ntiles), m0, n0);
+        describe(m0, n0);
+        stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+      }
+    };
+    const bool fold = p.ln_stats != nullptr;
+    if constexpr (RES) {
+      float* Cf = (float*)p.C;
+      const int grp64 = (cn0 + wn * 64) >> 6;
+      float4 rv[4][2][2];
+      auto load_res = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = min(cm0 + wm * 128 + (i0 + i) * 16 + l16, p.M - 1);
+          const float* rp = p.res + (int64_t)m * p.ldr + cn0 + wn * 64 + g * 8;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) rv[i][h][u] = *(const float4*)(rp + h * 32 + 4 * u);
+        }
+      };
+      auto finish = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = wm * 128 + (i0 + i) * 16 + l16;
+          const int m = cm0 + r;
+          const float2 st = fold ? lnst[r] : make_float2(1.f, 0.f);
+          float osum[2], osq[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int cl = wn * 64 + h * 32 + g * 8;
+            float4 f[2];
+            float cs_[2], cq_[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const float4 bias4 = *(const float4*)(coltab + cl + 4 * u), gam4 = *(const float4*)(coltab + 256 + cl + 4 * u), cs4 = *(const float4*)(coltab + 512 + cl + 4 * u);
+              const f32x4 a = acc[i0 + i][2 * h + u];
+              float v[4] = {fmaf(a[0], st.x, fmaf(st.y, cs4.x, bias4.x)), fmaf(a[1], st.x, fmaf(st.y, cs4.y, bias4.y)),
+                            fmaf(a[2], st.x, fmaf(st.y, cs4.z, bias4.z)), fmaf(a[3], st.x, fmaf(st.y, cs4.w, bias4.w))};
+              if (p.act == 1) {
+                gelu_erf4(v);
+              } else if (p.act == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+              }
+              // two roundings (scale, then add), as in the row-phase epilogues where an LDS round trip separates them: no fma contraction
+              const float4 q4 = rv[i][h][u];
+              f[u] = make_float4(mul_add_2r(v[0], gam4.x, q4.x), mul_add_2r(v[1], gam4.y, q4.y), mul_add_2r(v[2], gam4.z, q4.z), mul_add_2r(v[3], gam4.w, q4.w));
+              ln_acc4(f[u], cs_[u], cq_[u]);
+            }
+            if (m < p.M) {
+              float* dst = Cf + (int64_t)m * p.ldc + cn0 + cl;
+              *(float4*)dst = f[0];
+              *(float4*)(dst + 4) = f[1];
+              if (p.xcopy)
+                *(uint4*)((bf16_t*)p.xcopy + (int64_t)m * p.ldxc + cn0 + cl) =
+                    make_uint4(H16<F16>::pack(f[0].x, f[0].y), H16<F16>::pack(f[0].z, f[0].w), H16<F16>::pack(f[1].x, f[1].y), H16<F16>::pack(f[1].z, f[1].w));
+            }
+            // chunk pair -> quad (lane ^ 16) -> octet (lane ^ 32): the butterfly of row_sum<16>, same association
+            osum[h] = add_lane32(add_lane16(cs_[0] + cs_[1]));
+            osq[h] = add_lane32(add_lane16(cq_[0] + cq_[1]));
+          }
+          if (p.stats_out && g == 0 && m < p.M) *((float2*)p.stats_out + (int64_t)m * p.stats_ld + grp64) = make_float2(osum[0] + osum[1], osq[0] + osq[1]);
+        }
+      };
+      load_res(0);
+      __builtin_amdgcn_sched_barrier(0);
+      request_next();
+      __builtin_amdgcn_sched_barrier(0);
+      finish(0);
+      load_res(4);
+      finish(4);
+      par ^= 1;
+      if (!more) break;
+      continue;
     }
+    request_next();
 
     // ---- epilogue from the accumulators: lane (g, l16) owns row l16 of each row fragment and, per 32-column half, columns g*8 .. g*8+7
-    const bool fold = p.ln_stats != nullptr;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int cl = wn * 64 + h * 32 + g * 8;               // tile-local first column
@@ -521,25 +617,42 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
   return check_launch("gemm256");
 }
 
-// plain 16-bit row-major output (bias / activation / LayerScale / LayerNorm-fold consumer): the persistent kernel's class
-bool gemm256_persistent_ok(const pst_gemm_params& p) {
-  return !p.out_fp32 && !p.res && !p.rope_hd && !p.ps_p && !p.grp_in && !p.res_mod && !p.stats_out && !p.xcopy && p.N % 256 == 0 && (p.ldc & 7) == 0 &&
-         ((uintptr_t)p.C & 15) == 0 && (p.ln_stats == nullptr || p.ln_groups == 16 || p.ln_groups == 12 || p.ln_groups == 6 || p.ln_groups == 2) &&
-         (int64_t)p.M * p.ldc < (1ll << 31);
+// the persistent kernel's two classes: 1 = plain 16-bit row-major output (bias / activation / LayerScale / LayerNorm-fold consumer),
+// 2 = fp32 residual stream (C = res + ..., optional 16-bit copy + fold statistics); 0 = not eligible
+int gemm256_persistent_class(const pst_gemm_params& p) {
+  if (p.rope_hd || p.ps_p || p.grp_in || p.res_mod || p.N % 256 || p.trans_out || p.conv_c || p.batch > 1) return 0;
+  if (p.ln_stats && p.ln_groups != 16 && p.ln_groups != 12 && p.ln_groups != 6 && p.ln_groups != 2) return 0;
+  if (!p.out_fp32) {
+    if (p.res || p.stats_out || p.xcopy || (p.ldc & 7) || ((uintptr_t)p.C & 15) || (int64_t)p.M * p.ldc >= (1ll << 31)) return 0;
+    return 1;
+  }
+  if (!p.res || p.res_bf16 || (p.ldc & 3) || (p.ldr & 3) || (((uintptr_t)p.C | (uintptr_t)p.res) & 15)) return 0;
+  if (p.xcopy && ((p.ldxc & 7) || ((uintptr_t)p.xcopy & 15))) return 0;
+  if (p.stats_out && ((uintptr_t)p.stats_out & 7)) return 0;
+  return 2;
 }
+bool gemm256_persistent_ok(const pst_gemm_params& p) { return gemm256_persistent_class(p) != 0; }
 
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / 256;
   const int tiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
     attr_set = true;
   }
   const int grid = tiles < cus ? tiles : cus;
-  if (p.dtype16 == DT_F16) hipLaunchKernelGGL(gemm256p_kernel<true>, dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
-  else hipLaunchKernelGGL(gemm256p_kernel<false>, dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+  const bool h = p.dtype16 == DT_F16;
+  if (gemm256_persistent_class(p) == 2) {
+    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, true>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, true>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+  } else {
+    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+  }
   return check_launch("gemm256p");
 }
 

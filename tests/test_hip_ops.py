@@ -68,7 +68,7 @@ def test_gemm_asymmetric_identity():
     assert torch.equal(out.cpu(), w.T.contiguous())
 
 
-@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 128), (1000, 520, 192), (3000, 1024, 1024), (777, 260, 2816)])
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 128), (1000, 520, 192), (3000, 1024, 1024), (777, 260, 2816), (17000, 1280, 192)])
 def test_gemm256_bit_identical_to_gemm128(M, N, K):
     """The 256x256 8-wave counted-vmcnt kernel accumulates every output element in the same order as the 128x128 kernel:
     results must be bit-identical for every epilogue (also run 20x to screen the LDS-DMA pipeline for races)."""
@@ -611,7 +611,8 @@ def test_split3_gemm_is_near_fp32():
     assert e_split < 5e-5 and e_plain > 20 * e_split, (e_split, e_plain)
 
 
-@pytest.mark.parametrize('M,N,D,kern', [(300, 256, 128, 0), (768, 1024, 1024, 0), (2000, 2048, 1024, 256), (200, 192, 192, 0), (1000, 768, 384, 128)])
+@pytest.mark.parametrize('M,N,D,kern', [(300, 256, 128, 0), (768, 1024, 1024, 0), (2000, 2048, 1024, 256), (200, 192, 192, 0), (1000, 768, 384, 128),
+                                        (9000, 2048, 128, 256)])      # 288 tiles of 256x256: the persistent kernel's workgroups walk more than one tile
 def test_gemm_layernorm_fold_consumer(M, N, D, kern):
     """LayerNorm folded into the consuming GEMM: raw 16-bit rows + per-row statistics in, gamma / beta folded into W / bias at pack
     time, rstd (acc - mean colsum) + bias in the epilogue == LN(x) W^T + b (plain, GELU and transposed stores)."""
@@ -644,7 +645,8 @@ def test_gemm_layernorm_fold_consumer(M, N, D, kern):
         assert rel_l2(outt[:, :M].float().cpu().T, ref) < tol + 4e-3
 
 
-@pytest.mark.parametrize('M,N,K,kern', [(300, 256, 128, 0), (768, 1024, 1024, 0), (1500, 1024, 4096, 256), (130, 192, 64, 0), (5000, 384, 384, 128)])
+@pytest.mark.parametrize('M,N,K,kern', [(300, 256, 128, 0), (768, 1024, 1024, 0), (1500, 1024, 4096, 256), (130, 192, 64, 0), (5000, 384, 384, 128),
+                                        (18000, 1024, 128, 256)])     # 284 tiles: persistent residual-stream kernel, several tiles per workgroup
 def test_gemm_layernorm_fold_producer(M, N, K, kern):
     """The residual-writing GEMM also emits the 16-bit copy of the new stream and the per-row / per-64-column-group (sum, sumsq) the
     next block's consumer GEMMs normalise with -- bit-identical to rowstats run on its fp32 output."""

@@ -326,10 +326,14 @@ def main():
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
                     if pmc.get('_source_hash') != source_hash():
                         continue
+                    # PMC names carry every template argument ("gemm_kernel<4, 4, false, 2, true>"); the dispatch name is a prefix of it
+                    # ("gemm_kernel<4,4,false>") or the bare kernel name ("gemm256p_kernel": both epilogue classes, launch-weighted)
                     key = dom.replace(',', ', ')
-                    e = pmc.get(key) or next((v for k, v in pmc.items() if k.startswith(key[:-1] + ',')), None)   # PMC names carry every template argument
-                    if e and V == 50 and K == 16 and args.variant == 'v2':
-                        traffic = int(e['hbm_read_bytes_per_launch'] + e['hbm_write_bytes_per_launch'])
+                    pref = key[:-1] + ',' if key.endswith('>') else key + '<'
+                    es = [v for k, v in pmc.items() if isinstance(v, dict) and (k == key or k.startswith(pref))]
+                    if es and V == 50 and K == 16 and args.variant == 'v2':
+                        n = sum(e['launches'] for e in es)
+                        traffic = int(sum(e['launches'] * (e['hbm_read_bytes_per_launch'] + e['hbm_write_bytes_per_launch']) for e in es) / n)
                         traffic_note = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same kernel sources: %s)' % (fn, pmc['_source_hash'])
                     break
             except Exception:

@@ -189,6 +189,43 @@ def pp_finalize(best_q: Tensor, best_m: Tensor, seg_id: Tensor, n: int, mask_thr
     hip.pp_finalize(best_q, best_m, seg_id, n, mask_threshold, void_confidence, pan, conf)
 
 
+@_op('layernorm_batch', ('out_all',))
+def layernorm_batch(x_all: Tensor, gamma_all: Tensor, beta_all: Tensor, out_all: Tensor, eps: float, rows: Optional[int] = None,
+                    grp: Optional[List[int]] = None, add: Optional[Tensor] = None) -> None:
+    """the 12 per-layer norm_y(h_l + feedback) of a MUSt3R memory append in one launch"""
+    hip.layernorm_batch(x_all, gamma_all, beta_all, out_all, eps, rows=rows, grp=_t3(grp), add=add)
+
+
+@_op('pointmap_activate', ('pts3d', 'pts3d_local', 'conf'))
+def pointmap_activate(raw: Tensor, pts3d: Tensor, pts3d_local: Tensor, conf: Tensor, mode: int = 0) -> None:
+    hip.pointmap_activate(raw, pts3d, pts3d_local, conf, mode)
+
+
+@_op('focal_weiszfeld', ('focal',))
+def focal_weiszfeld(pts3d_local: Tensor, pp: Tensor, focal: Tensor, H: int, W: int, iters: int = 10) -> None:
+    hip.focal_weiszfeld(pts3d_local, pp, focal, H, W, iters)
+
+
+@_op('rigid_moments', ('out',))
+def rigid_moments(x: Tensor, y: Tensor, conf: Tensor, out: Tensor, weight_offset: float = -1.0) -> None:
+    hip.rigid_moments(x, y, conf, out, weight_offset)
+
+
+@_op('qubo_upsample', ('probs',))
+def qubo_upsample(logits: Tensor, probs: Tensor, Q: int, hm: int, wm: int, H: int, W: int) -> None:
+    hip.qubo_upsample(logits, probs, Q, hm, wm, H, W)
+
+
+@_op('qubo_overlap', ('Wacc',))
+def qubo_overlap(probs: Tensor, Q: int, P: int, Wacc: Tensor) -> None:
+    hip.qubo_overlap(probs, Q, P, Wacc)
+
+
+@_op('qubo_argmax', ('conf', 'inst'))
+def qubo_argmax(probs: Tensor, sel: Tensor, P: int, conf: Tensor, inst: Tensor) -> None:
+    hip.qubo_argmax(probs, sel, P, conf, inst)
+
+
 def registered_ops():
     """names under torch.ops.panst3r_hip"""
     return list(_REGISTERED)

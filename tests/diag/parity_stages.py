@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where does the bf16 error enter?  Full-size v2 model, 2 views / 2 keyframes at 384x512 (the bench's cpu_baseline sample):
+"""Where does the 16-bit error enter?  (PST_AMP=bf16 selects the bf16 operand format; f16 is the default.)  Full-size v2 model, 2 views / 2 keyframes at 384x512 (the bench's cpu_baseline sample):
 the HIP path and the fp32 CPU oracle (same weights) are compared stage by stage.  Diagnostic; the oracle is only the checker."""
 import sys, os, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,14 +7,15 @@ sys.path.insert(0, ROOT)
 import torch
 from panst3r_amd.panst3r import CONFIG_V2, build_from_config
 from panst3r_amd.synthetic import fill_module_, synth_image, synth_class_embeddings
-from panst3r_amd.model.common import Layout
+from panst3r_amd.model.common import Layout, PREC, amp_dtype, adt
 from oracle.pipeline import build as build_oracle
 from oracle.must3r import build_memory, mem_batches_for
 import bench
 
 H, W, V = 384, 512, 2
 dev = torch.device('cuda:0')
-BF = torch.bfloat16
+PREC.dtype = amp_dtype(os.environ.get('PST_AMP', 'fp16'))      # process-wide operand format for the module-level calls below
+BF = adt()
 model = build_from_config(CONFIG_V2).eval()
 fill_module_(model, seed=1)
 names, emb = synth_class_embeddings(100)

@@ -131,7 +131,8 @@ def test_torch_ops_registered():
         assert hasattr(torch.ops.panst3r_hip, n), n
     wrappers = {'gemm', 'attention', 'layernorm', 'rope2d_', 'patchify', 'dino_preprocess', 'add_cast', 'l2norm_rows', 'split3', 'mean4', 'resize_bilinear',
                 'attn_mask_from_logits', 'loftup_guidance_gn', 'groupnorm_stats', 'groupnorm_apply', 'loftup_lr_pe', 'pp_scores', 'pp_sigmoid',
-                'pp_argmax', 'pp_argmax_logits', 'pp_select', 'pp_finalize', 'image_prepare', 'patch_rows', 'rowstats'}
+                'pp_argmax', 'pp_argmax_logits', 'pp_select', 'pp_finalize', 'image_prepare', 'patch_rows', 'rowstats', 'layernorm_batch',
+                'pointmap_activate', 'focal_weiszfeld', 'rigid_moments', 'qubo_upsample', 'qubo_overlap', 'qubo_argmax'}
     assert wrappers <= names
     for n in wrappers:
         assert hasattr(hip, n), n

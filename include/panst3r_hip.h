@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 13
+#define PST_ABI_VERSION 14
 
 /* element type codes: every `*_type` / `dtype16` argument below (and the former `*_fp32` flags: 0 and 1 keep their meaning) */
 #define PST_BF16 0   /* bfloat16, raw uint16 */
@@ -64,6 +64,7 @@ typedef struct pst_gemm_params {
   /* RoPE-2D fused into the store (q,k projections): rope_hd == 64 enables (bf16 output, N % 64 == 0); rope_pos int32
      [rows, 2] (y, x) indexed by the A row m, rope_cs fp32 [npos, 16, 2] as for pst_rope2d_bf16. */
   const int32_t* rope_pos; const float* rope_cs; int32_t rope_hd;
+  int32_t rope_npos;                 /* rows of rope_cs (positions); lets a kernel keep the whole table in LDS.  0 = unknown */
   int32_t res_bf16;                  /* 1: `res` points to bf16 (same indexing, ldr in elements) instead of fp32 */
   int32_t kernel;                    /* 0 = auto; 128 / 256 force the 128x128 / 256x256 tile kernel (tests, benchmarks) */
   /* strided batch: batch > 1 runs `batch` independent problems of this shape in ONE launch; problem i uses

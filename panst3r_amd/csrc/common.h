@@ -131,6 +131,14 @@ __device__ __forceinline__ void rope_table(const pst_gemm_params& p, int m, int 
   for (int q = 0; q < 4; ++q) cs[q] = t[q];      // (cos, sin) of frequencies i0+2q, i0+2q+1
 }
 
+// one member of a rotated pair: x cos -/+ partner sin.  One rounded product + one explicit fma in EVERY kernel that rotates (the three GEMM
+// store phases, the persistent GEMM's accumulator-layout epilogue, rope2d_kernel): the fused and the stand-alone paths stay bit-identical
+// without relying on the compiler contracting `a*c - b*s` the same way at every site.
+__device__ __forceinline__ float rope_pair(float x, float y, float c, float s, bool second) {
+  const float t = y * s;
+  return fmaf(x, c, second ? t : -t);
+}
+
 template <bool F16>
 __device__ __forceinline__ uint4 rope_rotate(uint4 own, uint4 partner, const float4 (&cs)[4], int n) {
   const bool second = (n & 16) != 0;             // this chunk holds the (i + 16) members of the pairs
@@ -142,8 +150,8 @@ __device__ __forceinline__ uint4 rope_rotate(uint4 own, uint4 partner, const flo
   for (int q = 0; q < 4; ++q) {
     const float x0 = H16<F16>::lo(a[q]), x1 = H16<F16>::hi(a[q]);
     const float y0 = H16<F16>::lo(b[q]), y1 = H16<F16>::hi(b[q]);
-    const float r0 = second ? x0 * cs[q].x + y0 * cs[q].y : x0 * cs[q].x - y0 * cs[q].y;
-    const float r1 = second ? x1 * cs[q].z + y1 * cs[q].w : x1 * cs[q].z - y1 * cs[q].w;
+    const float r0 = rope_pair(x0, y0, cs[q].x, cs[q].y, second);
+    const float r1 = rope_pair(x1, y1, cs[q].z, cs[q].w, second);
     o[q] = H16<F16>::pack(r0, r1);
   }
   return out;

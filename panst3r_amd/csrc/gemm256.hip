@@ -18,6 +18,7 @@ namespace pst {
 constexpr int HALF_BYTES = 128 * 128;           // 128 rows x 64 bf16
 constexpr int BUF_BYTES = 4 * HALF_BYTES;       // A-lo, A-hi, B-lo, B-hi
 constexpr int G256_GROUP_M = 4;
+constexpr int LDS256P_TABLES = 2 * BUF_BYTES + 2 * 256 * 8 + 2 * 3 * 256 * 4;      // persistent kernel: operand buffers + two sets of fold rows / column constants
 
 __device__ __forceinline__ int perm_row4(int row) {      // see gemm.hip perm_row<4>: lane owns 16 contiguous columns
   const int sub = row >> 6, rho = row & 63;
@@ -403,6 +404,12 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
   // BEHIND the next tile's operand DMA in the in-order vmcnt queue and stall the epilogue for a full HBM round trip.
   float2* lnst_all = (float2*)(smem + 2 * BUF_BYTES);                     // [2][256]
   float* coltab_all = (float*)(smem + 2 * BUF_BYTES + 2 * 256 * 8);       // [2][3][256]
+  // fused RoPE-2D (q|k projections): the positions of the tile's rows per tile, the whole (cos, sin) table [npos][16][2] once
+  int2* postab_all = (int2*)(smem + LDS256P_TABLES);                      // [2][256]
+  float* ropetab = (float*)(smem + LDS256P_TABLES + 2 * 256 * 8);         // [npos <= 64][32]
+  const bool rope = !RES && p.rope_hd == 64;
+  if (rope)
+    for (int i = tid; i < p.rope_npos * 32; i += 512) ropetab[i] = p.rope_cs[i];
   int par = 0;
 
   f32x4 acc[8][4];
@@ -441,6 +448,8 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
     float2* lnst = lnst_all + par * 256;
     float* coltab = coltab_all + par * 768;
     if (p.ln_stats) ln_fold_prologue(p, lnst, tid, m0, 256);
+    int2* postab = postab_all + par * 256;
+    if (rope && tid < 256) postab[tid] = *(const int2*)(p.rope_pos + 2 * min(m0 + tid, p.M - 1));
     if (tid < 256) {
       coltab[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
       coltab[256 + tid] = p.gamma ? p.gamma[n0 + tid] : 1.f;
@@ -592,7 +601,22 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
           w[2 * u] = H16<F16>::pack(v[0], v[1]);
           w[2 * u + 1] = H16<F16>::pack(v[2], v[3]);
         }
-        if (m < p.M) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = make_uint4(w[0], w[1], w[2], w[3]);
+        uint4 val = make_uint4(w[0], w[1], w[2], w[3]);
+        if (rope) {
+          // the wave's 64 columns are one head: half h rotates with the row's y (h = 0) / x (h = 1) position, pairs are 16 columns apart,
+          // i.e. the partner chunk lives in lane ^ 32 (g ^ 2).  The 16-bit-rounded values are rotated, as in the LDS store phases.
+          uint32_t pw[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(w[q], w[q], false, false);
+            pw[q] = lane < 32 ? sw[1] : sw[0];
+          }
+          const int2 pp = postab[r];
+          const float4* t = (const float4*)(ropetab + (h == 0 ? pp.x : pp.y) * 32 + (g & 1) * 16);
+          const float4 cs[4] = {t[0], t[1], t[2], t[3]};
+          val = rope_rotate<F16>(val, make_uint4(pw[0], pw[1], pw[2], pw[3]), cs, nn);
+        }
+        if (m < p.M) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = val;
       }
     }
     par ^= 1;
@@ -601,7 +625,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
 }
 
 constexpr int LDS256 = 2 * BUF_BYTES + 256 * (int)sizeof(float2);      // operand buffers + the LayerNorm-fold row table
-constexpr int LDS256P = 2 * BUF_BYTES + 2 * 256 * (int)sizeof(float2) + 2 * 3 * 256 * (int)sizeof(float);      // persistent kernel: two sets of per-tile tables
+constexpr int LDS256P = LDS256P_TABLES + 2 * 256 * 8 + 64 * 32 * 4;      // + row positions (two sets) + the RoPE table (<= 64 positions)
 
 int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
@@ -620,7 +644,8 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
 // the persistent kernel's two classes: 1 = plain 16-bit row-major output (bias / activation / LayerScale / LayerNorm-fold consumer),
 // 2 = fp32 residual stream (C = res + ..., optional 16-bit copy + fold statistics); 0 = not eligible
 int gemm256_persistent_class(const pst_gemm_params& p) {
-  if (p.rope_hd || p.ps_p || p.grp_in || p.res_mod || p.N % 256 || p.trans_out || p.conv_c || p.batch > 1) return 0;
+  if (p.ps_p || p.grp_in || p.res_mod || p.N % 256 || p.trans_out || p.conv_c || p.batch > 1) return 0;
+  if (p.rope_hd && (p.rope_hd != 64 || p.rope_npos <= 0 || p.rope_npos > 64 || p.out_fp32)) return 0;
   if (p.ln_stats && p.ln_groups != 16 && p.ln_groups != 12 && p.ln_groups != 6 && p.ln_groups != 2) return 0;
   if (!p.out_fp32) {
     if (p.res || p.stats_out || p.xcopy || (p.ldc & 7) || ((uintptr_t)p.C & 15) || (int64_t)p.M * p.ldc >= (1ll << 31)) return 0;

@@ -172,8 +172,8 @@ __global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const f
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float c = t[2 * k], s = t[2 * k + 1];
-      oa[k] = a[k] * c - b[k] * s;
-      ob[k] = b[k] * c + a[k] * s;
+      oa[k] = rope_pair(a[k], b[k], c, s, false);
+      ob[k] = rope_pair(b[k], a[k], c, s, true);
     }
     store4(base, 0, tc, oa);
     store4(base, nf, tc, ob);

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -24,7 +24,7 @@ class GemmParams(C.Structure):
                 ('act', i32), ('out_fp32', i32), ('trans_out', i32),
                 ('grp_in', i32), ('grp_out', i32), ('grp_off', i32),
                 ('ps_p', i32), ('ps_c', i32), ('ps_h', i32), ('ps_w', i32),
-                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('rope_pos', vp), ('rope_cs', vp), ('rope_hd', i32), ('res_bf16', i32), ('kernel', i32),
+                ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('rope_pos', vp), ('rope_cs', vp), ('rope_hd', i32), ('rope_npos', i32), ('res_bf16', i32), ('kernel', i32),
                 ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('c_bs', i64), ('bias_bs', i64), ('dtype16', i32),
                 ('xcopy', vp), ('ldxc', i64), ('stats_out', vp), ('stats_ld', i32), ('ln_stats', vp), ('ln_groups', i32), ('ln_colsum', vp), ('ln_eps', f32)]
 
@@ -230,6 +230,7 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
     p.kernel = kernel
     if rope is not None:            # (pos int32 [rows,2], table fp32 [npos,16,2]): RoPE-2D fused into the store, hd 64
         p.rope_pos, p.rope_cs, p.rope_hd = _ptr(_dev(rope[0], torch.int32)), _ptr(_dev(rope[1], torch.float32)), 64
+        p.rope_npos = int(rope[1].shape[0])
     if grp is not None:
         p.grp_in, p.grp_out, p.grp_off = grp
     if xcopy is not None:

@@ -358,7 +358,7 @@ def test_rope2d(hd, H):
     assert torch.equal(got[:, 2], x.float().reshape(T, 3, H, hd)[:, 2])      # v untouched
 
 
-@pytest.mark.parametrize('kern,V', [(0, 2), (128, 5), (256, 6)])
+@pytest.mark.parametrize('kern,V', [(0, 2), (128, 5), (256, 6), (256, 400)])      # 400 views: 300 tiles of 256x256, the persistent kernel walks the list
 def test_gemm_fused_rope_equals_separate_kernel(kern, V):
     """q,k projection with RoPE fused into the GEMM store == GEMM followed by the stand-alone RoPE kernel (bit-exact)."""
     from panst3r_amd import hip

@@ -20,6 +20,10 @@ elif 'fold' in fl:                        # consumer side
     st = torch.zeros(M, K // 64, 2, dtype=torch.float32, device=dev)
     st[..., 1] = 64.0
     kw.update(ln=(st, w.float().sum(1).contiguous(), 1e-6))
+if 'rope' in fl:                         # fused RoPE-2D store (q|k projection): 24 x 32 token grid per view
+    ys, xs = torch.meshgrid(torch.arange(24), torch.arange(32), indexing='ij')
+    pos = torch.stack([ys, xs], -1).reshape(768, 2).to(torch.int32).repeat((M + 767) // 768, 1)[:M].contiguous().to(dev)
+    kw.update(rope=(pos, hip.rope_table(32, 64, 100.0, dev)))
 f = lambda: hip.gemm(a, w, out, **kw)
 if 'time' in fl:
     from tools.kbench import timeit

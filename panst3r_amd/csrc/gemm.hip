@@ -24,6 +24,8 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s);   // gemm256.hip
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus);
 bool gemm256_persistent_ok(const pst_gemm_params& p);
 int gemm256_persistent_class(const pst_gemm_params& p);
+int rowstream_class(const pst_gemm_params& p);                            // rowstream.hip
+int launch_rowstream(const pst_gemm_params& p, hipStream_t s, int cus);
 
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
@@ -572,6 +574,7 @@ extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
   if (int rc = gemm_validate(pp)) return rc;
   const pst_gemm_params& p = *pp;
   hipStream_t s = (hipStream_t)stream;
+  if (rowstream_class(p)) return launch_rowstream(p, s, num_cus());      // LoftUp's 384 x 384 GEMMs over ~10^6 rows: streamed, not tiled
   const int c = gemm_choice(p);
   // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
   if (p.trans_out) return c == 0 ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
@@ -581,6 +584,7 @@ extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
 
 extern "C" const char* pst_gemm_variant(const pst_gemm_params* pp) {
   if (gemm_validate(pp)) return nullptr;
+  if (pst::rowstream_class(*pp)) return "rowgemm384_kernel";
   const int c = gemm_choice(*pp);
   if (pp->trans_out) return c == 0 ? "gemm_kernel<2,2,true>" : "gemm_kernel<4,4,true>";
   return c == 2 ? (pst::gemm256_persistent_ok(*pp) ? "gemm256p_kernel" : "gemm256_kernel") : (c == 0 ? "gemm_kernel<2,2,false>" : "gemm_kernel<4,4,false>");

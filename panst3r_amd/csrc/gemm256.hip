@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         a_src[h][j] = min(m0 + h * 128 + lrow, p.M - 1) * (int)p.lda + sw;
-        b_src[h][j] = (n0 + h * 128 + perm_row8(lrow)) * (int)p.ldw + sw;
+        b_src[h][j] = min(n0 + h * 128 + perm_row8(lrow), p.N - 1) * (int)p.ldw + sw;      // N % 64 == 0: a ragged last column tile clamps
       }
     }
   };
@@ -451,9 +451,10 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
     int2* postab = postab_all + par * 256;
     if (rope && tid < 256) postab[tid] = *(const int2*)(p.rope_pos + 2 * min(m0 + tid, p.M - 1));
     if (tid < 256) {
-      coltab[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
-      coltab[256 + tid] = p.gamma ? p.gamma[n0 + tid] : 1.f;
-      coltab[512 + tid] = p.ln_stats ? p.ln_colsum[n0 + tid] : 0.f;
+      const int nc = min(n0 + tid, p.N - 1);
+      coltab[tid] = p.bias ? p.bias[nc] : 0.f;
+      coltab[256 + tid] = p.gamma ? p.gamma[nc] : 1.f;
+      coltab[512 + tid] = p.ln_stats ? p.ln_colsum[nc] : 0.f;
     }
     // ---- B of K tile 1 last: with the in-order vmcnt, "all but the 4 newest" = everything of K tile 0 (and every older store)
     stage(2, 1); stage(3, 1);
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
           const float4 cs[4] = {t[0], t[1], t[2], t[3]};
           val = rope_rotate<F16>(val, make_uint4(pw[0], pw[1], pw[2], pw[3]), cs, nn);
         }
-        if (m < p.M) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = val;
+        if (m < p.M && nn < p.N) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = val;
       }
     }
     par ^= 1;
@@ -644,14 +645,14 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
 // the persistent kernel's two classes: 1 = plain 16-bit row-major output (bias / activation / LayerScale / LayerNorm-fold consumer),
 // 2 = fp32 residual stream (C = res + ..., optional 16-bit copy + fold statistics); 0 = not eligible
 int gemm256_persistent_class(const pst_gemm_params& p) {
-  if (p.ps_p || p.grp_in || p.res_mod || p.N % 256 || p.trans_out || p.conv_c || p.batch > 1) return 0;
+  if (p.ps_p || p.grp_in || p.res_mod || p.N % 64 || p.trans_out || p.conv_c || p.batch > 1) return 0;
   if (p.rope_hd && (p.rope_hd != 64 || p.rope_npos <= 0 || p.rope_npos > 64 || p.out_fp32)) return 0;
   if (p.ln_stats && p.ln_groups != 16 && p.ln_groups != 12 && p.ln_groups != 6 && p.ln_groups != 2) return 0;
   if (!p.out_fp32) {
     if (p.res || p.stats_out || p.xcopy || (p.ldc & 7) || ((uintptr_t)p.C & 15) || (int64_t)p.M * p.ldc >= (1ll << 31)) return 0;
     return 1;
   }
-  if (!p.res || p.res_bf16 || (p.ldc & 3) || (p.ldr & 3) || (((uintptr_t)p.C | (uintptr_t)p.res) & 15)) return 0;
+  if (p.N % 256 || !p.res || p.res_bf16 || (p.ldc & 3) || (p.ldr & 3) || (((uintptr_t)p.C | (uintptr_t)p.res) & 15)) return 0;
   if (p.xcopy && ((p.ldxc & 7) || ((uintptr_t)p.xcopy & 15))) return 0;
   if (p.stats_out && ((uintptr_t)p.stats_out & 7)) return 0;
   return 2;
@@ -659,7 +660,7 @@ int gemm256_persistent_class(const pst_gemm_params& p) {
 bool gemm256_persistent_ok(const pst_gemm_params& p) { return gemm256_persistent_class(p) != 0; }
 
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus) {
-  const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / 256;
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const int tiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {

@@ -68,7 +68,7 @@ def test_gemm_asymmetric_identity():
     assert torch.equal(out.cpu(), w.T.contiguous())
 
 
-@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 128), (1000, 520, 192), (3000, 1024, 1024), (777, 260, 2816), (17000, 1280, 192)])
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 128), (1000, 520, 192), (3000, 1024, 1024), (777, 260, 2816), (17000, 1280, 192), (40000, 384, 192)])
 def test_gemm256_bit_identical_to_gemm128(M, N, K):
     """The 256x256 8-wave counted-vmcnt kernel accumulates every output element in the same order as the 128x128 kernel:
     results must be bit-identical for every epilogue (also run 20x to screen the LDS-DMA pipeline for races)."""
@@ -727,3 +727,48 @@ def test_attention_peaked_softmax(H, Nq, Nk, hd, gain):
         got = od.float().cpu().reshape(Nq, H, hd).permute(1, 0, 2)[None]
         assert torch.isfinite(got).all()
         assert rel_l2(got, ref) < (6e-3 if d16() == torch.bfloat16 else 1.5e-3), (ns, rel_l2(got, ref))
+
+
+@pytest.mark.parametrize('M', [16384, 32 * 1200, 32 * 4099])
+def test_rowstream_gemm_bit_identical_to_tiled(M):
+    """LoftUp's 384 x 384 GEMMs over ~10^6 rows take the row-streaming kernel (rowstream.hip: W resident in registers, whole-row tiles three
+    deep, counted waits).  Same K order, same epilogue arithmetic, same statistics tree as the tiled kernels: every output bit-identical
+    to the 128 x 128 kernel (kernel=128 forces it), for both classes, with several tiles per workgroup and a ragged last round."""
+    from panst3r_amd import hip
+    D = 384
+    a, w = bf(rn(970, M, D)).to(dev()), bf(rn(971, D, D, scale=D ** -0.5)).to(dev())
+    bias, gamma = rn(972, D).to(dev()), (1 + 0.1 * rn(973, D)).to(dev())
+    x = rn(974, M, D).to(dev()) * 1.5 + 0.3
+    xb = torch.empty(M, D, dtype=d16(), device=dev())
+    st = torch.empty(M, D // 64, 2, device=dev())
+    hip.rowstats(x, xb, st)
+    cs = w.float().sum(1).contiguous()
+    cases = [dict(), dict(bias=bias), dict(bias=bias, act='gelu'), dict(bias=bias, gamma=gamma), dict(bias=bias, act='gelu', ln=(st, cs, 1e-5)),
+             dict(bias=bias, gamma=gamma, ln=(st, cs, 1e-5)), dict(act='relu')]
+    assert hip.lib().pst_gemm_variant is not None
+    for kw in cases:
+        src = xb if 'ln' in kw else a
+        outs = []
+        for kern in (128, 0):
+            out = torch.full((M, D), float('nan'), dtype=d16(), device=dev())
+            hip.gemm(src, w, out, kernel=kern, **kw)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), sorted(kw.keys())
+    # residual-stream class: in place, with and without the fold statistics
+    r0 = bf(rn(975, M, D)).to(dev())
+    for with_stats in (False, True):
+        res = []
+        for kern in (128, 0):
+            o = r0.clone()
+            s3 = torch.full((M, D // 64, 2), float('nan'), device=dev())
+            hip.gemm(a, w, o, bias=bias, res=o, kernel=kern, stats_out=s3 if with_stats else None)
+            res.append((o, s3))
+        assert torch.equal(res[0][0], res[1][0])
+        if with_stats:
+            assert torch.equal(res[0][1], res[1][1])
+    ref = None                                              # race screen of the counted-wait pipeline
+    for it in range(10):
+        o = r0.clone()
+        hip.gemm(a, w, o, bias=bias, res=o)
+        ref = o if ref is None else ref
+        assert torch.equal(o, ref)

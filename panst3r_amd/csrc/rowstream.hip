@@ -22,18 +22,19 @@ constexpr int RS_D = 384;                      // N == K
 constexpr int RS_BM = 32;                      // rows per tile
 constexpr int RS_WAVES = 12, RS_THREADS = 64 * RS_WAVES;
 constexpr int RS_TILE = RS_BM * RS_D * 2;      // 24 576 B
-constexpr int RS_RING = 3;
+constexpr int RS_RING0 = 4, RS_RING1 = 3;     // ring depth of the plain / residual-stream class (the latter holds two tiles per slot)
 constexpr int RS_KS = RS_D / 32;               // 12 MFMA K steps
 constexpr int RS_LNRAW = 2048;                 // raw fold statistics of a tile: 32 rows x 6 x (sum, sumsq) = 1536 B, padded
 
 // LDS: [A ring][class 1: residual ring | class 0: raw statistics ring][column constants 3 x 384][class 1: wave partials 2 x 12 x 32 float2]
-constexpr int RS_OFF_X = RS_RING * RS_TILE;
-constexpr int RS_OFF_COL0 = RS_OFF_X + RS_RING * RS_LNRAW, RS_OFF_COL1 = RS_OFF_X + RS_RING * RS_TILE;
+constexpr int RS_OFF_X0 = RS_RING0 * RS_TILE, RS_OFF_X1 = RS_RING1 * RS_TILE;
+constexpr int RS_OFF_COL0 = RS_OFF_X0 + RS_RING0 * RS_LNRAW, RS_OFF_COL1 = RS_OFF_X1 + RS_RING1 * RS_TILE;
 constexpr int RS_LDS0 = RS_OFF_COL0 + 3 * RS_D * 4;
 constexpr int RS_OFF_OCT = RS_OFF_COL1 + 3 * RS_D * 4;
 constexpr int RS_LDS1 = RS_OFF_OCT + 2 * RS_WAVES * RS_BM * 8;
+static_assert(RS_LDS0 <= 160 * 1024 && RS_LDS1 <= 160 * 1024, "LDS budget of a CU");
 
-__device__ __forceinline__ void wait_vm(int n) {      // s_waitcnt takes an immediate
+__device__ __forceinline__ void wait_vm(int n) {      // s_waitcnt takes an immediate (6 bits on gfx9)
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -49,7 +50,41 @@ __device__ __forceinline__ void wait_vm(int n) {      // s_waitcnt takes an imme
     case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
     case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+    case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
+    case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+    case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
+    case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+    case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
   }
 }
 
@@ -74,6 +109,8 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
   const bool stats = RES && p.stats_out != nullptr;
   float* coltab = (float*)(smem + (RES ? RS_OFF_COL1 : RS_OFF_COL0));
   float2* oct = (float2*)(smem + RS_OFF_OCT);
+  constexpr int RING = RES ? RS_RING1 : RS_RING0, DIST = RING - 1;          // prefetch distance in tiles
+  constexpr int OFF_X = RES ? RS_OFF_X1 : RS_OFF_X0;
 
   // ---- once per workgroup: the wave's W slice as MFMA A-operand fragments (row 4g'+r' of fragment f = column wave*32 + g'*8 + f*4 + r',
   // so that the accumulators of a lane are 8 CONSECUTIVE output columns), and the column constants
@@ -104,32 +141,37 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
   const int Sx_w = (stats && wave < 3) ? 1 : 0;                              // + the deferred statistics store of waves 0..2
   auto stage = [&](int it) {                                                 // tile index it-th of this workgroup
     const int64_t t = blockIdx.x + (int64_t)it * gridDim.x;
-    const int b = it % RS_RING;
+    const int b = it % RING;
     const char* ga = (const char*)p.A + t * RS_TILE;
 #pragma unroll
     for (int j = 0; j < 2; ++j) glds16(ga + src_off[j], smem + b * RS_TILE + (j * RS_THREADS + wave * 64) * 16);
     if (RES) {
       const char* gr = (const char*)p.res + t * RS_TILE;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) glds16(gr + src_off[j], smem + RS_OFF_X + b * RS_TILE + (j * RS_THREADS + wave * 64) * 16);
+      for (int j = 0; j < 2; ++j) glds16(gr + src_off[j], smem + OFF_X + b * RS_TILE + (j * RS_THREADS + wave * 64) * 16);
     } else if (fold && wave == 0) {
       const char* gs = (const char*)p.ln_stats + t * (RS_BM * 48);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) glds16(gs + min(j * 64 + lane, 95) * 16, smem + RS_OFF_X + b * RS_LNRAW + j * 1024);
+      for (int j = 0; j < 2; ++j) glds16(gs + min(j * 64 + lane, 95) * 16, smem + OFF_X + b * RS_LNRAW + j * 1024);
     }
   };
 
   const int mine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // tiles of this workgroup
-  if (mine > 0) stage(0);
-  if (mine > 1) stage(1);
+  for (int k = 0; k < DIST && k < mine; ++k) stage(k);
 
   for (int it = 0; it < mine; ++it) {
-    // DMA(it) was issued two iterations ago; everything younger may stay in flight: the stores of the two tiles in between and the
-    // prefetch of tile it + 1 (in-order retirement: older operations are complete when at most this many are outstanding)
-    const int stores_since = it == 0 ? 0 : (it == 1 ? 2 : (it == 2 ? 4 + Sx_w : 4 + 2 * Sx_w));
-    wait_vm((it + 1 < mine ? P_w : 0) + stores_since);
+    // DMA(it) was issued DIST iterations ago (or in the prologue).  Everything YOUNGER may stay in flight -- the prefetches of the next
+    // tiles and the stores of the tiles in between (vmcnt retires in order and counts stores): count exactly those.  Per iteration j a wave
+    // issues: stage(j + DIST) if that tile exists (P_w), the deferred statistics store of tile j - 1 (Sx_w, j >= 1), 2 data stores.
+    int younger = 0;
+    if (it < DIST) younger = (min(DIST, mine) - 1 - it) * P_w;                // later prologue stages
+    for (int j = max(it - DIST, 0); j < it; ++j) {
+      const bool first = (j == it - DIST);                                    // that iteration's stage IS DMA(it): only what followed it
+      younger += ((!first && j + DIST < mine) ? P_w : 0) + (j >= 1 ? Sx_w : 0) + 2;
+    }
+    wait_vm(younger);
     __builtin_amdgcn_s_barrier();               // tile `it` is visible to every wave; every wave has left tile it - 1 (its ring slot is free)
-    if (it + 2 < mine) stage(it + 2);
+    if (it + DIST < mine) stage(it + DIST);
     const int64_t tile = blockIdx.x + (int64_t)it * gridDim.x;
     if (stats && it > 0 && tid < RS_BM * 6) {   // finish the statistics of the previous tile: 64-column group = two waves' 32-column sums
       const int row = tid / 6, grp = tid - row * 6;
@@ -139,12 +181,13 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
     }
 
     // ---- 32 x 32 outputs of this wave: 2 row fragments x 2 column fragments x 12 K steps
-    const char* abuf = smem + (it % RS_RING) * RS_TILE;
+    const char* abuf = smem + (it % RING) * RS_TILE;
     f32x4 acc[2][2];
 #pragma unroll
     for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
       for (int f = 0; f < 2; ++f) acc[rf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef RS_ABL_NOMMA
 #pragma unroll
     for (int ks = 0; ks < RS_KS; ++ks) {
       const int c = ks * 4 + g;
@@ -152,13 +195,18 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
 #pragma unroll
       for (int rf = 0; rf < 2; ++rf) {
         const int m = rf * 16 + l16;
+#ifndef RS_ABL_NOLDS
         xa[rf] = *(const bf16x8*)(abuf + m * 768 + (((c & ~15) | ((c ^ m) & 15)) << 4));
+#else
+        xa[rf] = wf[rf][(ks + 1) % RS_KS];
+#endif
       }
 #pragma unroll
       for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
         for (int f = 0; f < 2; ++f) acc[rf][f] = H16<F16>::mfma(wf[f][ks], xa[rf], acc[rf][f]);
     }
+#endif
 
     // ---- epilogue: lane (g, l16) owns row l16 of each row fragment and columns wave*32 + g*8 .. +7
     const int n8 = wave * 32 + g * 8;
@@ -168,7 +216,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
       const int64_t m = tile * RS_BM + ml;
       float2 st = make_float2(1.f, 0.f);
       if (fold) {                                // the consumer prologue of the tiled kernels, per lane (ln_fold_prologue, 6 groups)
-        const float4* raw = (const float4*)(smem + RS_OFF_X + (it % RS_RING) * RS_LNRAW + ml * 48);
+        const float4* raw = (const float4*)(smem + OFF_X + (it % RING) * RS_LNRAW + ml * 48);
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -205,7 +253,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
       }
       if (RES) {                                 // 16-bit residual stream: the rounded product + the residual, in fp32, one more rounding
         const int c = wave * 4 + g;
-        const uint4 rq = *(const uint4*)(smem + RS_OFF_X + (it % RS_RING) * RS_TILE + ml * 768 + (((c & ~15) | ((c ^ ml) & 15)) << 4));
+        const uint4 rq = *(const uint4*)(smem + OFF_X + (it % RING) * RS_TILE + ml * 768 + (((c & ~15) | ((c ^ ml) & 15)) << 4));
         const uint32_t r32[4] = {rq.x, rq.y, rq.z, rq.w};
         float ssum = 0.f, ssq = 0.f;
 #pragma unroll
@@ -220,7 +268,11 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
           if (g == 0) oct[(it & 1) * (RS_WAVES * RS_BM) + wave * RS_BM + ml] = make_float2(ssum, ssq);
         }
       }
+#ifndef RS_ABL_NOSTORE
       *(uint4*)((bf16_t*)p.C + m * p.ldc + n8) = make_uint4(w[0], w[1], w[2], w[3]);
+#else
+      if (w[0] == 0x12345678u && w[1] == 0x9abcdef0u) *(uint4*)((bf16_t*)p.C + m * p.ldc + n8) = make_uint4(w[0], w[1], w[2], w[3]);
+#endif
     }
   }
   if (stats && mine > 0) {                        // statistics of the last tile

@@ -157,7 +157,9 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
   };
 
   const int mine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // tiles of this workgroup
+#ifndef RS_ABL_NODMA
   for (int k = 0; k < DIST && k < mine; ++k) stage(k);
+#endif
 
   for (int it = 0; it < mine; ++it) {
     // DMA(it) was issued DIST iterations ago (or in the prologue).  Everything YOUNGER may stay in flight -- the prefetches of the next
@@ -169,9 +171,13 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
       const bool first = (j == it - DIST);                                    // that iteration's stage IS DMA(it): only what followed it
       younger += ((!first && j + DIST < mine) ? P_w : 0) + (j >= 1 ? Sx_w : 0) + 2;
     }
+#ifndef RS_ABL_NODMA
     wait_vm(younger);
+#endif
     __builtin_amdgcn_s_barrier();               // tile `it` is visible to every wave; every wave has left tile it - 1 (its ring slot is free)
+#ifndef RS_ABL_NODMA
     if (it + DIST < mine) stage(it + DIST);
+#endif
     const int64_t tile = blockIdx.x + (int64_t)it * gridDim.x;
     if (stats && it > 0 && tid < RS_BM * 6) {   // finish the statistics of the previous tile: 64-column group = two waves' 32-column sums
       const int row = tid / 6, grp = tid - row * 6;
@@ -182,6 +188,15 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
 
     // ---- 32 x 32 outputs of this wave: 2 row fragments x 2 column fragments x 12 K steps
     const char* abuf = smem + (it % RING) * RS_TILE;
+    uint4 rq2[2];                                // residual chunks of both row fragments: requested now, their LDS latency hides under the MFMAs
+    if (RES) {
+      const int c = wave * 4 + g;
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf) {
+        const int ml = rf * 16 + l16;
+        rq2[rf] = *(const uint4*)(smem + OFF_X + (it % RING) * RS_TILE + ml * 768 + (((c & ~15) | ((c ^ ml) & 15)) << 4));
+      }
+    }
     f32x4 acc[2][2];
 #pragma unroll
     for (int rf = 0; rf < 2; ++rf)
@@ -252,9 +267,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
         w[2 * f + 1] = H16<F16>::pack(v[2], v[3]);
       }
       if (RES) {                                 // 16-bit residual stream: the rounded product + the residual, in fp32, one more rounding
-        const int c = wave * 4 + g;
-        const uint4 rq = *(const uint4*)(smem + OFF_X + (it % RING) * RS_TILE + ml * 768 + (((c & ~15) | ((c ^ ml) & 15)) << 4));
-        const uint32_t r32[4] = {rq.x, rq.y, rq.z, rq.w};
+        const uint32_t r32[4] = {rq2[rf].x, rq2[rf].y, rq2[rf].z, rq2[rf].w};
         float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -19,7 +19,7 @@ dev, dt = 'cuda:0', torch.float16
 a = torch.randn(M, D, device=dev).to(dt); w = (torch.randn(D, D, device=dev) * D ** -0.5).to(dt); b = torch.randn(D, device=dev)
 out = torch.zeros(M, D, dtype=dt, device=dev)
 sel = sys.argv[1:]
-for tag, flags in [t for t in [('base', []), ('nomma', ['-DRS_ABL_NOMMA']), ('nostore', ['-DRS_ABL_NOSTORE']), ('nomma_nostore', ['-DRS_ABL_NOMMA', '-DRS_ABL_NOSTORE']), ('nolds', ['-DRS_ABL_NOLDS'])] if not sel or t[0] in sel]:
+for tag, flags in [t for t in [('base', []), ('nomma', ['-DRS_ABL_NOMMA']), ('nostore', ['-DRS_ABL_NOSTORE']), ('nomma_nostore', ['-DRS_ABL_NOMMA', '-DRS_ABL_NOSTORE']), ('nolds', ['-DRS_ABL_NOLDS']), ('nodma', ['-DRS_ABL_NODMA']), ('nodma_nostore', ['-DRS_ABL_NODMA', '-DRS_ABL_NOSTORE'])] if not sel or t[0] in sel]:
     lib = build(tag, flags)
     res = []
     for resid in (False, True):

@@ -509,7 +509,9 @@ static int gemm_validate(const pst_gemm_params* pp) {
   const pst_gemm_params& p = *pp;
   if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("gemm: dtype16 must be PST_BF16 or PST_F16"); return PST_EINVAL; }
   if (p.kernel != 0 && p.kernel != 128 && p.kernel != 256) { set_error("gemm: kernel must be 0 (auto), 128 or 256"); return PST_EINVAL; }
-  if (p.kernel == 256 && (p.conv_c > 0 || p.trans_out)) { set_error("gemm: the 256x256 kernel has no conv / trans_out mode"); return PST_EINVAL; }
+  if (p.kernel == 256 && (p.conv_c > 0 || (p.trans_out && pst::gemm256_persistent_class(p) != 3))) {
+    set_error("gemm: the 256x256 kernel has no conv mode, and trans_out only in its persistent class (16-bit, ldc %% 8 == 0, N %% 64 == 0)"); return PST_EINVAL;
+  }
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) { set_error("gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K); return PST_EINVAL; }
   if (p.K % 64 || p.N % 4) { set_error("gemm: need K%%64==0 and N%%4==0 (K=%d N=%d)", p.K, p.N); return PST_EINVAL; }
   if (!p.A || !p.W || !p.C) { set_error("gemm: null operand"); return PST_EINVAL; }
@@ -553,10 +555,13 @@ static int gemm_choice(const pst_gemm_params& p) {
   // 2-7 views per rank of an 8-GPU scene): 192 tiles -> 64x64 wins for K = 1024 (348 vs 326 TFLOP/s) and loses for K = 4096
   // (505 vs 536); 288 tiles -> 128x128 wins for both (397 vs 377, 614 vs 532).
   const bool small = p.kernel == 0 && big_tiles < (p.K >= 2048 ? 176 : 256);
-  if (p.trans_out) return small ? 0 : 1;
   // large plain GEMMs: 256x256 tiles, 8 waves, counted-vmcnt pipeline (>= 3 full rounds of the 256 CUs, or forced)
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool fits32 = (int64_t)p.M * p.lda < (1ll << 31) && (int64_t)p.N * p.ldw < (1ll << 31);
+  if (p.trans_out) {       // V^T projections: the persistent kernel's transposed class from 1.5 rounds of tiles on, else the 128 / 64 tiles
+    const bool p3 = pst::gemm256_persistent_class(p) == 3 && fits32 && p.batch <= 1 && (p.kernel == 256 || (p.kernel == 0 && tiles256 >= 384 && p.K >= 512));
+    return p3 ? 2 : (small ? 0 : 1);
+  }
   // measured on MI355X: the 256^2 kernel wins for deep K / wide N (v1 MLPs +10 %, 8192^3 +20 %), loses for K < 1024 or ragged N
   const bool shape256 = p.N % 256 == 0 && p.K >= 1024 && (p.N >= 2048 || p.K >= 2048) && tiles256 >= 3 * 256 - 64;
   // the persistent variant (plain 16-bit row-major outputs) has no per-round fixed cost and wins from 1.5 rounds of tiles and K >= 512 on
@@ -577,8 +582,8 @@ extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
   if (rowstream_class(p)) return launch_rowstream(p, s, num_cus());      // LoftUp's 384 x 384 GEMMs over ~10^6 rows: streamed, not tiled
   const int c = gemm_choice(p);
   // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
-  if (p.trans_out) return c == 0 ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
   if (c == 2) return gemm256_persistent_ok(p) ? launch_gemm256p(p, s, num_cus()) : launch_gemm256(p, s);
+  if (p.trans_out) return c == 0 ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
   return c == 0 ? launch<2, 2, false, 4>(p, s) : launch<4, 4, false, 2>(p, s);
 }
 
@@ -586,6 +591,6 @@ extern "C" const char* pst_gemm_variant(const pst_gemm_params* pp) {
   if (gemm_validate(pp)) return nullptr;
   if (pst::rowstream_class(*pp)) return "rowgemm384_kernel";
   const int c = gemm_choice(*pp);
-  if (pp->trans_out) return c == 0 ? "gemm_kernel<2,2,true>" : "gemm_kernel<4,4,true>";
+  if (pp->trans_out && c != 2) return c == 0 ? "gemm_kernel<2,2,true>" : "gemm_kernel<4,4,true>";
   return c == 2 ? (pst::gemm256_persistent_ok(*pp) ? "gemm256p_kernel" : "gemm256_kernel") : (c == 0 ? "gemm_kernel<2,2,false>" : "gemm_kernel<4,4,false>");
 }

@@ -351,7 +351,9 @@ __device__ __forceinline__ float mul_add_2r(float a, float b, float c) {
 // RES: fp32 output = fp32 residual + ..., with the LayerNorm-fold producer outputs (16-bit copy, per-row (sum, sumsq) of each 64-column
 // group) -- the residual-stream GEMMs (proj, fc2).  The statistics reproduce the summation tree of the row-phase epilogues bit for bit:
 // 4-column chunks summed in order, chunk pairs, quads, octets, halves.
-template <bool F16, bool RES>
+// TRANS: C^T (the attention V^T operand) -- the MFMA operands swap roles, so a lane owns one output column and, with perm_row8 on the A rows
+// instead of the W rows, 8 consecutive ROWS of it: 16-byte stores along V^T's contiguous axis.
+template <bool F16, bool RES, bool TRANS>
 __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -379,8 +381,8 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
       const int sw = ((pos ^ ((lrow >> 1) & 7)) << 3);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        a_src[h][j] = min(m0 + h * 128 + lrow, p.M - 1) * (int)p.lda + sw;
-        b_src[h][j] = min(n0 + h * 128 + perm_row8(lrow), p.N - 1) * (int)p.ldw + sw;      // N % 64 == 0: a ragged last column tile clamps
+        a_src[h][j] = min(m0 + h * 128 + (TRANS ? perm_row8(lrow) : lrow), p.M - 1) * (int)p.lda + sw;
+        b_src[h][j] = min(n0 + h * 128 + (TRANS ? lrow : perm_row8(lrow)), p.N - 1) * (int)p.ldw + sw;      // N % 64 == 0: a ragged last column tile clamps
       }
     }
   };
@@ -435,7 +437,8 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[mi * 4 + i][ni * 2 + j] = H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
+          acc[mi * 4 + i][ni * 2 + j] = TRANS ? H16<F16>::mfma(af[i][kk], bfr[ni][j][kk], acc[mi * 4 + i][ni * 2 + j])
+                                              : H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -569,6 +572,46 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
     }
     request_next();
 
+    if constexpr (TRANS) {
+      // lane (g, l16): column l16 of each column fragment; per pair of row fragments the 8 consecutive rows (sub-block, half, g*8 ..)
+      bf16_t* Ct = (bf16_t*)p.C;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int nl = wn * 64 + jj * 16 + l16;
+        const int n = cn0 + nl;
+        const float b = coltab[nl], cs = coltab[512 + nl];
+#pragma unroll
+        for (int ip = 0; ip < 4; ++ip) {
+          const int r8 = wm * 128 + (ip >> 1) * 64 + (ip & 1) * 32 + g * 8;           // tile-local first row of the lane's run
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float2 st = fold ? lnst[r8 + k] : make_float2(1.f, 0.f);
+            v[k] = fmaf(acc[2 * ip + (k >> 2)][jj][k & 3], st.x, fmaf(st.y, cs, b));
+          }
+          if (p.act == 1) {
+            gelu_erf4(*(float (*)[4])v);
+            gelu_erf4(*(float (*)[4])(v + 4));
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+          }
+          const int m = cm0 + r8;
+          if (n < p.N) {
+            bf16_t* dst = Ct + (int64_t)n * p.ldc + m;
+            if (m + 8 <= p.M) {
+              *(uint4*)dst = make_uint4(H16<F16>::pack(v[0], v[1]), H16<F16>::pack(v[2], v[3]), H16<F16>::pack(v[4], v[5]), H16<F16>::pack(v[6], v[7]));
+            } else {
+              for (int k = 0; k < 8 && m + k < p.M; ++k) dst[k] = H16<F16>::from_f(v[k]);
+            }
+          }
+        }
+      }
+      par ^= 1;
+      if (!more) break;
+      continue;
+    }
+
     // ---- epilogue from the accumulators: lane (g, l16) owns row l16 of each row fragment and, per 32-column half, columns g*8 .. g*8+7
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -645,7 +688,9 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
 // the persistent kernel's two classes: 1 = plain 16-bit row-major output (bias / activation / LayerScale / LayerNorm-fold consumer),
 // 2 = fp32 residual stream (C = res + ..., optional 16-bit copy + fold statistics); 0 = not eligible
 int gemm256_persistent_class(const pst_gemm_params& p) {
-  if (p.ps_p || p.grp_in || p.res_mod || p.N % 64 || p.trans_out || p.conv_c || p.batch > 1) return 0;
+  if (p.ps_p || p.grp_in || p.res_mod || p.N % 64 || p.conv_c || p.batch > 1) return 0;
+  if (p.trans_out)        // class 3: transposed 16-bit store (bias / activation / fold consumer)
+    return (p.out_fp32 || p.res || p.gamma || p.rope_hd || p.stats_out || p.xcopy || (p.ldc & 7) || ((uintptr_t)p.C & 15) || (int64_t)p.N * p.ldc >= (1ll << 31)) ? 0 : 3;
   if (p.rope_hd && (p.rope_hd != 64 || p.rope_npos <= 0 || p.rope_npos > 64 || p.out_fp32)) return 0;
   if (p.ln_stats && p.ln_groups != 16 && p.ln_groups != 12 && p.ln_groups != 6 && p.ln_groups != 2) return 0;
   if (!p.out_fp32) {
@@ -664,20 +709,25 @@ int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus) {
   const int tiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
+    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
     attr_set = true;
   }
   const int grid = tiles < cus ? tiles : cus;
   const bool h = p.dtype16 == DT_F16;
-  if (gemm256_persistent_class(p) == 2) {
-    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, true>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, true>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+  if (gemm256_persistent_class(p) == 3) {
+    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, false, true>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, true>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+  } else if (gemm256_persistent_class(p) == 2) {
+    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, true, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, true, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
   } else {
-    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, false, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm256p_kernel<false, false, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
   }
   return check_launch("gemm256p");
 }

@@ -772,3 +772,29 @@ def test_rowstream_gemm_bit_identical_to_tiled(M):
         hip.gemm(a, w, o, bias=bias, res=o)
         ref = o if ref is None else ref
         assert torch.equal(o, ref)
+
+
+@pytest.mark.parametrize('M,N,K', [(3000, 1024, 1024), (40000, 768, 128), (2605, 256, 192), (9001, 320, 64)])
+def test_gemm256_persistent_transposed_store_bit_identical(M, N, K):
+    """V^T projections on the persistent 256 x 256 kernel (swapped MFMA operands, a lane owns 8 consecutive rows of one output column):
+    bit-identical to the 128 x 128 transposed kernel, incl. ragged M (scalar tail), ragged N (multiple of 64) and the fold consumer."""
+    from panst3r_amd import hip
+    a, w, b = bf(rn(980, M, K)).to(dev()), bf(rn(981, N, K, scale=K ** -0.5)).to(dev()), rn(982, N).to(dev())
+    ldc = (M + 7) // 8 * 8 + 8
+    cases = [dict(bias=b), dict(bias=b, act='gelu'), dict()]
+    if K % 64 == 0:
+        x = rn(983, M, K).to(dev()) * 1.3 + 0.2
+        xb = torch.empty(M, K, dtype=d16(), device=dev())
+        st = torch.empty(M, K // 64, 2, device=dev())
+        hip.rowstats(x, xb, st)
+        cases.append(dict(bias=b, ln=(st, w.float().sum(1).contiguous(), 1e-6), src=xb))
+    for kw in cases:
+        kw = dict(kw)
+        src = kw.pop('src', a)
+        outs = []
+        for kern in (128, 256):
+            o = torch.zeros(N, ldc, dtype=d16(), device=dev())
+            hip.gemm(src, w, o, trans_out=True, kernel=kern, **kw)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]), sorted(kw.keys())
+        assert float(outs[1][:, M:].abs().max()) == 0.0               # nothing written past row M

@@ -13,7 +13,9 @@ w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
 b = torch.randn(N, device=dev)
 out = torch.zeros(M, N, dtype=torch.float32 if ('f32' in fl or ('res' in fl and 'res16' not in fl)) else dt, device=dev)
 kern = ([int(x[1:]) for x in fl if x[0] == 'k' and x[1:].isdigit()] + [0])[0]
-kw = dict(kernel=kern, bias=b, act='gelu' if 'gelu' in fl else None, res=out if ('res' in fl or 'res16' in fl) else None)
+if 'trans' in fl:
+    out = torch.zeros(N, (M + 7) // 8 * 8 + 8, dtype=dt, device=dev)
+kw = dict(kernel=kern, trans_out='trans' in fl, bias=b, act='gelu' if 'gelu' in fl else None, res=out if ('res' in fl or 'res16' in fl) else None)
 if 'fold' in fl and 'res' in fl:          # producer side of the LayerNorm fold
     kw.update(xcopy=torch.zeros(M, N, dtype=dt, device=dev), stats_out=torch.zeros(M, N // 64, 2, dtype=torch.float32, device=dev))
 elif 'fold' in fl:                        # consumer side

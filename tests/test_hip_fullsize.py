@@ -7,7 +7,8 @@ logits rel-L2 <= 3e-2 AND sign agreement >= 99.5 % of the pixels (all views of t
 rel-L2 <= 2e-2.  They are asserted, unrelaxed, for the shipped default format (f16 operands, amp='fp16' / amp=False) on
   * 2 views / 2 keyframes (v2)                       -- the bench.py parity sample,
   * 5 views / 3 keyframes, v1 AND v2                 -- heads-only (non-keyframe) views, a real memory bank, split-K attention,
-  * 3 views / 2 keyframes with the "sharp" weight set -- QK weights x8, softmax far from uniform,
+  * 3 views / 2 keyframes with the "sharp" weight set -- every attention logit x2 (see test_full_size_sharp_weight_set for why not more),
+  * 4 views of three different shapes, one of them portrait (the multi-aspect-ratio entry point),
 and against reference-GENERATED goldens for the full-dimension MaskTransformer (G2).
 amp='bf16' (the range-safe fallback: same speed, 3 fewer mantissa bits) meets four of the five; its sign agreement is 99.3 % on the
 zero-centred random-init logits (rel-L2 2.1e-2 -> ~0.7 % flips), asserted at the level it holds so a regression shows."""
@@ -286,3 +287,36 @@ def test_full_size_c5_200_views_32_keyframes(full):
     assert torch.equal(s1['out_queries'], s2['out_queries']) and torch.equal(s1['out_queries'], s3['out_queries'])
     for k in (0, 1, 99, 199):
         assert torch.equal(r1[k][0], r2[k][0]) and torch.equal(r1[k][1], r2[k][1]) and torch.equal(r1[k][0], r3[k][0]) and torch.equal(r1[k][1], r3[k][1]), k
+
+
+def test_full_size_mixed_aspect_ratio_and_portrait(full):
+    """forward_inference_multi_ar at FULL size on views of different shapes, one of them portrait in native orientation (reference a1 / a6 /
+    a7 / a11: per-shape batching, update_pair_tokens on a landscape + portrait pair, transposed DINOv2 input, transposed-grid key PE,
+    LoftUp's anisotropic attention-mask resize) against the oracle's own forward_inference_multi_ar with the same weights."""
+    import bench
+    from oracle.pipeline import build as build_oracle
+    from panst3r_amd.synthetic import synth_image
+    model, state, names, emb = full
+    torch.set_num_threads(bench.usable_cores())
+    o = build_oracle('v2')
+    o.load_state_dict(state, strict=True)
+    o.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
+    shapes = [(384, 512), (512, 384), (384, 512), (336, 512)]
+    imgs = [synth_image(40 + i, a, b) for i, (a, b) in enumerate(shapes)]
+    ts = torch.tensor(shapes)
+    with torch.no_grad():
+        pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, names, num_keyframes=3, outdevice='cpu')
+        model._runners.clear()
+        pm_h, pan_h = model.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, names, num_keyframes=3, outdevice='cpu')
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    num = den = agree = npix = 0.0
+    for i, (a, b) in enumerate(shapes):
+        assert pm_h[i].shape == pm_o[i].shape == (1, a, b, 7)
+        assert pan_h['pred_masks'][i].shape == pan_o['pred_masks'][i].shape == (1, 200, a // 2, b // 2)
+        assert rel(pm_h[i], pm_o[i]) <= 2e-2, (i, rel(pm_h[i], pm_o[i]))
+        x, y = pan_h['pred_masks'][i].double(), pan_o['pred_masks'][i].double()
+        num += float(((x - y) ** 2).sum()); den += float((y ** 2).sum())
+        agree += float(((x > 0) == (y > 0)).sum()); npix += y.numel()
+    assert (num / den) ** 0.5 <= 3e-2 and agree / npix >= 0.995, ((num / den) ** 0.5, agree / npix)        # pooled over the scene's pixels
+    assert rel(pan_h['out_queries'].cpu(), pan_o['out_queries'].cpu()) <= 2e-2
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits'].cpu()).abs().max()) <= 0.05

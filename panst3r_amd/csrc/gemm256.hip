@@ -641,7 +641,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
           }
-          v[0] *= gam4[u].x; v[1] *= gam4[u].y; v[2] *= gam4[u].z; v[3] *= gam4[u].w;
+          if (p.gamma) { v[0] *= gam4[u].x; v[1] *= gam4[u].y; v[2] *= gam4[u].z; v[3] *= gam4[u].w; }      // (x 1.0f is exact: skipping it changes no bit)
           w[2 * u] = H16<F16>::pack(v[0], v[1]);
           w[2 * u + 1] = H16<F16>::pack(v[2], v[3]);
         }

@@ -219,6 +219,40 @@ __global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const fl
   }
 }
 
+// The 384-channel GroupNorms of the guidance branch (16-bit in, 16-bit out, ldx == ldy == C): one thread owns 8 consecutive channels
+// of a fixed set of rows -- its group's (mean, rstd) and its 8 (gamma, beta) are loaded once, rows stream through 16-byte loads / stores
+// with no per-element index arithmetic.  Same expression per element as gn_apply_kernel.
+__global__ __launch_bounds__(256) void gn_apply8_kernel(const bf16_t* x, const float* stats, const float* gamma, const float* beta, bf16_t* y, int P, int C, int G,
+                                                         float eps, int relu, int tc, int rows_per_block) {
+  const int view = blockIdx.y, c8n = C / 8;
+  const int chunk = threadIdx.x % c8n, rsub = threadIdx.x / c8n, rpb = blockDim.x / c8n;
+  const int c = chunk * 8, grp = c / (C / G);
+  const float inv_n = 1.0f / ((float)P * (C / G));
+  const float sm = stats[((int64_t)view * G + grp) * 2], sq = stats[((int64_t)view * G + grp) * 2 + 1];
+  const float mean = sm * inv_n;
+  const float rstd = rsqrtf(fmaxf(sq * inv_n - mean * mean, 0.f) + eps);
+  float gm[8], bt[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { gm[k] = gamma[c + k]; bt[k] = beta[c + k]; }
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, P);
+  const int64_t base = (int64_t)view * P * C + c;
+#pragma unroll 2
+  for (int r = r0 + rsub; r < r1; r += rpb) {
+    const uint4 t = *(const uint4*)(x + base + (int64_t)r * C);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v0, v1;
+      unpack2(w[q], tc, v0, v1);
+      float a = (v0 - mean) * rstd * gm[2 * q] + bt[2 * q], b = (v1 - mean) * rstd * gm[2 * q + 1] + bt[2 * q + 1];
+      if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+      o[q] = pack2(a, b, tc);
+    }
+    *(uint4*)(y + base + (int64_t)r * C) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // low-res positional features: 20 channels = sin(f*2+d) x10, cos x10 on the (h, w) token grid
 __global__ void lr_pe_kernel(const float* biases, bf16_t* out, int64_t ld, int col0, int nimg, int h, int w, int tc) {
   const int64_t total = (int64_t)nimg * h * w * 20;
@@ -281,6 +315,12 @@ extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float
 extern "C" int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
                                    void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, int dtype16, void* stream) {
   if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !x || !stats || !gamma || !beta || !y || nimg <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G || ldy < C) { set_error("groupnorm_apply: bad argument"); return PST_EINVAL; }
+  if (x_fp32 == dtype16 && C % 8 == 0 && (C / G) % 8 == 0 && ldx == C && ldy == C && C / 8 <= 256 && !(((uintptr_t)x | (uintptr_t)y) & 15)) {
+    const int c8n = C / 8, rpb = 256 / c8n, rows_per_block = 16 * rpb;
+    hipLaunchKernelGGL(gn_apply8_kernel, dim3((P + rows_per_block - 1) / rows_per_block, nimg), dim3(c8n * rpb), 0, (hipStream_t)stream, (const bf16_t*)x, stats, gamma, beta,
+                       (bf16_t*)y, P, C, G, eps, relu, dtype16, rows_per_block);
+    return check_launch("groupnorm_apply");
+  }
   const bool vec = (C % 4 == 0) && ((C / G) % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0);
   const int64_t total = (int64_t)nimg * P * (vec ? ldy / 4 : ldy);
   int64_t g = (total + 255) / 256;

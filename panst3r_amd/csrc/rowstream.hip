@@ -261,8 +261,10 @@ __global__ __launch_bounds__(RS_THREADS, 1) void rowgemm384_kernel(const pst_gem
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
         }
-        const float4 g4 = *(const float4*)(coltab + RS_D + n8 + 4 * f);
-        v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
+        if (p.gamma) {                          // (x 1.0f is exact: skipping it changes no bit)
+          const float4 g4 = *(const float4*)(coltab + RS_D + n8 + 4 * f);
+          v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
+        }
         w[2 * f] = H16<F16>::pack(v[0], v[1]);
         w[2 * f + 1] = H16<F16>::pack(v[2], v[3]);
       }

@@ -798,3 +798,21 @@ def test_gemm256_persistent_transposed_store_bit_identical(M, N, K):
             outs.append(o)
         assert torch.equal(outs[0], outs[1]), sorted(kw.keys())
         assert float(outs[1][:, M:].abs().max()) == 0.0               # nothing written past row M
+
+
+@pytest.mark.parametrize('C,G,P,relu', [(384, 8, 700, True), (64, 8, 96, False), (384, 8, 33, True)])
+def test_groupnorm_apply_streaming_16bit(C, G, P, relu):
+    """the 16-bit -> 16-bit GroupNorm apply of the LoftUp guidance branch (one thread = 8 channels of a fixed set of rows, 16-byte loads /
+    stores): == F.group_norm on the same (rounded) input, statistics from pst_groupnorm_stats."""
+    from panst3r_amd import hip
+    n = 3
+    x = bf(rn(990, n * P, C) * 1.7 + 0.4).to(dev())
+    g, b = 1 + 0.1 * rn(991, C), 0.1 * rn(992, C)
+    st = hip.stats_buffer(n, G, dev())
+    hip.groupnorm_stats(x, st, n, P, C, G)
+    out = torch.full((n * P, C), 7.0, dtype=d16(), device=dev())
+    hip.groupnorm_apply(x, st, g.to(dev()), b.to(dev()), out, n, P, C, G, 1e-5, relu)
+    ref = F.group_norm(x.float().cpu().reshape(n, P, C).permute(0, 2, 1), G, g, b, 1e-5).permute(0, 2, 1).reshape(n * P, C)
+    if relu:
+        ref = F.relu(ref)
+    assert rel_l2(out.float().cpu(), ref) < (6e-3 if d16() == torch.bfloat16 else 1e-3)

@@ -89,6 +89,8 @@ def _scene_errors(pm_h, pan_h, pm_o, pan_o):
     den = sum(float(b.double().pow(2).sum()) for _, b in mk)
     agree = sum(float(((a > 0) == (b > 0)).sum()) for a, b in mk) / sum(b.numel() for _, b in mk)
     return {'pointmaps_rel_l2': round(max(rel(a, b) for a, b in zip(pm_h, pm_o)), 5),
+            'pointmaps_rel_l2_per_view': [round(rel(a, b), 5) for a, b in zip(pm_h, pm_o)],        # view id order (= keyframe index when V == K)
+            'mask_logits_rel_l2_per_view': [round(rel(a, b), 5) for a, b in mk],
             'mask_logits_rel_l2': round((num / max(den, 1e-300)) ** 0.5, 5),
             'mask_sign_agreement': round(agree, 5),
             'worst_view': {'mask_logits_rel_l2': round(max(rel(a, b) for a, b in mk), 5),
@@ -120,10 +122,9 @@ def full_size_parity(model, dev, ref, imgs, ts, names, amp='fp16', K=2):
     mt = model.panoptic_decoder.mask_transformer
     inp = [i.to(dev) for i in imgs]
     with torch.no_grad():
-        model._runners.clear()            # instrumented runs must be eager first calls (a cached runner would replay captured graphs)
-        mt.mask_log = []
-        pm_h, pan_h = model.forward_inference_multi_ar(inp, ts, names, num_keyframes=K, amp=amp)
-        log, mt.mask_log = mt.mask_log, None
+        log = []
+        with mt.instrument(log=log):       # (forward_inference_multi_ar runs eagerly unless cache_graphs=True: nothing is captured here)
+            pm_h, pan_h = model.forward_inference_multi_ar(inp, ts, names, num_keyframes=K, amp=amp)
     torch.cuda.synchronize()
     res = {'scene': '%d views / %d keyframes, full-size weights (the cpu_baseline sample)' % (len(imgs), K), 'amp': amp}
     res.update(_scene_errors(pm_h, pan_h, pm_o, pan_o))
@@ -133,15 +134,16 @@ def full_size_parity(model, dev, ref, imgs, ts, names, amp='fp16', K=2):
     if om:
         res['attention_mask_bit_agreement'] = round(min(float((a.cpu() == b).float().mean()) for a, b in zip(log, om)), 5)
         with torch.no_grad():
-            model._runners.clear()
-            mt.forced_masks = [m.to(dev) for m in om]
-            pm_f, pan_f = model.forward_inference_multi_ar(inp, ts, names, num_keyframes=K, amp=amp)
-            mt.forced_masks = None
-            model._runners.clear()
+            with mt.instrument(forced=[m.to(dev) for m in om]):
+                pm_f, pan_f = model.forward_inference_multi_ar(inp, ts, names, num_keyframes=K, amp=amp)
         torch.cuda.synchronize()
         dm = _scene_errors(pm_f, pan_f, pm_o, pan_o)
         dm['within_tolerance_every_view'] = _within(dm, worst=True)
         res['decisions_matched'] = dm
+    # which bound each number refers to: the top-level keys are the FREE-RUNNING scene (pooled over views), the
+    # `decisions_matched` keys the run with the oracle's attention-mask bits; the stated SURVEY 8(d) tolerances are `tolerance`
+    res['bounds_met'] = {'free_running_stated_tolerances': res['within_tolerance'],
+                         'decisions_matched_stated_tolerances_every_view': res.get('decisions_matched', {}).get('within_tolerance_every_view')}
     return res
 
 
@@ -207,6 +209,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-c2', action='store_true', help='also time the reduced C2 sample (v1, 8 views / 8 keyframes) on the host: ~1 min')
     ap.add_argument('--no-alt-dtype', action='store_true', help='skip the short measurement of the other 16-bit format')
+    ap.add_argument('--no-depth-parity', action='store_true', help='skip the K = 16 parity scene (16 views = 16 keyframes = BASELINE configs[2]; ~1.5 min of host time)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--overlap', action='store_true', help='MEASUREMENT ONLY: run the memory build beside the independent encoder/DINOv2 work on a second stream '
                     '(+8 %% frames/s; was not reproducible until one kernel was fixed, mechanism not understood: DESIGN.md section 4); default: back to back')
@@ -367,6 +370,15 @@ def main():
                                           'frames_per_s': round(V / (scene_flops / 1e12 / cpu_tflops), 4), 'host_tflops_fp32': round(cpu_tflops, 3)}
             out['cpu_baseline']['other_configs'] = samples
             out['parity'] = full_size_parity(model, dev, ref, ref_imgs, ref_ts, names, args.amp)
+            if not args.no_depth_parity:
+                # parity at the benchmark's own memory depth: 16 views = 16 keyframes (BASELINE configs[2] as stated; 15 sequential memory updates
+                # as in the timed 50 / 16 scene), oracle on the host (timed: a MEASURED C3 next to the extrapolated C4), HIP path free-running and
+                # decisions-matched
+                rec16, ref16, imgs16, ts16 = cpu_baseline(args.variant, H, W, state, names, emb, threads, V=16, K=16)
+                samples['C3_measured'] = {'config': 'C3: %s, 16 views / 16 keyframes, %dx%d, fp32 torch on %d host threads' % (args.variant, H, W, threads),
+                                          'frames_per_s': rec16['value']}
+                out['parity']['K16'] = full_size_parity(model, dev, ref16, imgs16, ts16, names, args.amp, K=16)
+                del ref16
             if not out['parity']['within_tolerance']:
                 print('WARNING: full-size parity outside the stated tolerance: %s' % out['parity'], file=sys.stderr)
         sys.stdout.flush()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 14
+#define PST_ABI_VERSION 15
 
 /* element type codes: every `*_type` / `dtype16` argument below (and the former `*_fp32` flags: 0 and 1 keep their meaning) */
 #define PST_BF16 0   /* bfloat16, raw uint16 */
@@ -90,6 +90,14 @@ int pst_gemm(const pst_gemm_params* p, void* stream);
 /* name of the kernel variant pst_gemm dispatches `p` to ("gemm_kernel<4,4,false>", "gemm256_kernel", ...), without launching:
  * what a profiler row of this call is called (bench.py attributes its HIP-event timings with it). NULL for a rejected argument. */
 const char* pst_gemm_variant(const pst_gemm_params* p);
+/* Tuning knobs of the GEMM dispatch (process-wide; measurement tools and tests only - results never depend on them, every GEMM variant
+ * is bit-identical):  PST_TUNE_G2_AUTO  1 = GEMMs of the persistent 256x256 kernel's classes go to the two-workgroups-per-CU kernel
+ * (gemm2g.hip) when it is eligible, 0 = never (kernel == 2 still forces it);  PST_TUNE_G2_MODE  de-phasing of the CU's two workgroups:
+ * bit 0 static priority for the first dispatch wave, bit 1 start delay of the second (bits 4.. = delay in units of ~4 K cycles).
+ * Returns the previous value, or -1 for an unknown knob.  Initial values: environment PST_G2_AUTO / PST_G2_MODE, else the defaults. */
+#define PST_TUNE_G2_AUTO 1
+#define PST_TUNE_G2_MODE 2
+int pst_tune(int knob, int value);
 
 /* ---------------------------------------------------------------- fused attention forward (flash style)
  * O[b,h,q,:] = softmax_k( scale * Q[b,h,q,:] . K[b,h,k,:]  (+ -inf where mask[b,q,k]) ) V[b,h,k,:]

@@ -17,6 +17,9 @@ namespace pst {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// Function attributes (MaxDynamicSharedMemorySize) are PER DEVICE: `run` executes once per (call site, current device), under a lock
+// (a second thread may not launch before the first one has finished setting the attributes).  `seen` = the call site's static bitmask.
+void once_per_device(unsigned long long& seen, void (*run)());
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 

@@ -674,12 +674,11 @@ constexpr int LDS256P = LDS256P_TABLES + 2 * 256 * 8 + 64 * 32 * 4;      // + ro
 int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const int tiles = tiles_m * tiles_n;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  once_per_device(attr_seen, [] {
     (void)hipFuncSetAttribute((const void*)gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
     (void)hipFuncSetAttribute((const void*)gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
-    attr_set = true;
-  }
+  });
   if (p.dtype16 == DT_F16) hipLaunchKernelGGL(gemm256_kernel<true>, dim3(tiles), dim3(512), LDS256, s, p, tiles, tiles_m, tiles_n);
   else hipLaunchKernelGGL(gemm256_kernel<false>, dim3(tiles), dim3(512), LDS256, s, p, tiles, tiles_m, tiles_n);
   return check_launch("gemm256");
@@ -707,16 +706,15 @@ bool gemm256_persistent_ok(const pst_gemm_params& p) { return gemm256_persistent
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const int tiles = tiles_m * tiles_n;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  once_per_device(attr_seen, [] {
     (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
     (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
     (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
     (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
     (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
     (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    attr_set = true;
-  }
+  });
   const int grid = tiles < cus ? tiles : cus;
   const bool h = p.dtype16 == DT_F16;
   if (gemm256_persistent_class(p) == 3) {

@@ -1,0 +1,393 @@
+// Persistent 16-bit MFMA GEMM with TWO unsynchronised workgroups per CU (round 3) -- the big batched GEMMs of the PanSt3R path.
+//
+// Why: the persistent 256x256 kernel (gemm256.hip) runs its main loop at ~1.2-1.3 PFLOP/s-equivalent but spends ~12 us of every K = 1024
+// tile (38 us) in an epilogue during which the CU's matrix cores idle: its 8 waves are ONE workgroup, they reach the epilogue together
+// (SQ anatomy, profiles/r2_sq_*.md: 4.4 VALU-class instructions per MFMA in fc1 + GELU).  MFMA and VALU are separate pipes of a SIMD, and
+// a SIMD arbitrates between its resident waves instruction by instruction -- so the epilogue of one wave can run UNDER the MFMAs of
+// another, provided the two are not in lock-step.  Here a CU holds two independent workgroups of 4 waves (one wave of each per SIMD):
+//   * workgroup tile 256 x 128, wave tile 128 x 64 (2 x 2 waves): the same accumulator / fragment layout and therefore the same
+//     accumulator-layout epilogues as gemm256p_kernel (perm_row8 staging: a lane owns 8-column runs, 64 contiguous bytes per 4 lanes);
+//   * BK = 32 (ONE v_mfma_f32_16x16x32 K step per stage), a 3-stage LDS ring of 24 KiB stages (A 256 rows x 64 B, B 128 rows x 64 B):
+//     72 KiB + 5.5 KiB of per-tile tables per workgroup, 2 x 77.5 KiB = 155 of the CU's 160 KiB; stages are filled by LDS-DMA
+//     (global_load_lds_dwordx4) two stages ahead and waited for with a COUNTED s_waitcnt vmcnt (in-order retirement);
+//   * 64-byte LDS rows: the 16-byte chunk index is XOR-swizzled with K4[(row >> 2) & 3], K4 = {0, 3, 2, 1}, which makes every
+//     16-lane group of a ds_read_b128 (MI355X_MICROARCH.md, LDS table: {0-3,12-15,20-27}, ...) cover 16 distinct 16-byte slots of a
+//     256-byte bank row; as everywhere the swizzle is applied to the LDS-DMA SOURCE address and again on the read side;
+//   * persistent: a workgroup walks the tile list; the next tile's first two stages are requested before the epilogue of the current
+//     one.  The two workgroups of a CU start in phase; `mode` bit 0 gives the workgroups of the second dispatch wave (blockIdx >=
+//     gridDim / 2, which the dispatcher places beside the first 256) a lower static priority so that the pair drifts into anti-phase
+//     (main loop of one over the epilogue of the other) during the first tile instead of sharing both pipes in lock-step.
+// Per-element K order = every other tile size (one MFMA per 32 of K, ascending): bit-identical results (tests/test_hip_ops.py).
+#include "common.h"
+#include "../../include/panst3r_hip.h"
+
+namespace pst {
+
+int gemm256_persistent_class(const pst_gemm_params& p);       // gemm256.hip: the same three epilogue classes
+
+constexpr int G2_STAGES = 3;
+constexpr int G2_A_BYTES = 256 * 64;                           // 256 rows x 32 K x 2 B
+constexpr int G2_B_BYTES = 128 * 64;
+constexpr int G2_STAGE_BYTES = G2_A_BYTES + G2_B_BYTES;        // 24 KiB
+constexpr int G2_TAB_LN = G2_STAGES * G2_STAGE_BYTES;          // float2 [256]   LayerNorm-fold rows (rstd, -mean rstd)
+constexpr int G2_TAB_COL = G2_TAB_LN + 256 * 8;                // float  [3][128] bias, gamma, fold column sums
+constexpr int G2_TAB_POS = G2_TAB_COL + 3 * 128 * 4;           // int2   [256]   RoPE positions (y, x) of the tile's rows
+constexpr int G2_LDS = G2_TAB_POS + 256 * 8;                   // 79 360 B
+
+__device__ __forceinline__ int g2_perm_row8(int row) {         // = perm_row8 of gemm256.hip: LDS row (fragment f, fragment row 4g + r) -> tile column it holds
+  const int sub = row >> 6, rho = row & 63;
+  const int f = rho >> 4, g = (rho >> 2) & 3, r = rho & 3;
+  return (sub << 6) + (f >> 1) * 32 + g * 8 + (f & 1) * 4 + r;
+}
+__device__ __forceinline__ int g2_key(int row) { return (0x6C >> (((row >> 2) & 3) << 1)) & 3; }     // K4 = {0, 3, 2, 1} packed in 0b01101100
+
+__device__ __forceinline__ float g2_add_lane16(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float g2_add_lane32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float g2_mul_add_2r(float a, float b, float c) {      // a * b rounded, + c rounded (never one fma)
+#pragma clang fp contract(off)
+  const float t = a * b;
+  return t + c;
+}
+
+#define PST_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// RES / TRANS: the epilogue classes 2 / 3 of gemm256p_kernel (fp32 residual stream + fold producer outputs / transposed 16-bit store)
+template <bool F16, bool RES, bool TRANS>
+__global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n, const int mode) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, l16 = lane & 15;
+  const bf16_t* Ab = (const bf16_t*)p.A;
+  const bf16_t* Wb = (const bf16_t*)p.W;
+  const int nk = p.K / 32;
+
+  auto tile_origin = [&](int t, int& m0, int& n0) {        // grouped order: 4 row-tiles share their W column-tiles in L2
+    const int grp = t / (4 * tiles_n);
+    const int first_m = grp * 4;
+    const int gm = min(4, tiles_m - first_m);
+    const int tl = t - grp * 4 * tiles_n;
+    m0 = (first_m + tl % gm) * 256;
+    n0 = (tl / gm) * 128;
+  };
+  // ---- staging descriptors: a stage is 1024 + 512 16-byte chunks = 4 + 2 per thread; chunk c -> LDS row c >> 2, physical position c & 3,
+  // which holds the logical chunk (c & 3) ^ key(row).  32-bit element offsets (M * lda, N * ldw < 2^31 checked on the host).
+  int a_src[4], b_src[2];
+  auto describe = [&](int m0, int n0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = j * 256 + tid, lrow = c >> 2, pos = c & 3;
+      a_src[j] = min(m0 + (TRANS ? g2_perm_row8(lrow) : lrow), p.M - 1) * (int)p.lda + ((pos ^ g2_key(lrow)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = j * 256 + tid, lrow = c >> 2, pos = c & 3;
+      b_src[j] = min(n0 + (TRANS ? lrow : g2_perm_row8(lrow)), p.N - 1) * (int)p.ldw + ((pos ^ g2_key(lrow)) << 3);
+    }
+  };
+  auto stage = [&](int kt) {                               // K step kt -> ring slot kt % 3
+    if (kt >= nk) return;
+    char* dst = smem + (kt % G2_STAGES) * G2_STAGE_BYTES + wave * 1024;
+    const int k0 = kt * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(Ab + (a_src[j] + k0), dst + j * 4096);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(Wb + (b_src[j] + k0), dst + G2_A_BYTES + j * 4096);
+  };
+
+  const int key = g2_key(l16);                             // fragment row offsets are multiples of 16: the key depends on l16 only
+  const int a_off = (wm * 128 + l16) * 64 + ((g ^ key) << 4);
+  const int b_off = G2_A_BYTES + (wn * 64 + l16) * 64 + ((g ^ key) << 4);
+  float2* lnst = (float2*)(smem + G2_TAB_LN);
+  float* coltab = (float*)(smem + G2_TAB_COL);
+  int2* postab = (int2*)(smem + G2_TAB_POS);
+  const bool rope = !RES && !TRANS && p.rope_hd == 64;
+  const bool fold = p.ln_stats != nullptr;
+
+  // de-phasing of the CU's two workgroups (see the header): the second dispatch wave yields to the first
+  if ((mode & 1) && (int)blockIdx.x < (int)(gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
+  if ((mode & 2) && (int)blockIdx.x >= (int)(gridDim.x >> 1)) {
+#pragma unroll 1
+    for (int i = 0; i < 64 * (mode >> 4); ++i) __builtin_amdgcn_s_sleep(64);
+  }
+
+  f32x4 acc[8][4];
+  int slot = blockIdx.x;
+  int m0, n0;
+  tile_origin(xcd_remap(slot, ntiles), m0, n0);
+  describe(m0, n0);
+  stage(0); stage(1);
+  for (;;) {
+    // ---- per-tile tables (the previous tile's epilogue is over for every wave: barrier at the end of the loop body)
+    if (fold) ln_fold_prologue(p, lnst, tid, m0, 256);
+    if (rope) postab[tid] = *(const int2*)(p.rope_pos + 2 * min(m0 + tid, p.M - 1));
+    if (tid < 128) {
+      const int nc = min(n0 + tid, p.N - 1);
+      coltab[tid] = p.bias ? p.bias[nc] : 0.f;
+      coltab[128 + tid] = p.gamma ? p.gamma[nc] : 1.f;
+      coltab[256 + tid] = fold ? p.ln_colsum[nc] : 0.f;
+    }
+    stage(2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage kt has landed once at most the 6 LDS-DMA ops of stage kt + 1 are outstanding (in-order vmcnt; at kt = 0 the 6 newest are
+      // stage 2, i.e. the wait is stricter than needed by stage 1, which was requested a whole epilogue ago)
+      if (kt + 1 < nk) PST_VMCNT(6); else PST_VMCNT(0);
+      __builtin_amdgcn_s_barrier();          // ... for every wave; and every wave is done reading slot (kt + 2) % 3 (K step kt - 1)
+      if (kt > 0) stage(kt + 2);
+      const char* buf = smem + (kt % G2_STAGES) * G2_STAGE_BYTES;
+      bf16x8 af[8], bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(buf + b_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(buf + a_off + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = TRANS ? H16<F16>::mfma(af[i], bfr[j], acc[i][j]) : H16<F16>::mfma(bfr[j], af[i], acc[i][j]);
+    }
+    __builtin_amdgcn_s_barrier();            // every wave is done with the operand slots: the next tile may be requested
+
+    const int cm0 = m0, cn0 = n0;
+    slot += gridDim.x;
+    const bool more = slot < ntiles;
+    auto request_next = [&]() {
+      if (more) {
+        tile_origin(xcd_remap(slot, ntiles), m0, n0);
+        describe(m0, n0);
+        stage(0); stage(1);
+      }
+    };
+
+    if constexpr (RES) {
+      float* Cf = (float*)p.C;
+      const int grp64 = (cn0 + wn * 64) >> 6;
+      float4 rv[1][2][2];           // one row fragment at a time (the other workgroup of the CU covers the load latency: no deep prefetch needed)
+      auto load_res = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < 1; ++i) {
+          const int m = min(cm0 + wm * 128 + (i0 + i) * 16 + l16, p.M - 1);
+          const float* rp = p.res + (int64_t)m * p.ldr + cn0 + wn * 64 + g * 8;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) rv[i][h][u] = *(const float4*)(rp + h * 32 + 4 * u);
+        }
+      };
+      auto finish = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < 1; ++i) {
+          const int r = wm * 128 + (i0 + i) * 16 + l16;
+          const int m = cm0 + r;
+          const float2 st = fold ? lnst[r] : make_float2(1.f, 0.f);
+          float osum[2], osq[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int cl = wn * 64 + h * 32 + g * 8;
+            float4 f[2];
+            float cs_[2], cq_[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const float4 bias4 = *(const float4*)(coltab + cl + 4 * u), gam4 = *(const float4*)(coltab + 128 + cl + 4 * u), cs4 = *(const float4*)(coltab + 256 + cl + 4 * u);
+              const f32x4 a = acc[i0 + i][2 * h + u];
+              float v[4] = {fmaf(a[0], st.x, fmaf(st.y, cs4.x, bias4.x)), fmaf(a[1], st.x, fmaf(st.y, cs4.y, bias4.y)),
+                            fmaf(a[2], st.x, fmaf(st.y, cs4.z, bias4.z)), fmaf(a[3], st.x, fmaf(st.y, cs4.w, bias4.w))};
+              if (p.act == 1) {
+                gelu_erf4(v);
+              } else if (p.act == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+              }
+              const float4 q4 = rv[i][h][u];
+              f[u] = make_float4(g2_mul_add_2r(v[0], gam4.x, q4.x), g2_mul_add_2r(v[1], gam4.y, q4.y), g2_mul_add_2r(v[2], gam4.z, q4.z), g2_mul_add_2r(v[3], gam4.w, q4.w));
+              ln_acc4(f[u], cs_[u], cq_[u]);
+            }
+            if (m < p.M) {
+              float* dst = Cf + (int64_t)m * p.ldc + cn0 + cl;
+              *(float4*)dst = f[0];
+              *(float4*)(dst + 4) = f[1];
+              if (p.xcopy)
+                *(uint4*)((bf16_t*)p.xcopy + (int64_t)m * p.ldxc + cn0 + cl) =
+                    make_uint4(H16<F16>::pack(f[0].x, f[0].y), H16<F16>::pack(f[0].z, f[0].w), H16<F16>::pack(f[1].x, f[1].y), H16<F16>::pack(f[1].z, f[1].w));
+            }
+            // chunk pair -> quad (lane ^ 16) -> octet (lane ^ 32): the butterfly of row_sum<16>, same association as every other producer
+            osum[h] = g2_add_lane32(g2_add_lane16(cs_[0] + cs_[1]));
+            osq[h] = g2_add_lane32(g2_add_lane16(cq_[0] + cq_[1]));
+          }
+          if (p.stats_out && g == 0 && m < p.M) *((float2*)p.stats_out + (int64_t)m * p.stats_ld + grp64) = make_float2(osum[0] + osum[1], osq[0] + osq[1]);
+        }
+      };
+      load_res(0);
+      __builtin_amdgcn_sched_barrier(0);
+      request_next();
+      __builtin_amdgcn_sched_barrier(0);
+      finish(0);
+#pragma unroll
+      for (int i0 = 1; i0 < 8; ++i0) {
+        load_res(i0);
+        finish(i0);
+      }
+    } else if constexpr (TRANS) {
+      request_next();
+      // lane (g, l16): column l16 of each column fragment; per pair of row fragments the 8 consecutive rows (sub-block, half, g*8 ..)
+      bf16_t* Ct = (bf16_t*)p.C;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int nl = wn * 64 + jj * 16 + l16;
+        const int n = cn0 + nl;
+        const float b = coltab[nl], cs = coltab[256 + nl];
+#pragma unroll
+        for (int ip = 0; ip < 4; ++ip) {
+          const int r8 = wm * 128 + (ip >> 1) * 64 + (ip & 1) * 32 + g * 8;           // tile-local first row of the lane's run
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float2 st = fold ? lnst[r8 + k] : make_float2(1.f, 0.f);
+            v[k] = fmaf(acc[2 * ip + (k >> 2)][jj][k & 3], st.x, fmaf(st.y, cs, b));
+          }
+          if (p.act == 1) {
+            gelu_erf4(*(float (*)[4])v);
+            gelu_erf4(*(float (*)[4])(v + 4));
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+          }
+          const int m = cm0 + r8;
+          if (n < p.N) {
+            bf16_t* dst = Ct + (int64_t)n * p.ldc + m;
+            if (m + 8 <= p.M) {
+              *(uint4*)dst = make_uint4(H16<F16>::pack(v[0], v[1]), H16<F16>::pack(v[2], v[3]), H16<F16>::pack(v[4], v[5]), H16<F16>::pack(v[6], v[7]));
+            } else {
+              for (int k = 0; k < 8 && m + k < p.M; ++k) dst[k] = H16<F16>::from_f(v[k]);
+            }
+          }
+        }
+      }
+    } else {
+      request_next();
+      // ---- epilogue from the accumulators: lane (g, l16) owns row l16 of each row fragment and, per 32-column half, columns g*8 .. g*8+7
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cl = wn * 64 + h * 32 + g * 8;               // tile-local first column
+        const int nn = cn0 + cl;
+        float4 bias4[2], gam4[2], cs4[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          bias4[u] = *(const float4*)(coltab + cl + 4 * u);
+          gam4[u] = *(const float4*)(coltab + 128 + cl + 4 * u);
+          cs4[u] = *(const float4*)(coltab + 256 + cl + 4 * u);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = wm * 128 + i * 16 + l16;
+          const int m = cm0 + r;
+          const float2 st = fold ? lnst[r] : make_float2(1.f, 0.f);
+          uint32_t w[4];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x4 a = acc[i][2 * h + u];
+            float v[4] = {fmaf(a[0], st.x, fmaf(st.y, cs4[u].x, bias4[u].x)), fmaf(a[1], st.x, fmaf(st.y, cs4[u].y, bias4[u].y)),
+                          fmaf(a[2], st.x, fmaf(st.y, cs4[u].z, bias4[u].z)), fmaf(a[3], st.x, fmaf(st.y, cs4[u].w, bias4[u].w))};
+            if (p.act == 1) {
+              gelu_erf4(v);
+            } else if (p.act == 2) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            if (p.gamma) { v[0] *= gam4[u].x; v[1] *= gam4[u].y; v[2] *= gam4[u].z; v[3] *= gam4[u].w; }
+            w[2 * u] = H16<F16>::pack(v[0], v[1]);
+            w[2 * u + 1] = H16<F16>::pack(v[2], v[3]);
+          }
+          uint4 val = make_uint4(w[0], w[1], w[2], w[3]);
+          if (rope) {
+            // the wave's 64 columns are one head: half h rotates with the row's y (h = 0) / x (h = 1) position, pairs are 16 columns apart,
+            // i.e. the partner chunk lives in lane ^ 32 (g ^ 2).  The 16-bit-rounded values are rotated, as in every other store phase.  The
+            // (cos, sin) rows come from the global table (8 KiB, cache resident): the other workgroup of the CU covers their latency.
+            uint32_t pw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(w[q], w[q], false, false);
+              pw[q] = lane < 32 ? sw[1] : sw[0];
+            }
+            const int2 pp = postab[r];
+            const float4* t = (const float4*)(p.rope_cs + (h == 0 ? pp.x : pp.y) * 32 + (g & 1) * 16);
+            const float4 cs[4] = {t[0], t[1], t[2], t[3]};
+            val = rope_rotate<F16>(val, make_uint4(pw[0], pw[1], pw[2], pw[3]), cs, nn);
+          }
+          if (m < p.M && nn < p.N) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = val;
+        }
+      }
+    }
+    if (!more) break;
+    __builtin_amdgcn_s_barrier();            // every wave has read this tile's tables: they may be refilled
+  }
+}
+
+// eligibility: the epilogue classes of the persistent 256x256 kernel (class 2 needs N % 128 == 0 here, not N % 256)
+int gemm2g_class(const pst_gemm_params& p) {
+  if (p.out_fp32 && !p.trans_out && p.res && !p.res_bf16 && p.N % 256 != 0 && p.N % 128 == 0) {
+    pst_gemm_params q = p;
+    q.N = (p.N + 255) / 256 * 256;           // only the divisibility test of the class function differs
+    return gemm256_persistent_class(q) == 2 ? 2 : 0;
+  }
+  return gemm256_persistent_class(p);
+}
+
+static int g_mode = -1;
+static int g2_mode() {                       // PST_TUNE_G2_MODE / PST_G2_MODE; default: static priority for the first dispatch wave
+  if (g_mode < 0) {
+    const char* e = getenv("PST_G2_MODE");
+    g_mode = e ? atoi(e) : 1;
+  }
+  return g_mode;
+}
+int gemm2g_mode(int set) {
+  const int prev = g2_mode();
+  if (set >= 0) g_mode = set;
+  return prev;
+}
+
+int launch_gemm2g(const pst_gemm_params& p, hipStream_t s, int cus) {
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 127) / 128;
+  const int tiles = tiles_m * tiles_n;
+  static unsigned long long attr_seen = 0;
+  once_per_device(attr_seen, [] {
+    (void)hipFuncSetAttribute((const void*)gemm2g_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2g_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2g_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2g_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2g_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2g_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+  });
+  const int grid = tiles < 2 * cus ? tiles : 2 * cus;
+  const bool h = p.dtype16 == DT_F16;
+  const int mode = g2_mode();
+  const int cls = gemm2g_class(p);
+  if (cls == 3) {
+    if (h) hipLaunchKernelGGL((gemm2g_kernel<true, false, true>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
+    else hipLaunchKernelGGL((gemm2g_kernel<false, false, true>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
+  } else if (cls == 2) {
+    if (h) hipLaunchKernelGGL((gemm2g_kernel<true, true, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
+    else hipLaunchKernelGGL((gemm2g_kernel<false, true, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
+  } else {
+    if (h) hipLaunchKernelGGL((gemm2g_kernel<true, false, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
+    else hipLaunchKernelGGL((gemm2g_kernel<false, false, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
+  }
+  return check_launch("gemm2g");
+}
+
+}  // namespace pst

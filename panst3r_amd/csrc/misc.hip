@@ -1,6 +1,7 @@
 // HBM-bound helper kernels of the PanSt3R forward path (gfx950): LayerNorm, RoPE-2D, patchify, DINO preprocessing,
 // add/cast, L2 row normalisation, 2x2-centre mean of mask features, attention-mask bits.
 // All are coalesced, vectorised (8-16 B per lane) streaming kernels; none of them reshapes work into GEMMs.
+#include <mutex>
 #include "common.h"
 #include "../../include/panst3r_hip.h"
 #include <stdarg.h>
@@ -15,6 +16,17 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+void once_per_device(unsigned long long& seen, void (*run)()) {
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) { run(); return; }       // unknown ordinal: set the attributes every time (cheap)
+  std::lock_guard<std::mutex> lk(mu);
+  if (!(seen >> dev & 1ull)) {
+    run();
+    seen |= 1ull << dev;
+  }
 }
 
 int check_launch(const char* what) {

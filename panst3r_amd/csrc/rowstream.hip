@@ -320,14 +320,13 @@ int rowstream_class(const pst_gemm_params& p) {
 int launch_rowstream(const pst_gemm_params& p, hipStream_t s, int cus) {
   const int ntiles = p.M / RS_BM;
   const int grid = ntiles < cus ? ntiles : cus;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  once_per_device(attr_seen, [] {
     (void)hipFuncSetAttribute((const void*)rowgemm384_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS0);
     (void)hipFuncSetAttribute((const void*)rowgemm384_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS0);
     (void)hipFuncSetAttribute((const void*)rowgemm384_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS1);
     (void)hipFuncSetAttribute((const void*)rowgemm384_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS1);
-    attr_set = true;
-  }
+  });
   const bool h = p.dtype16 == DT_F16;
   if (rowstream_class(p) == 2) {
     if (h) hipLaunchKernelGGL((rowgemm384_kernel<true, true>), dim3(grid), dim3(RS_THREADS), RS_LDS1, s, p, ntiles);

@@ -30,10 +30,26 @@ def adt():
     return PREC.dtype
 
 
-def amp_dtype(amp):
-    """`amp` argument of the reference API (False | 'bf16' | 'fp16', utils.py:206-215) -> storage dtype.  amp=False is the
-    reference's fp32 mode: the HIP path has no fp32 MFMA variant, it runs its default (most precise) 16-bit format, f16."""
+_WARNED = set()
+
+
+def warn_once(key, msg):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def amp_dtype(amp, quiet=False):
+    """`amp` argument of the reference API (False | 'bf16' | 'fp16', utils.py:206-215) -> 16-bit storage / MFMA operand dtype.
+    amp=False is the reference's fp32 mode (tools/demo_panst3r.py:88 default).  The HIP path has no fp32-operand variant: it computes
+    amp=False scenes with f16 operands (11-bit mantissa; fp32 accumulation, residual streams, softmax and statistics) and SAYS SO once
+    per process; PanSt3R.forward_inference_multi_ar re-runs such a scene with bf16 operands if an f16 store overflowed."""
     if amp is None or amp is False:
+        if not quiet:
+            warn_once('amp_false', "panst3r_amd: amp=False (the reference's fp32 mode) runs with f16 MFMA operands and fp32 accumulation on the "
+                                   "HIP path - 16-bit tolerances apply (pointmaps rel-L2 <= 2e-2, measured ~1e-3); pass amp='fp16' / 'bf16' to choose the "
+                                   "format explicitly")
         return torch.float16
     if amp not in AMP_DTYPES:
         raise ValueError("amp must be False, 'bf16' or 'fp16' (got %r)" % (amp,))
@@ -42,7 +58,7 @@ def amp_dtype(amp):
 
 class precision:
     def __init__(self, dtype):
-        self.dtype = amp_dtype(dtype)
+        self.dtype = amp_dtype(dtype, quiet=True)        # internal plumbing (runners, tests): the API entry points do the telling
 
     def __enter__(self):
         self.prev, PREC.dtype = PREC.dtype, self.dtype

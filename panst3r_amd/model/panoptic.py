@@ -472,6 +472,23 @@ class MaskTransformer(HipModule):
             hip.resize_bilinear(mask_feats, fm, n, Hm, Wm, gh, gw, C)
         return fm
 
+    _instr = None          # (forced attention-mask bits per layer | None, list collecting the bits | None): set ONLY inside instrument()
+
+    def instrument(self, forced=None, log=None):
+        """Parity instrumentation of decode_tokens (tests / bench.py, never the product path): `forced` = per-layer attention-mask bits
+        to use instead of the thresholded logits (isolates arithmetic from the hard threshold at logit 0), `log` = a list that receives
+        the bits of every layer.  A context manager: reset on exit even when the body raises, refused under graph capture."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._instr = self._instr, (forced, log)
+            try:
+                yield self
+            finally:
+                self._instr = prev
+        return ctx()
+
     @torch.no_grad()
     def decode_tokens(self, fpn, fm, grids, cls_bf16, portrait=None):
         """Query decoding on the keyframes.
@@ -501,7 +518,9 @@ class MaskTransformer(HipModule):
         mask = torch.zeros(Q, NKm, dtype=torch.uint8, device=dev)
         logits_attn = empty(Q, NK, torch.float32, dev)
 
-        forced, log = getattr(self, 'forced_masks', None), getattr(self, 'mask_log', None)
+        forced, log = self._instr if self._instr is not None else (None, None)
+        if (forced is not None or log is not None) and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('MaskTransformer.instrument(): parity instrumentation must not be baked into a captured HIP graph')
         step = [0]
 
         def next_mask(o):

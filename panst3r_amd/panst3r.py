@@ -54,19 +54,30 @@ class PanSt3R(nn.Module):
         self._runners.clear()
 
     # ------------------------------------------------------------------ reference stage methods (panst3r.py:47-86,127-167)
+    # The reference runs these under the caller's torch.autocast (panst3r.py:174,204); here `amp=` ('fp16' | 'bf16') selects the 16-bit
+    # format of the call, None keeps the ambient `panst3r_amd.model.common.precision(...)` context (process default: f16).
+    @staticmethod
+    def _fmt(amp):
+        import contextlib
+        return contextlib.nullcontext() if amp is None else precision(amp)
+
     @torch.no_grad()
-    def forward_dino(self, imgs, true_shape, max_bs=None, verbose=None):
+    def forward_dino(self, imgs, true_shape, max_bs=None, verbose=None, amp=None):
         """DINOv2 forward pass (panst3r.py:47-54; engine/dino.py:8-22 maps the encoder over the flattened (B, n) views):
         imgs [B,n,3,H,W], true_shape [B,n,2] -> [B,n,T,1024].  `max_bs` chunks the work in the reference; here the views of a call are
         batched through every GEMM."""
         B, n = imgs.shape[:2]
-        x = self.dino_encoder(imgs.flatten(0, 1), true_shape.flatten(0, 1))
+        with self._fmt(amp):
+            x = self.dino_encoder(imgs.flatten(0, 1), true_shape.flatten(0, 1))
         return x.reshape(B, n, *x.shape[1:])
 
     @torch.no_grad()
-    def forward_must3r_encoder(self, imgs, true_shape, max_bs=None):
+    def forward_must3r_encoder(self, imgs, true_shape, max_bs=None, amp=None):
         """MUSt3R encoder (panst3r.py:56-63; engine/must3r.py:8-26): imgs [B,n,3,H,W] -> (x [B,n,T,1024], pos [B,n,T,2]); a LIST of
         [3,H_i,W_i] images (multi-aspect-ratio input, encoder_multi_ar) -> per-image lists (x[i] [T_i,1024], pos[i] [T_i,2])."""
+        if amp is not None:
+            with precision(amp):
+                return self.forward_must3r_encoder(imgs, true_shape, max_bs)
         if isinstance(imgs, (list, tuple)):
             xs, ps = [None] * len(imgs), [None] * len(imgs)
             groups = {}
@@ -82,9 +93,12 @@ class PanSt3R(nn.Module):
         return x.reshape(B, n, *x.shape[1:]), pos.reshape(B, n, *pos.shape[1:])
 
     @torch.no_grad()
-    def forward_must3r_decoder(self, x_must3r, pos_must3r, true_shape, max_bs=None):
+    def forward_must3r_decoder(self, x_must3r, pos_must3r, true_shape, max_bs=None, amp=None):
         """MUSt3R decoder (panst3r.py:72-86): sequential memory build over the batches [2,1,1,...] (engine/must3r.py:28-69), then every
         view is rendered against the accumulated memory (:71-129).  Returns (y_must3r [B,n,T,768], pointmaps [B,n,H,W,7], mem)."""
+        if amp is not None:
+            with precision(amp):
+                return self.forward_must3r_decoder(x_must3r, pos_must3r, true_shape, max_bs)
         mem, start = None, 0
         for nb in self.get_must3r_mem_batches(x_must3r.shape[1]):
             sl = slice(start, start + nb)
@@ -96,11 +110,14 @@ class PanSt3R(nn.Module):
 
     @torch.no_grad()
     def _forward_decoder_render(self, imgs, x_must3r, pos_must3r, true_shape, mem_must3r, mem_panst3r, classes, max_bs=None, multi_ar=False,
-                                outdevice=None):
+                                outdevice=None, amp=None):
         """Render-only pass for views that are not keyframes (panst3r.py:127-167): MUSt3R render against the frozen memory, DINOv2,
         then the panoptic heads with the frozen queries `mem_panst3r`.  multi_ar=False: imgs [B,n,3,H,W] (and matching tensors)
         -> (pointmaps [B*n,H,W,7], masks [B*n,Q,H/2,W/2]); multi_ar=True: lists of same-shape stacks ([1,n_i,...]) -> lists.  The
         reference walks the views in slices of max_bs (batched_map); here a stack is one batch through every GEMM."""
+        if amp is not None:
+            with precision(amp):
+                return self._forward_decoder_render(imgs, x_must3r, pos_must3r, true_shape, mem_must3r, mem_panst3r, classes, max_bs, multi_ar, outdevice)
         stacks = list(zip(imgs, x_must3r, pos_must3r, true_shape)) if multi_ar else [(imgs, x_must3r, pos_must3r, true_shape)]
         pms, mks = [], []
         for im, x, pos, ts in stacks:
@@ -181,13 +198,15 @@ class PanSt3R(nn.Module):
     # ------------------------------------------------------------------ reference API
     @torch.no_grad()
     def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=None,
-                                   outdevice=None, amp=False, sim_matrix=None, keyframes=None, check_finite=True):
+                                   outdevice=None, amp=False, sim_matrix=None, keyframes=None, check_finite=True, cache_graphs=False):
         """imgs: list[V] of [3,H,W] in [-1,1]; true_shape [V,2]; returns (pointmaps list[V] of [1,H,W,7],
         {'pred_logits' [1,Q,Ncls], 'pred_masks' list[V] of [1,Q,H/2,W/2], 'out_queries' [Q,1,768]}).
         Keyframes: linspace over the views (panst3r.py:183-186) by default.  `use_retrieval=True` (panst3r.py:179-180) takes the
         V x V image-similarity matrix as `sim_matrix` - the ASMK retriever that produces it in the reference needs asmk / faiss and
         is outside this build - and applies the reference's selection (schedule.keyframes_from_similarity: farthest-point sampling
-        on 1 - sim, then the greedy overlap ordering of panst3r.py:105-123).  `keyframes=` passes an explicit list instead."""
+        on 1 - sim, then the greedy overlap ordering of panst3r.py:105-123).  `keyframes=` passes an explicit list instead.
+        `cache_graphs=True` (not in the reference) keeps the scene's runner: repeated calls with the same signature replay captured HIP
+        graphs (see _runner_for; `clear_runners()` frees them).  Default: one eager pass, nothing kept."""
         if use_retrieval and keyframes is None:
             if sim_matrix is None:
                 raise NotImplementedError('use_retrieval=True needs sim_matrix= (the ASMK / faiss retriever is outside this build, SURVEY 8(f)3)')
@@ -197,16 +216,55 @@ class PanSt3R(nn.Module):
         dev = imgs[0].device
         shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
         H, W = shapes[0]
-        # Scene signature: everything the captured graphs depend on.  The FIRST call with a signature runs eagerly (a one-off scene
-        # should not pay a warm-up + capture); from the second call on the scene replays three captured HIP graphs with the new images
-        # copied into the runner's static input buffers.
-        gens = tuple(m.generation for m in (self.must3r_encoder, self.must3r_decoder, self.dino_encoder, self.panoptic_decoder))
+        fmt = amp_dtype(amp)                    # tells (once) that amp=False is computed with f16 operands
+        runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs)
+        res, scene = runner.run(outdevice)
+        if check_finite and fmt == torch.float16:
+            # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: ONE fused flag over everything the
+            # call returns (queries, class logits, pointmaps, mask logits), one host sync.  amp=False never asked for f16: it falls back to
+            # the range-safe format; an explicit amp='fp16' raises, as the reference's "--amp fp16 might be unstable" would show up.
+            ok = torch.isfinite(scene['out_queries']).all() & torch.isfinite(scene['pred_logits']).all()
+            for i in range(V):
+                ok = ok & torch.isfinite(res[i][0]).all() & torch.isfinite(res[i][1]).all()
+            if not bool(ok):
+                if amp is False or amp is None:
+                    from .model.common import warn_once
+                    warn_once('f16_overflow', "panst3r_amd: an activation left the f16 range (non-finite outputs); amp=False scenes are re-run "
+                                              "with bf16 operands (8-bit mantissa, fp32 range)")
+                    if not cache_graphs:
+                        runner.release()
+                    return self.forward_inference_multi_ar(imgs, true_shape, classes, num_keyframes, use_retrieval, max_bs, outdevice, 'bf16',
+                                                           sim_matrix, keyframes, check_finite=False, cache_graphs=cache_graphs)
+                raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16'")
+        panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
+                  'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
+        pms = [res[i][0] for i in range(V)]
+        if not cache_graphs:
+            runner.release()                    # a one-off scene keeps no intermediates (stacked inputs, features, mask features) alive
+        return pms, panout
+
+    def _runner_for(self, imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs):
+        """The SceneRunner of a call.  Default: a fresh eager runner, dropped after the call (what the reference's per-call execution
+        costs in memory).  cache_graphs=True: runners are kept per scene SIGNATURE - everything a captured graph depends on: shapes,
+        keyframe schedule, class list, device, format, and the version of every weight and class embedding (module generations bumped
+        by load_state_dict / invalidate(), plus the in-place edit counters `Tensor._version` of all parameters and of the class
+        embeddings in use) - and from the second call on with a signature the scene replays three captured HIP graphs with the new
+        images copied into the runner's static input buffers."""
+        from .scene import SceneRunner, HipBackend
+        V = len(imgs)
+        H, W = shapes[0]
+        if not cache_graphs:
+            return SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
+                               keyframes=keyframes, amp=amp)
+        from .model.common import HipModule
         te = self.panoptic_decoder.text_encoder
-        key = (tuple(shapes), num_keyframes, None if keyframes is None else tuple(int(k) for k in keyframes), tuple(classes), str(dev),
-               amp_dtype(amp), gens, getattr(te, '_cls_gen', 0))
+        gens = tuple(m.generation for m in self.modules() if isinstance(m, HipModule))
+        pver = sum(p._version for p in self.parameters())
+        cver = tuple((c, te.class_embeddings[c].data_ptr(), te.class_embeddings[c]._version) if c in te.class_embeddings else (c,) for c in classes)
+        key = (tuple(shapes), num_keyframes, None if keyframes is None else tuple(int(k) for k in keyframes), str(dev),
+               amp_dtype(amp, quiet=True), gens, pver, cver)
         ent = self._runners.get(key)
         if ent is None:
-            from .scene import SceneRunner, HipBackend
             while len(self._runners) >= max(1, self.max_cached_runners):
                 self._runners.pop(next(iter(self._runners)))
             runner = SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
@@ -216,18 +274,11 @@ class PanSt3R(nn.Module):
             ent[1].set_images(imgs)
             ent[1].use_graphs = True          # captured lazily by run()
         ent[0] += 1
-        res, scene = ent[1].run(outdevice)
-        if check_finite and amp_dtype(amp) == torch.float16:
-            # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: one reduction over the small scene
-            # outputs + the pointmaps tells; the remedy is amp='bf16' (same speed, 3 fewer mantissa bits)
-            ok = torch.isfinite(scene['out_queries']).all() & torch.isfinite(scene['pred_logits']).all()
-            for i in range(V):
-                ok = ok & torch.isfinite(res[i][0]).all()
-            if not bool(ok):
-                raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16'")
-        panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
-                  'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
-        return [res[i][0] for i in range(V)], panout
+        return ent[1]
+
+    def clear_runners(self):
+        """Drop every cached scene runner (captured graphs, their memory pools and static buffers)."""
+        self._runners.clear()
 
     @torch.no_grad()
     def forward_inference_sharded(self, get_image, V, H, W, classes, num_keyframes=None, outdevice=None, group=None, amp=False):
@@ -249,13 +300,14 @@ class PanSt3R(nn.Module):
         return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes, amp=amp)
 
     @torch.no_grad()
-    def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):
-        """Same-shape batch variant (panst3r.py:286-296): imgs [1,n,3,H,W] -> (panout, pointmaps [1,n,H,W,7]);
-        every view is a memory view (mem batches [2,1,...]) and every view is rendered."""
+    def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False):
+        """Same-shape batch variant (panst3r.py:286-296): imgs [B,n,3,H,W] -> (panout, pointmaps [B,n,H,W,7]);
+        every view is a memory view (mem batches [2,1,...]) and every view is rendered.  `amp` as forward_inference_multi_ar (the reference
+        runs this entry point under the caller's autocast)."""
         B, n = imgs.shape[:2]
         outs = []
         for b in range(B):                      # the scenes of a batch are independent (own memory, own queries)
-            pms, panout = self.forward_inference_multi_ar(list(imgs[b]), true_shape[b], classes, num_keyframes=n, outdevice=outdevice)
+            pms, panout = self.forward_inference_multi_ar(list(imgs[b]), true_shape[b], classes, num_keyframes=n, outdevice=outdevice, amp=amp)
             outs.append((torch.stack([m[0] for m in panout['pred_masks']])[None], torch.stack([p[0] for p in pms])[None], panout))
         panout = {'pred_logits': torch.cat([o[2]['pred_logits'] for o in outs]), 'pred_masks': torch.cat([o[0] for o in outs]),
                   'out_queries': torch.cat([o[2]['out_queries'] for o in outs], dim=1)}

@@ -239,6 +239,13 @@ class SceneRunner:
     def _eager(self):
         self.stage1(); self.gather1(); self.stage2(); self.gather2(); self.stage3()
 
+    def release(self):
+        """Drop everything the runner holds on the device (stacked inputs, feature / mask-feature buffers, gathered keyframe rows, captured
+        graphs).  Outputs already handed out by results() stay valid: they are tensors of their own."""
+        for g in self.groups:
+            g.imgs = g.cat = g.pointmaps = g.fpn = g.mf = g.guid = None
+        self.enc_kf = self.both_kf = self.enc_send = self.both_send = self.out = self.graphs = self._refs = None
+
     def set_images(self, images):
         """Load a new scene of the SAME shapes / schedule into the static input buffers (the captured graphs read them in place).
         images: {view_id: [3,H,W] tensor} or a list indexed by view id; only this rank's views are read."""

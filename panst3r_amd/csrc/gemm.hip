@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
 
   // LDS read offsets: fragment i of a wave lives 16 rows further (same swizzle key), K-half kk flips chunk bit 2
   const int a_row = wr * (16 * FM) + l16, b_row = wc * (16 * FN) + l16;
+  const uint32_t lds_as = lds_addr(As), lds_bs = lds_addr(Bs);
   const int a_off = a_row * 128 + ((g ^ ((a_row >> 1) & 7)) << 4);
   const int b_off = b_row * 128 + ((g ^ ((b_row >> 1) & 7)) << 4);
 
@@ -341,23 +342,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
     else wait_vm0();
     __builtin_amdgcn_s_barrier();   // ... for every wave, and everybody is done reading the buffer that is refilled next
     if (kt + NST - 1 < nk) stage(kt + NST - 1, (kt + NST - 1) % NST);
-    const char* a_buf = As + (kt % NST) * (BM * 128);
-    const char* b_buf = Bs + (kt % NST) * (BN * 128);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[FM], bfv[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(a_buf + ((a_off ^ (kk << 6)) + i * 2048));
-#pragma unroll
-      for (int j = 0; j < FN; ++j) bfv[j] = *(const bf16x8*)(b_buf + ((b_off ^ (kk << 6)) + j * 2048));
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
+    // all 2 (FM + FN) fragment reads of the K step are issued back to back; MFMA group (kk, i) waits (counted) for the reads it needs
+    const uint32_t a_lds = lds_as + (uint32_t)((kt % NST) * (BM * 128)), b_lds = lds_bs + (uint32_t)((kt % NST) * (BN * 128));
+    bf16x8 af[2][FM], bfv[2][FN];
+    static_for<0, 2>([&](auto kk) {
+      static_for<0, FN>([&](auto j) { ds_read128<j * 2048>(bfv[kk][j], b_lds + (uint32_t)(b_off ^ (kk << 6))); });
+      static_for<0, FM>([&](auto i) { ds_read128<i * 2048>(af[kk][i], a_lds + (uint32_t)(a_off ^ (kk << 6))); });
+    });
+    static_for<0, 2>([&](auto kk) {
+      static_for<0, FM>([&](auto i) {
+        constexpr int total = 2 * (FM + FN), done = kk * (FM + FN) + FN + i + 1;
+        lgkm_wait<total - done>(af[kk][i]);
+        if constexpr (i == 0) static_for<0, FN>([&](auto j) { lds_tie(bfv[kk][j]); });
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          if (TRANS) acc[i][j] = H16<F16>::mfma(af[i], bfv[j], acc[i][j]);
-          else       acc[i][j] = H16<F16>::mfma(bfv[j], af[i], acc[i][j]);
+          if (TRANS) acc[i][j] = H16<F16>::mfma(af[kk][i], bfv[kk][j], acc[i][j]);
+          else       acc[i][j] = H16<F16>::mfma(bfv[kk][j], af[kk][i], acc[i][j]);
         }
-    }
+        __builtin_amdgcn_sched_barrier(0);      // the group stays between its wait and the next one
+      });
+    });
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -555,7 +559,7 @@ static int gemm_validate(const pst_gemm_params* pp) {
 
 static int gemm_choice0(const pst_gemm_params& p);
 constexpr int G2_AUTO_DEFAULT = 0;
-namespace pst { int gemm2g_mode(int set); }
+namespace pst { int gemm2g_mode(int set); void gemm2g_trace(void* buf, int tiles); }
 // experiment switch: PST_G2_AUTO=1 sends every GEMM the persistent 256x256 kernel would take to the two-workgroup kernel instead
 static int g_g2_auto = -1;
 static bool g2_auto() {
@@ -613,6 +617,11 @@ extern "C" int pst_tune(int knob, int value) {
   if (knob == PST_TUNE_G2_AUTO) { const int prev = g2_auto() ? 1 : 0; g_g2_auto = value != 0; return prev; }
   if (knob == PST_TUNE_G2_MODE) return pst::gemm2g_mode(value);
   return -1;
+}
+
+extern "C" int pst_debug_g2_trace(void* buf, int tiles_per_workgroup) {
+  pst::gemm2g_trace(buf, tiles_per_workgroup);
+  return PST_OK;
 }
 
 extern "C" const char* pst_gemm_variant(const pst_gemm_params* pp) {

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
   const int key = (l16 >> 1) & 7;
   const int a_off = wm * HALF_BYTES + l16 * 128 + ((g ^ key) << 4);
   const int b_off = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + ((wn & 1) * 64 + l16) * 128 + ((g ^ key) << 4);
+  const uint32_t lds0 = lds_addr(smem);
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -91,27 +92,49 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
   bf16x8 af[4][2];        // current A sub-tile: 4 row fragments x 2 K halves
   bf16x8 bfr[2][2][2];    // both B sub-tiles: [n sub-tile][fragment][K half]
 
-  auto read_a = [&](const char* buf, int mi) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) af[i][kk] = *(const bf16x8*)(buf + ((a_off ^ (kk << 6)) + (mi * 64 + i * 16) * 128));
+  // hand-placed fragment reads (common.h): issued in program order, consumed behind counted lgkm_wait<>s
+  auto read_a = [&](uint32_t buf, auto mi) {
+    static_for<0, 4>([&](auto i) {
+      static_for<0, 2>([&](auto kk) { ds_read128<(mi * 64 + i * 16) * 128>(af[i][kk], buf + (uint32_t)(a_off ^ (kk << 6))); });
+    });
   };
-  auto read_b = [&](const char* buf, int ni) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) bfr[ni][j][kk] = *(const bf16x8*)(buf + ((b_off ^ (kk << 6)) + (ni * 32 + j * 16) * 128));
+  auto read_b = [&](uint32_t buf, auto ni) {
+    static_for<0, 2>([&](auto j) {
+      static_for<0, 2>([&](auto kk) { ds_read128<(ni * 32 + j * 16) * 128>(bfr[ni][j][kk], buf + (uint32_t)(b_off ^ (kk << 6))); });
+    });
   };
-  auto mma = [&](int mi, int ni) {
+  // 16 MFMAs of quadrant (mi, ni), row fragment i outer (per accumulator the K halves stay in the order kk = 0, 1: same bits as ever).
+  //   mma_a: right after the A fragments were read (reads in the order B(ni) [earlier], A i = 0..3, then `pend` further reads): group i waits
+  //          until at most pend + 2 (3 - i) reads are outstanding, i.e. for af[i][*] only - the first MFMAs start after 2 of the 8 A reads;
+  //   mma_b: A valid already, waits for everything outstanding (the B fragments of this quadrant);   mma_n: all operands valid.
+  auto mma_group = [&](auto mi, auto ni, auto i) {
+    static_for<0, 2>([&](auto kk) {
+      static_for<0, 2>([&](auto j) {
+        acc[mi * 4 + i][ni * 2 + j] = H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
+      });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma_a = [&](auto mi, auto ni, auto pend) {
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[mi * 4 + i][ni * 2 + j] = H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
+    static_for<0, 4>([&](auto i) {
+      lgkm_wait<pend + 2 * (3 - i)>(af[i][1]);
+      lds_tie(af[i][0]);
+      if constexpr (i == 0) static_for<0, 2>([&](auto j) { static_for<0, 2>([&](auto kk) { lds_tie(bfr[ni][j][kk]); }); });
+      mma_group(mi, ni, i);
+    });
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma_b = [&](auto mi, auto ni) {
+    __builtin_amdgcn_s_setprio(1);
+    lgkm_wait<0>(bfr[ni][0][0]);
+    lds_tie(bfr[ni][0][1]); lds_tie(bfr[ni][1][0]); lds_tie(bfr[ni][1][1]);
+    static_for<0, 4>([&](auto i) { mma_group(mi, ni, i); });
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma_n = [&](auto mi, auto ni) {
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, 4>([&](auto i) { mma_group(mi, ni, i); });
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -124,22 +147,25 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
   __builtin_amdgcn_s_barrier();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const char* buf = smem + (kt & 1) * BUF_BYTES;
+    const uint32_t buf = lds0 + (uint32_t)((kt & 1) * BUF_BYTES);
+    constexpr std::integral_constant<int, 0> c0{};
+    constexpr std::integral_constant<int, 1> c1{};
+    constexpr std::integral_constant<int, 4> c4{};
     // phase 0 / 1: quadrants (m0,n0), (m0,n1); B(n1) is fetched while (m0,n0) is multiplied
-    read_a(buf, 0);
-    read_b(buf, 0);
+    read_b(buf, c0);
+    read_a(buf, c0);
     stage(0, kt + 1);
-    read_b(buf, 1);
-    mma(0, 0);
+    read_b(buf, c1);
+    mma_a(c0, c0, c4);                   // 4 = the B(n1) reads issued behind the A reads
     stage(1, kt + 1);
-    mma(0, 1);
+    mma_b(c0, c1);
     __builtin_amdgcn_s_barrier();        // every wave has finished its B reads of this buffer -> B halves may be refilled
     // phase 2 / 3: quadrants (m1,n1), (m1,n0)
-    read_a(buf, 1);
+    read_a(buf, c1);
     stage(2, kt + 2);
-    mma(1, 1);
+    mma_a(c1, c1, c0);
     stage(3, kt + 2);
-    mma(1, 0);
+    mma_n(c1, c0);
     if (kt + 2 < nk) PST_VMCNT(4); else PST_VMCNT(0);     // tile kt+1 complete (only B(kt+2) may still be in flight)
     __builtin_amdgcn_s_barrier();        // ... for every wave; also: all A reads of this buffer are done
   }
@@ -400,6 +426,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
   const int key = (l16 >> 1) & 7;
   const int a_off = wm * HALF_BYTES + l16 * 128 + ((g ^ key) << 4);
   const int b_off = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + ((wn & 1) * 64 + l16) * 128 + ((g ^ key) << 4);
+  const uint32_t lds0 = lds_addr(smem);
   // per-tile tables behind the operand buffers, double buffered by tile parity (a fast wave may already fill the next tile's
   // tables while a slow one still reads this tile's in its epilogue): LayerNorm-fold rows (rstd, -mean rstd) and the column
   // constants (bias, LayerScale / q-scale, fold column sum).  The epilogue reads them from LDS: a global load there would sit
@@ -417,28 +444,50 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
   f32x4 acc[8][4];
   bf16x8 af[4][2];
   bf16x8 bfr[2][2][2];
-  auto read_a = [&](const char* buf, int mi) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) af[i][kk] = *(const bf16x8*)(buf + ((a_off ^ (kk << 6)) + (mi * 64 + i * 16) * 128));
+  // hand-placed fragment reads (common.h): issued in program order, consumed behind counted lgkm_wait<>s
+  auto read_a = [&](uint32_t buf, auto mi) {
+    static_for<0, 4>([&](auto i) {
+      static_for<0, 2>([&](auto kk) { ds_read128<(mi * 64 + i * 16) * 128>(af[i][kk], buf + (uint32_t)(a_off ^ (kk << 6))); });
+    });
   };
-  auto read_b = [&](const char* buf, int ni) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) bfr[ni][j][kk] = *(const bf16x8*)(buf + ((b_off ^ (kk << 6)) + (ni * 32 + j * 16) * 128));
+  auto read_b = [&](uint32_t buf, auto ni) {
+    static_for<0, 2>([&](auto j) {
+      static_for<0, 2>([&](auto kk) { ds_read128<(ni * 32 + j * 16) * 128>(bfr[ni][j][kk], buf + (uint32_t)(b_off ^ (kk << 6))); });
+    });
   };
-  auto mma = [&](int mi, int ni) {
+  // 16 MFMAs of quadrant (mi, ni), row fragment i outer (per accumulator the K halves stay in the order kk = 0, 1: same bits as ever).
+  //   mma_a: right after the A fragments were read (reads in the order B(ni) [earlier], A i = 0..3, then `pend` further reads): group i waits
+  //          until at most pend + 2 (3 - i) reads are outstanding, i.e. for af[i][*] only - the first MFMAs start after 2 of the 8 A reads;
+  //   mma_b: A valid already, waits for everything outstanding (the B fragments of this quadrant);   mma_n: all operands valid.
+  auto mma_group = [&](auto mi, auto ni, auto i) {
+    static_for<0, 2>([&](auto kk) {
+      static_for<0, 2>([&](auto j) {
+        acc[mi * 4 + i][ni * 2 + j] = TRANS ? H16<F16>::mfma(af[i][kk], bfr[ni][j][kk], acc[mi * 4 + i][ni * 2 + j])
+                                            : H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
+      });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma_a = [&](auto mi, auto ni, auto pend) {
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[mi * 4 + i][ni * 2 + j] = TRANS ? H16<F16>::mfma(af[i][kk], bfr[ni][j][kk], acc[mi * 4 + i][ni * 2 + j])
-                                              : H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
+    static_for<0, 4>([&](auto i) {
+      lgkm_wait<pend + 2 * (3 - i)>(af[i][1]);
+      lds_tie(af[i][0]);
+      if constexpr (i == 0) static_for<0, 2>([&](auto j) { static_for<0, 2>([&](auto kk) { lds_tie(bfr[ni][j][kk]); }); });
+      mma_group(mi, ni, i);
+    });
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma_b = [&](auto mi, auto ni) {
+    __builtin_amdgcn_s_setprio(1);
+    lgkm_wait<0>(bfr[ni][0][0]);
+    lds_tie(bfr[ni][0][1]); lds_tie(bfr[ni][1][0]); lds_tie(bfr[ni][1][1]);
+    static_for<0, 4>([&](auto i) { mma_group(mi, ni, i); });
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma_n = [&](auto mi, auto ni) {
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, 4>([&](auto i) { mma_group(mi, ni, i); });
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -469,20 +518,25 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; ++kt) {
-      const char* buf = smem + (kt & 1) * BUF_BYTES;
-      read_a(buf, 0);
-      read_b(buf, 0);
+      const uint32_t buf = lds0 + (uint32_t)((kt & 1) * BUF_BYTES);
+      constexpr std::integral_constant<int, 0> c0{};
+      constexpr std::integral_constant<int, 1> c1{};
+      constexpr std::integral_constant<int, 4> c4{};
+      // phase 0 / 1: quadrants (m0,n0), (m0,n1); B(n1) is fetched while (m0,n0) is multiplied
+      read_b(buf, c0);
+      read_a(buf, c0);
       stage(0, kt + 1);
-      read_b(buf, 1);
-      mma(0, 0);
+      read_b(buf, c1);
+      mma_a(c0, c0, c4);                   // 4 = the B(n1) reads issued behind the A reads
       stage(1, kt + 1);
-      mma(0, 1);
-      __builtin_amdgcn_s_barrier();
-      read_a(buf, 1);
+      mma_b(c0, c1);
+      __builtin_amdgcn_s_barrier();        // every wave has finished its B reads of this buffer -> B halves may be refilled
+      // phase 2 / 3: quadrants (m1,n1), (m1,n0)
+      read_a(buf, c1);
       stage(2, kt + 2);
-      mma(1, 1);
+      mma_a(c1, c1, c0);
       stage(3, kt + 2);
-      mma(1, 0);
+      mma_n(c1, c0);
       if (kt + 2 < nk) PST_VMCNT(4); else PST_VMCNT(0);
       __builtin_amdgcn_s_barrier();
     }

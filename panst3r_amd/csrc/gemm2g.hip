@@ -58,10 +58,24 @@ __device__ __forceinline__ float g2_mul_add_2r(float a, float b, float c) {     
 }
 
 #define PST_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// LDS fragment read at a 32-bit LDS byte address + immediate offset; the waits below tie the MFMAs that consume a fragment to the counted wait
+// that makes it valid (the "+v" operands: the compiler may not move such an MFMA above the wait)
+#define G2_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define G2_LGKM_WAIT(n, a, b0, b1, b2, b3) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3))
+#define G2_LGKM_WAIT1(n, a) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a))
+
+template <bool F16, bool TRANS>
+__device__ __forceinline__ void g2_mfma_row(f32x4 (&acc)[4], const bf16x8& a, const bf16x8 (&b)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = TRANS ? H16<F16>::mfma(a, b[j], acc[j]) : H16<F16>::mfma(b[j], a, acc[j]);
+}
 
 // RES / TRANS: the epilogue classes 2 / 3 of gemm256p_kernel (fp32 residual stream + fold producer outputs / transposed 16-bit store)
-template <bool F16, bool RES, bool TRANS>
-__global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n, const int mode) {
+// ABL: timing ablations of the main loop (tools/g2bench.py; results are garbage): 1 = no MFMAs, 2 = no LDS reads and no MFMAs (the load
+// pipeline alone), 3 = no LDS-DMA in the loop (compute on stale LDS), 0 = the kernel
+template <bool F16, bool RES, bool TRANS, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n, const int mode,
+                                                        long long* trace, const int trace_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p,
   const int key = g2_key(l16);                             // fragment row offsets are multiples of 16: the key depends on l16 only
   const int a_off = (wm * 128 + l16) * 64 + ((g ^ key) << 4);
   const int b_off = G2_A_BYTES + (wn * 64 + l16) * 64 + ((g ^ key) << 4);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of the dynamic segment
   float2* lnst = (float2*)(smem + G2_TAB_LN);
   float* coltab = (float*)(smem + G2_TAB_COL);
   int2* postab = (int2*)(smem + G2_TAB_POS);
@@ -117,8 +132,16 @@ __global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p,
   if ((mode & 1) && (int)blockIdx.x < (int)(gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
   if ((mode & 2) && (int)blockIdx.x >= (int)(gridDim.x >> 1)) {
 #pragma unroll 1
-    for (int i = 0; i < 64 * (mode >> 4); ++i) __builtin_amdgcn_s_sleep(64);
+    for (int i = 0; i < ((mode >> 4) & 15); ++i) __builtin_amdgcn_s_sleep(37);        // ~1 us each (37 x 64 cycles)
   }
+
+  // phase trace (pst_debug_g2_trace; measurement only): per workgroup [1 + 4 * tile] 100 MHz timestamps: HW id | tile start, loop start, loop end, epilogue end
+  long long* tr = (trace && tid == 0) ? trace + (int64_t)blockIdx.x * (1 + 4 * trace_tiles) : nullptr;
+  int tr_n = 0;
+  auto stamp = [&]() {
+    if (tr && tr_n < 4 * trace_tiles) tr[1 + tr_n++] = (long long)__builtin_amdgcn_s_memrealtime();
+  };
+  if (tr) tr[0] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);   // HW_REG_HW_ID | XCC_ID << 32
 
   f32x4 acc[8][4];
   int slot = blockIdx.x;
@@ -127,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p,
   describe(m0, n0);
   stage(0); stage(1);
   for (;;) {
+    stamp();
     // ---- per-tile tables (the previous tile's epilogue is over for every wave: barrier at the end of the loop body)
     if (fold) ln_fold_prologue(p, lnst, tid, m0, 256);
     if (rope) postab[tid] = *(const int2*)(p.rope_pos + 2 * min(m0 + tid, p.M - 1));
@@ -141,26 +165,44 @@ __global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p,
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stamp();
 
     for (int kt = 0; kt < nk; ++kt) {
       // stage kt has landed once at most the 6 LDS-DMA ops of stage kt + 1 are outstanding (in-order vmcnt; at kt = 0 the 6 newest are
       // stage 2, i.e. the wait is stricter than needed by stage 1, which was requested a whole epilogue ago)
       if (kt + 1 < nk) PST_VMCNT(6); else PST_VMCNT(0);
       __builtin_amdgcn_s_barrier();          // ... for every wave; and every wave is done reading slot (kt + 2) % 3 (K step kt - 1)
-      if (kt > 0) stage(kt + 2);
-      const char* buf = smem + (kt % G2_STAGES) * G2_STAGE_BYTES;
+      if (kt > 0 && ABL != 3) stage(kt + 2);
+      const uint32_t sbase = lds0 + (uint32_t)((kt % G2_STAGES) * G2_STAGE_BYTES);
+      if constexpr (ABL == 2) continue;
+      // The 12 fragment reads of the stage are issued back to back and the MFMA groups wait with COUNTED lgkmcnt (the LDS returns in issue
+      // order): group i needs the 4 B fragments and A fragment i = the first 5 + i reads.  Hand-placed (inline asm) because the compiler
+      // either sinks the reads between the MFMA groups (read, lgkmcnt(0), 4 MFMAs, read, ...: the LDS latency exposed eight times per stage,
+      // measured 1 030 cycles per stage for 512 cycles of MFMA) or, fenced, waits for all twelve before the first MFMA.
       bf16x8 af[8], bfr[4];
+      G2_DS_READ(bfr[0], sbase + b_off, 0); G2_DS_READ(bfr[1], sbase + b_off, 1024); G2_DS_READ(bfr[2], sbase + b_off, 2048); G2_DS_READ(bfr[3], sbase + b_off, 3072);
+      G2_DS_READ(af[0], sbase + a_off, 0); G2_DS_READ(af[1], sbase + a_off, 1024); G2_DS_READ(af[2], sbase + a_off, 2048); G2_DS_READ(af[3], sbase + a_off, 3072);
+      G2_DS_READ(af[4], sbase + a_off, 4096); G2_DS_READ(af[5], sbase + a_off, 5120); G2_DS_READ(af[6], sbase + a_off, 6144); G2_DS_READ(af[7], sbase + a_off, 7168);
+      if constexpr (ABL == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(buf + b_off + j * 1024);
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(bfr[j]));
 #pragma unroll
-      for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(buf + a_off + i * 1024);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = TRANS ? H16<F16>::mfma(af[i], bfr[j], acc[i][j]) : H16<F16>::mfma(bfr[j], af[i], acc[i][j]);
+        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(af[i]));
+        continue;
+      }
+      G2_LGKM_WAIT(7, af[0], bfr[0], bfr[1], bfr[2], bfr[3]);
+      g2_mfma_row<F16, TRANS>(acc[0], af[0], bfr); __builtin_amdgcn_sched_barrier(0);
+      G2_LGKM_WAIT1(6, af[1]); g2_mfma_row<F16, TRANS>(acc[1], af[1], bfr); __builtin_amdgcn_sched_barrier(0);
+      G2_LGKM_WAIT1(5, af[2]); g2_mfma_row<F16, TRANS>(acc[2], af[2], bfr); __builtin_amdgcn_sched_barrier(0);
+      G2_LGKM_WAIT1(4, af[3]); g2_mfma_row<F16, TRANS>(acc[3], af[3], bfr); __builtin_amdgcn_sched_barrier(0);
+      G2_LGKM_WAIT1(3, af[4]); g2_mfma_row<F16, TRANS>(acc[4], af[4], bfr); __builtin_amdgcn_sched_barrier(0);
+      G2_LGKM_WAIT1(2, af[5]); g2_mfma_row<F16, TRANS>(acc[5], af[5], bfr); __builtin_amdgcn_sched_barrier(0);
+      G2_LGKM_WAIT1(1, af[6]); g2_mfma_row<F16, TRANS>(acc[6], af[6], bfr); __builtin_amdgcn_sched_barrier(0);
+      G2_LGKM_WAIT1(0, af[7]); g2_mfma_row<F16, TRANS>(acc[7], af[7], bfr); __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_barrier();            // every wave is done with the operand slots: the next tile may be requested
+    stamp();
 
     const int cm0 = m0, cn0 = n0;
     slot += gridDim.x;
@@ -332,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p,
         }
       }
     }
+    stamp();
     if (!more) break;
     __builtin_amdgcn_s_barrier();            // every wave has read this tile's tables: they may be refilled
   }
@@ -347,6 +390,9 @@ int gemm2g_class(const pst_gemm_params& p) {
   return gemm256_persistent_class(p);
 }
 
+static long long* g_trace = nullptr;         // pst_debug_g2_trace
+static int g_trace_tiles = 0;
+void gemm2g_trace(void* buf, int tiles) { g_trace = (long long*)buf; g_trace_tiles = buf ? tiles : 0; }
 static int g_mode = -1;
 static int g2_mode() {                       // PST_TUNE_G2_MODE / PST_G2_MODE; default: static priority for the first dispatch wave
   if (g_mode < 0) {
@@ -372,20 +418,29 @@ int launch_gemm2g(const pst_gemm_params& p, hipStream_t s, int cus) {
     (void)hipFuncSetAttribute((const void*)gemm2g_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
     (void)hipFuncSetAttribute((const void*)gemm2g_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
     (void)hipFuncSetAttribute((const void*)gemm2g_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2g_kernel<true, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2g_kernel<true, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm2g_kernel<true, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
   });
-  const int grid = tiles < 2 * cus ? tiles : 2 * cus;
-  const bool h = p.dtype16 == DT_F16;
   const int mode = g2_mode();
+  const int per_cu = (mode & 8) ? 1 : 2;       // bit 3: one workgroup per CU (measurement: what co-residency is worth)
+  const int grid = tiles < per_cu * cus ? tiles : per_cu * cus;
+  const bool h = p.dtype16 == DT_F16;
   const int cls = gemm2g_class(p);
   if (cls == 3) {
-    if (h) hipLaunchKernelGGL((gemm2g_kernel<true, false, true>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
-    else hipLaunchKernelGGL((gemm2g_kernel<false, false, true>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
+    if (h) hipLaunchKernelGGL((gemm2g_kernel<true, false, true>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode, g_trace, g_trace_tiles);
+    else hipLaunchKernelGGL((gemm2g_kernel<false, false, true>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode, g_trace, g_trace_tiles);
   } else if (cls == 2) {
-    if (h) hipLaunchKernelGGL((gemm2g_kernel<true, true, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
-    else hipLaunchKernelGGL((gemm2g_kernel<false, true, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
+    if (h) hipLaunchKernelGGL((gemm2g_kernel<true, true, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode, g_trace, g_trace_tiles);
+    else hipLaunchKernelGGL((gemm2g_kernel<false, true, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode, g_trace, g_trace_tiles);
+  } else if (h && (mode >> 8) != 0) {       // ablations (plain f16 class only; timing tools)
+    const int abl = mode >> 8;
+    if (abl == 1) hipLaunchKernelGGL((gemm2g_kernel<true, false, false, 1>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode, g_trace, g_trace_tiles);
+    else if (abl == 2) hipLaunchKernelGGL((gemm2g_kernel<true, false, false, 2>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode, g_trace, g_trace_tiles);
+    else hipLaunchKernelGGL((gemm2g_kernel<true, false, false, 3>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode, g_trace, g_trace_tiles);
   } else {
-    if (h) hipLaunchKernelGGL((gemm2g_kernel<true, false, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
-    else hipLaunchKernelGGL((gemm2g_kernel<false, false, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode);
+    if (h) hipLaunchKernelGGL((gemm2g_kernel<true, false, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode, g_trace, g_trace_tiles);
+    else hipLaunchKernelGGL((gemm2g_kernel<false, false, false>), dim3(grid), dim3(256), G2_LDS, s, p, tiles, tiles_m, tiles_n, mode, g_trace, g_trace_tiles);
   }
   return check_launch("gemm2g");
 }

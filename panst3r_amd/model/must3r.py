@@ -196,8 +196,6 @@ class MUSt3R(HipModule):
         D, H, L = self.embed_dim, self.num_heads, self.depth
         hd = D // H
         T = h * w
-        if T % 4:
-            raise NotImplementedError('HIP memory bank needs T %% 4 == 0 tokens per view (got %d)' % T)
         if not ((n == 2 and bank.n == 0) or (n == 1 and bank.n > 0)):
             raise NotImplementedError('memory batches other than [2,1,1,...] are not on the HIP path')
         lay = Layout(n, T)
@@ -263,8 +261,6 @@ class MUSt3R(HipModule):
         hd = D // H
         assert bank.n == 0 and bank.nimgs == 0
         Ts = [h * w for h, w in grids]
-        if any(T % 4 for T in Ts):
-            raise NotImplementedError('HIP memory bank needs T %% 4 == 0 tokens per view (got %s)' % Ts)
         lays = [Layout(1, T) for T in Ts]
         xs = [self._embed(pk, x_enc[i], lays[i], first_is_ref=(i == 0)) for i in range(2)]
         poss = [grid_pos(1, h, w, lay.Tp, 0, dev) for (h, w), lay in zip(grids, lays)]
@@ -327,8 +323,17 @@ class MUSt3R(HipModule):
                 hip.layernorm(hs[l], c['norm_y'][0], c['norm_y'][1], y[l], c['norm_y'][2], rows=rows, grp=lay.grp, add=fb)
         hip.gemm(y[0], pk['mem_kw'][0], bank.K_all[0, bank.n: bank.n + rows], bias=pk['mem_kb'][0],
                  batch=(L, rows * D, pk['mem_kw'].stride(0), bank.K_all.stride(0), D))
-        hip.gemm(y[0], pk['mem_vw'][0], bank.Vt_all[0][:, bank.n:], bias=pk['mem_vb'][0], trans_out=True,
-                 batch=(L, rows * D, pk['mem_vw'].stride(0), bank.Vt_all.stride(0), D))
+        if bank.n % 4 == 0:
+            hip.gemm(y[0], pk['mem_vw'][0], bank.Vt_all[0][:, bank.n:], bias=pk['mem_vb'][0], trans_out=True,
+                     batch=(L, rows * D, pk['mem_vw'].stride(0), bank.Vt_all.stride(0), D))
+        else:
+            # token grids with T % 4 != 0 (e.g. 336 x 336: 21 x 21 = 441 tokens, tools/demo_panst3r.py:72): the bank stays DENSE (no pad keys
+            # inside the softmax), so the new columns start at an address the transposed store's 8-byte vectors cannot take: project into an
+            # aligned scratch and place the block with one strided device copy (plumbing: no arithmetic)
+            tmp = torch.empty(L, D, (rows + 7) // 8 * 8 + 8, dtype=adt(), device=dev)
+            hip.gemm(y[0], pk['mem_vw'][0], tmp[0], bias=pk['mem_vb'][0], trans_out=True,
+                     batch=(L, rows * D, pk['mem_vw'].stride(0), tmp.stride(0), D))
+            bank.Vt_all[:, :, bank.n:bank.n + rows].copy_(tmp[:, :, :rows])
         bank.n += n * T
         bank.labels += list(range(bank.nimgs, bank.nimgs + n))
         bank.nimgs += n

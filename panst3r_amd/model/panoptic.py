@@ -514,9 +514,13 @@ class MaskTransformer(HipModule):
                 o0 += h * w
         out = pk['qf'].clone()
         qpos = pk['qe']
-        NKm = ceil_to(NK, 4)
+        NKm = ceil_to(NK, 4)                   # mask rows are 4-byte aligned and the logit GEMM wants N % 4 == 0: odd token grids (21 x 21 at 336 x 336)
         mask = torch.zeros(Q, NKm, dtype=torch.uint8, device=dev)
-        logits_attn = empty(Q, NK, torch.float32, dev)
+        logits_attn = empty(Q, NKm, torch.float32, dev)[:, :NK]
+        if NKm != NK:                          # ... get up to 3 zero key rows behind the real ones (their logits are never looked at)
+            fm_p = torch.zeros(NKm, C, dtype=fm.dtype, device=dev)
+            fm_p[:NK].copy_(fm)
+            fm = fm_p
 
         forced, log = self._instr if self._instr is not None else (None, None)
         if (forced is not None or log is not None) and torch.cuda.is_current_stream_capturing():
@@ -526,16 +530,14 @@ class MaskTransformer(HipModule):
         def next_mask(o):
             dn, emb = self._embed(pk, o)
             if forced is not None:           # parity instrumentation (tests / bench.py): take the attention-mask BITS of this decoder layer from
-                mask.copy_(forced[step[0]])  # outside, so that the hard threshold at logit 0 cannot amplify a 1e-3 difference into another query
+                mask[:, :NK].copy_(forced[step[0]])  # outside, so that the hard threshold at logit 0 cannot amplify a 1e-3 difference into another query
             else:
-                hip.gemm(emb, fm, logits_attn)
-                hip.attn_mask_from_logits(logits_attn, mask[:, :NK] if NKm == NK else mask)
+                hip.gemm(emb, fm, logits_attn if NKm == NK else logits_attn.as_strided((Q, NKm), (NKm, 1)))
+                hip.attn_mask_from_logits(logits_attn, mask)          # row stride NKm = NK rounded up to 4 bytes; columns >= NK are never read
             if log is not None:
-                log.append(mask.clone())
+                log.append(mask[:, :NK].clone())
             step[0] += 1
             return dn, emb
-        if NKm != NK:
-            raise NotImplementedError('total keyframe tokens must be a multiple of 4')
         next_mask(out)
         qin, ob = empty(Q, d, adt(), dev), empty(Q, d, adt(), dev)
         t32 = empty(Q, d, torch.float32, dev)

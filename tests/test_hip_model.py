@@ -355,3 +355,27 @@ def test_scene_at_benchmark_depth(pair, V, K):
     assert max(pm_err) < 2e-2, pm_err
     assert q_err < 2e-2 and l_err < 0.05, (q_err, l_err)
     assert mask_err < 3e-2 and agree >= sign_floor(h), (mask_err, agree)          # bf16: 0.9944-0.9971 measured          # pooled over the scene's pixels, as SURVEY 8(d) states it
+
+
+@pytest.mark.parametrize('H,W,V,K', [(112, 112, 5, 3), (80, 112, 4, 4)])
+def test_scene_odd_token_grids(pair, H, W, V, K):
+    """Token grids whose size is not a multiple of 4 (the demo's --image_size 336 gives 21 x 21 = 441 tokens, tools/demo_panst3r.py:72): here
+    7 x 7 = 49 and 5 x 7 = 35 tokens per view.  The memory bank stays dense (appends at unaligned key offsets), the query decoder's key count
+    K * T is odd (147) - against the oracle, and graph replay == eager."""
+    variant, o, h = pair
+    imgs = tiny.images(V, H, W)
+    ts = torch.tensor([[H, W]] * V)
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K)
+    pm_h, pan_h = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K, amp=h.amp)
+    for a, b in zip(pm_h, pm_o):
+        assert rel_l2(a.cpu(), b) < 2e-2
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 2e-2
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.05
+    for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
+        assert rel_l2(a.cpu(), b) < mask_tol(h)
+    runner = h.scene_runner({i: im.to(DEV) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=h.amp)
+    runner.run()
+    res, scene = runner.run()
+    assert torch.equal(scene['out_queries'], pan_h['out_queries'])
+    for i in range(V):
+        assert torch.equal(res[i][0], pm_h[i]) and torch.equal(res[i][1], pan_h['pred_masks'][i])

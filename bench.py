@@ -215,6 +215,8 @@ def main():
                     '(+8 %% frames/s; was not reproducible until one kernel was fixed, mechanism not understood: DESIGN.md section 4); default: back to back')
     ap.add_argument('--no-overlap', action='store_true', help=argparse.SUPPRESS)       # former switch; serial is the default now
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying HIP graphs')
+    ap.add_argument('--plan', default='replicated', choices=['replicated', 'broadcast'],
+                    help="multi-GPU plan (panst3r_amd/scene.py): every rank repeats the memory build | rank 0 builds and broadcasts the banks")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -246,7 +248,7 @@ def main():
     model.to(dev)
 
     from panst3r_amd.scene import assign_views
-    _, order, owner = assign_views(V, K, world)
+    _, order, owner = assign_views(V, K, world, plan=args.plan)
     mine = {order[i] for i in range(V) if owner[i] == rank}
     images = {i: synth_image(i, H, W).to(dev) for i in sorted(mine)}        # inputs resident in HBM before timing
 
@@ -257,7 +259,7 @@ def main():
 
     def measure(amp, steps, warmup, instrument):
         """W untimed warm-up steps (the first also captures the three HIP graphs), then EXACTLY `steps` timed steps between two fences."""
-        runner = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager, overlap=args.overlap and not args.no_overlap, amp=amp)
+        runner = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager, overlap=args.overlap and not args.no_overlap, amp=amp, plan=args.plan)
         for _ in range(max(warmup, 1)):
             runner.run(copy=False)
         timer = None
@@ -298,7 +300,7 @@ def main():
             'config': {'workload': 'PanSt3R_%s_512 scene: %d views, %d keyframes, %dx%d, 100 classes, random-init full-size weights'
                                    % (args.variant, V, K, H, W),
                        'variant': args.variant, 'views': V, 'keyframes': K, 'resolution': [H, W],
-                       'parallelism': 'views sharded over %d rank(s)' % world,
+                       'parallelism': 'views sharded over %d rank(s), plan %s' % (world, args.plan),
                        'operands': "%s MFMA operands, fp32 accumulate / residual streams / softmax / statistics (reference --amp %s, tools/demo_panst3r.py:88)"
                                    % ('f16' if args.amp == 'fp16' else 'bf16', args.amp),
                        'launch': 'eager' if args.eager else 'HIP-graph replay (3 graphs per scene; last timed step eager + HIP-event instrumented)',

@@ -167,11 +167,19 @@ __global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p,
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     stamp();
 
+    if (mode & 4) __builtin_amdgcn_s_setprio(2);     // phase priority: a workgroup in its main loop outranks its partner's epilogue at the issue port
+    // fine trace (mode bit 10, with pst_debug_g2_trace on; workgroup 0, thread 0, first tile, no RoPE): per K step three 100 MHz stamps -
+    // top of the iteration, after the vmcnt wait, after the barrier - kept in the (unused) position table, dumped behind the phase trace
+    const bool fine = tr && (mode & 1024) && blockIdx.x == 0 && tr_n == 2 && !rope;
+    long long* fst = (long long*)postab;
     for (int kt = 0; kt < nk; ++kt) {
+      if (fine && kt < 80) fst[3 * kt] = (long long)__builtin_amdgcn_s_memrealtime();
       // stage kt has landed once at most the 6 LDS-DMA ops of stage kt + 1 are outstanding (in-order vmcnt; at kt = 0 the 6 newest are
       // stage 2, i.e. the wait is stricter than needed by stage 1, which was requested a whole epilogue ago)
       if (kt + 1 < nk) PST_VMCNT(6); else PST_VMCNT(0);
+      if (fine && kt < 80) fst[3 * kt + 1] = (long long)__builtin_amdgcn_s_memrealtime();
       __builtin_amdgcn_s_barrier();          // ... for every wave; and every wave is done reading slot (kt + 2) % 3 (K step kt - 1)
+      if (fine && kt < 80) { fst[3 * kt + 2] = (long long)__builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
       if (kt > 0 && ABL != 3) stage(kt + 2);
       const uint32_t sbase = lds0 + (uint32_t)((kt % G2_STAGES) * G2_STAGE_BYTES);
       if constexpr (ABL == 2) continue;
@@ -202,7 +210,12 @@ __global__ __launch_bounds__(256, 2) void gemm2g_kernel(const pst_gemm_params p,
       G2_LGKM_WAIT1(0, af[7]); g2_mfma_row<F16, TRANS>(acc[7], af[7], bfr); __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_barrier();            // every wave is done with the operand slots: the next tile may be requested
+    if (mode & 4) __builtin_amdgcn_s_setprio(0);
     stamp();
+    if (fine) {
+      long long* dst = trace + (int64_t)gridDim.x * (1 + 4 * trace_tiles);
+      for (int i = 0; i < 3 * min(nk, 80); ++i) dst[i] = fst[i];
+    }
 
     const int cm0 = m0, cn0 = n0;
     slot += gridDim.x;

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')
+LIB_PATH = os.environ.get('PST_LIB') or os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')      # PST_LIB: A/B builds of the same ABI (measurement)
 ABI_VERSION = 15
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None

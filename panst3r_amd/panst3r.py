@@ -281,15 +281,17 @@ class PanSt3R(nn.Module):
         self._runners.clear()
 
     @torch.no_grad()
-    def forward_inference_sharded(self, get_image, V, H, W, classes, num_keyframes=None, outdevice=None, group=None, amp=False):
+    def forward_inference_sharded(self, get_image, V, H, W, classes, num_keyframes=None, outdevice=None, group=None, amp=False, plan='replicated'):
         """View-sharded scene over the ranks of `group` (one process per GPU, RCCL): returns this rank's
-        {view_id: (pointmap, masks)} and the scene-level dict.  See panst3r_amd/scene.py for the plan."""
+        {view_id: (pointmap, masks)} and the scene-level dict.  See panst3r_amd/scene.py for the two plans ('replicated': every rank
+        repeats the memory build; 'broadcast': rank 0 builds and broadcasts the banks while the others encode)."""
         import torch.distributed as dist
         from .scene import run_scene, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-        return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice, amp=amp)
+        return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice, amp=amp, plan=plan)
 
-    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None, keyframes=None, amp=False):
+    def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None, keyframes=None, amp=False,
+                     plan='replicated'):
         """Static-shape scene runner (panst3r_amd/scene.py): `images` = {view_id: [3,H,W] device tensor} of the views
         this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True.
         `overlap=True` runs the memory build beside the bulk encoder work on a second stream (faster, NOT reproducible on this
@@ -297,7 +299,8 @@ class PanSt3R(nn.Module):
         import torch.distributed as dist
         from .scene import SceneRunner, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes, amp=amp)
+        return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes, amp=amp,
+                           plan=plan)
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False):

@@ -10,6 +10,11 @@ Plan (one process per GPU; RCCL over xGMI when the backend is "nccl", gloo in th
   E. each rank computes the query x pixel masks of its views                                       -- no collective
 The math per view is independent of the sharding, so results equal the 1-GPU run of the same build.
 
+Second plan, `plan='broadcast'` (SURVEY 8(e) option 2): the build is a chain of ~3 300 tiny kernels (25.7 ms at K = 16) that every rank of the
+replicated plan repeats.  Here ONLY rank 0 builds: it owns no view but its keyframes, builds right after gather B and broadcasts the projected
+K / V^T banks (27 MiB x K), while ranks 1.. spend that time on their (larger) share of the encoder / DINOv2 work; then everyone renders.  Same
+results (the bank is built once, by the same kernels, and copied bit for bit).
+
 `run_scene` is written against a small stage backend so that the same orchestration is exercised on the GPU
 (HipBackend: the HIP kernels) and in the world_size-2 gloo tests on CPU (tests/ provide an oracle-driven backend).
 """
@@ -19,10 +24,17 @@ import torch.distributed as dist
 from .schedule import select_keyframes, view_order
 
 
-def assign_views(V, K, world, keyframes=None):
+PLANS = ('replicated', 'broadcast')
+
+
+def assign_views(V, K, world, keyframes=None, plan='replicated'):
     """keyframes (in schedule order) dealt round-robin to ranks, then the remaining views continue the deal.
     Returns (keyframes, order, owner) with owner[i] = rank of order[i].  `keyframes`: an explicit list of distinct view ids in
-    memory-build order (e.g. schedule.keyframes_from_similarity, the reference's retrieval mode) instead of the linspace schedule."""
+    memory-build order (e.g. schedule.keyframes_from_similarity, the reference's retrieval mode) instead of the linspace schedule.
+    plan='broadcast': rank 0 (the only rank that builds the memory) gets no view beyond its keyframes; the other views are dealt over
+    ranks 1 .. world-1."""
+    if plan not in PLANS:
+        raise ValueError('plan must be one of %s (got %r)' % (PLANS, plan))
     if keyframes is None:
         keyframes = select_keyframes(V, K)
     else:
@@ -30,7 +42,11 @@ def assign_views(V, K, world, keyframes=None):
         if len(set(keyframes)) != len(keyframes) or not all(0 <= k < V for k in keyframes) or len(keyframes) < 2:
             raise ValueError('keyframes must be >= 2 distinct view ids in [0, %d): %s' % (V, keyframes))
     order, _ = view_order(V, keyframes)
-    owner = [i % world for i in range(V)]
+    Kn = len(keyframes)
+    if plan == 'broadcast' and world > 1:
+        owner = [i % world for i in range(Kn)] + [1 + (i % (world - 1)) for i in range(V - Kn)]
+    else:
+        owner = [i % world for i in range(V)]
     return keyframes, order, owner
 
 
@@ -67,6 +83,14 @@ def gather_keyframe_rows(local_rows, K, T, rank, world, group):
     return out
 
 
+def broadcast_tensors(tensors, src, world, group):
+    """broadcast a list of equally-shaped-on-every-rank tensors from `src` (byte views: every backend moves uint8)."""
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return
+    for t in tensors:
+        dist.broadcast(t.view(torch.uint8) if t.is_contiguous() else t, src, group=group)
+
+
 # Run the two independent branches of stage 2 (sequential memory build || bulk encoder + DINOv2) on two streams.  OFF by default:
 # with two HIP queues active, the output of the first DINOv2 kernel intermittently lost 64-byte half-lines (seen as DINOv2 tokens of
 # whole views deviating), in captured graphs as well as eager launches, depending on the scene shape, and triggered just as well by a
@@ -97,7 +121,7 @@ class SceneRunner:
     (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
     def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None,
-                 amp=None):
+                 amp=None, plan='replicated'):
         self.b, self.V, self.classes = backend, V, classes
         self.amp = amp                # False | 'bf16' | 'fp16' (reference utils.py:206-215): 16-bit format of this runner, fixed for its lifetime
         self._refs = None             # packed weights / tables the captured graphs point into (kept alive with the runner)
@@ -109,8 +133,14 @@ class SceneRunner:
         self.K = K = len(keyframes) if keyframes is not None else (V if (K is None or K > V) else max(int(K), 2))
         if V < world:
             raise ValueError('need at least one view per rank (V=%d, world=%d)' % (V, world))
+        if plan == 'broadcast' and world > 1 and K < world:
+            raise ValueError("plan='broadcast' deals the keyframes over all ranks and the other views over ranks 1..: it needs K >= world (K=%d, world=%d)" % (K, world))
         self.shapes = [tuple(sh) for sh in shapes] if shapes is not None else [(H, W)] * V      # per view id
-        self.keyframes, self.order, owner = assign_views(V, K, world, keyframes)
+        self.plan = plan
+        self.keyframes, self.order, owner = assign_views(V, K, world, keyframes, plan)
+        self.builder = plan == 'replicated' or rank == 0        # this rank runs the sequential memory build
+        # the broadcast plan's split stage 2 also runs on a 1-rank process group (PST_FORCE_DIST=1: the collectives execute on RCCL at world = 1)
+        self.split = plan == 'broadcast' and (world > 1 or (dist.is_available() and dist.is_initialized()))
         self.mine = [i for i in range(V) if owner[i] == rank]       # positions in `order`; keyframe positions first
         self.n_local = len(self.mine)
         self.k_local = sum(1 for i in self.mine if i < K)
@@ -145,7 +175,7 @@ class SceneRunner:
         self.serial = not (OVERLAP_DEFAULT if overlap is None else overlap)      # True: the two branches of stage 2 run back-to-back
         self.graphs = None
         self.enc_kf = self.both_kf = None
-        self.out = None
+        self.out = self.bank = None
 
     def _kf_rows(self, per_group_rows):
         """concatenate this rank's keyframe rows (one [k_g*T_g, C] tensor per group) in deal order."""
@@ -187,10 +217,25 @@ class SceneRunner:
             self.enc_kf.copy_(kf)
 
     def stage2(self):
-        """The sequential memory build is a chain of thousands of tiny kernels that leaves most CUs idle; with `overlap` the
-        independent bulk work (_encode_rest) runs concurrently on a second stream (a parallel branch of the captured graph)."""
+        """replicated plan: everything between the two all-gathers as ONE stage (one captured graph)."""
+        self.stage2a()
+        self.stage2b()
+
+    def stage2a(self):
+        """Up to the point where the memory bank exists on the rank that builds it.
+        The sequential memory build is a chain of thousands of tiny kernels that leaves most CUs idle; with `overlap` the
+        independent bulk work (_encode_rest) runs concurrently on a second stream (a parallel branch of the captured graph).
+        plan='broadcast': rank 0 builds and nothing else (its own encoder / DINOv2 work follows in stage2b, behind the broadcast); the other
+        ranks do their bulk work here and allocate the bank they receive."""
         b = self.b
         dev = self.groups[0].imgs.device
+        if self.split:
+            if self.builder:
+                self.bank = b.build_memory(self.enc_kf, self.K, self.kf_grids)
+            else:
+                self._encode_rest()
+                self.bank = b.bank_alloc(self.K, self.kf_grids, dev)
+            return
         # (measured +5 % frames/s at 50 views, but unsafe on this platform - see OVERLAP_DEFAULT - hence only when asked for)
         side = b.side_stream(dev) if not self.serial else None
         if side is None:
@@ -208,6 +253,18 @@ class SceneRunner:
             else:
                 bank = b.build_memory(self.enc_kf, self.K, self.kf_grids)
                 main.wait_stream(side)
+        self.bank = bank
+
+    def bank_exchange(self):
+        """plan='broadcast': the projected K / V^T caches of all layers go from rank 0 to everybody (RCCL broadcast over xGMI; 27 MiB x K)."""
+        if self.split:
+            broadcast_tensors(self.b.bank_payload(self.bank), 0, self.world, self.group)
+
+    def stage2b(self):
+        b = self.b
+        if self.split and self.builder:
+            self._encode_rest()                    # rank 0's own (keyframe) views: DINOv2 + guidance, after the bank is on its way
+        bank = self.bank
         rows = []
         for g in self.groups:
             n = len(g.idx)
@@ -236,15 +293,25 @@ class SceneRunner:
                 masks[j] = b.masks(head, g.mf, r)
         self.out = (outq, b.logits(head), masks)
 
+    def _segments(self):
+        """[(stage, collective run eagerly behind it | None)]: the replicated plan has three stages, the broadcast plan splits stage 2 around the
+        bank broadcast"""
+        if self.split:
+            return [(self.stage1, self.gather1), (self.stage2a, self.bank_exchange), (self.stage2b, self.gather2), (self.stage3, None)]
+        return [(self.stage1, self.gather1), (self.stage2, self.gather2), (self.stage3, None)]
+
     def _eager(self):
-        self.stage1(); self.gather1(); self.stage2(); self.gather2(); self.stage3()
+        for stage, coll in self._segments():
+            stage()
+            if coll is not None:
+                coll()
 
     def release(self):
         """Drop everything the runner holds on the device (stacked inputs, feature / mask-feature buffers, gathered keyframe rows, captured
         graphs).  Outputs already handed out by results() stay valid: they are tensors of their own."""
         for g in self.groups:
             g.imgs = g.cat = g.pointmaps = g.fpn = g.mf = g.guid = None
-        self.enc_kf = self.both_kf = self.enc_send = self.both_send = self.out = self.graphs = self._refs = None
+        self.enc_kf = self.both_kf = self.enc_send = self.both_send = self.out = self.graphs = self._refs = self.bank = None
 
     def set_images(self, images):
         """Load a new scene of the SAME shapes / schedule into the static input buffers (the captured graphs read them in place).
@@ -262,7 +329,7 @@ class SceneRunner:
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         self.graphs = []
-        for stage, gather in ((self.stage1, self.gather1), (self.stage2, self.gather2), (self.stage3, None)):
+        for stage, gather in self._segments():
             g = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of torch.distributed may query events while we capture
             with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
@@ -291,7 +358,10 @@ class SceneRunner:
                 if self.graphs is None:
                     self._capture()
                 else:
-                    self.graphs[0].replay(); self.gather1(); self.graphs[1].replay(); self.gather2(); self.graphs[2].replay()
+                    for g, (_, coll) in zip(self.graphs, self._segments()):
+                        g.replay()
+                        if coll is not None:
+                            coll()
             else:
                 self._eager()
         return self.results(outdevice, copy=copy)
@@ -313,15 +383,15 @@ class SceneRunner:
 
 
 @torch.no_grad()
-def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None, keyframes=None, amp=None):
+def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None, keyframes=None, amp=None, plan='replicated'):
     """Run one scene eagerly.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
     Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
     {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W);
     `keyframes`: optional explicit keyframe list in memory-build order (overrides the linspace schedule of K)."""
     Kc = V if (K is None or K > V) else max(int(K), 2)
-    _, order, owner = assign_views(V, Kc, world, keyframes)
+    _, order, owner = assign_views(V, Kc, world, keyframes, plan)
     images = {order[i]: get_image(order[i]) for i in range(V) if owner[i] == rank}
-    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes, amp=amp).run(outdevice)
+    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes, amp=amp, plan=plan).run(outdevice)
 
 
 class HipBackend:
@@ -365,6 +435,16 @@ class HipBackend:
 
     def build_memory(self, enc_kf, K, grids):
         return self.m.build_memory(enc_kf, K, grids=grids)
+
+    def bank_payload(self, bank):
+        return [bank.K_all, bank.Vt_all]
+
+    def bank_alloc(self, K, grids, device):
+        """an empty memory bank of the shape build_memory leaves behind (plan='broadcast': filled by the broadcast from rank 0)"""
+        n = sum(a * c for a, c in grids)
+        bank = self.m.must3r_decoder.new_bank(device, n)
+        bank.n, bank.labels, bank.nimgs = n, list(range(K)), K
+        return bank
 
     def render(self, cat, n, h, w, bank):
         return self.m.render_views(cat, n, h, w, bank)

@@ -55,6 +55,14 @@ class OracleBackend:
         return build_memory(self.m.must3r_decoder, xs, [self._pos(h, w)[0] for h, w in grids], [[h * p, w * p] for h, w in grids],
                             mem_batches_for(K))
 
+    def bank_payload(self, bank):
+        return list(bank[0]) + [bank[1]]
+
+    def bank_alloc(self, K, grids, device):
+        n = sum(a * c for a, c in grids)
+        vals = [torch.zeros(1, n, self.Dd) for _ in range(self.m.must3r_decoder.depth)]
+        return (vals, torch.zeros(1, n, dtype=torch.long), K, 0, 0)
+
     def render(self, cat, n, h, w, bank):
         T, p = h * w, self.patch_size
         pms = []

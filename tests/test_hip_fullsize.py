@@ -265,15 +265,15 @@ def test_full_size_graph_replay_equals_eager(full):
             assert torch.equal(r[k][0], ref[k][0]) and torch.equal(r[k][1], ref[k][1]), (kw, k)
 
 
-def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, keyframes=None, amp='fp16'):
+def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, keyframes=None, amp='fp16', plan='replicated'):
     """N ranks of the view-sharded plan on ONE GPU: N SceneRunners stepped in lock-step, the two all-gathers replaced by a fake that
     hands every rank the rows the others would send (the RCCL transport itself is covered by PST_FORCE_DIST / the driver's runs)."""
     import panst3r_amd.scene as S
-    order_owner = S.assign_views(V, V if (K is None or K > V) else max(int(K), 2), world, keyframes)
+    order_owner = S.assign_views(V, V if (K is None or K > V) else max(int(K), 2), world, keyframes, plan)
     runners = []
     for r in range(world):
         mine = {order_owner[1][i]: imgs[order_owner[1][i]] for i in range(V) if order_owner[2][i] == r}
-        runners.append(S.SceneRunner(S.HipBackend(model), mine, V, H, W, K, names, rank=r, world=world, keyframes=keyframes, amp=amp))
+        runners.append(S.SceneRunner(S.HipBackend(model), mine, V, H, W, K, names, rank=r, world=world, keyframes=keyframes, amp=amp, plan=plan))
     sends = []
     monkeypatch.setattr(S, '_all_gather_rows', lambda t, counts, w, g: [s[:c] for s, c in zip(sends, counts)])
     with torch.no_grad():
@@ -282,8 +282,21 @@ def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, k
         sends[:] = [rn.enc_send for rn in runners]
         for rn in runners:
             rn.gather1()
-        for rn in runners:
-            rn.stage2()
+        if plan == 'broadcast':                # rank 0 builds, the others encode; the broadcast = a device copy of rank 0's banks
+            from panst3r_amd.model.common import precision
+            for rn in runners:
+                with precision(amp):
+                    rn.stage2a()
+            src = runners[0].b.bank_payload(runners[0].bank)
+            for rn in runners[1:]:
+                for d, t in zip(rn.b.bank_payload(rn.bank), src):
+                    d.copy_(t)
+            for rn in runners:
+                with precision(amp):
+                    rn.stage2b()
+        else:
+            for rn in runners:
+                rn.stage2()
         sends[:] = [rn.both_send for rn in runners]
         for rn in runners:
             rn.gather2()
@@ -296,8 +309,8 @@ def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, k
     return res, scenes
 
 
-@pytest.mark.parametrize('V,K,world', [(13, 4, 2), (50, 16, 8)])
-def test_full_size_sharded_equals_unsharded_on_one_gpu(full, monkeypatch, V, K, world):
+@pytest.mark.parametrize('V,K,world,plan', [(13, 4, 2, 'replicated'), (50, 16, 8, 'replicated'), (50, 16, 8, 'broadcast')])
+def test_full_size_sharded_equals_unsharded_on_one_gpu(full, monkeypatch, V, K, world, plan):
     """what `bench.py --gpus 8` computes (50 views, 16 keyframes, 6-7 views per rank) equals the 1-GPU scene BIT FOR BIT -
     every launch is row-independent and the smaller per-rank launches pick bit-compatible kernel variants (GEMM tile sizes, attention
     split-K choice).  All ranks must also hold identical frozen queries / class logits."""
@@ -308,7 +321,7 @@ def test_full_size_sharded_equals_unsharded_on_one_gpu(full, monkeypatch, V, K, 
     imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
     with torch.no_grad():
         ref, sref = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=False).run()
-    res, scenes = run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch)
+    res, scenes = run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, plan=plan)
     assert sorted(res) == list(range(V))
     for s in scenes:
         assert torch.equal(s['out_queries'], sref['out_queries']) and torch.equal(s['pred_logits'], sref['pred_logits'])

@@ -379,3 +379,34 @@ def test_scene_odd_token_grids(pair, H, W, V, K):
     assert torch.equal(scene['out_queries'], pan_h['out_queries'])
     for i in range(V):
         assert torch.equal(res[i][0], pm_h[i]) and torch.equal(res[i][1], pan_h['pred_masks'][i])
+
+
+def test_rccl_collectives_at_world_1(pair):
+    """The collectives of both multi-GPU plans on the real transport (backend "nccl" = RCCL) with a 1-rank process group on this GPU (what
+    PST_FORCE_DIST=1 does for bench.py): the two uneven all-gathers of keyframe rows (byte views) and, for plan='broadcast', the broadcast of the
+    memory banks between the split stage-2 graphs - eager and as captured-graph replay - must reproduce the scene computed without a process
+    group, bit for bit."""
+    import socket
+    import torch.distributed as dist
+    variant, o, h = pair
+    V, K, H, W = 5, 3, 64, 96
+    imgs = {i: im.to(DEV) for i, im in enumerate(tiny.images(V, H, W))}
+    with torch.no_grad():
+        ref, sref = h.scene_runner(imgs, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=False, amp=h.amp).run()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        for plan in ('replicated', 'broadcast'):
+            for graphs in (False, True):
+                runner = h.scene_runner(imgs, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=graphs, amp=h.amp, plan=plan)
+                assert runner.split == (plan == 'broadcast')
+                with torch.no_grad():
+                    runner.run()
+                    res, scene = runner.run()
+                assert torch.equal(scene['out_queries'], sref['out_queries']), (plan, graphs)
+                for i in range(V):
+                    assert torch.equal(res[i][0], ref[i][0]) and torch.equal(res[i][1], ref[i][1]), (plan, graphs, i)
+    finally:
+        dist.destroy_process_group()

@@ -16,12 +16,12 @@ from panst3r_amd.scene import run_scene, assign_views, gather_keyframe_rows
 H, W = 64, 96
 
 
-def _scene(variant, V, K, rank=0, world=1, group=None):
+def _scene(variant, V, K, rank=0, world=1, group=None, plan='replicated'):
     torch.set_num_threads(2)
     model = tiny.build(tiny.OracleNS, variant)
     imgs = tiny.images(V, H, W)
     with torch.no_grad():
-        return run_scene(OracleBackend(model), lambda i: imgs[i], V, H, W, K, tiny.NAMES, rank, world, group)
+        return run_scene(OracleBackend(model), lambda i: imgs[i], V, H, W, K, tiny.NAMES, rank, world, group, plan=plan)
 
 
 def test_assign_views():
@@ -30,6 +30,14 @@ def test_assign_views():
     assert sorted(order) == list(range(50)) and order[:16] == kf
     assert max(owner.count(r) for r in range(8)) - min(owner.count(r) for r in range(8)) <= 1
     assert [owner[i] for i in range(16)] == [i % 8 for i in range(16)]
+    # plan='broadcast' (SURVEY 8(e) option 2): rank 0 builds the memory and owns nothing but its keyframes
+    kf2, order2, owner2 = assign_views(50, 16, 8, plan='broadcast')
+    assert kf2 == kf and order2 == order and owner2[:16] == owner[:16]
+    assert owner2.count(0) == 2 and all(r != 0 for r in owner2[16:])
+    assert max(owner2.count(r) for r in range(1, 8)) - min(owner2.count(r) for r in range(1, 8)) <= 1
+    assert assign_views(50, 16, 1, plan='broadcast')[2] == [0] * 50
+    with pytest.raises(ValueError):
+        assign_views(50, 16, 8, plan='ring')
 
 
 @pytest.mark.parametrize('variant', ['v1', 'v2'])
@@ -123,7 +131,7 @@ def _scene_kind(kind):
     return PORTRAIT_AR, [tiny.synth_image(i, h, w, 11) for i, (h, w) in enumerate(PORTRAIT_AR)]
 
 
-def _worker(rank, world, port, variant, V, K, q):
+def _worker(rank, world, port, variant, V, K, q, plan='replicated'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -133,9 +141,9 @@ def _worker(rank, world, port, variant, V, K, q):
             shapes, imgs = _scene_kind(V)
             with torch.no_grad():
                 res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], len(shapes), None, None, K, tiny.NAMES, rank, world, None,
-                                       shapes=shapes)
+                                       shapes=shapes, plan=plan)
         else:
-            res, scene = _scene(variant, V, K, rank, world, None)
+            res, scene = _scene(variant, V, K, rank, world, None, plan)
         t = torch.arange(6, dtype=torch.bfloat16).reshape(3, 2) + 10 * rank if rank == 0 else torch.arange(4, dtype=torch.bfloat16).reshape(2, 2) + 10
         g = gather_keyframe_rows(t, 5, 1, rank, world, None)                # K=5 dealt 3/2 over two ranks, bf16 payload
         # numpy payloads are pickled by value: torch tensors would travel as shared-memory fds that die with this process
@@ -148,14 +156,17 @@ def _worker(rank, world, port, variant, V, K, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('variant,V,K', [('v1', 5, 3), ('v2', 4, 2), ('v1', 'multi_ar', 4), ('v2', 'portrait', 3)])
-def test_two_rank_gloo_equals_single(variant, V, K):
+@pytest.mark.parametrize('variant,V,K,plan', [('v1', 5, 3, 'replicated'), ('v2', 4, 2, 'replicated'), ('v1', 'multi_ar', 4, 'replicated'), ('v2', 'portrait', 3, 'replicated'),
+                                              ('v2', 5, 3, 'broadcast'), ('v1', 'multi_ar', 4, 'broadcast')])
+def test_two_rank_gloo_equals_single(variant, V, K, plan):
+    """both multi-GPU plans over a world_size-2 gloo group == the unsharded scene, bit for bit ('broadcast': rank 0 builds the memory and
+    broadcasts the banks, rank 1 owns every non-keyframe view)"""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, variant, V, K, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, variant, V, K, q, plan)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(2)]

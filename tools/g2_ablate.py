@@ -14,7 +14,7 @@ print('shape %s fc1 + GELU, fold consumer; us (TFLOP/s-equivalent)' % ((M, N, K)
 for tag, kern, mode in [('auto (256p)', 0, None), ('128x128', 128, None), ('2g', 2, 0), ('2g prio', 2, 1), ('2g one workgroup per CU', 2, 8),
                         ('2g no MFMA', 2, 256), ('2g no MFMA, 1 wg/CU', 2, 256 + 8), ('2g loads only', 2, 512), ('2g loads only, 1 wg/CU', 2, 512 + 8),
                         ('2g compute only (no DMA in loop)', 2, 768), ('2g compute only, 1 wg/CU', 2, 768 + 8),
-                        ('2g delay 4us', 2, 2 + 16 * 4), ('2g delay 8us', 2, 2 + 16 * 8), ('2g delay 12us', 2, 2 + 16 * 12), ('2g delay 8us + prio', 2, 3 + 16 * 8)]:
+                        ('2g phase priority', 2, 4), ('2g phase priority + delay 8us', 2, 4 + 2 + 16 * 8), ('2g phase priority + static', 2, 5), ('2g (again)', 2, 0), ('2g phase priority (again)', 2, 4)]:
     if mode is not None:
         hip.tune(hip.TUNE_G2_MODE, mode)
     t = burst(lambda: hip.gemm(a, w, out, kernel=kern, **kw))

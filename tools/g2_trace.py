@@ -22,12 +22,14 @@ for _ in range(3):
 torch.cuda.synchronize()
 TT = 24
 nwg = 512
-buf = torch.zeros(nwg, 1 + 4 * TT, dtype=torch.int64, device='cuda:0')
+buf = torch.zeros(nwg * (1 + 4 * TT) + 256, dtype=torch.int64, device='cuda:0')
 L.pst_debug_g2_trace(C.c_void_p(buf.data_ptr()), TT)
 hip.gemm(a, w, out, kernel=2, **kw)
 torch.cuda.synchronize()
 L.pst_debug_g2_trace(None, 0)
-t = buf.cpu().numpy()
+raw = buf.cpu().numpy()
+t = raw[:nwg * (1 + 4 * TT)].reshape(nwg, 1 + 4 * TT)
+fine = raw[nwg * (1 + 4 * TT):]
 hw = t[:, 0]
 ts = t[:, 1:].reshape(nwg, TT, 4).astype(np.float64) * 0.01          # us (100 MHz)
 used = (t[:, 1:].reshape(nwg, TT, 4)[:, :, 3] != 0)
@@ -73,3 +75,13 @@ if ov:
 b0 = pairs[0] if pairs else [0, 256]
 for b in b0:
     print('  block %3d (hw xcc %d se %d sh %d cu %d): ' % (b, xcc[b], se[b], sh[b], cu[b]) + ' | '.join('%.1f %.1f %.1f %.1f' % tuple(ts[b, i]) for i in range(min(ntile[b], 4))))
+
+if mode & 1024 and fine.any():
+    nk = min(K // 32, 80)
+    f = fine[:3 * nk].reshape(nk, 3).astype(np.float64) * 0.01
+    top, aw, ab = f[:, 0], f[:, 1], f[:, 2]
+    nxt = np.append(top[1:], np.nan)
+    print('  fine trace of workgroup 0 / wave 0, first tile (us per K step; 100 MHz clock = 0.01 us resolution):')
+    print('    vmcnt wait  mean %.3f   barrier wait mean %.3f   issue + reads + MFMAs mean %.3f   step mean %.3f' %
+          ((aw - top).mean(), (ab - aw).mean(), np.nanmean(nxt - ab), np.nanmean(nxt - top)))
+    print('    per step (vmcnt | barrier | compute): ' + ' '.join('%.2f|%.2f|%.2f' % (aw[i] - top[i], ab[i] - aw[i], (nxt[i] - ab[i]) if i + 1 < nk else 0) for i in range(nk)))

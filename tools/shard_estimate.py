@@ -2,8 +2,13 @@
 """Per-rank critical path of the view-sharded scene, measured on ONE GPU: N SceneRunners stepped in lock-step (the all-gathers replaced
 by a fake that hands out the other ranks' rows), each stage of each rank captured into a HIP graph and timed on replay.
     python tools/shard_estimate.py [--views 50 --keyframes 16 --ranks 1 2 4 8]
-Projection for N GPUs = max over ranks of (stage1 + stage2 + stage3) + nothing for the two <= 30 MiB all-gathers (latency-bound, tens of
-microseconds over xGMI); the driver's SCALE run measures the real thing."""
+    python tools/shard_estimate.py --plans replicated broadcast
+Projection for N GPUs: the collectives are synchronisation points, so the critical path is  max_r stage1 + [stage 2] + max_r stage3  with
+  replicated: [stage 2] = max_r stage2 (every rank repeats the memory build), the two <= 30 MiB all-gathers counted as zero (latency-bound);
+  broadcast : rank 0 builds (stage2a) while the others encode; the banks (2 x 12 layers x K*T x 768 x 2 B = 453 MB at K = 16) arrive
+              bytes / --bcast-gbps later (default 100 GB/s effective: one xGMI link is 153 GB/s peak; an ASSUMPTION, the driver's SCALE run
+              measures the real thing); rank r then runs stage2b from max(own stage2a end, bank arrival).
+"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +21,8 @@ def main():
     ap.add_argument('--keyframes', type=int, default=16)
     ap.add_argument('--ranks', type=int, nargs='+', default=[1, 2, 4, 8])
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--plans', nargs='+', default=['replicated'], choices=['replicated', 'broadcast'])
+    ap.add_argument('--bcast-gbps', type=float, default=100.0)
     args = ap.parse_args()
     from panst3r_amd.panst3r import CONFIG_V1, CONFIG_V2, build_from_config
     from panst3r_amd.synthetic import fill_module_, synth_image, synth_class_embeddings
@@ -32,34 +39,56 @@ def main():
     S._all_gather_rows = lambda t, counts, w, g: [s[:c] for s, c in zip(sends, counts)]
     out = {}
     base = None
-    for world in args.ranks:
-        _, order, owner = S.assign_views(V, K, world)
+    for plan in args.plans:
+      for world in args.ranks:
+        if plan == 'broadcast' and world == 1:
+            continue
+        _, order, owner = S.assign_views(V, K, world, plan=plan)
         runners = [S.SceneRunner(S.HipBackend(model), {order[i]: imgs[order[i]] for i in range(V) if owner[i] == r}, V, H, W, K, names,
-                                 rank=r, world=world) for r in range(world)]
+                                 rank=r, world=world, plan=plan) for r in range(world)]
+        split = plan == 'broadcast'
+        for rn in runners:
+            rn.split = split
+        nseg = 4 if split else 3
 
-        def step(fn):
-            for rn in runners:
-                fn(rn)
+        def seg(rn, k):
+            return ([rn.stage1, rn.stage2a, rn.stage2b, rn.stage3] if split else [rn.stage1, rn.stage2, rn.stage3])[k]
+
+        def exchange(k):
+            if k == 0:
+                sends[:] = [rn.enc_send for rn in runners]
+                for rn in runners:
+                    rn.gather1()
+            elif split and k == 1:
+                src = runners[0].b.bank_payload(runners[0].bank)
+                for rn in runners[1:]:
+                    for d, t in zip(rn.b.bank_payload(rn.bank), src):
+                        d.copy_(t)
+            elif k == nseg - 2:
+                sends[:] = [rn.both_send for rn in runners]
+                for rn in runners:
+                    rn.gather2()
+
         with torch.no_grad():
-            def scene(stage):
-                stage(0); sends[:] = [rn.enc_send for rn in runners]; step(lambda rn: rn.gather1())
-                stage(1); sends[:] = [rn.both_send for rn in runners]; step(lambda rn: rn.gather2())
-                stage(2)
-            scene(lambda k: step(lambda rn: (rn.stage1, rn.stage2, rn.stage3)[k]()))          # warm-up
+            def scene(run):
+                for k in range(nseg):
+                    run(k)
+                    exchange(k)
+            scene(lambda k: [seg(rn, k)() for rn in runners])          # warm-up
             torch.cuda.synchronize()
-            graphs = [[None] * 3 for _ in runners]
+            graphs = [[None] * nseg for _ in runners]
             pools = [torch.cuda.graph_pool_handle() for _ in runners]
 
             def capture(k):
                 for r, rn in enumerate(runners):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, pool=pools[r], capture_error_mode='thread_local'):
-                        (rn.stage1, rn.stage2, rn.stage3)[k]()
+                        seg(rn, k)()
                     graphs[r][k] = g
                     g.replay()
             scene(capture)
             torch.cuda.synchronize()
-            ms = [[0.0] * 3 for _ in runners]
+            ms = [[0.0] * nseg for _ in runners]
 
             def timed(k):
                 for r in range(world):
@@ -68,13 +97,22 @@ def main():
                     ms[r][k] += a.elapsed_time(b) / args.reps
             for _ in range(args.reps):
                 scene(timed)
-        per_rank = [sum(m) for m in ms]
-        crit = max(per_rank)
+        t1 = max(m[0] for m in ms)
+        if split:
+            bank_bytes = sum(t.numel() * t.element_size() for t in runners[0].b.bank_payload(runners[0].bank))
+            bcast = bank_bytes / (args.bcast_gbps * 1e9) * 1e3
+            arrive = t1 + ms[0][1] + bcast
+            t2 = max(max(t1 + m[1], arrive) + m[2] for m in ms)
+            extra = dict(bank_MB=round(bank_bytes / 1e6, 1), assumed_bcast_ms=round(bcast, 2), build_ms_rank0=round(ms[0][1], 2))
+        else:
+            t2 = t1 + max(m[1] for m in ms)
+            extra = {}
+        crit = t2 + max(m[-1] for m in ms)
         base = base or crit
-        out[world] = dict(views_per_rank=[rn.n_local for rn in runners], stage_ms_of_slowest_rank=[round(x, 2) for x in ms[per_rank.index(crit)]],
-                          critical_path_ms=round(crit, 2), projected_frames_per_s=round(V / crit * 1e3, 1),
-                          projected_efficiency=round(base / crit / world, 3))
-        print(world, json.dumps(out[world]), flush=True)
+        out['%s/%d' % (plan, world)] = dict(plan=plan, ranks=world, views_per_rank=[rn.n_local for rn in runners],
+                                            stage_ms_per_rank=[[round(x, 2) for x in m] for m in ms], critical_path_ms=round(crit, 2),
+                                            projected_frames_per_s=round(V / crit * 1e3, 1), projected_efficiency=round(base / crit / world, 3), **extra)
+        print(plan, world, json.dumps(out['%s/%d' % (plan, world)]), flush=True)
         del runners, graphs, pools
         torch.cuda.empty_cache()
     print(json.dumps({'workload': '%s, %d views, %d keyframes, 384x512; ranks simulated on one GPU, stage graphs timed on replay' % (args.variant, V, K), 'ranks': out}))

@@ -215,8 +215,9 @@ def main():
                     '(+8 %% frames/s; was not reproducible until one kernel was fixed, mechanism not understood: DESIGN.md section 4); default: back to back')
     ap.add_argument('--no-overlap', action='store_true', help=argparse.SUPPRESS)       # former switch; serial is the default now
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying HIP graphs')
-    ap.add_argument('--plan', default='replicated', choices=['replicated', 'broadcast'],
-                    help="multi-GPU plan (panst3r_amd/scene.py): every rank repeats the memory build | rank 0 builds and broadcasts the banks")
+    ap.add_argument('--plan', default='auto', choices=['auto', 'replicated', 'broadcast'],
+                    help="multi-GPU plan (panst3r_amd/scene.py): every rank repeats the memory build | rank 0 builds and broadcasts the banks; "
+                         "auto = broadcast from 4 ranks on (projection: profiles/r3_shard_estimate.txt)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -247,7 +248,8 @@ def main():
     model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
     model.to(dev)
 
-    from panst3r_amd.scene import assign_views
+    from panst3r_amd.scene import assign_views, resolve_plan
+    args.plan = resolve_plan(args.plan, world)
     _, order, owner = assign_views(V, K, world, plan=args.plan)
     mine = {order[i] for i in range(V) if owner[i] == rank}
     images = {i: synth_image(i, H, W).to(dev) for i in sorted(mine)}        # inputs resident in HBM before timing

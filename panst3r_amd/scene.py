@@ -27,6 +27,17 @@ from .schedule import select_keyframes, view_order
 PLANS = ('replicated', 'broadcast')
 
 
+def resolve_plan(plan, world):
+    """'auto' -> the plan the one-GPU projection favours (tools/shard_estimate.py, profiles/r3_shard_estimate.txt: 50 views / 16 keyframes, critical path
+    replicated vs broadcast: 2 ranks 104.7 vs 123.4 ms, 4 ranks 71.3 vs 57.5 ms, 8 ranks 58.1 vs 44.5 ms with the 453 MB of banks at an ASSUMED 100 GB/s):
+    'broadcast' from 4 ranks on, 'replicated' below."""
+    if plan in (None, 'auto'):
+        return 'broadcast' if world >= 4 else 'replicated'
+    if plan not in PLANS:
+        raise ValueError("plan must be 'auto' or one of %s (got %r)" % (PLANS, plan))
+    return plan
+
+
 def assign_views(V, K, world, keyframes=None, plan='replicated'):
     """keyframes (in schedule order) dealt round-robin to ranks, then the remaining views continue the deal.
     Returns (keyframes, order, owner) with owner[i] = rank of order[i].  `keyframes`: an explicit list of distinct view ids in
@@ -136,7 +147,7 @@ class SceneRunner:
         if plan == 'broadcast' and world > 1 and K < world:
             raise ValueError("plan='broadcast' deals the keyframes over all ranks and the other views over ranks 1..: it needs K >= world (K=%d, world=%d)" % (K, world))
         self.shapes = [tuple(sh) for sh in shapes] if shapes is not None else [(H, W)] * V      # per view id
-        self.plan = plan
+        self.plan = plan = resolve_plan(plan, world)
         self.keyframes, self.order, owner = assign_views(V, K, world, keyframes, plan)
         self.builder = plan == 'replicated' or rank == 0        # this rank runs the sequential memory build
         # the broadcast plan's split stage 2 also runs on a 1-rank process group (PST_FORCE_DIST=1: the collectives execute on RCCL at world = 1)
@@ -389,6 +400,7 @@ def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=No
     {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W);
     `keyframes`: optional explicit keyframe list in memory-build order (overrides the linspace schedule of K)."""
     Kc = V if (K is None or K > V) else max(int(K), 2)
+    plan = resolve_plan(plan, world)
     _, order, owner = assign_views(V, Kc, world, keyframes, plan)
     images = {order[i]: get_image(order[i]) for i in range(V) if owner[i] == rank}
     return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes, amp=amp, plan=plan).run(outdevice)

@@ -187,7 +187,7 @@ def hbm_stage_table(timer, V, H, W, variant):
     for n, t in pm:
         add('pointmap head + pixel-shuffle store (M=%d)' % t[0], lambda nn, tt, t=t: nn == n and tt == t, t[0] * 768 * 2 + t[0] * 1792 * 4)
     summ = timer.summary()
-    for k in ('layernorm', 'rowstats', 'groupnorm_stats', 'groupnorm_apply', 'loftup_guidance_gn', 'mean4', 'patch_rows'):
+    for k in ('mask_head_kernel', 'layernorm', 'rowstats', 'groupnorm_stats', 'groupnorm_apply', 'loftup_guidance_gn', 'mean4', 'patch_rows'):
         d = summ.get(k)
         if d and d['launches']:
             out[k] = {'launches': d['launches'], 'bytes_per_launch': int(d['bytes'] / d['launches']), 'avg_us': round(1e3 * d['ms'] / d['launches'], 2),

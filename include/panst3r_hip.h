@@ -103,6 +103,15 @@ int pst_tune(int knob, int value);
  * epilogue end).  tools/g2_trace.py turns them into phase durations and the overlap of the two workgroups of a CU. */
 int pst_debug_g2_trace(void* buf, int tiles_per_workgroup);
 
+/* ---------------------------------------------------------------- query x pixel mask einsum (HBM-bound streaming form)
+ * pred_masks[v][q][p] = sum_c E[q][c] * F[v][p][c]  (reference mask_transformer.py:280 "bqc,bnchw->bnqhw" with pixel-major mask features):
+ * E 16-bit [Q, C] (row stride lde), F 16-bit [nviews][P][C] (view stride f_view_stride elements), out fp32 [nviews][Q][P] (view stride
+ * out_view_stride elements).  One launch for all views of a shape group: E stays in registers, F is streamed once.  Bit-identical to pst_gemm
+ * on the same operands.  Supported: Q <= 256, P % 64 == 0, C in {256, 384} (pst_mask_head_supported); other shapes: pst_gemm. */
+int pst_mask_head_supported(int Q, int P, int C);
+int pst_mask_head(const void* E, int64_t lde, const void* F, int64_t f_view_stride, float* out, int64_t out_view_stride, int nviews, int Q, int P, int C,
+                  int dtype16, void* stream);
+
 /* ---------------------------------------------------------------- fused attention forward (flash style)
  * O[b,h,q,:] = softmax_k( scale * Q[b,h,q,:] . K[b,h,k,:]  (+ -inf where mask[b,q,k]) ) V[b,h,k,:]
  * bf16 in/out, fp32 softmax/accumulate, head dim 64 or 96.  V is given TRANSPOSED: Vt[b,h,d,k] (k contiguous).

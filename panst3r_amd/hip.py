@@ -39,7 +39,7 @@ class AttnParams(C.Structure):
                 ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64), ('dtype16', i32), ('prescaled', i32)]
 
 
-EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_tune', 'pst_debug_g2_trace', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_tune', 'pst_debug_g2_trace', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
            'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
@@ -265,6 +265,29 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
 
 
 # ----------------------------------------------------------------------------------------------------------- attention
+def mask_head_supported(Q, P, C):
+    return bool(lib().pst_mask_head_supported(int(Q), int(P), int(C)))
+
+
+def mask_head(embed, feats, out):
+    """pred_masks of ALL views of a shape group in one launch (pst_mask_head): embed 16-bit [Q, C], feats 16-bit [n, P, C] (or [n, Hm, Wm, C]),
+    out fp32 [n, Q, P] (or [n, Q, Hm, Wm]); bit-identical to n calls of gemm(embed, feats[i], out[i])."""
+    _dev(embed, *H16); _dev(feats, *H16); _dev(out, torch.float32)
+    n, C = feats.shape[0], feats.shape[-1]
+    P = feats.numel() // (n * C)
+    Q = embed.shape[0]
+    assert feats.is_contiguous() and out.is_contiguous() and out.numel() == n * Q * P and embed.shape[1] == C and embed.stride(1) == 1
+    ev = None
+    if TIMER is not None:
+        ev = TIMER.bracket('mask_head_kernel', 2.0 * n * Q * P * C, ('bytes', float(n * (C * P * 2 + Q * P * 4))))
+        ev[0].record()
+    _check(lib().pst_mask_head(_ptr(embed), i64(embed.stride(0)), _ptr(feats), i64(P * C), _ptr(out), i64(Q * P), n, Q, P, C, _same16(embed, feats), _stream()),
+           'pst_mask_head')
+    if ev is not None:
+        ev[1].record()
+    return out
+
+
 def auto_nsplit(B, H, Nq, Nk):
     """Key-range splits for few-query / many-key attention (memory build, query decoder): fill ~2 blocks per CU."""
     blocks = ((Nq + 63) // 64) * H * B

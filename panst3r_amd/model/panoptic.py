@@ -457,6 +457,21 @@ class MaskTransformer(HipModule):
         return out
 
     @torch.no_grad()
+    def masks_for_group(self, embed, mask_feats):
+        """pred_masks of ALL views of a shape group: embed 16-bit [Q,C] x mask_feats 16-bit [n,Hm,Wm,C] -> fp32 [n,Q,Hm,Wm].  One launch of the
+        streaming mask-head kernel (pst_mask_head: the query matrix stays in registers, the features are read once) where it applies
+        (C in {256, 384}: the released configurations), else one GEMM per view; the two are bit-identical."""
+        n, Hm, Wm, C = mask_feats.shape
+        Q = embed.shape[0]
+        out = torch.empty(n, Q, Hm, Wm, dtype=torch.float32, device=embed.device)
+        if hip.mask_head_supported(Q, Hm * Wm, C) and mask_feats.is_contiguous():
+            hip.mask_head(embed, mask_feats, out)
+        else:
+            for i in range(n):
+                self.masks_for(embed, mask_feats[i], out[i])
+        return out
+
+    @torch.no_grad()
     def attn_feats(self, mask_feats, grid=None):
         """Mask features bilinearly resized to the key grid: bf16 [n, Hm, Wm, C] -> [n*T, C] (the only part of the
         full-resolution masks the 6 intermediate decoder layers look at, mask_transformer.py:283-287; the resize is
@@ -739,7 +754,7 @@ class PanopticDecoder(HipModule):
         else:
             outq = memory_queries.reshape(-1, mt.hidden_dim).float().to(dev).contiguous()
             hs = mt.head_state(outq, cls)
-        masks = [torch.stack([mt.masks_for(hs.embed, mf[i]) for i in range(mf.shape[0])])[None] for mf in mfs]
+        masks = [mt.masks_for_group(hs.embed, mf)[None] for mf in mfs]
         if outdevice is not None:
             masks = [m.to(outdevice) for m in masks]
         res = {'pred_logits': hs.logits[None], 'pred_masks': masks if multi_ar else masks[0]}

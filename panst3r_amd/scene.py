@@ -300,8 +300,9 @@ class SceneRunner:
                               self.classes, self.kf_portrait)
         masks = [None] * self.n_local
         for g in self.groups:
+            gm = b.masks_group(head, g.mf)          # [n, Q, Hm, Wm]: all views of the shape group in one launch where the backend can
             for r, j in enumerate(g.idx):
-                masks[j] = b.masks(head, g.mf, r)
+                masks[j] = gm[r]
         self.out = (outq, b.logits(head), masks)
 
     def _segments(self):
@@ -483,6 +484,9 @@ class HipBackend:
 
     def masks(self, head, mf, j):
         return self.m.panoptic_decoder.mask_transformer.masks_for(head.embed, mf[j])
+
+    def masks_group(self, head, mf):
+        return self.m.panoptic_decoder.mask_transformer.masks_for_group(head.embed, mf)
 
     def logits(self, head):
         return head.logits

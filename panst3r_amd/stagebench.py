@@ -48,8 +48,14 @@ def standalone_hbm_stages(dev, variant='v2', H=384, W=512, dtype=torch.float16, 
     F = [torch.randn(P, C, generator=g).to(dtype).to(dev) for _ in range(views)]            # 38 MB per view: 16 views = 600 MB > MALL
     M = [torch.empty(Q, P, dtype=torch.float32, device=dev) for _ in range(views)]
     us = _replay_us(lambda: [hip.gemm(E, F[i], M[i]) for i in range(views)], views)
-    out['mask_head (query x pixel einsum, per view)'] = _entry(C * P * 2 + Q * P * 4, us, views)
+    out['mask_head as tiled GEMM (one launch per view)'] = _entry(C * P * 2 + Q * P * 4, us, views)
     del F, M
+    if hip.mask_head_supported(Q, P, C):
+        Fg = torch.randn(views, P, C, generator=g).to(dtype).to(dev)
+        Mg = torch.empty(views, Q, P, dtype=torch.float32, device=dev)
+        us = _replay_us(lambda: hip.mask_head(E, Fg, Mg), 1)
+        out['mask_head streaming kernel (one launch, %d views)' % views] = _entry(views * (C * P * 2 + Q * P * 4), us, 1)
+        del Fg, Mg
     # ---- pointmap head + pixel-shuffle store: [V*T, 768] x [1792, 768]^T -> fp32 [V, H, W, 7]
     T, D, p, ch = (H // 16) * (W // 16), 768, 16, 7
     Vv = views

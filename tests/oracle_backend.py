@@ -125,5 +125,8 @@ class OracleBackend:
     def masks(self, head, mf, j):
         return torch.einsum('qc,chw->qhw', head[1], mf[j])
 
+    def masks_group(self, head, mf):
+        return [self.masks(head, mf, j) for j in range(mf.shape[0])]
+
     def logits(self, head):
         return head[0]

@@ -898,3 +898,26 @@ def test_gemm2g_fused_rope(V):
     out = torch.empty_like(ref)
     hip.gemm(a, w, out, bias=b, kernel=2, rope=(pos, table))
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('C', [256, 384])
+@pytest.mark.parametrize('Q,P,n', [(200, 49152, 3), (200, 640, 5), (24, 128, 2), (256, 1024, 1), (130, 64, 7)])
+def test_mask_head_streaming_kernel(C, Q, P, n):
+    """pst_mask_head (the query x pixel einsum of mask_transformer.py:280 as a streaming kernel: E in registers, F read once, one launch for all
+    views of a group) == one tiled GEMM per view, BIT FOR BIT (same MFMA, same operand order, same K order), and both match the fp32 einsum."""
+    from panst3r_amd import hip
+    assert hip.mask_head_supported(Q, P, C) and not hip.mask_head_supported(Q, P + 8, C) and not hip.mask_head_supported(Q, P, 192)
+    E = bf(rn(1300, Q, C)).to(dev())
+    F_ = bf(rn(1301, n, P, C)).to(dev())
+    out = torch.full((n, Q, P), float('nan'), device=dev())
+    hip.mask_head(E, F_, out)
+    for i in range(n):
+        ref = torch.empty(Q, P, device=dev())
+        hip.gemm(E, F_[i], ref)
+        assert torch.equal(out[i], ref), i
+    want = torch.einsum('qc,npc->nqp', E.float().cpu(), F_.float().cpu())
+    assert rel_l2(out.cpu(), want) < 2e-3
+    again = torch.empty_like(out)
+    for _ in range(5):
+        hip.mask_head(E, F_, again)
+        assert torch.equal(again, out)

@@ -1,22 +1,30 @@
-// Persistent 16-bit MFMA GEMM with TWO unsynchronised workgroups per CU (round 3) -- the big batched GEMMs of the PanSt3R path.
+// Persistent 16-bit MFMA GEMM with TWO unsynchronised workgroups per CU (round 3) -- an EXPERIMENT that lost, kept as the measured record.
+// NOT dispatched by default (pst_tune PST_TUNE_G2_AUTO = 0; pst_gemm_params.kernel = 2 forces it; bit-identical to every other variant:
+// tests/test_hip_ops.py::test_gemm2g_*).  Numbers: profiles/r3_gemm_dispatch_bench.txt, r3_gemm2g_ablation_trace.txt, r3_gemm2g_fine_trace.txt.
 //
-// Why: the persistent 256x256 kernel (gemm256.hip) runs its main loop at ~1.2-1.3 PFLOP/s-equivalent but spends ~12 us of every K = 1024
-// tile (38 us) in an epilogue during which the CU's matrix cores idle: its 8 waves are ONE workgroup, they reach the epilogue together
-// (SQ anatomy, profiles/r2_sq_*.md: 4.4 VALU-class instructions per MFMA in fc1 + GELU).  MFMA and VALU are separate pipes of a SIMD, and
-// a SIMD arbitrates between its resident waves instruction by instruction -- so the epilogue of one wave can run UNDER the MFMAs of
-// another, provided the two are not in lock-step.  Here a CU holds two independent workgroups of 4 waves (one wave of each per SIMD):
+// Idea (DESIGN.md section 8 item 1 of round 2): the persistent 256x256 kernel spends ~12 us of every K = 1024 tile (38 us) in
+// an epilogue during which the CU's matrix cores idle, because its 8 waves are ONE workgroup and reach the epilogue together.  MFMA and VALU
+// are separate pipes and a SIMD arbitrates between its resident waves instruction by instruction, so the epilogue of one wave can run UNDER the
+// MFMAs of another if the two are not in lock-step.  Here a CU holds two independent workgroups of 4 waves (one wave of each per SIMD):
 //   * workgroup tile 256 x 128, wave tile 128 x 64 (2 x 2 waves): the same accumulator / fragment layout and therefore the same
 //     accumulator-layout epilogues as gemm256p_kernel (perm_row8 staging: a lane owns 8-column runs, 64 contiguous bytes per 4 lanes);
-//   * BK = 32 (ONE v_mfma_f32_16x16x32 K step per stage), a 3-stage LDS ring of 24 KiB stages (A 256 rows x 64 B, B 128 rows x 64 B):
-//     72 KiB + 5.5 KiB of per-tile tables per workgroup, 2 x 77.5 KiB = 155 of the CU's 160 KiB; stages are filled by LDS-DMA
-//     (global_load_lds_dwordx4) two stages ahead and waited for with a COUNTED s_waitcnt vmcnt (in-order retirement);
-//   * 64-byte LDS rows: the 16-byte chunk index is XOR-swizzled with K4[(row >> 2) & 3], K4 = {0, 3, 2, 1}, which makes every
-//     16-lane group of a ds_read_b128 (MI355X_MICROARCH.md, LDS table: {0-3,12-15,20-27}, ...) cover 16 distinct 16-byte slots of a
-//     256-byte bank row; as everywhere the swizzle is applied to the LDS-DMA SOURCE address and again on the read side;
-//   * persistent: a workgroup walks the tile list; the next tile's first two stages are requested before the epilogue of the current
-//     one.  The two workgroups of a CU start in phase; `mode` bit 0 gives the workgroups of the second dispatch wave (blockIdx >=
-//     gridDim / 2, which the dispatcher places beside the first 256) a lower static priority so that the pair drifts into anti-phase
-//     (main loop of one over the epilogue of the other) during the first tile instead of sharing both pipes in lock-step.
+//   * LDS: 2 x 80 KiB per CU forces BK = 32 (ONE v_mfma_f32_16x16x32 K step per stage), a 3-stage ring of 24 KiB stages (A 256 rows x 64 B,
+//     B 128 rows x 64 B) + 5.5 KiB of per-tile tables per workgroup; stages are filled by LDS-DMA two stages ahead, counted s_waitcnt vmcnt;
+//   * 64-byte LDS rows: the 16-byte chunk index is XOR-swizzled with K4[(row >> 2) & 3], K4 = {0, 3, 2, 1}, which makes every 16-lane group of a
+//     ds_read_b128 cover 16 distinct 16-byte slots of a 256-byte bank row (SQ_LDS_BANK_CONFLICT = 0 measured);
+//   * hand-placed fragment reads with counted lgkmcnt; persistent tile walk; the next tile's first two stages requested before the epilogue.
+// What the measurements say (phase trace pst_debug_g2_trace / tools/g2_trace.py, fc1 + GELU 38400 x 4096 x 1024, f16):
+//   * the overlap happens by itself (55-70 % of every epilogue runs under the partner's main loop; `mode` bits add static / phase priority or a
+//     start delay: +-2 %), and with both workgroups in their main loops the per-wave compute section is 0.49-0.52 us per 32-MFMA stage against
+//     0.43 us if the two waves of a SIMD shared the matrix pipe perfectly: the main loop is near its bound when it runs;
+//   * but a tile costs prologue 2.5-3 us (per-tile tables behind a drained vmcnt queue) + main loop 17.5-19 us + epilogue 15.7-17 us (9 us alone:
+//     the partner's main loop takes issue slots), 37 us per PAIR of 256 x 128 tiles = the 38 us per 256 x 256 tile of the one-workgroup kernel;
+//   * BK = 32 makes every L2 -> L1 line fill half useful (64-byte row segments): loads alone run at 27 B/clk/CU, and the operand traffic of a
+//     256 x 128 tile is 1.5 x that of a 256 x 256 tile per FLOP;
+//   * in the sustained state, interleaved with the other variants (tools/dispatch_bench.py): 5-30 % SLOWER than the persistent 256 x 256 kernel
+//     on every shape of the scene.  A second version (A through LDS at BK = 64, W fragments straight from L2 into registers: full-line fetches,
+//     half the barriers) was 70 % slower still - 16-row x 64-byte register loads are a poor fit for the texture path - and is not kept
+//     (profiles/r3_gemm2g_v2_bdirect_dispatch.txt).
 // Per-element K order = every other tile size (one MFMA per 32 of K, ascending): bit-identical results (tests/test_hip_ops.py).
 #include "common.h"
 #include "../../include/panst3r_hip.h"

@@ -12,8 +12,9 @@ Same call signatures and output structure; what changed is HOW the scene is exec
     one [Q,C]x[C,P] GEMM (the reference recomputes the heads per chunk, panoptic_decoder.py:71);
   * MinMaxScaler is per view (the demo's max_bs=1 convention), see SURVEY quirk 5.
 `amp` (False | 'bf16' | 'fp16', reference utils.py:206-215) selects the 16-bit storage / MFMA operand format of the scene:
-'bf16' and 'fp16' as in the reference's autocast; amp=False is the reference's fp32 mode, for which the HIP path (no fp32 MFMA
-variant) runs its most precise format, f16.  Accumulation, residual streams, softmax and normalisation statistics are fp32 always.
+'bf16' and 'fp16' as in the reference's autocast; amp=False is the reference's fp32 mode: the HIP path has no fp32-operand variant, it
+computes such scenes with f16 operands (its most precise format), says so once (RuntimeWarning) and re-runs a scene in bf16 if an f16 store
+overflowed.  Accumulation, residual streams, softmax and normalisation statistics are fp32 always.
 """
 from argparse import Namespace
 import numpy as np
@@ -304,14 +305,33 @@ class PanSt3R(nn.Module):
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False):
-        """Same-shape batch variant (panst3r.py:286-296): imgs [B,n,3,H,W] -> (panout, pointmaps [B,n,H,W,7]);
-        every view is a memory view (mem batches [2,1,...]) and every view is rendered.  `amp` as forward_inference_multi_ar (the reference
+        """Same-shape batch variant (panst3r.py:286-296): imgs [B,n,3,H,W] -> (panout, pointmaps [B,n,H,W,7]); B scenes, each with its own
+        memory and queries; every view is a memory view (mem batches [2,1,...]) and every view is rendered.  `amp` as forward_inference_multi_ar (the reference
         runs this entry point under the caller's autocast)."""
         B, n = imgs.shape[:2]
+        Ht, Wt = int(imgs.shape[-2]), int(imgs.shape[-1])
         outs = []
         for b in range(B):                      # the scenes of a batch are independent (own memory, own queries)
-            pms, panout = self.forward_inference_multi_ar(list(imgs[b]), true_shape[b], classes, num_keyframes=n, outdevice=outdevice, amp=amp)
-            outs.append((torch.stack([m[0] for m in panout['pred_masks']])[None], torch.stack([p[0] for p in pms])[None], panout))
+            # DUSt3R storage convention (utils.py:8-61 transpose_to_landscape): a same-shape batch may hold PORTRAIT views stored transposed, marked
+            # by true_shape = (W_tensor, H_tensor).  They are computed in their true orientation ("predict in the correct aspect-ratio") and their
+            # results transposed back into the storage layout, as the reference's wrapper does for every head output.
+            views, stored = [], []
+            for i in range(n):
+                th, tw = (int(v) for v in true_shape[b, i].tolist())
+                if (th, tw) == (Ht, Wt):
+                    views.append(imgs[b, i])
+                elif (th, tw) == (Wt, Ht):
+                    views.append(imgs[b, i].transpose(-1, -2).contiguous())
+                    stored.append(i)
+                else:
+                    raise ValueError('view %d: true_shape %s matches neither the tensor shape (%d, %d) nor its transpose' % (i, (th, tw), Ht, Wt))
+            ts = torch.tensor([list(v.shape[-2:]) for v in views])
+            pms, panout = self.forward_inference_multi_ar(views, ts, classes, num_keyframes=n, outdevice=outdevice, amp=amp)
+            masks = list(panout['pred_masks'])
+            for i in stored:
+                pms[i] = pms[i].transpose(1, 2)
+                masks[i] = masks[i].transpose(-1, -2)
+            outs.append((torch.stack([m[0] for m in masks])[None], torch.stack([p[0] for p in pms])[None], panout))
         panout = {'pred_logits': torch.cat([o[2]['pred_logits'] for o in outs]), 'pred_masks': torch.cat([o[0] for o in outs]),
                   'out_queries': torch.cat([o[2]['out_queries'] for o in outs], dim=1)}
         return panout, torch.cat([o[1] for o in outs])

@@ -410,3 +410,28 @@ def test_rccl_collectives_at_world_1(pair):
                     assert torch.equal(res[i][0], ref[i][0]) and torch.equal(res[i][1], ref[i][1]), (plan, graphs, i)
     finally:
         dist.destroy_process_group()
+
+
+def test_forward_batch_and_dust3r_storage_convention(pair):
+    """PanSt3R.forward (panst3r.py:286-296) on a batch of B = 2 scenes whose second scene holds a PORTRAIT view in the DUSt3R storage convention
+    (stored transposed in the landscape-shaped tensor, true_shape = its real (H, W); utils.py:8-61): each scene == the same views run natively
+    through forward_inference_multi_ar, with the stored view's pointmaps / masks transposed into the storage layout."""
+    variant, o, h = pair
+    H, W, n = 64, 96, 3
+    a = tiny.images(n, H, W)                                             # scene 0: three landscape views
+    b = [tiny.synth_image(10, H, W, 5), tiny.synth_image(11, W, H, 5), tiny.synth_image(12, H, W, 5)]       # scene 1: the middle view is 96 x 64
+    stored = [b[0], b[1].transpose(-1, -2).contiguous(), b[2]]
+    imgs = torch.stack([torch.stack(a), torch.stack(stored)]).to(DEV)
+    ts = torch.tensor([[[H, W]] * n, [[H, W], [W, H], [H, W]]])
+    pan, pm = h.forward(imgs, ts, tiny.NAMES, amp=h.amp)
+    assert pm.shape == (2, n, H, W, 7) and pan['pred_masks'].shape == (2, n, 24, H // 2, W // 2) and pan['out_queries'].shape[1] == 2
+    for s, views in enumerate((a, b)):
+        t2 = torch.tensor([list(v.shape[-2:]) for v in views])
+        pm_n, pan_n = h.forward_inference_multi_ar([v.to(DEV) for v in views], t2, tiny.NAMES, num_keyframes=n, amp=h.amp)
+        assert torch.equal(pan['out_queries'][:, s], pan_n['out_queries'][:, 0])
+        for i in range(n):
+            back = views[i].shape[-2] != H
+            assert torch.equal(pm[s, i], pm_n[i][0].transpose(0, 1) if back else pm_n[i][0]), (s, i)
+            assert torch.equal(pan['pred_masks'][s, i], pan_n['pred_masks'][i][0].transpose(-1, -2) if back else pan_n['pred_masks'][i][0]), (s, i)
+    with pytest.raises(ValueError):
+        h.forward(imgs, torch.tensor([[[H, W]] * n, [[H, W], [W + 16, H], [H, W]]]), tiny.NAMES, amp=h.amp)

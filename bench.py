@@ -352,6 +352,13 @@ def main():
             out['kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 2),
                                   'tflops': round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1)} for k, v in sorted(summ.items())}
             out['hbm_stages'] = hbm_stage_table(timer, V, H, W, args.variant)
+            # the same stages stand-alone: one captured HIP graph per stage on scene-sized cold operands, replay timed as a whole (the eager numbers
+            # above carry 5-10 us of HIP-event overhead per 20-35 us launch)
+            try:
+                from panst3r_amd.stagebench import standalone_hbm_stages
+                out['hbm_stages_standalone'] = standalone_hbm_stages(dev, args.variant, H, W, torch.float16 if args.amp == 'fp16' else torch.bfloat16)
+            except Exception as e:          # a measurement leg must not take the bench line down
+                out['hbm_stages_standalone'] = {'error': repr(e)}
         if host_legs and not args.no_alt_dtype:
             alt = 'bf16' if args.amp == 'fp16' else 'fp16'
             e2, m2, _ = measure(alt, max(3, args.steps // 4), 1, False)

@@ -10,17 +10,17 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-@pytest.mark.parametrize('Hs,Ws,size', [(480, 640, 512), (1200, 1600, 512), (333, 517, 224), (640, 480, 512), (96, 128, 512)])
+@pytest.mark.parametrize('Hs,Ws,size', [(480, 640, 512), (1200, 1600, 512), (333, 517, 224), (640, 480, 512), (96, 128, 512), (1000, 1000, 512), (540, 960, 512), (500, 700, 384)])
 def test_image_prepare_matches_torch_antialias(Hs, Ws, size):
     from panst3r_amd.engine.images import prepare_image, resize_recipe
     g = np.random.Generator(np.random.PCG64(Hs * 7 + Ws))
     img = g.integers(0, 256, size=(Hs, Ws, 3), dtype=np.uint8)
     img[:, :, 1] = (np.arange(Ws)[None, :] * 255 // Ws).astype(np.uint8)          # a ramp: exposes coordinate / transposition mistakes
     out = prepare_image(img, size, 16, DEV)
-    (Hr, Wr), (top, left), (Hc, Wc) = resize_recipe(size, 16, Hs, Ws)
-    assert out.shape == (3, Hc, Wc) and max(Hc, Wc) <= size and Hc % 16 == 0 and Wc % 16 == 0
+    (top, left), (Hc, Wc), (Ho, Wo) = resize_recipe(size, 16, Hs, Ws)          # centre crop to the trained aspect ratio, then resize
+    assert out.shape == (3, Ho, Wo) and max(Ho, Wo) == size and Ho % 16 == 0 and Wo % 16 == 0
     t = (torch.from_numpy(img).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5        # ToTensor + Normalize(0.5, 0.5) == ImgNorm
-    ref = F.interpolate(t[None], size=(Hr, Wr), mode='bilinear', align_corners=False, antialias=True)[0][:, top:top + Hc, left:left + Wc]
+    ref = F.interpolate(t[None][:, :, top:top + Hc, left:left + Wc], size=(Ho, Wo), mode='bilinear', align_corners=False, antialias=True)[0]
     assert float((out.cpu() - ref).abs().max()) < 2e-5
     assert float(out.min()) >= -1.0001 and float(out.max()) <= 1.0001
 
@@ -67,5 +67,5 @@ def test_load_images_pair_and_shapes(tmp_path):
     views = load_images([str(path)], size=512, patch_size=16, verbose=False, device=DEV)
     assert len(views) == 2 and views[0]['img'].shape == (3, 384, 512) and list(views[0]['true_shape']) == [384, 512]
     again = load_images([arr, arr[:, ::-1].copy()], size=224, verbose=False, device=DEV)
-    assert again[0]['img'].shape == (3, 160, 224)
+    assert again[0]['img'].shape == (3, 224, 224)              # 224 is a trained resolution: centre crop to 1:1, then resize
     assert float((again[0]['img'].flip(-1) - again[1]['img']).abs().max()) < 1e-4          # the filter is symmetric: mirrored input, mirrored output

@@ -330,7 +330,8 @@ class PanSt3R(nn.Module):
             masks = list(panout['pred_masks'])
             for i in stored:
                 pms[i] = pms[i].transpose(1, 2)
-                masks[i] = masks[i].transpose(-1, -2)
+                if tuple(masks[i].shape[-2:]) != (Ht // 2, Wt // 2):      # (the pixel-shuffle variant hands portrait masks back landscape-shaped already,
+                    masks[i] = masks[i].transpose(-1, -2)                 #  utils.py:47-49 via panoptic_decoder.py:26; LoftUp's are native)
             outs.append((torch.stack([m[0] for m in masks])[None], torch.stack([p[0] for p in pms])[None], panout))
         panout = {'pred_logits': torch.cat([o[2]['pred_logits'] for o in outs]), 'pred_masks': torch.cat([o[0] for o in outs]),
                   'out_queries': torch.cat([o[2]['out_queries'] for o in outs], dim=1)}

@@ -126,7 +126,7 @@ def full_size_parity(model, dev, ref, imgs, ts, names, amp='fp16', K=2):
         with mt.instrument(log=log):       # (forward_inference_multi_ar runs eagerly unless cache_graphs=True: nothing is captured here)
             pm_h, pan_h = model.forward_inference_multi_ar(inp, ts, names, num_keyframes=K, amp=amp)
     torch.cuda.synchronize()
-    res = {'scene': '%d views / %d keyframes, full-size weights (the cpu_baseline sample)' % (len(imgs), K), 'amp': amp}
+    res = {'scene': '%d views / %d keyframes, full-size weights (the cpu_baseline sample)' % (len(imgs), K), 'amp': amp if amp else 'False (fp32 mode)'}
     res.update(_scene_errors(pm_h, pan_h, pm_o, pan_o))
     res['tolerance'] = dict(TOLERANCE)
     res['within_tolerance'] = _within(res)
@@ -364,6 +364,13 @@ def main():
             e2, m2, _ = measure(alt, max(3, args.steps // 4), 1, False)
             out['alt_dtype'] = {'dtype': 'bf16' if alt == 'bf16' else 'f16', 'value': round(V * max(3, args.steps // 4) / e2, 3),
                                 'note': 'the other 16-bit format of the reference (--amp %s), same scene, %d timed steps' % (alt, max(3, args.steps // 4))}
+        if host_legs and not args.no_alt_dtype:
+            try:          # the reference's default mode (amp=False: fp32 end to end) on the fp32-FMA kernels: the precision path, not the benchmark
+                e3, _, _ = measure(False, 2, 1, False)
+                out['fp32_mode'] = {'dtype': 'f32', 'value': round(V * 2 / e3, 3), 'unit': 'frames/s',
+                                    'note': 'amp=False: float32 operands / activations, fp32-FMA GEMM + attention kernels (no MFMA), same scene, 2 timed steps'}
+            except Exception as e:
+                out['fp32_mode'] = {'error': repr(e)}
         if host_legs:
             threads = usable_cores()
             out['cpu_baseline'], ref, ref_imgs, ref_ts = cpu_baseline(args.variant, H, W, state, names, emb, threads)
@@ -381,6 +388,7 @@ def main():
                                           'frames_per_s': round(V / (scene_flops / 1e12 / cpu_tflops), 4), 'host_tflops_fp32': round(cpu_tflops, 3)}
             out['cpu_baseline']['other_configs'] = samples
             out['parity'] = full_size_parity(model, dev, ref, ref_imgs, ref_ts, names, args.amp)
+            out['parity']['fp32_mode'] = full_size_parity(model, dev, ref, ref_imgs, ref_ts, names, False)
             if not args.no_depth_parity:
                 # parity at the benchmark's own memory depth: 16 views = 16 keyframes (BASELINE configs[2] as stated; 15 sequential memory updates
                 # as in the timed 50 / 16 scene), oracle on the host (timed: a MEASURED C3 next to the extrapolated C4), HIP path free-running and

@@ -13,6 +13,13 @@
  * Conventions: "16-bit" tensors are raw uint16 in ONE of two formats chosen per call by `dtype16` (PST_BF16 / PST_F16; all 16-bit
  * operands of a call share it; "bf16" in the text below reads "the 16-bit format"); activations are token-major [rows, channels]
  * row-major with an explicit leading dimension (elements); weights are torch nn.Linear layout [N, K] (K contiguous).
+ *
+ * fp32 mode (ABI 16; reference amp=False, tools/demo_panst3r.py:88: torch.float32 end to end): `dtype16` = PST_F32 is accepted by pst_gemm,
+ * pst_attn_fwd, pst_rope2d, pst_patchify, pst_patch_rows, pst_l2norm_rows, pst_mean4, pst_resize_bilinear, pst_loftup_guidance_gn,
+ * pst_groupnorm_apply and pst_loftup_lr_pe: the "16-bit" tensors of that call are then float (leading dimensions / strides still in
+ * elements).  GEMM and attention run on fp32-FMA kernels (gemm_f32.hip, attn_f32.hip: no MFMA, ~20x slower) with the same epilogues;
+ * rejected in this mode: a 16-bit C / residual, fused RoPE, the LayerNorm-fold arguments, pst_gemm_params.kernel != 0, attention
+ * split-K, pst_mask_head, pst_split3, pst_rowstats (16-bit precision devices with nothing to do in fp32).
  */
 #ifndef PANST3R_HIP_H
 #define PANST3R_HIP_H
@@ -21,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 15
+#define PST_ABI_VERSION 16
 
 /* element type codes: every `*_type` / `dtype16` argument below (and the former `*_fp32` flags: 0 and 1 keep their meaning) */
 #define PST_BF16 0   /* bfloat16, raw uint16 */
@@ -72,7 +79,7 @@ typedef struct pst_gemm_params {
      unused.  (The 12 per-layer K and V^T projections of a MUSt3R memory append are one launch each instead of 12.) */
   int32_t batch;
   int64_t a_bs, w_bs, c_bs, bias_bs;
-  int32_t dtype16;                   /* PST_BF16 / PST_F16: format of A, W, a 16-bit C and a 16-bit residual */
+  int32_t dtype16;                   /* PST_BF16 / PST_F16: format of A, W, a 16-bit C and a 16-bit residual; PST_F32: A, W, C, res all float (fp32 mode, above) */
   /* ---- LayerNorm folded into the GEMMs around it (pre-LN blocks: x += f(LN(x)) ; no stand-alone LayerNorm pass).
      PRODUCER side (the GEMM that writes the residual stream; plain row-major store, N % 64 == 0):
        xcopy      16-bit copy of the stored C values [M, N] with leading dim ldxc (C fp32 only; the consumer's A operand), or NULL
@@ -132,7 +139,7 @@ typedef struct pst_attn_params {
      query block; partial (O, max, sum) go to `ws` (fp32, >= pst_attn_workspace_bytes) and a combine kernel merges. */
   int32_t nsplit;
   void* ws; int64_t ws_bytes;
-  int32_t dtype16;                             /* PST_BF16 / PST_F16: format of Q, K, Vt, O */
+  int32_t dtype16;                             /* PST_BF16 / PST_F16 / PST_F32 (fp32 mode: hd 64 / 96, nsplit <= 1): format of Q, K, Vt, O */
   /* 1: Q already carries scale * log2(e) (the model path folds it into the q projection's epilogue, pst_gemm_params.gamma, so it is
      applied in fp32 before q is rounded): the kernel computes p = exp2(q.k - m) with no per-score multiply and ignores `scale`. */
   int32_t prescaled;

@@ -382,13 +382,22 @@ static int launch_attn(const pst_attn_params& p, hipStream_t s) {
   return p.prescaled ? launch_attn4<HD, QF, F16, true>(p, s) : launch_attn4<HD, QF, F16, false>(p, s);
 }
 
+int attn_f32_validate(const pst_attn_params& p);          // attn_f32.hip: fp32 operands (the reference's amp=False arithmetic)
+int launch_attn_f32(const pst_attn_params& p, hipStream_t s);
+
 }  // namespace pst
 
 static int attn_validate(const pst_attn_params* pp) {
   using namespace pst;
   if (!pp) { set_error("attn: null params"); return PST_EINVAL; }
   const pst_attn_params& p = *pp;
-  if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("attn: dtype16 must be PST_BF16 or PST_F16"); return PST_EINVAL; }
+  if (p.dtype16 == DT_F32) {
+    if (p.prescaled != 0 && p.prescaled != 1) { set_error("attn: prescaled must be 0 or 1"); return PST_EINVAL; }
+    if (!p.prescaled && !(p.scale > 0.f)) { set_error("attn: scale must be positive"); return PST_EINVAL; }
+    if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || !p.Q || !p.K || !p.Vt || !p.O) { set_error("attn: bad shape / null operand"); return PST_EINVAL; }
+    return attn_f32_validate(p);
+  }
+  if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("attn: dtype16 must be PST_BF16, PST_F16 or PST_F32"); return PST_EINVAL; }
   if (p.prescaled != 0 && p.prescaled != 1) { set_error("attn: prescaled must be 0 or 1"); return PST_EINVAL; }
   if (!p.prescaled && !(p.scale > 0.f)) { set_error("attn: scale must be positive"); return PST_EINVAL; }
   if (p.hd != 64 && p.hd != 96) { set_error("attn: head dim %d unsupported (64 or 96)", p.hd); return PST_EINVAL; }
@@ -419,6 +428,7 @@ extern "C" int pst_attn_fwd(const pst_attn_params* pp, void* stream) {
   if (int rc = attn_validate(pp)) return rc;
   const pst_attn_params& p = *pp;
   hipStream_t s = (hipStream_t)stream;
+  if (p.dtype16 == DT_F32) return launch_attn_f32(p, s);
   const bool big = attn_big(p), h = p.dtype16 == DT_F16;
   if (p.hd == 64) {
     if (big) return h ? launch_attn<64, 2, true>(p, s) : launch_attn<64, 2, false>(p, s);
@@ -430,6 +440,7 @@ extern "C" int pst_attn_fwd(const pst_attn_params* pp, void* stream) {
 
 extern "C" const char* pst_attn_variant(const pst_attn_params* pp) {
   if (attn_validate(pp)) return nullptr;
+  if (pp->dtype16 == pst::DT_F32) return pp->hd == 64 ? "attn_f32_kernel<64>" : "attn_f32_kernel<96>";
   const bool big = attn_big(*pp);
   if (pp->hd == 64) return big ? "attn_kernel<64,2>" : "attn_kernel<64,1>";
   return big ? "attn_kernel<96,2>" : "attn_kernel<96,1>";

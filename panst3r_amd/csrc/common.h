@@ -79,6 +79,10 @@ struct H16 {
 // run-time format selection (HBM-bound streaming kernels: the branch is wave-uniform and free next to the memory traffic)
 __device__ __forceinline__ float ld16(uint16_t v, int tc) { return tc == DT_F16 ? h2f(v) : bf2f(v); }
 __device__ __forceinline__ uint16_t st16(float f, int tc) { return tc == DT_F16 ? f2h(f) : f2bf(f); }
+__device__ __forceinline__ void store1(void* base, int64_t idx, int tc, float v) {       // one element of a tensor of type code tc (DT_F32 too)
+  if (tc == DT_F32) ((float*)base)[idx] = v;
+  else ((uint16_t*)base)[idx] = st16(v, tc);
+}
 __device__ __forceinline__ uint32_t pack2(float a, float b, int tc) { return tc == DT_F16 ? pack2h(a, b) : pack2bf(a, b); }
 __device__ __forceinline__ void unpack2(uint32_t w, int tc, float& a, float& b) {
   if (tc == DT_F16) { a = H16<true>::lo(w); b = H16<true>::hi(w); } else { a = H16<false>::lo(w); b = H16<false>::hi(w); }

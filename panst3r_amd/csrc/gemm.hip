@@ -24,6 +24,8 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s);   // gemm256.hip
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus);
 bool gemm256_persistent_ok(const pst_gemm_params& p);
 int gemm256_persistent_class(const pst_gemm_params& p);
+int gemm_f32_validate(const pst_gemm_params& p);                          // gemm_f32.hip: fp32 operands (the reference's amp=False arithmetic)
+int launch_gemm_f32(const pst_gemm_params& p, hipStream_t s);
 int gemm2g_class(const pst_gemm_params& p);                               // gemm2g.hip: two workgroups per CU, 256 x 128 tiles
 int launch_gemm2g(const pst_gemm_params& p, hipStream_t s, int cus);
 int rowstream_class(const pst_gemm_params& p);                            // rowstream.hip
@@ -513,7 +515,12 @@ static int gemm_validate(const pst_gemm_params* pp) {
   using namespace pst;
   if (!pp) { set_error("gemm: null params"); return PST_EINVAL; }
   const pst_gemm_params& p = *pp;
-  if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("gemm: dtype16 must be PST_BF16 or PST_F16"); return PST_EINVAL; }
+  if (p.dtype16 == DT_F32) {               // fp32 operands: the precision path (gemm_f32.hip), its own argument rules
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.W || !p.C) { set_error("gemm: bad shape / null operand"); return PST_EINVAL; }
+    if (p.kernel != 0) { set_error("gemm (fp32 operands): kernel must be 0"); return PST_EINVAL; }
+    return pst::gemm_f32_validate(p);
+  }
+  if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("gemm: dtype16 must be PST_BF16, PST_F16 or PST_F32"); return PST_EINVAL; }
   if (p.kernel != 0 && p.kernel != 128 && p.kernel != 256 && p.kernel != 2) { set_error("gemm: kernel must be 0 (auto), 128, 256 or 2 (two-workgroup persistent)"); return PST_EINVAL; }
   if (p.kernel == 2 && (pst::gemm2g_class(p) == 0 || (int64_t)p.M * p.lda >= (1ll << 31) || (int64_t)p.N * p.ldw >= (1ll << 31))) {
     set_error("gemm: the two-workgroup kernel takes the persistent kernel's classes only (plain 16-bit / fp32 residual stream / transposed 16-bit, N %% 64 == 0)"); return PST_EINVAL;
@@ -604,6 +611,7 @@ extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
   if (int rc = gemm_validate(pp)) return rc;
   const pst_gemm_params& p = *pp;
   hipStream_t s = (hipStream_t)stream;
+  if (p.dtype16 == DT_F32) return launch_gemm_f32(p, s);
   if (rowstream_class(p)) return launch_rowstream(p, s, num_cus());      // LoftUp's 384 x 384 GEMMs over ~10^6 rows: streamed, not tiled
   const int c = gemm_choice(p);
   // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
@@ -626,6 +634,7 @@ extern "C" int pst_debug_g2_trace(void* buf, int tiles_per_workgroup) {
 
 extern "C" const char* pst_gemm_variant(const pst_gemm_params* pp) {
   if (gemm_validate(pp)) return nullptr;
+  if (pp->dtype16 == pst::DT_F32) return "gemm_f32_kernel";
   if (pst::rowstream_class(*pp)) return "rowgemm384_kernel";
   const int c = gemm_choice(*pp);
   if (c == 3) return "gemm2g_kernel";

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void image_prepare_kernel(const uint8_t* src, 
 // DINOv2 branch, bit-identical to dino_pre_kernel + patchify_kernel (same expression, contraction off): ImageNet normalisation of
 // the taps, then the bilinear resize (align_corners=False) from (H, W) to (gh*pd, gw*pd).  `transposed`: the DINOv2 input is the
 // TRANSPOSED image (reference dinov2_transpose for portrait views, model/dino.py:15-47): token grid gw x gh, sampling with swapped axes.
-__global__ __launch_bounds__(256) void patch_rows_kernel(const float* img, bf16_t* enc, int64_t ld_enc, bf16_t* dino, int64_t ld_dino, int nimg, int H, int W,
+__global__ __launch_bounds__(256) void patch_rows_kernel(const float* img, void* enc, int64_t ld_enc, void* dino, int64_t ld_dino, int nimg, int H, int W,
                                                          int pe, int pd, int transposed, int tc) {
 #pragma clang fp contract(off)
   const int gh = H / pe, gw = W / pe, T = gh * gw;
@@ -74,18 +74,18 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(const float* img, bf16_
     const int n = (int)(tok / T), t = (int)(tok - (int64_t)n * T);
     const float* im = img + (int64_t)n * 3 * H * W;
     if (r < per_e) {                                      // ---- encoder row: plain 16x16 patch, columns (c*p + dy)*p + dx
-      bf16_t* orow = enc + tok * ld_enc;
-      if (r == 3 * pe) { for (int c = 3 * pe * pe; c < ld_enc; ++c) orow[c] = 0; continue; }
+      const int64_t orow = tok * ld_enc;
+      if (r == 3 * pe) { for (int c = 3 * pe * pe; c < ld_enc; ++c) store1(enc, orow + c, tc, 0.f); continue; }
       const int c = r / pe, dy = r - c * pe;
       const int ty = t / gw, tx = t - ty * gw;
       const float* s = im + ((int64_t)c * H + ty * pe + dy) * W + tx * pe;
-      bf16_t* d = orow + (c * pe + dy) * pe;
-      for (int dx = 0; dx < pe; ++dx) d[dx] = st16(s[dx], tc);
+      const int64_t d = orow + (c * pe + dy) * pe;
+      for (int dx = 0; dx < pe; ++dx) store1(enc, d + dx, tc, s[dx]);
       continue;
     }
     r -= per_e;                                           // ---- DINOv2 row
-    bf16_t* orow = dino + tok * ld_dino;
-    if (r == 3 * pd) { for (int c = 3 * pd * pd; c < ld_dino; ++c) orow[c] = 0; continue; }
+    const int64_t orow = tok * ld_dino;
+    if (r == 3 * pd) { for (int c = 3 * pd * pd; c < ld_dino; ++c) store1(dino, orow + c, tc, 0.f); continue; }
     const int c = r / pd, dy = r - c * pd;
     const int ty = t / gwd, tx = t - ty * gwd;
     const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f), stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(const float* img, bf16_
     const float ly = fy - y0;
     const float* pl = im + (int64_t)c * H * W;
     auto px = [&](int y, int x) { const float v = transposed ? pl[(int64_t)x * W + y] : pl[(int64_t)y * W + x]; return ((v * 0.5f + 0.5f) - mean) / stdv; };
-    bf16_t* d = orow + (c * pd + dy) * pd;
+    const int64_t d = orow + (c * pd + dy) * pd;
     for (int dx = 0; dx < pd; ++dx) {
       const int ox = tx * pd + dx;
       const float fx = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(const float* img, bf16_
       const float lx = fx - x0;
       const float topv = px(y0, x0) * (1.f - lx) + px(y0, x1) * lx;
       const float botv = px(y1, x0) * (1.f - lx) + px(y1, x1) * lx;
-      d[dx] = st16(topv * (1.f - ly) + botv * ly, tc);
+      store1(dino, d + dx, tc, topv * (1.f - ly) + botv * ly);
     }
   }
 }
@@ -126,14 +126,14 @@ extern "C" int pst_image_prepare(const uint8_t* src, int Hs, int Ws, float* dst,
 
 extern "C" int pst_patch_rows(const float* img, void* enc, int64_t ld_enc, void* dino, int64_t ld_dino, int nimg, int H, int W, int p_enc, int p_dino,
                               int dino_transposed, int dtype16, void* stream) {
-  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !img || (!enc && !dino) || nimg <= 0 || p_enc <= 0 || H % p_enc || W % p_enc ||
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16 && dtype16 != DT_F32) || !img || (!enc && !dino) || nimg <= 0 || p_enc <= 0 || H % p_enc || W % p_enc ||
       (enc && ld_enc < 3 * (int64_t)p_enc * p_enc) || (dino && (p_dino <= 0 || ld_dino < 3 * (int64_t)p_dino * p_dino))) {
     set_error("patch_rows: bad argument (H=%d W=%d p=%d/%d)", H, W, p_enc, p_dino); return PST_EINVAL;
   }
   const int64_t total = (int64_t)nimg * (H / p_enc) * (W / p_enc) * ((enc ? 3 * p_enc + 1 : 0) + (dino ? 3 * p_dino + 1 : 0));
   int64_t g = (total + 255) / 256;
   if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(patch_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)enc, ld_enc, (bf16_t*)dino, ld_dino, nimg, H, W,
+  hipLaunchKernelGGL(patch_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, enc, ld_enc, dino, ld_dino, nimg, H, W,
                      p_enc, p_dino, dino_transposed, dtype16);
   return check_launch("patch_rows");
 }

@@ -98,6 +98,11 @@ __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, con
     for (int c = 0; c < 3; ++c) base[2 + c] = (img2[((int64_t)(view * 3 + c)) * P + pc] - lo[c]) / sc[c] - 0.5f;
     const int ts = (int)ldy + 8;            // tile row stride: +16 B so the 64 lanes' 2-byte writes to one column spread over 16 banks (4-way instead of 64-way conflicts)
     bf16_t* trow = tile + (int64_t)px * ts;
+    // fp32 rows (tc == DT_F32, the amp=False mode): straight to global memory, no 16-bit tile
+    auto put = [&](int col, float val) {
+      if (tc == DT_F32) { if (ok) ((float*)y)[((int64_t)view * P + pix) * ldy + col] = val; }
+      else trow[col] = st16(val, tc);
+    };
     for (int f = cg; f < nf; f += 4) {
       const float fr = freq[f];
 #pragma unroll
@@ -105,8 +110,8 @@ __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, con
         const float vs = sinf(base[d] * fr + biases[f * 5 + d]);
         const float vc = cosf(base[d] * fr + biases[5 * nf + f * 5 + d]);
         if (APPLY) {
-          trow[f * 5 + d] = st16((vs - mean) * rstd * gamma[f * 5 + d] + beta[f * 5 + d], tc);
-          trow[5 * nf + f * 5 + d] = st16((vc - mean) * rstd * gamma[5 * nf + f * 5 + d] + beta[5 * nf + f * 5 + d], tc);
+          put(f * 5 + d, (vs - mean) * rstd * gamma[f * 5 + d] + beta[f * 5 + d]);
+          put(5 * nf + f * 5 + d, (vc - mean) * rstd * gamma[5 * nf + f * 5 + d] + beta[5 * nf + f * 5 + d]);
         } else if (ok) {
           s += vs + vc;
           s2 += vs * vs + vc * vc;
@@ -117,11 +122,13 @@ __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, con
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float v = base[2 + c];
-        if (APPLY) trow[10 * nf + c] = st16((v - mean) * rstd * gamma[10 * nf + c] + beta[10 * nf + c], tc);
+        if (APPLY) put(10 * nf + c, (v - mean) * rstd * gamma[10 * nf + c] + beta[10 * nf + c]);
         else if (ok) { s += v; s2 += v * v; }
       }
     }
-    if (APPLY) {
+    if (APPLY && tc == DT_F32) {
+      for (int c = CH + cg; c < ldy; c += 4) put(c, 0.f);
+    } else if (APPLY) {
       for (int c = CH + cg; c < ldy; c += 4) trow[c] = 0;                  // zero padding up to the GEMM's K
       __syncthreads();
       const int cpr = (int)(ldy >> 3);                                       // 16-byte chunks per row
@@ -186,7 +193,7 @@ __global__ void gn_stats_kernel(const void* x, int64_t ldx, int x_fp32, float* p
 // VEC=4: one thread = 4 consecutive channels (8-16 B loads, 8 B stores); VEC=1 is the generic path (C = 203).
 template <int VEC>
 __global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
-                                bf16_t* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, int tc) {
+                                void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, int tc) {
   const int64_t cols = ldy / VEC;
   const int64_t total = (int64_t)nimg * P * cols;
   const float inv_n = 1.0f / ((float)P * (C / G));
@@ -214,8 +221,9 @@ __global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const fl
         if (relu) o[k] = fmaxf(o[k], 0.f);
       }
     }
-    if (VEC == 4) *(uint2*)(y + row * ldy + c) = make_uint2(pack2(o[0], o[1], tc), pack2(o[2], o[3], tc));
-    else y[row * ldy + c] = st16(o[0], tc);
+    if (VEC == 4 && tc == DT_F32) *(float4*)((float*)y + row * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    else if (VEC == 4) *(uint2*)((bf16_t*)y + row * ldy + c) = make_uint2(pack2(o[0], o[1], tc), pack2(o[2], o[3], tc));
+    else store1(y, row * ldy + c, tc, o[0]);
   }
 }
 
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const bf16_t* x, const f
 }
 
 // low-res positional features: 20 channels = sin(f*2+d) x10, cos x10 on the (h, w) token grid
-__global__ void lr_pe_kernel(const float* biases, bf16_t* out, int64_t ld, int col0, int nimg, int h, int w, int tc) {
+__global__ void lr_pe_kernel(const float* biases, void* out, int64_t ld, int col0, int nimg, int h, int w, int tc) {
   const int64_t total = (int64_t)nimg * h * w * 20;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int ch = (int)(i % 20);
@@ -263,7 +271,7 @@ __global__ void lr_pe_kernel(const float* biases, bf16_t* out, int64_t ld, int c
     const int kind = ch / 10, r = ch - kind * 10, f = r / 2, d = r - f * 2;
     const float base = d == 0 ? (h > 1 ? -1.f + 2.f * y / (h - 1) : -1.f) : (w > 1 ? -1.f + 2.f * x / (w - 1) : -1.f);
     const float ph = base * expf(-2.f + 3.f * f) + biases[kind * 10 + f * 2 + d];
-    out[tok * ld + col0 + ch] = st16(kind == 0 ? sinf(ph) : cosf(ph), tc);
+    store1(out, tok * ld + col0 + ch, tc, kind == 0 ? sinf(ph) : cosf(ph));
   }
 }
 
@@ -274,7 +282,7 @@ using namespace pst;
 extern "C" int pst_loftup_guidance_gn(const float* img, const float* biases, const float* gamma, const float* beta, float eps,
                                       float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, int dtype16, void* stream) {
   const int CHc = 10 * nf + 3;
-  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !img || !biases || !gamma || !beta || !scratch || !stats || !y || nimg <= 0 || H % 2 || W % 2 || nf < 2 || nf > 64 || ldy < CHc ||
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16 && dtype16 != DT_F32) || !img || !biases || !gamma || !beta || !scratch || !stats || !y || nimg <= 0 || H % 2 || W % 2 || nf < 2 || nf > 64 || ldy < CHc ||
       ldy % 8 || ldy > 512 || ((uintptr_t)y & 15)) {
     set_error("loftup_guidance_gn: bad argument (nf=%d ldy=%lld)", nf, (long long)ldy); return PST_EINVAL;
   }
@@ -314,8 +322,8 @@ extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float
 
 extern "C" int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
                                    void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, int dtype16, void* stream) {
-  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !x || !stats || !gamma || !beta || !y || nimg <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G || ldy < C) { set_error("groupnorm_apply: bad argument"); return PST_EINVAL; }
-  if (x_fp32 == dtype16 && C % 8 == 0 && (C / G) % 8 == 0 && ldx == C && ldy == C && C / 8 <= 256 && !(((uintptr_t)x | (uintptr_t)y) & 15)) {
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16 && dtype16 != DT_F32) || !x || !stats || !gamma || !beta || !y || nimg <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G || ldy < C) { set_error("groupnorm_apply: bad argument"); return PST_EINVAL; }
+  if (x_fp32 == dtype16 && dtype16 != DT_F32 && C % 8 == 0 && (C / G) % 8 == 0 && ldx == C && ldy == C && C / 8 <= 256 && !(((uintptr_t)x | (uintptr_t)y) & 15)) {
     const int c8n = C / 8, rpb = 256 / c8n, rows_per_block = 16 * rpb;
     hipLaunchKernelGGL(gn_apply8_kernel, dim3((P + rows_per_block - 1) / rows_per_block, nimg), dim3(c8n * rpb), 0, (hipStream_t)stream, (const bf16_t*)x, stats, gamma, beta,
                        (bf16_t*)y, P, C, G, eps, relu, dtype16, rows_per_block);
@@ -325,16 +333,16 @@ extern "C" int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const
   const int64_t total = (int64_t)nimg * P * (vec ? ldy / 4 : ldy);
   int64_t g = (total + 255) / 256;
   if (g > 16384) g = 16384;
-  if (vec) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu, dtype16);
-  else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, (bf16_t*)y, ldy, nimg, P, C, G, eps, relu, dtype16);
+  if (vec) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, y, ldy, nimg, P, C, G, eps, relu, dtype16);
+  else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, ldx, x_fp32, stats, gamma, beta, y, ldy, nimg, P, C, G, eps, relu, dtype16);
   return check_launch("groupnorm_apply");
 }
 
 extern "C" int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int nimg, int h, int w, int dtype16, void* stream) {
-  if ((dtype16 != DT_BF16 && dtype16 != DT_F16) || !biases || !out || nimg <= 0 || h <= 0 || w <= 0 || col0 < 0 || col0 + 20 > ld) { set_error("loftup_lr_pe: bad argument"); return PST_EINVAL; }
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16 && dtype16 != DT_F32) || !biases || !out || nimg <= 0 || h <= 0 || w <= 0 || col0 < 0 || col0 + 20 > ld) { set_error("loftup_lr_pe: bad argument"); return PST_EINVAL; }
   const int64_t total = (int64_t)nimg * h * w * 20;
   int64_t g = (total + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(lr_pe_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, biases, (bf16_t*)out, ld, col0, nimg, h, w, dtype16);
+  hipLaunchKernelGGL(lr_pe_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, biases, out, ld, col0, nimg, h, w, dtype16);
   return check_launch("loftup_lr_pe");
 }

@@ -165,7 +165,7 @@ __global__ void split3_kernel(const float* x, int64_t ldx, bf16_t* out, int64_t 
 
 // ------------------------------------------------------------------ RoPE-2D in place
 // thread = (row, head, half, 4 consecutive frequencies): rotates pairs (i, i + hd/4) of that half.
-__global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, int tc) {
+__global__ void rope2d_kernel(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, int tc) {
   const int nf = hd / 4;                 // frequencies per half
   const int per_row = nheads * 2 * (nf / 4);
   const int64_t total = (int64_t)rows * per_row;
@@ -175,10 +175,10 @@ __global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const f
     const int fq = (r % (nf / 4)) * 4; r /= (nf / 4);
     const int half = r & 1, head = r >> 1;
     const int pp = pos[2 * row + half];
-    bf16_t* base = x + (int64_t)row * ld + head * hd + half * (hd / 2) + fq;
+    const int64_t e = (int64_t)row * ld + head * hd + half * (hd / 2) + fq;
     float a[4], b[4];
-    load4(base, 0, tc, a);
-    load4(base, nf, tc, b);
+    load4(x, e, tc, a);
+    load4(x, e + nf, tc, b);
     const float* t = cs + ((int64_t)pp * nf + fq) * 2;
     float oa[4], ob[4];
 #pragma unroll
@@ -187,30 +187,30 @@ __global__ void rope2d_kernel(bf16_t* x, int64_t ld, const int32_t* pos, const f
       oa[k] = rope_pair(a[k], b[k], c, s, false);
       ob[k] = rope_pair(b[k], a[k], c, s, true);
     }
-    store4(base, 0, tc, oa);
-    store4(base, nf, tc, ob);
+    store4(x, e, tc, oa);
+    store4(x, e + nf, tc, ob);
   }
 }
 
 // ------------------------------------------------------------------ patchify: thread = (token, c, dy) -> p pixels
-__global__ void patchify_kernel(const float* img, bf16_t* out, int64_t ld, int nimg, int C, int H, int W, int p, int tc) {
+__global__ void patchify_kernel(const float* img, void* out, int64_t ld, int nimg, int C, int H, int W, int p, int tc) {
   const int gh = H / p, gw = W / p;
   const int per_tok = C * p + 1;                       // +1: the thread that zero-fills the K padding
   const int64_t total = (int64_t)nimg * gh * gw * per_tok;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t tok = i / per_tok;
     const int r = (int)(i - tok * per_tok);
-    bf16_t* orow = out + tok * ld;
+    const int64_t orow = tok * ld;
     if (r == C * p) {
-      for (int c = C * p * p; c < ld; ++c) orow[c] = 0;
+      for (int c = C * p * p; c < ld; ++c) store1(out, orow + c, tc, 0.f);
       continue;
     }
     const int c = r / p, dy = r - c * p;
     const int n = (int)(tok / (gh * gw)), t = (int)(tok - (int64_t)n * gh * gw);
     const int ty = t / gw, tx = t - ty * gw;
     const float* src = img + (((int64_t)n * C + c) * H + ty * p + dy) * W + tx * p;
-    bf16_t* dst = orow + (c * p + dy) * p;
-    for (int dx = 0; dx < p; ++dx) dst[dx] = st16(src[dx], tc);
+    const int64_t dst = orow + (c * p + dy) * p;
+    for (int dx = 0; dx < p; ++dx) store1(out, dst + dx, tc, src[dx]);
   }
 }
 
@@ -273,18 +273,18 @@ __global__ void add_cast_kernel(const void* a, int64_t lda, int a_fp32, const vo
 }
 
 // ------------------------------------------------------------------ y = x / (||x|| + eps), one wave per row
-__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, int64_t ldx, bf16_t* y, int64_t ldy, int rows, int D, float eps, int tc) {
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps, int tc) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float s = 0.f;
   for (int c = lane; c < D; c += 64) { const float v = x[(int64_t)row * ldx + c]; s += v * v; }
   const float inv = 1.0f / (sqrtf(wave_sum(s)) + eps);
-  for (int c = lane; c < D; c += 64) y[(int64_t)row * ldy + c] = st16(x[(int64_t)row * ldx + c] * inv, tc);
+  for (int c = lane; c < D; c += 64) store1(y, (int64_t)row * ldy + c, tc, x[(int64_t)row * ldx + c] * inv);
 }
 
 // ------------------------------------------------------------------ mean of the central 2x2 pixels of every 8x8 block
-__global__ void mean4_kernel(const bf16_t* F, bf16_t* Fm, int nimg, int Hm, int Wm, int C, int tc) {
+__global__ void mean4_kernel(const void* F, void* Fm, int nimg, int Hm, int Wm, int C, int tc) {
   const int th = Hm / 8, tw = Wm / 8, c4 = C / 4;
   const int64_t total = (int64_t)nimg * th * tw * c4;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -292,12 +292,12 @@ __global__ void mean4_kernel(const bf16_t* F, bf16_t* Fm, int nimg, int Hm, int 
     const int64_t tok = i / c4;
     const int tx = (int)(tok % tw), ty = (int)((tok / tw) % th);
     const int64_t n = tok / ((int64_t)tw * th);
-    const bf16_t* base = F + ((n * Hm + ty * 8 + 3) * Wm + tx * 8 + 3) * (int64_t)C + c;
+    const int64_t base = ((n * Hm + ty * 8 + 3) * Wm + tx * 8 + 3) * (int64_t)C + c;
     float a[4], b[4], d[4], e[4];
-    load4(base, 0, tc, a);
-    load4(base, C, tc, b);
-    load4(base, (int64_t)Wm * C, tc, d);
-    load4(base, (int64_t)Wm * C + C, tc, e);
+    load4(F, base, tc, a);
+    load4(F, base + C, tc, b);
+    load4(F, base + (int64_t)Wm * C, tc, d);
+    load4(F, base + (int64_t)Wm * C + C, tc, e);
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = 0.25f * (a[k] + b[k] + d[k] + e[k]);
@@ -308,7 +308,7 @@ __global__ void mean4_kernel(const bf16_t* F, bf16_t* Fm, int nimg, int Hm, int 
 // ------------------------------------------------------------------ general bilinear resize of pixel-major features
 // F [nimg, Hs, Ws, C] bf16 -> Fd [nimg, Hd, Wd, C] bf16 with torch's align_corners=False, antialias=False rule:
 // src = (dst + 0.5) * (S / D) - 0.5 clamped at 0, taps floor(src) and min(floor(src) + 1, S - 1).
-__global__ void resize_bilinear_kernel(const bf16_t* F, bf16_t* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, int tc) {
+__global__ void resize_bilinear_kernel(const void* F, void* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, int tc) {
   const int c4 = C / 4;
   const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
   const int64_t total = (int64_t)nimg * Hd * Wd * c4;
@@ -321,12 +321,12 @@ __global__ void resize_bilinear_kernel(const bf16_t* F, bf16_t* Fd, int nimg, in
     const int y0 = min((int)fy, Hs - 1), x0 = min((int)fx, Ws - 1);
     const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
     const float wy = fy - (float)y0, wx = fx - (float)x0;
-    const bf16_t* img = F + n * Hs * (int64_t)Ws * C + c;
+    const int64_t img = n * Hs * (int64_t)Ws * C + c;
     float a[4], b[4], d[4], e[4];
-    load4(img, ((int64_t)y0 * Ws + x0) * C, tc, a);
-    load4(img, ((int64_t)y0 * Ws + x1) * C, tc, b);
-    load4(img, ((int64_t)y1 * Ws + x0) * C, tc, d);
-    load4(img, ((int64_t)y1 * Ws + x1) * C, tc, e);
+    load4(F, img + ((int64_t)y0 * Ws + x0) * C, tc, a);
+    load4(F, img + ((int64_t)y0 * Ws + x1) * C, tc, b);
+    load4(F, img + ((int64_t)y1 * Ws + x0) * C, tc, d);
+    load4(F, img + ((int64_t)y1 * Ws + x1) * C, tc, e);
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -422,17 +422,17 @@ extern "C" int pst_split3(const float* x, int64_t ldx, void* out, int64_t ldo, i
 }
 
 extern "C" int pst_rope2d(void* x, int64_t ld, const int32_t* pos, const float* cs, int rows, int nheads, int hd, int dtype16, void* stream) {
-  if (bad16(dtype16) || !x || !pos || !cs || rows <= 0 || nheads <= 0) { set_error("rope2d: null/empty argument"); return PST_EINVAL; }
+  if (badtc(dtype16) || !x || !pos || !cs || rows <= 0 || nheads <= 0) { set_error("rope2d: null/empty argument"); return PST_EINVAL; }
   if (hd % 16 || ld % 4) { set_error("rope2d: need hd%%16==0 and ld%%4==0 (hd=%d)", hd); return PST_EINVAL; }
   const int64_t total = (int64_t)rows * nheads * 2 * (hd / 16);
-  hipLaunchKernelGGL(rope2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ld, pos, cs, rows, nheads, hd, dtype16);
+  hipLaunchKernelGGL(rope2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ld, pos, cs, rows, nheads, hd, dtype16);
   return check_launch("rope2d");
 }
 
 extern "C" int pst_patchify(const float* img, void* out, int64_t ld, int nimg, int C, int H, int W, int p, int dtype16, void* stream) {
-  if (bad16(dtype16) || !img || !out || nimg <= 0 || p <= 0 || H % p || W % p || ld < (int64_t)C * p * p) { set_error("patchify: bad argument"); return PST_EINVAL; }
+  if (badtc(dtype16) || !img || !out || nimg <= 0 || p <= 0 || H % p || W % p || ld < (int64_t)C * p * p) { set_error("patchify: bad argument"); return PST_EINVAL; }
   const int64_t total = (int64_t)nimg * (H / p) * (W / p) * (C * p + 1);
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, ld, nimg, C, H, W, p, dtype16);
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, out, ld, nimg, C, H, W, p, dtype16);
   return check_launch("patchify");
 }
 
@@ -454,22 +454,22 @@ extern "C" int pst_add_cast(const void* a, int64_t lda, int a_fp32, const void* 
 }
 
 extern "C" int pst_l2norm_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, float eps, int dtype16, void* stream) {
-  if (bad16(dtype16) || !x || !y || rows <= 0 || D <= 0) { set_error("l2norm_rows: bad argument"); return PST_EINVAL; }
-  hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, rows, D, eps, dtype16);
+  if (badtc(dtype16) || !x || !y || rows <= 0 || D <= 0) { set_error("l2norm_rows: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, D, eps, dtype16);
   return check_launch("l2norm_rows");
 }
 
 extern "C" int pst_mean4(const void* F, void* Fm, int nimg, int Hm, int Wm, int C, int dtype16, void* stream) {
-  if (bad16(dtype16) || !F || !Fm || nimg <= 0 || Hm % 8 || Wm % 8 || C % 4) { set_error("mean4: bad argument"); return PST_EINVAL; }
+  if (badtc(dtype16) || !F || !Fm || nimg <= 0 || Hm % 8 || Wm % 8 || C % 4) { set_error("mean4: bad argument"); return PST_EINVAL; }
   const int64_t total = (int64_t)nimg * (Hm / 8) * (Wm / 8) * (C / 4);
-  hipLaunchKernelGGL(mean4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)F, (bf16_t*)Fm, nimg, Hm, Wm, C, dtype16);
+  hipLaunchKernelGGL(mean4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, F, Fm, nimg, Hm, Wm, C, dtype16);
   return check_launch("mean4");
 }
 
 extern "C" int pst_resize_bilinear(const void* F, void* Fd, int nimg, int Hs, int Ws, int Hd, int Wd, int C, int dtype16, void* stream) {
-  if (bad16(dtype16) || !F || !Fd || nimg <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || C <= 0 || C % 4) { set_error("resize_bilinear: bad argument"); return PST_EINVAL; }
+  if (badtc(dtype16) || !F || !Fd || nimg <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || C <= 0 || C % 4) { set_error("resize_bilinear: bad argument"); return PST_EINVAL; }
   const int64_t total = (int64_t)nimg * Hd * Wd * (C / 4);
-  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)F, (bf16_t*)Fd, nimg, Hs, Ws, Hd, Wd, C, dtype16);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, F, Fd, nimg, Hs, Ws, Hd, Wd, C, dtype16);
   return check_launch("resize_bilinear");
 }
 

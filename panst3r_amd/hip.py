@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PST_LIB') or os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')      # PST_LIB: A/B builds of the same ABI (measurement)
-ABI_VERSION = 15
+ABI_VERSION = 16
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -93,6 +93,7 @@ def _ptr(t):
 
 
 H16 = (torch.bfloat16, torch.float16)        # the two 16-bit storage formats (amp='bf16' / amp='fp16'); all 16-bit operands of a call share one
+FMT = H16 + (torch.float32,)                 # ... and fp32 operands: the reference's amp=False mode (gemm_f32 / attn_f32, the precision path)
 _TC = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}     # element type codes of the C ABI (PST_BF16 / PST_F32 / PST_F16)
 
 
@@ -105,6 +106,14 @@ def _same16(*ts):
     dts = {t.dtype for t in ts if t is not None and t.dtype in H16}
     if len(dts) != 1:
         raise RuntimeError('16-bit operands of one call must share one format, got %s' % sorted(str(d) for d in dts))
+    return _TC[dts.pop()]
+
+
+def _fmt(*ts):
+    """operand format code of a call whose operands all share ONE storage format (16-bit or, in the amp=False mode, fp32)"""
+    dts = {t.dtype for t in ts if t is not None}
+    if len(dts) != 1 or next(iter(dts)) not in FMT:
+        raise RuntimeError('the operands of this call must share one of the formats bf16 / f16 / f32, got %s' % sorted(str(d) for d in dts))
     return _TC[dts.pop()]
 
 
@@ -198,11 +207,12 @@ ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
          M=None, kernel=0, rope=None, batch=None, xcopy=None, stats_out=None, ln=None):
     """out = epi(a @ w.T).  a [M,K] 16-bit (row-major view), w [N,K] 16-bit, out 16-bit / fp32 2-D view (or raw buffer for ps).
+    a, w, out (and res) all fp32: the amp=False mode's fp32-FMA GEMM (same epilogues; no fused RoPE, no LayerNorm fold).
     LayerNorm fold (include/panst3r_hip.h): producer side `xcopy` (16-bit copy of an fp32 out) and `stats_out` (fp32 [M, N/64, 2]);
     consumer side `ln` = (stats [M, groups, 2], colsum [N], eps) with `a` the raw rows and `w` / `bias` folded at pack time."""
-    _dev(a, *H16); _dev(w, *H16); _dev(out, torch.bfloat16, torch.float16, torch.float32)
+    _dev(a, *FMT); _dev(w, *FMT); _dev(out, *FMT)
     p = GemmParams()
-    p.dtype16 = _same16(a, w, out, res)
+    p.dtype16 = _fmt(a, w) if a.dtype == torch.float32 else _same16(a, w, out, res)       # fp32 operands: C / res must be fp32 too (checked by the C side)
     N, K = w.shape
     if conv is not None:
         cc, ch, cw = conv
@@ -303,9 +313,9 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
               mask_strides=(0, 0), nsplit=None, ws=None, prescaled=False):
     """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row).
     prescaled: q was produced with scale * LOG2E folded in (see `qscale`): softmax in the exp2 domain without a per-score multiply."""
-    _dev(q, *H16); _dev(k, *H16); _dev(vt, *H16); _dev(out, *H16)
+    _dev(q, *FMT); _dev(k, *FMT); _dev(vt, *FMT); _dev(out, *FMT)
     p = AttnParams()
-    p.dtype16 = _same16(q, k, vt, out)
+    p.dtype16 = _fmt(q, k, vt, out)
     p.Q, (p.q_bs, p.q_hs, p.q_rs) = _ptr(q), q_strides
     p.K, (p.k_bs, p.k_hs, p.k_rs) = _ptr(k), k_strides
     p.Vt, (p.v_bs, p.v_hs, p.v_ds) = _ptr(vt), v_strides
@@ -318,6 +328,8 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
     p.prescaled = 1 if prescaled else 0
     p.zeros = _ptr(zeros_page(q.device))
     ns = auto_nsplit(B, H, Nq, Nk) if nsplit is None else nsplit
+    if q.dtype == torch.float32 and nsplit is None:
+        ns = 1                      # the fp32 kernel does not split the key range
     if ns > 1:
         n = ns * B * H * Nq * (hd + 2)
         if ws is None:          # caller-owned workspace preferred (C ABI: the caller owns every buffer); else one from torch's caching allocator
@@ -411,7 +423,7 @@ def pack_split3(weight, dtype=torch.bfloat16):
 
 def rope2d_(x, pos, table, nheads, hd):
     """In-place RoPE-2D on the first nheads*hd columns of the row-major bf16 view x; pos int32 [rows,2]."""
-    _dev(x, *H16); _dev(pos, torch.int32); _dev(table, torch.float32)
+    _dev(x, *FMT); _dev(pos, torch.int32); _dev(table, torch.float32)
     _check(lib().pst_rope2d(_ptr(x), i64(_rowmajor(x)), _ptr(pos), _ptr(table), x.shape[0], nheads, hd, _tc(x), _stream()),
            'pst_rope2d')
     return x
@@ -426,7 +438,7 @@ def rope_table(npos, hd, base=100.0, device='cuda'):
 
 
 def patchify(img, out, p):
-    _dev(img, torch.float32); _dev(out, *H16)
+    _dev(img, torch.float32); _dev(out, *FMT)
     n, c, h, w = img.shape
     assert img.is_contiguous()
     _check(lib().pst_patchify(_ptr(img), _ptr(out), i64(_rowmajor(out)), n, c, h, w, p, _tc(out), _stream()), 'pst_patchify')
@@ -458,7 +470,7 @@ def patch_rows(img, enc=None, dino=None, p_enc=16, p_dino=14, dino_transposed=Fa
     _dev(img, torch.float32)
     assert img.is_contiguous() and (enc is not None or dino is not None)
     n, _, H, W = img.shape
-    d16 = _same16(enc, dino)
+    d16 = _fmt(enc, dino)
     _check(lib().pst_patch_rows(_ptr(img), _ptr(enc), i64(_rowmajor(enc) if enc is not None else 0), _ptr(dino),
                                 i64(_rowmajor(dino) if dino is not None else 0), n, H, W, p_enc, p_dino, int(dino_transposed), d16, _stream()),
            'pst_patch_rows')
@@ -476,7 +488,7 @@ def add_cast(a, out, b=None, b_mod=0):
 
 
 def l2norm_rows(x, out, eps):
-    _dev(x, torch.float32); _dev(out, *H16)
+    _dev(x, torch.float32); _dev(out, *FMT)
     _check(lib().pst_l2norm_rows(_ptr(x), i64(_rowmajor(x)), _ptr(out), i64(_rowmajor(out)), x.shape[0], x.shape[1], f32(eps),
                                  _tc(out), _stream()), 'pst_l2norm_rows')
     return out
@@ -484,14 +496,14 @@ def l2norm_rows(x, out, eps):
 
 @hbm_timed('mean4', lambda F, Fm, nimg, Hm, Wm, Cc: Fm.numel() * 2 * 5)
 def mean4(F, Fm, nimg, Hm, Wm, Cc):
-    _dev(F, *H16); _dev(Fm, *H16)
-    _check(lib().pst_mean4(_ptr(F), _ptr(Fm), nimg, Hm, Wm, Cc, _same16(F, Fm), _stream()), 'pst_mean4')
+    _dev(F, *FMT); _dev(Fm, *FMT)
+    _check(lib().pst_mean4(_ptr(F), _ptr(Fm), nimg, Hm, Wm, Cc, _fmt(F, Fm), _stream()), 'pst_mean4')
     return Fm
 
 
 def resize_bilinear(F, Fd, nimg, Hs, Ws, Hd, Wd, Cc):
-    _dev(F, *H16); _dev(Fd, *H16)
-    _check(lib().pst_resize_bilinear(_ptr(F), _ptr(Fd), nimg, Hs, Ws, Hd, Wd, Cc, _same16(F, Fd), _stream()), 'pst_resize_bilinear')
+    _dev(F, *FMT); _dev(Fd, *FMT)
+    _check(lib().pst_resize_bilinear(_ptr(F), _ptr(Fd), nimg, Hs, Ws, Hd, Wd, Cc, _fmt(F, Fd), _stream()), 'pst_resize_bilinear')
     return Fd
 
 
@@ -511,7 +523,7 @@ def stats_buffer(nimg, G, device):
 @hbm_timed('loftup_guidance_gn', lambda img, biases, gamma, beta, eps, scratch, stats, out, nf: img.numel() * 4 + out.numel() * 2)
 def loftup_guidance_gn(img, biases, gamma, beta, eps, scratch, stats, out, nf):
     """Fourier guidance features + GroupNorm(1) straight to bf16 `out` [nimg*P, ld] (zero-padded columns); no fp32 feature buffer."""
-    _dev(img, torch.float32); _dev(biases, torch.float32); _dev(scratch, torch.float32); _dev(stats, torch.float32); _dev(out, *H16)
+    _dev(img, torch.float32); _dev(biases, torch.float32); _dev(scratch, torch.float32); _dev(stats, torch.float32); _dev(out, *FMT)
     n, _, h, w = img.shape
     assert img.is_contiguous() and scratch.numel() >= n * (3 * (h // 2) * (w // 2) + 6)
     _check(lib().pst_loftup_guidance_gn(_ptr(img), _ptr(biases), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)), f32(eps),
@@ -529,14 +541,14 @@ def groupnorm_stats(x, stats, nimg, P, Cc, G):
 
 @hbm_timed('groupnorm_apply', lambda x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu: nimg * P * (Cc * _esz(x) + out.shape[1] * 2))
 def groupnorm_apply(x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu):
-    _dev(x); _dev(out, *H16)
+    _dev(x); _dev(out, *FMT)
     _check(lib().pst_groupnorm_apply(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(stats), _ptr(gamma), _ptr(beta),
                                      _ptr(out), i64(_rowmajor(out)), nimg, P, Cc, G, f32(eps), int(relu), _tc(out), _stream()), 'pst_groupnorm_apply')
     return out
 
 
 def loftup_lr_pe(biases, out, col0, nimg, h, w):
-    _dev(biases, torch.float32); _dev(out, *H16)
+    _dev(biases, torch.float32); _dev(out, *FMT)
     _check(lib().pst_loftup_lr_pe(_ptr(biases), _ptr(out), i64(_rowmajor(out)), col0, nimg, h, w, _tc(out), _stream()), 'pst_loftup_lr_pe')
     return out
 

@@ -14,15 +14,17 @@ F16 = torch.float16
 
 
 class _Precision:
-    """The 16-bit storage / MFMA operand format of everything the HIP path computes: bfloat16 (amp='bf16') or IEEE half
-    (amp='fp16'; reference tools/demo_panst3r.py:88, utils.py:206-215).  Accumulation, residual streams, softmax and normalisation
-    statistics are fp32 in both.  Process-wide, switched by the `precision(...)` context (a SceneRunner enters it around every
+    """The storage / operand format of everything the HIP path computes: bfloat16 (amp='bf16') or IEEE half (amp='fp16'; reference
+    tools/demo_panst3r.py:88, utils.py:206-215) on the MFMA kernels, or float32 (amp=False, the reference's default: fp32 end to end) on
+    the fp32-FMA GEMM / attention kernels - the precision path, ~20x slower.  Accumulation, residual streams, softmax and normalisation
+    statistics are fp32 in all three.  Process-wide, switched by the `precision(...)` context (a SceneRunner enters it around every
     stage, so graphs are captured - and weights packed - in the runner's format)."""
     dtype = torch.float16
 
 
 PREC = _Precision()
-AMP_DTYPES = {'bf16': torch.bfloat16, 'fp16': torch.float16, torch.bfloat16: torch.bfloat16, torch.float16: torch.float16}
+AMP_DTYPES = {'bf16': torch.bfloat16, 'fp16': torch.float16, torch.bfloat16: torch.bfloat16, torch.float16: torch.float16,
+              'fp32': torch.float32, torch.float32: torch.float32}
 
 
 def adt():
@@ -41,16 +43,15 @@ def warn_once(key, msg):
 
 
 def amp_dtype(amp, quiet=False):
-    """`amp` argument of the reference API (False | 'bf16' | 'fp16', utils.py:206-215) -> 16-bit storage / MFMA operand dtype.
-    amp=False is the reference's fp32 mode (tools/demo_panst3r.py:88 default).  The HIP path has no fp32-operand variant: it computes
-    amp=False scenes with f16 operands (11-bit mantissa; fp32 accumulation, residual streams, softmax and statistics) and SAYS SO once
-    per process; PanSt3R.forward_inference_multi_ar re-runs such a scene with bf16 operands if an f16 store overflowed."""
-    if amp is None or amp is False:
+    """`amp` argument of the reference API (False | 'bf16' | 'fp16', utils.py:206-215) -> storage / operand dtype of the HIP path.
+    amp=False is the reference's fp32 mode (tools/demo_panst3r.py:88 default): float32 activations and weights, the fp32-FMA GEMM
+    (csrc/gemm_f32.hip) and attention (csrc/attn_f32.hip) kernels - the reference's arithmetic, at fp32-FMA speed (no MFMA: ~20x the time of
+    a 16-bit scene), said once per process.  ('fp32' is accepted as a synonym of False.)"""
+    if amp is None or amp is False or amp == 'fp32' or amp is torch.float32:
         if not quiet:
-            warn_once('amp_false', "panst3r_amd: amp=False (the reference's fp32 mode) runs with f16 MFMA operands and fp32 accumulation on the "
-                                   "HIP path - 16-bit tolerances apply (pointmaps rel-L2 <= 2e-2, measured ~1e-3); pass amp='fp16' / 'bf16' to choose the "
-                                   "format explicitly")
-        return torch.float16
+            warn_once('amp_false', "panst3r_amd: amp=False is the fp32 mode (float32 operands on the fp32-FMA kernels, no MFMA): exact to ~1e-5 but "
+                                   "~20x slower than amp='fp16' / 'bf16' - pass one of those for the fast path")
+        return torch.float32
     if amp not in AMP_DTYPES:
         raise ValueError("amp must be False, 'bf16' or 'fp16' (got %r)" % (amp,))
     return AMP_DTYPES[amp]
@@ -58,7 +59,8 @@ def amp_dtype(amp, quiet=False):
 
 class precision:
     def __init__(self, dtype):
-        self.dtype = amp_dtype(dtype, quiet=True)        # internal plumbing (runners, tests): the API entry points do the telling
+        # internal plumbing (runners, tests): the API entry points do the telling.  None = keep the format in effect (default: f16)
+        self.dtype = PREC.dtype if dtype is None else amp_dtype(dtype, quiet=True)
 
     def __enter__(self):
         self.prev, PREC.dtype = PREC.dtype, self.dtype
@@ -73,7 +75,7 @@ def ceil_to(x, m):
 
 
 class Packed:
-    """bf16 weight [N, Kpad] (K zero-padded to a multiple of 64) + fp32 bias."""
+    """weight [N, Kpad] in the format in effect (K zero-padded to a multiple of 64) + fp32 bias."""
     __slots__ = ('w', 'b', 'n', 'k', 'cs', 'eps', 'ln')
 
     def __init__(self, weight, bias=None, device=None, row_perm=None):
@@ -221,7 +223,7 @@ def self_attention(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
     qk = empty(lay.rows, 2 * D, adt(), dev)
     xn, lq = s.operand(w_qk)
     qs = qscale(D, 2 * D, hd, dev)                                          # softmax scale * log2(e) folded into q (linear: commutes with RoPE)
-    if rope is not None and hd == 64:
+    if rope is not None and hd == 64 and adt() != torch.float32:
         hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, gamma=qs, rope=(pos, rope), ln=lq)      # RoPE-2D applied in the GEMM's store phase
     else:
         hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, gamma=qs, ln=lq)

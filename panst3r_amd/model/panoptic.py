@@ -390,7 +390,8 @@ class MaskTransformer(HipModule):
                     lang=Packed(self.lang_embed.weight, self.lang_embed.bias, device),
                     me=[Packed(l.weight, l.bias, device) for l in self.mask_embed.layers],
                     # the same MLP for split-precision evaluation: weights [W_hi | W_lo | W_hi] bf16, fp32 bias
-                    me3=[(hip.pack_split3(l.weight, adt()).to(device), f32(l.bias, device)) for l in self.mask_embed.layers],
+                    me3=None if adt() == torch.float32 else
+                    [(hip.pack_split3(l.weight, adt()).to(device), f32(l.bias, device)) for l in self.mask_embed.layers],
                     scale=float(self.cls_logit_scale.detach().exp()), pe={})
 
     def _pe(self, pk, h, w, portrait, device):
@@ -412,6 +413,12 @@ class MaskTransformer(HipModule):
         # (tests/diag/parity_maskhead.py).  The three GEMMs are tiny, so the 3x longer K costs nothing.
         a = empty(Q, d, torch.float32, dev)
         hip.layernorm(out, pk['dn'][0], pk['dn'][1], a, pk['dn'][2])
+        if pk['me3'] is None:                   # fp32 operands (amp=False): the plain MLP already carries 24 mantissa bits
+            for j, w in enumerate(pk['me']):
+                b = empty(Q, w.n, torch.float32, dev)
+                hip.gemm(a, w.w, b, bias=w.b, act=None if j == len(pk['me']) - 1 else 'relu')
+                a = b
+            return dn, a
         for j, (w3, b3) in enumerate(pk['me3']):
             a3 = empty(Q, w3.shape[1], adt(), dev)
             hip.split3(a, a3)
@@ -464,7 +471,7 @@ class MaskTransformer(HipModule):
         n, Hm, Wm, C = mask_feats.shape
         Q = embed.shape[0]
         out = torch.empty(n, Q, Hm, Wm, dtype=torch.float32, device=embed.device)
-        if hip.mask_head_supported(Q, Hm * Wm, C) and mask_feats.is_contiguous():
+        if embed.dtype != torch.float32 and hip.mask_head_supported(Q, Hm * Wm, C) and mask_feats.is_contiguous():
             hip.mask_head(embed, mask_feats, out)
         else:
             for i in range(n):

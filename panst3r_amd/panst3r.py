@@ -11,10 +11,10 @@ Same call signatures and output structure; what changed is HOW the scene is exec
   * decoder_norm -> class logits -> mask_embed of the frozen queries is computed once per scene, each view then costs
     one [Q,C]x[C,P] GEMM (the reference recomputes the heads per chunk, panoptic_decoder.py:71);
   * MinMaxScaler is per view (the demo's max_bs=1 convention), see SURVEY quirk 5.
-`amp` (False | 'bf16' | 'fp16', reference utils.py:206-215) selects the 16-bit storage / MFMA operand format of the scene:
-'bf16' and 'fp16' as in the reference's autocast; amp=False is the reference's fp32 mode: the HIP path has no fp32-operand variant, it
-computes such scenes with f16 operands (its most precise format), says so once (RuntimeWarning) and re-runs a scene in bf16 if an f16 store
-overflowed.  Accumulation, residual streams, softmax and normalisation statistics are fp32 always.
+`amp` (False | 'bf16' | 'fp16', reference utils.py:206-215) selects the storage / operand format of the scene: 'bf16' and 'fp16' as in the
+reference's autocast (MFMA kernels); amp=False is the reference's fp32 mode: float32 weights and activations on the fp32-FMA GEMM / attention
+kernels (csrc/gemm_f32.hip, attn_f32.hip) - the reference's default arithmetic, ~20x slower, said once (RuntimeWarning).  Accumulation,
+residual streams, softmax and normalisation statistics are fp32 always.
 """
 from argparse import Namespace
 import numpy as np
@@ -217,26 +217,20 @@ class PanSt3R(nn.Module):
         dev = imgs[0].device
         shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
         H, W = shapes[0]
-        fmt = amp_dtype(amp)                    # tells (once) that amp=False is computed with f16 operands
+        fmt = amp_dtype(amp)                    # tells (once) that amp=False is the slow fp32 mode
         runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs)
         res, scene = runner.run(outdevice)
         if check_finite and fmt == torch.float16:
             # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: ONE fused flag over everything the
-            # call returns (queries, class logits, pointmaps, mask logits), one host sync.  amp=False never asked for f16: it falls back to
-            # the range-safe format; an explicit amp='fp16' raises, as the reference's "--amp fp16 might be unstable" would show up.
+            # call returns (queries, class logits, pointmaps, mask logits), one host sync; raises, as the reference's "--amp fp16 might be
+            # unstable" would show up.  (amp=False is fp32 and amp='bf16' has the fp32 range: neither can overflow this way.)
             ok = torch.isfinite(scene['out_queries']).all() & torch.isfinite(scene['pred_logits']).all()
             for i in range(V):
                 ok = ok & torch.isfinite(res[i][0]).all() & torch.isfinite(res[i][1]).all()
             if not bool(ok):
-                if amp is False or amp is None:
-                    from .model.common import warn_once
-                    warn_once('f16_overflow', "panst3r_amd: an activation left the f16 range (non-finite outputs); amp=False scenes are re-run "
-                                              "with bf16 operands (8-bit mantissa, fp32 range)")
-                    if not cache_graphs:
-                        runner.release()
-                    return self.forward_inference_multi_ar(imgs, true_shape, classes, num_keyframes, use_retrieval, max_bs, outdevice, 'bf16',
-                                                           sim_matrix, keyframes, check_finite=False, cache_graphs=cache_graphs)
-                raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16'")
+                if not cache_graphs:
+                    runner.release()
+                raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16' (or amp=False)")
         panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
                   'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
         pms = [res[i][0] for i in range(V)]

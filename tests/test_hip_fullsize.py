@@ -252,7 +252,7 @@ def test_full_size_graph_replay_equals_eager(full):
     dev = torch.device('cuda:0')
     V, K, H, W = 13, 4, 384, 512
     imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
-    runner = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=True)
+    runner = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=True, amp='fp16')
     assert runner.serial, 'the two-stream stage 2 must stay opt-in'
     r1, s1 = runner.run()                                   # warm-up + capture (the captured pass itself is executed)
     ref = {k: (a.clone(), b.clone()) for k, (a, b) in r1.items()}
@@ -320,7 +320,7 @@ def test_full_size_sharded_equals_unsharded_on_one_gpu(full, monkeypatch, V, K, 
     H, W = 384, 512
     imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
     with torch.no_grad():
-        ref, sref = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=False).run()
+        ref, sref = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=False, amp='fp16').run()
     res, scenes = run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, plan=plan)
     assert sorted(res) == list(range(V))
     for s in scenes:
@@ -353,8 +353,10 @@ def test_full_size_c5_200_views_32_keyframes(full):
         assert torch.equal(r1[k][0], r2[k][0]) and torch.equal(r1[k][1], r2[k][1]) and torch.equal(r1[k][0], r3[k][0]) and torch.equal(r1[k][1], r3[k][1]), k
 
 
-def test_full_size_mixed_aspect_ratio_and_portrait(full):
-    """forward_inference_multi_ar at FULL size on views of different shapes, one of them portrait in native orientation (reference a1 / a6 /
+@pytest.mark.parametrize('amp', ['fp16', False])
+def test_full_size_mixed_aspect_ratio_and_portrait(full, amp):
+    """amp=False: the fp32 mode (fp32-FMA GEMM / attention kernels, the reference's default arithmetic) - two orders of magnitude tighter bounds.
+    forward_inference_multi_ar at FULL size on views of different shapes, one of them portrait in native orientation (reference a1 / a6 /
     a7 / a11: per-shape batching, update_pair_tokens on a landscape + portrait pair, transposed DINOv2 input, transposed-grid key PE,
     LoftUp's anisotropic attention-mask resize) against the oracle's own forward_inference_multi_ar with the same weights."""
     import bench
@@ -370,16 +372,25 @@ def test_full_size_mixed_aspect_ratio_and_portrait(full):
     ts = torch.tensor(shapes)
     with torch.no_grad():
         pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, names, num_keyframes=3, outdevice='cpu')
-        pm_h, pan_h = model.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, names, num_keyframes=3, outdevice='cpu')
+        pm_h, pan_h = model.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, names, num_keyframes=3, outdevice='cpu', amp=amp)
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     num = den = agree = npix = 0.0
     for i, (a, b) in enumerate(shapes):
         assert pm_h[i].shape == pm_o[i].shape == (1, a, b, 7)
         assert pan_h['pred_masks'][i].shape == pan_o['pred_masks'][i].shape == (1, 200, a // 2, b // 2)
-        assert rel(pm_h[i], pm_o[i]) <= 2e-2, (i, rel(pm_h[i], pm_o[i]))
+        assert rel(pm_h[i], pm_o[i]) <= (2e-2 if amp else 1e-4), (i, rel(pm_h[i], pm_o[i]))
         x, y = pan_h['pred_masks'][i].double(), pan_o['pred_masks'][i].double()
         num += float(((x - y) ** 2).sum()); den += float((y ** 2).sum())
         agree += float(((x > 0) == (y > 0)).sum()); npix += y.numel()
+    _record('full-size mixed aspect ratio / portrait scene (4 views, 3 keyframes)', dict(variant='v2', amp=str(amp), pointmaps_max=max(rel(a, b) for a, b in zip(pm_h, pm_o)),
+            masks_pooled=(num / den) ** 0.5, mask_sign_agreement=agree / npix, queries=rel(pan_h['out_queries'].cpu(), pan_o['out_queries'].cpu()),
+            logits_maxabs=float((pan_h['pred_logits'].cpu() - pan_o['pred_logits'].cpu()).abs().max())))
+    if not amp:           # fp32 operands against the fp32 oracle: only summation order differs - except in LoftUp's guidance features (sin / cos of
+        # phases up to e^10 rad in fp32, reference loftup.py ImplicitFeaturizer: two correct fp32 evaluations differ by ~1e-3), the floor of v2's masks
+        assert (num / den) ** 0.5 <= 5e-3 and agree / npix >= 0.999, ((num / den) ** 0.5, agree / npix)
+        assert rel(pan_h['out_queries'].cpu(), pan_o['out_queries'].cpu()) <= 5e-3                         # measured 1.1e-3 (f16: 3.6e-3)
+        assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits'].cpu()).abs().max()) <= 1e-2        # measured 2.1e-3 (f16: 4.4e-3)
+        return
     assert (num / den) ** 0.5 <= 3e-2 and agree / npix >= 0.995, ((num / den) ** 0.5, agree / npix)        # pooled over the scene's pixels
     assert rel(pan_h['out_queries'].cpu(), pan_o['out_queries'].cpu()) <= 2e-2
     assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits'].cpu()).abs().max()) <= 0.05

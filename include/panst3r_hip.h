@@ -104,6 +104,7 @@ const char* pst_gemm_variant(const pst_gemm_params* p);
  * Returns the previous value, or -1 for an unknown knob.  Initial values: environment PST_G2_AUTO / PST_G2_MODE, else the defaults. */
 #define PST_TUNE_G2_AUTO 1
 #define PST_TUNE_G2_MODE 2
+#define PST_TUNE_G256_PP 3      /* 1 (default): ping-pong K loop of the persistent 256x256 kernel, 0: the lock-step loop (A/B measurements) */
 int pst_tune(int knob, int value);
 /* Measurement only: phase trace of the two-workgroup GEMM.  `buf` = device int64 [workgroups][1 + 4 * tiles_per_workgroup] (NULL: off); every
  * workgroup writes its hardware id and, per tile it processes, four 100 MHz timestamps (tile start, main loop start, main loop end,

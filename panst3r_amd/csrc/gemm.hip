@@ -566,7 +566,7 @@ static int gemm_validate(const pst_gemm_params* pp) {
 
 static int gemm_choice0(const pst_gemm_params& p);
 constexpr int G2_AUTO_DEFAULT = 0;
-namespace pst { int gemm2g_mode(int set); void gemm2g_trace(void* buf, int tiles); }
+namespace pst { int gemm2g_mode(int set); void gemm2g_trace(void* buf, int tiles); int gemm256_pp(int set); }
 // experiment switch: PST_G2_AUTO=1 sends every GEMM the persistent 256x256 kernel would take to the two-workgroup kernel instead
 static int g_g2_auto = -1;
 static bool g2_auto() {
@@ -624,6 +624,7 @@ extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
 extern "C" int pst_tune(int knob, int value) {
   if (knob == PST_TUNE_G2_AUTO) { const int prev = g2_auto() ? 1 : 0; g_g2_auto = value != 0; return prev; }
   if (knob == PST_TUNE_G2_MODE) return pst::gemm2g_mode(value);
+  if (knob == PST_TUNE_G256_PP) return pst::gemm256_pp(value);
   return -1;
 }
 

@@ -15,6 +15,11 @@
 
 namespace pst {
 
+#ifdef PST_ABL
+#define PST_ABL_E PST_ABL
+#else
+#define PST_ABL_E 0
+#endif
 constexpr int HALF_BYTES = 128 * 128;           // 128 rows x 64 bf16
 constexpr int BUF_BYTES = 4 * HALF_BYTES;       // A-lo, A-hi, B-lo, B-hi
 constexpr int G256_GROUP_M = 4;
@@ -379,7 +384,16 @@ __device__ __forceinline__ float mul_add_2r(float a, float b, float c) {
 // 4-column chunks summed in order, chunk pairs, quads, octets, halves.
 // TRANS: C^T (the attention V^T operand) -- the MFMA operands swap roles, so a lane owns one output column and, with perm_row8 on the A rows
 // instead of the W rows, 8 consecutive ROWS of it: 16-byte stores along V^T's contiguous axis.
-template <bool F16, bool RES, bool TRANS>
+// PP (ping-pong, the default): the two 4-wave groups wm = 0 / 1 (one wave of each per SIMD) run the K loop ONE BARRIER APART.  A K tile is 4
+// phases of [L: ds_read the phase's fragments + issue LDS-DMA, wait for the reads | barrier | M: 16 MFMAs, nothing else | barrier]; while one
+// group is in an M segment the other is in an L segment, so every SIMD's matrix pipe is fed by one wave at a time with the other wave's LDS
+// reads, DMA issue and waits hidden behind it (guide: "256^2 8-phase template", the wr == 1 stagger).  Whole K tiles are prefetched TWO tiles
+// ahead into the buffer being consumed: B(t+2) in L2 (every B read of tile t retired before the barrier that ends slot 3), A(t+2) in L3
+// (A-lo is read by group 0 only, A-hi by group 1 only; last reads in their L2).  One counted wait per tile: L3's vmcnt(4) = everything but
+// L2's four pieces = all of tile t+1, followed by two barriers before any wave reads it.  Slot table (global slots between barriers):
+//   group 0:  L0 M0 L1 M1 L2 M2 L3 M3 | L0' ...          L0: A(m0) B(n0)   L1: B(n1)   L2: A(m1) + DMA B(t+2)   L3: vmcnt + DMA A(t+2)
+//   group 1:     L0 M0 L1 M1 L2 M2 L3 | M3 L0' ...       M0: (m0,n0)  M1: (m0,n1)  M2: (m1,n1)  M3: (m1,n0)      -- same K order: same bits
+template <bool F16, bool RES, bool TRANS, bool PP>
 __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -508,15 +522,73 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
       coltab[256 + tid] = p.gamma ? p.gamma[nc] : 1.f;
       coltab[512 + tid] = p.ln_stats ? p.ln_colsum[nc] : 0.f;
     }
-    // ---- B of K tile 1 last: with the in-order vmcnt, "all but the 4 newest" = everything of K tile 0 (and every older store)
-    stage(2, 1); stage(3, 1);
-    if (nk > 1) PST_VMCNT(4); else PST_VMCNT(0);
+    if constexpr (PP) {
+      // ---- all of K tile 1 behind K tile 0: with the in-order vmcnt, "all but the 8 newest" = everything of K tile 0 (and every older store)
+      stage(2, 1); stage(3, 1); stage(0, 1); stage(1, 1);
+      if (nk > 1) PST_VMCNT(8); else PST_VMCNT(0);
+    } else {
+      // ---- B of K tile 1 last: with the in-order vmcnt, "all but the 4 newest" = everything of K tile 0 (and every older store)
+      stage(2, 1); stage(3, 1);
+      if (nk > 1) PST_VMCNT(4); else PST_VMCNT(0);
+    }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (PP) {
+      constexpr std::integral_constant<int, 0> c0{};
+      constexpr std::integral_constant<int, 1> c1{};
+#ifndef PST_ABL
+#define PST_ABL 0                          // measurement builds only (tools/pp_ablate.sh): 1 no DMA, 2 no LDS reads, 4 no barriers, 8 no MFMAs in the K loop
+#endif
+      auto seg_end = [&]() {               // end of an L or M segment: nothing moves across it
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(PST_ABL & 4)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto stage_l = [&](int which, int kt) { if (!(PST_ABL & 1)) stage(which, kt); };
+      auto read_a_l = [&](uint32_t b, auto mi) { if (!(PST_ABL & 2)) read_a(b, mi); };
+      auto read_b_l = [&](uint32_t b, auto ni) { if (!(PST_ABL & 2)) read_b(b, ni); };
+      auto mma_l = [&](auto mi, auto ni) { if (!(PST_ABL & 8)) mma_n(mi, ni); };
+      auto reads_done_a = [&]() {          // every outstanding LDS read of this wave has returned (the A fragments among them)
+        lgkm_wait<0>(af[0][0]);
+        static_for<0, 4>([&](auto i) { static_for<0, 2>([&](auto kk) { lds_tie(af[i][kk]); }); });
+      };
+      auto reads_done_b = [&](auto ni) {
+        lgkm_wait<0>(bfr[ni][0][0]);
+        static_for<0, 2>([&](auto j) { static_for<0, 2>([&](auto kk) { lds_tie(bfr[ni][j][kk]); }); });
+      };
+      if (wm == 1) seg_end();              // group 1 runs one barrier behind group 0
+      for (int kt = 0; kt < nk; ++kt) {
+        const uint32_t buf = lds0 + (uint32_t)((kt & 1) * BUF_BYTES);
+        read_b_l(buf, c0);                   // L0
+        read_a_l(buf, c0);
+        reads_done_a();
+        reads_done_b(c0);
+        seg_end();
+        mma_l(c0, c0);                     // M0
+        seg_end();
+        read_b_l(buf, c1);                   // L1
+        reads_done_b(c1);
+        seg_end();
+        mma_l(c0, c1);                     // M1
+        seg_end();
+        read_a_l(buf, c1);                   // L2: the B halves of this buffer are dead (both groups' B reads retired two barriers ago)
+        stage_l(2, kt + 2); stage_l(3, kt + 2);
+        reads_done_a();
+        seg_end();
+        mma_l(c1, c1);                     // M2
+        seg_end();
+        if (kt + 2 < nk) PST_VMCNT(4); else PST_VMCNT(0);      // L3: K tile kt + 1 has landed (this wave's share); A of this buffer is dead
+        stage_l(0, kt + 2); stage_l(1, kt + 2);
+        seg_end();
+        mma_l(c1, c0);                     // M3
+        seg_end();
+      }
+      if (wm == 0) seg_end();              // re-align the groups for the epilogue
+    } else
     for (int kt = 0; kt < nk; ++kt) {
       const uint32_t buf = lds0 + (uint32_t)((kt & 1) * BUF_BYTES);
       constexpr std::integral_constant<int, 0> c0{};
@@ -666,40 +738,45 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
       continue;
     }
 
-    // ---- epilogue from the accumulators: lane (g, l16) owns row l16 of each row fragment and, per 32-column half, columns g*8 .. g*8+7
+    // ---- epilogue from the accumulators: lane (g, l16) owns row l16 of each row fragment and, per 32-column half, columns g*8 .. g*8+7.
+    // Row fragment outer, half inner: the two 64-byte halves of a row leave in consecutive store instructions and meet in the same 128-byte line
+    // on their way out (measured on fc1, M = 38800: 380 -> 352 us against half-outer order; an exchange of halves between lanes l16 and l16 ^ 8 so
+    // that ONE instruction writes 8 whole 128-byte rows was slower, 403 us: profiles/r3_gemm_pp_ablation.txt).
+    float4 bias4[2][2], gam4[2][2], cs4[2][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int cl = wn * 64 + h * 32 + g * 8;               // tile-local first column
-      const int nn = cn0 + cl;
-      float4 bias4[2], gam4[2], cs4[2];
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        bias4[u] = *(const float4*)(coltab + cl + 4 * u);
-        gam4[u] = *(const float4*)(coltab + 256 + cl + 4 * u);
-        cs4[u] = *(const float4*)(coltab + 512 + cl + 4 * u);
+        const int cl = wn * 64 + h * 32 + g * 8 + 4 * u;               // tile-local column
+        bias4[h][u] = *(const float4*)(coltab + cl);
+        gam4[h][u] = *(const float4*)(coltab + 256 + cl);
+        cs4[h][u] = *(const float4*)(coltab + 512 + cl);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = wm * 128 + i * 16 + l16;
-        const int m = cm0 + r;
-        const float2 st = fold ? lnst[r] : make_float2(1.f, 0.f);
+    for (int i = 0; i < 8; ++i) {
+      const int r = wm * 128 + i * 16 + l16;
+      const float2 st = fold ? lnst[r] : make_float2(1.f, 0.f);
+      uint4 val[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int nn = cn0 + wn * 64 + h * 32 + g * 8;
         uint32_t w[4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const f32x4 a = acc[i][2 * h + u];
-          float v[4] = {fmaf(a[0], st.x, fmaf(st.y, cs4[u].x, bias4[u].x)), fmaf(a[1], st.x, fmaf(st.y, cs4[u].y, bias4[u].y)),
-                        fmaf(a[2], st.x, fmaf(st.y, cs4[u].z, bias4[u].z)), fmaf(a[3], st.x, fmaf(st.y, cs4[u].w, bias4[u].w))};
-          if (p.act == 1) {
+          float v[4] = {fmaf(a[0], st.x, fmaf(st.y, cs4[h][u].x, bias4[h][u].x)), fmaf(a[1], st.x, fmaf(st.y, cs4[h][u].y, bias4[h][u].y)),
+                        fmaf(a[2], st.x, fmaf(st.y, cs4[h][u].z, bias4[h][u].z)), fmaf(a[3], st.x, fmaf(st.y, cs4[h][u].w, bias4[h][u].w))};
+          if (p.act == 1 && !(PST_ABL_E & 32)) {
             gelu_erf4(v);
           } else if (p.act == 2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
           }
-          if (p.gamma) { v[0] *= gam4[u].x; v[1] *= gam4[u].y; v[2] *= gam4[u].z; v[3] *= gam4[u].w; }      // (x 1.0f is exact: skipping it changes no bit)
+          if (p.gamma) { v[0] *= gam4[h][u].x; v[1] *= gam4[h][u].y; v[2] *= gam4[h][u].z; v[3] *= gam4[h][u].w; }      // (x 1.0f is exact: skipping it changes no bit)
           w[2 * u] = H16<F16>::pack(v[0], v[1]);
           w[2 * u + 1] = H16<F16>::pack(v[2], v[3]);
         }
-        uint4 val = make_uint4(w[0], w[1], w[2], w[3]);
+        val[h] = make_uint4(w[0], w[1], w[2], w[3]);
         if (rope) {
           // the wave's 64 columns are one head: half h rotates with the row's y (h = 0) / x (h = 1) position, pairs are 16 columns apart,
           // i.e. the partner chunk lives in lane ^ 32 (g ^ 2).  The 16-bit-rounded values are rotated, as in the LDS store phases.
@@ -712,9 +789,13 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
           const int2 pp = postab[r];
           const float4* t = (const float4*)(ropetab + (h == 0 ? pp.x : pp.y) * 32 + (g & 1) * 16);
           const float4 cs[4] = {t[0], t[1], t[2], t[3]};
-          val = rope_rotate<F16>(val, make_uint4(pw[0], pw[1], pw[2], pw[3]), cs, nn);
+          val[h] = rope_rotate<F16>(val[h], make_uint4(pw[0], pw[1], pw[2], pw[3]), cs, nn);
         }
-        if (m < p.M && nn < p.N) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = val;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int m = cm0 + r, nn = cn0 + wn * 64 + h * 32 + g * 8;
+        if (!(PST_ABL_E & 16) && m < p.M && nn < p.N) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = val[h];
       }
     }
     par ^= 1;
@@ -757,30 +838,41 @@ int gemm256_persistent_class(const pst_gemm_params& p) {
 }
 bool gemm256_persistent_ok(const pst_gemm_params& p) { return gemm256_persistent_class(p) != 0; }
 
+// PST_TUNE_G256_PP: 1 (default) = the ping-pong K loop, 0 = the lock-step loop of rounds 2-3 (A/B measurements; bit-identical)
+static int g_g256_pp = 1;
+int gemm256_pp(int set) {
+  const int prev = g_g256_pp;
+  if (set == 0 || set == 1) g_g256_pp = set;
+  return prev;
+}
+
+template <bool F16, bool RES, bool TRANS, bool PP>
+static void launch_256p_t(const pst_gemm_params& p, hipStream_t s, int grid, int tiles, int tiles_m, int tiles_n) {
+  static unsigned long long attr_seen = 0;
+  once_per_device(attr_seen, [] { (void)hipFuncSetAttribute((const void*)gemm256p_kernel<F16, RES, TRANS, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P); });
+  hipLaunchKernelGGL((gemm256p_kernel<F16, RES, TRANS, PP>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+}
+
+template <bool RES, bool TRANS>
+static void launch_256p_c(const pst_gemm_params& p, hipStream_t s, int grid, int tiles, int tiles_m, int tiles_n) {
+  const bool h = p.dtype16 == DT_F16;
+  if (g_g256_pp) {
+    if (h) launch_256p_t<true, RES, TRANS, true>(p, s, grid, tiles, tiles_m, tiles_n);
+    else launch_256p_t<false, RES, TRANS, true>(p, s, grid, tiles, tiles_m, tiles_n);
+  } else {
+    if (h) launch_256p_t<true, RES, TRANS, false>(p, s, grid, tiles, tiles_m, tiles_n);
+    else launch_256p_t<false, RES, TRANS, false>(p, s, grid, tiles, tiles_m, tiles_n);
+  }
+}
+
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const int tiles = tiles_m * tiles_n;
-  static unsigned long long attr_seen = 0;
-  once_per_device(attr_seen, [] {
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-    (void)hipFuncSetAttribute((const void*)gemm256p_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P);
-  });
   const int grid = tiles < cus ? tiles : cus;
-  const bool h = p.dtype16 == DT_F16;
-  if (gemm256_persistent_class(p) == 3) {
-    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, false, true>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, false, true>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
-  } else if (gemm256_persistent_class(p) == 2) {
-    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, true, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, true, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
-  } else {
-    if (h) hipLaunchKernelGGL((gemm256p_kernel<true, false, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm256p_kernel<false, false, false>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
-  }
+  const int cls = gemm256_persistent_class(p);
+  if (cls == 3) launch_256p_c<false, true>(p, s, grid, tiles, tiles_m, tiles_n);
+  else if (cls == 2) launch_256p_c<true, false>(p, s, grid, tiles, tiles_m, tiles_n);
+  else launch_256p_c<false, false>(p, s, grid, tiles, tiles_m, tiles_n);
   return check_launch("gemm256p");
 }
 

@@ -71,7 +71,7 @@ def lib():
     return L
 
 
-TUNE_G2_AUTO, TUNE_G2_MODE = 1, 2
+TUNE_G2_AUTO, TUNE_G2_MODE, TUNE_G256_PP = 1, 2, 3
 
 
 def tune(knob, value):

@@ -921,3 +921,52 @@ def test_mask_head_streaming_kernel(C, Q, P, n):
     for _ in range(5):
         hip.mask_head(E, F_, again)
         assert torch.equal(again, out)
+
+
+@pytest.mark.parametrize('M,N,K', [(3000, 1024, 64), (3000, 1024, 128), (2605, 768, 192), (9001, 512, 1024), (70000, 256, 320)])
+def test_gemm256_ping_pong_loop_bit_identical_to_lock_step(M, N, K):
+    """The persistent 256 x 256 kernel's two K loops (pst_tune PST_TUNE_G256_PP: 1 = the two wave groups one barrier apart, whole K tiles prefetched
+    two tiles ahead; 0 = the lock-step loop) on its three classes - plain 16-bit (+ GELU, fused RoPE, fold consumer), fp32 residual stream with the
+    fold producer outputs, transposed 16-bit - for 1, 2, 3, 5 and 16 K tiles (the prologue / tail of the counted waits): same bits, and the same
+    bits again over 20 launches (race screen of the LDS-DMA pipeline)."""
+    from panst3r_amd import hip
+    a, w, b = bf(rn(990, M, K)).to(dev()), bf(rn(991, N, K, scale=K ** -0.5)).to(dev()), rn(992, N).to(dev())
+    res0 = rn(993, M, N).to(dev())
+    ldc = (M + 7) // 8 * 8 + 8
+    T = 768
+    ys, xs = torch.meshgrid(torch.arange(24), torch.arange(32), indexing='ij')
+    pos = torch.stack([ys, xs], -1).reshape(T, 2).to(torch.int32).repeat(M // T + 1, 1)[:M].contiguous().to(dev())
+    table = hip.rope_table(32, 64, 100.0, dev())
+
+    def run(pp):
+        prev = hip.tune(hip.TUNE_G256_PP, pp)
+        try:
+            outs = []
+            for kw in (dict(bias=b), dict(bias=b, act='gelu'), dict(bias=b, gamma=torch.ones(N, device=dev()), rope=(pos, table))):
+                o = torch.full((M, N), float('nan'), dtype=d16(), device=dev())
+                hip.gemm(a, w, o, kernel=256, **kw)
+                outs.append(o)
+            if N % 256 == 0:
+                r = res0.clone()
+                xc = torch.empty(M, N, dtype=d16(), device=dev())
+                st = torch.empty(M, N // 64, 2, device=dev())
+                hip.gemm(a, w, r, bias=b, res=r, xcopy=xc, stats_out=st, kernel=256)
+                outs += [r, xc, st]
+            ot = torch.zeros(N, ldc, dtype=d16(), device=dev())
+            hip.gemm(a, w, ot, bias=b, trans_out=True, kernel=256)
+            outs.append(ot)
+            return outs
+        finally:
+            hip.tune(hip.TUNE_G256_PP, prev)
+
+    hip.TIMER = hip.KernelTimer()
+    try:
+        hip.gemm(a, w, torch.empty(M, N, dtype=d16(), device=dev()), bias=b, kernel=256)
+        assert [r[0] for r in hip.TIMER.records] == ['gemm256p_kernel']          # the persistent kernel is what runs
+    finally:
+        hip.TIMER = None
+    lock, pp = run(0), run(1)
+    assert all(torch.equal(x, y) for x, y in zip(lock, pp))
+    for _ in range(20):
+        assert all(torch.equal(x, y) for x, y in zip(pp, run(1)))
+    assert hip.tune(hip.TUNE_G256_PP, 1) == 1 and hip.tune(99, 0) == -1

@@ -88,15 +88,15 @@ def _scene_errors(pm_h, pan_h, pm_o, pan_o):
     num = sum(float((a.double() - b.double()).pow(2).sum()) for a, b in mk)
     den = sum(float(b.double().pow(2).sum()) for _, b in mk)
     agree = sum(float(((a > 0) == (b > 0)).sum()) for a, b in mk) / sum(b.numel() for _, b in mk)
-    return {'pointmaps_rel_l2': round(max(rel(a, b) for a, b in zip(pm_h, pm_o)), 5),
-            'pointmaps_rel_l2_per_view': [round(rel(a, b), 5) for a, b in zip(pm_h, pm_o)],        # view id order (= keyframe index when V == K)
-            'mask_logits_rel_l2_per_view': [round(rel(a, b), 5) for a, b in mk],
-            'mask_logits_rel_l2': round((num / max(den, 1e-300)) ** 0.5, 5),
+    return {'pointmaps_rel_l2': sig(max(rel(a, b) for a, b in zip(pm_h, pm_o))),
+            'pointmaps_rel_l2_per_view': [sig(rel(a, b)) for a, b in zip(pm_h, pm_o)],        # view id order (= keyframe index when V == K)
+            'mask_logits_rel_l2_per_view': [sig(rel(a, b)) for a, b in mk],
+            'mask_logits_rel_l2': sig((num / max(den, 1e-300)) ** 0.5),
             'mask_sign_agreement': round(agree, 5),
-            'worst_view': {'mask_logits_rel_l2': round(max(rel(a, b) for a, b in mk), 5),
+            'worst_view': {'mask_logits_rel_l2': sig(max(rel(a, b) for a, b in mk)),
                            'mask_sign_agreement': round(min(float(((a > 0) == (b > 0)).float().mean()) for a, b in mk), 5)},
-            'class_logits_max_abs': round(float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()), 5),
-            'out_queries_rel_l2': round(rel(pan_h['out_queries'], pan_o['out_queries']), 5)}
+            'class_logits_max_abs': sig(float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max())),
+            'out_queries_rel_l2': sig(rel(pan_h['out_queries'], pan_o['out_queries']))}
 
 
 def _within(e, worst=False):
@@ -105,6 +105,11 @@ def _within(e, worst=False):
     return bool(e['pointmaps_rel_l2'] <= t['pointmaps_rel_l2'] and m['mask_logits_rel_l2'] <= t['mask_logits_rel_l2'] and
                 m['mask_sign_agreement'] >= t['mask_sign_agreement'] and e['class_logits_max_abs'] <= t['class_logits_max_abs'] and
                 e['out_queries_rel_l2'] <= t['out_queries_rel_l2'])
+
+
+def sig(x, digits=3):
+    """x to `digits` significant digits (the fp32 mode's errors are ~1e-6: fixed decimals would print 0)"""
+    return float('%.*g' % (digits, x))
 
 
 def full_size_parity(model, dev, ref, imgs, ts, names, amp='fp16', K=2):

@@ -9,6 +9,45 @@ namespace pst {
 int check_launch(const char* what);
 void set_error(const char* fmt, ...);
 
+// ---- the reference's fp32 arithmetic of ImplicitFeaturizer (loftup.py:40-79), operation by operation.  The features are sin / cos of phases up to
+// e^10 = 22026 rad, where one fp32 ulp of the phase is 2e-3 rad: any other association (an fma, a different linspace formula, a 1-ulp different exp)
+// gives a CORRECT fp32 result that differs from torch's by ~1e-3.  So: torch.linspace(a, b, n)[i] = fma(step, i, a) below the middle, fma(-step, n-1-i, b)
+// above it, step = (b - a) / (n - 1) (CPU kernel of torch 2.x; checked bit for bit for n <= 256); the frequencies exp(linspace(-2, 10, nf)) correctly
+// rounded (through double); phase = round(round(coordinate * frequency) + bias), two roundings as two torch ops; then sin / cos of that fp32 number.
+__device__ __forceinline__ float torch_linspace(float a, float b, int n, int i) {
+  if (n <= 1) return a;
+  const float step = (b - a) / (float)(n - 1);
+  return i < n / 2 ? fmaf(step, (float)i, a) : fmaf(-step, (float)(n - 1 - i), b);
+}
+__device__ __forceinline__ float exp_rn(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float phase_2r(float coord, float freq, float bias) {
+#pragma clang fp contract(off)
+  const float t = coord * freq;
+  return t + bias;
+}
+// sin / cos of an fp32 argument |x| < 6e4 to 1e-7 absolute: Cody-Waite reduction by multiples of pi/2 in three fma steps (the first constant has 8
+// significant bits: q * C1 is exact for |q| < 2^16), degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4] (Cephes sinf / cosf), quadrant select.
+// ~22 VALU operations - ocml's sinf / cosf carry the Payne-Hanek path for huge arguments (~150 instructions each) and made this kernel VALU-bound.
+__device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
+  const float q = rintf(x * 0.636619772367581343f);
+  float r = fmaf(-q, 1.5703125f, x);
+  r = fmaf(-q, 4.837512969970703125e-4f, r);
+  r = fmaf(-q, 7.54978995489188216e-8f, r);
+  const float z = r * r;
+  float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(ps, z, -1.6666654611e-1f);
+  ps = fmaf(ps * z, r, r);
+  float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(pc, z, 4.166664568298827e-2f);
+  pc = fmaf(pc * z, z, fmaf(z, -0.5f, 1.0f));
+  const int n = (int)q & 3;
+  const float a = (n & 1) ? pc : ps, b = (n & 1) ? ps : pc;
+  s = (n & 2) ? -a : a;                       // sin: { s, c, -s, -c }[n]
+  c = ((n + 1) & 2) ? -b : b;                 // cos: { c, -s, -c, s }[n]
+}
+__device__ __forceinline__ float sin_cw(float x) { float s, c; sincos_cw(x, s, c); return s; }
+__device__ __forceinline__ float cos_cw(float x) { float s, c; sincos_cw(x, s, c); return c; }
+
 __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max, bool is_min) {
   // 256-thread block reduction (sum / max / min)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -63,14 +102,14 @@ __global__ __launch_bounds__(1024) void down2_minmax_kernel(const float* img, fl
 template <bool APPLY>
 __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, const float* mm, const float* biases, float* part,
                                                           const float* stats, const float* gamma, const float* beta, float eps,
-                                                          bf16_t* y, int64_t ldy, int H2, int W2, int nf, float f_lo, float f_step, int tc) {
+                                                          bf16_t* y, int64_t ldy, int H2, int W2, int nf, int tc) {
   extern __shared__ float shm[];             // [nf] frequencies, [4] reduction scratch, then (APPLY) the [64][ldy] bf16 tile
   float* freq = shm;
   float* red = shm + nf;
   bf16_t* tile = (bf16_t*)(shm + ((nf + 4 + 3) & ~3));       // 16-byte aligned for the uint4 row copies
   const int view = blockIdx.y, P = H2 * W2, CH = 10 * nf + 3;
   const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
-  if (threadIdx.x < nf) freq[threadIdx.x] = expf(f_lo + f_step * threadIdx.x);
+  if (threadIdx.x < nf) freq[threadIdx.x] = exp_rn(torch_linspace(-2.f, 10.f, nf, threadIdx.x));
   float lo[3], sc[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -92,8 +131,8 @@ __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, con
     const int pc = ok ? pix : P - 1;
     const int yy = pc / W2, xx = pc - yy * W2;
     float base[5];
-    base[0] = H2 > 1 ? -1.f + 2.f * yy / (H2 - 1) : -1.f;
-    base[1] = W2 > 1 ? -1.f + 2.f * xx / (W2 - 1) : -1.f;
+    base[0] = torch_linspace(-1.f, 1.f, H2, yy);
+    base[1] = torch_linspace(-1.f, 1.f, W2, xx);
 #pragma unroll
     for (int c = 0; c < 3; ++c) base[2 + c] = (img2[((int64_t)(view * 3 + c)) * P + pc] - lo[c]) / sc[c] - 0.5f;
     const int ts = (int)ldy + 8;            // tile row stride: +16 B so the 64 lanes' 2-byte writes to one column spread over 16 banks (4-way instead of 64-way conflicts)
@@ -107,8 +146,8 @@ __global__ __launch_bounds__(256) void guidance_px_kernel(const float* img2, con
       const float fr = freq[f];
 #pragma unroll
       for (int d = 0; d < 5; ++d) {
-        const float vs = sinf(base[d] * fr + biases[f * 5 + d]);
-        const float vc = cosf(base[d] * fr + biases[5 * nf + f * 5 + d]);
+        const float vs = sin_cw(phase_2r(base[d], fr, biases[f * 5 + d]));
+        const float vc = cos_cw(phase_2r(base[d], fr, biases[5 * nf + f * 5 + d]));
         if (APPLY) {
           put(f * 5 + d, (vs - mean) * rstd * gamma[f * 5 + d] + beta[f * 5 + d]);
           put(5 * nf + f * 5 + d, (vc - mean) * rstd * gamma[5 * nf + f * 5 + d] + beta[5 * nf + f * 5 + d]);
@@ -269,9 +308,9 @@ __global__ void lr_pe_kernel(const float* biases, void* out, int64_t ld, int col
     const int64_t tok = i / 20;
     const int t = (int)(tok % (h * w)), y = t / w, x = t - y * w;
     const int kind = ch / 10, r = ch - kind * 10, f = r / 2, d = r - f * 2;
-    const float base = d == 0 ? (h > 1 ? -1.f + 2.f * y / (h - 1) : -1.f) : (w > 1 ? -1.f + 2.f * x / (w - 1) : -1.f);
-    const float ph = base * expf(-2.f + 3.f * f) + biases[kind * 10 + f * 2 + d];
-    store1(out, tok * ld + col0 + ch, tc, kind == 0 ? sinf(ph) : cosf(ph));
+    const float base = d == 0 ? torch_linspace(-1.f, 1.f, h, y) : torch_linspace(-1.f, 1.f, w, x);
+    const float ph = phase_2r(base, exp_rn(torch_linspace(-2.f, 10.f, 5, f)), biases[kind * 10 + f * 2 + d]);
+    store1(out, tok * ld + col0 + ch, tc, kind == 0 ? sin_cw(ph) : cos_cw(ph));
   }
 }
 
@@ -291,16 +330,15 @@ extern "C" int pst_loftup_guidance_gn(const float* img, const float* biases, con
   float* img2 = scratch;                                 // [nimg][3][P]
   float* mm = img2 + (int64_t)nimg * 3 * P;              // [nimg][3][2]
   hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(1024), 0, s, img, img2, mm, H, W);
-  const float f_lo = -2.f, f_step = 12.f / (nf - 1);
   const int ntile = (P + 63) / 64;
   const int gx = ntile < PST_STATS_BLOCKS ? ntile : PST_STATS_BLOCKS;
   float* part = stats + 2 * nimg;                        // [nimg][gx][2] partial sums behind the result
   const size_t lds0 = ((nf + 4 + 3) & ~3) * sizeof(float);
   hipLaunchKernelGGL((guidance_px_kernel<false>), dim3(gx, nimg), dim3(256), lds0, s, img2, mm, biases, part, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, 0.f, (bf16_t*)nullptr, ldy, H2, W2, nf, f_lo, f_step, dtype16);
+                     (const float*)nullptr, (const float*)nullptr, 0.f, (bf16_t*)nullptr, ldy, H2, W2, nf, dtype16);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 3) / 4), dim3(256), 0, s, part, stats, nimg, gx, 2);
   hipLaunchKernelGGL((guidance_px_kernel<true>), dim3(ntile, nimg), dim3(256), lds0 + 64 * (ldy + 8) * sizeof(bf16_t), s, img2, mm, biases,
-                     (float*)nullptr, stats, gamma, beta, eps, (bf16_t*)y, ldy, H2, W2, nf, f_lo, f_step, dtype16);
+                     (float*)nullptr, stats, gamma, beta, eps, (bf16_t*)y, ldy, H2, W2, nf, dtype16);
   return check_launch("loftup_guidance_gn");
 }
 

@@ -385,11 +385,13 @@ def test_full_size_mixed_aspect_ratio_and_portrait(full, amp):
     _record('full-size mixed aspect ratio / portrait scene (4 views, 3 keyframes)', dict(variant='v2', amp=str(amp), pointmaps_max=max(rel(a, b) for a, b in zip(pm_h, pm_o)),
             masks_pooled=(num / den) ** 0.5, mask_sign_agreement=agree / npix, queries=rel(pan_h['out_queries'].cpu(), pan_o['out_queries'].cpu()),
             logits_maxabs=float((pan_h['pred_logits'].cpu() - pan_o['pred_logits'].cpu()).abs().max())))
-    if not amp:           # fp32 operands against the fp32 oracle: only summation order differs - except in LoftUp's guidance features (sin / cos of
-        # phases up to e^10 rad in fp32, reference loftup.py ImplicitFeaturizer: two correct fp32 evaluations differ by ~1e-3), the floor of v2's masks
-        assert (num / den) ** 0.5 <= 5e-3 and agree / npix >= 0.999, ((num / den) ** 0.5, agree / npix)
-        assert rel(pan_h['out_queries'].cpu(), pan_o['out_queries'].cpu()) <= 5e-3                         # measured 1.1e-3 (f16: 3.6e-3)
-        assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits'].cpu()).abs().max()) <= 1e-2        # measured 2.1e-3 (f16: 4.4e-3)
+    if not amp:
+        # fp32 operands against the fp32 oracle: only summation order differs (pointmaps 1.2e-6).  On the panoptic side a 1e-6 difference that flips one
+        # attention-mask bit of the query decoder (mask logit thresholded at 0, mask_transformer.py:264-268) moves that query by several %: measured
+        # masks 1.5e-3 pooled / 99.987 % signs, queries 6.9e-4, class logits 1.9e-3 (f16: 9.1e-3 / 99.77 % / 3.7e-3 / 4.5e-3)
+        assert (num / den) ** 0.5 <= 3e-3 and agree / npix >= 0.9995, ((num / den) ** 0.5, agree / npix)
+        assert rel(pan_h['out_queries'].cpu(), pan_o['out_queries'].cpu()) <= 2e-3
+        assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits'].cpu()).abs().max()) <= 5e-3
         return
     assert (num / den) ** 0.5 <= 3e-2 and agree / npix >= 0.995, ((num / den) ** 0.5, agree / npix)        # pooled over the scene's pixels
     assert rel(pan_h['out_queries'].cpu(), pan_o['out_queries'].cpu()) <= 2e-2

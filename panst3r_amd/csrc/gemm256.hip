@@ -638,7 +638,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) rv[i][h][u] = (PST_ABL_E & 64) ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(rp + h * 32 + 4 * u);
+            for (int u = 0; u < 2; ++u) rv[i][h][u] = *(const float4*)(rp + h * 32 + 4 * u);
         }
       };
       auto finish = [&](int i0) {
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
               f[u] = make_float4(mul_add_2r(v[0], gam4.x, q4.x), mul_add_2r(v[1], gam4.y, q4.y), mul_add_2r(v[2], gam4.z, q4.z), mul_add_2r(v[3], gam4.w, q4.w));
               ln_acc4(f[u], cs_[u], cq_[u]);
             }
-            if (m < ((PST_ABL_E & 128) ? -1 : p.M)) {
+            if (m < p.M) {
               float* dst = Cf + (int64_t)m * p.ldc + cn0 + cl;
               *(float4*)dst = f[0];
               *(float4*)(dst + 4) = f[1];

@@ -97,6 +97,12 @@ int pst_gemm(const pst_gemm_params* p, void* stream);
 /* name of the kernel variant pst_gemm dispatches `p` to ("gemm_kernel<4,4,false>", "gemm256_kernel", ...), without launching:
  * what a profiler row of this call is called (bench.py attributes its HIP-event timings with it). NULL for a rejected argument. */
 const char* pst_gemm_variant(const pst_gemm_params* p);
+/* Two INDEPENDENT GEMMs, `a` with a row-major store and `b` with trans_out (the q|k and V^T projections of an attention layer: croco Attention's
+ * qkv Linear, models/blocks.py - same A operand, different epilogues), in ONE launch when both resolve to the 64 x 64-tile kernel (the 768-row GEMMs of
+ * the sequential memory build: launch latency and the cold first operand fetch are shared); any other pair runs as two pst_gemm launches.  Results are
+ * bit-identical to two pst_gemm calls either way.  pst_gemm_pair_variant: "gemm_pair_kernel<2,2>", or "" when the pair is not fused. */
+int pst_gemm_pair(const pst_gemm_params* a, const pst_gemm_params* b, void* stream);
+const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_params* b);
 /* Tuning knobs of the GEMM dispatch (process-wide; measurement tools and tests only - results never depend on them, every GEMM variant
  * is bit-identical):  PST_TUNE_G2_AUTO  1 = GEMMs of the persistent 256x256 kernel's classes go to the two-workgroups-per-CU kernel
  * (gemm2g.hip) when it is eligible, 0 = never (kernel == 2 still forces it);  PST_TUNE_G2_MODE  de-phasing of the CU's two workgroups:

@@ -421,7 +421,9 @@ static int attn_validate(const pst_attn_params* pp) {
 }
 
 // the ONE dispatch rule (launch and variant name): 128-query blocks once they fill the chip; split-K always uses 64-query blocks
-static bool attn_big(const pst_attn_params& p) { return p.nsplit <= 1 && (long)((p.Nq + 127) / 128) * p.H * p.B >= 256; }
+// 128-query blocks (two 16-row fragments per wave: every K / V fragment read feeds two MFMAs) when they alone fill the chip; with a key-range split,
+// when blocks x splits do (the memory build's 768 queries x 12 heads = 72 blocks: the caller asks for ~8 splits of the 1 500 ... 11 500 keys)
+static bool attn_big(const pst_attn_params& p) { return (long)((p.Nq + 127) / 128) * p.H * p.B * (p.nsplit > 1 ? p.nsplit : 1) >= 256; }
 
 extern "C" int pst_attn_fwd(const pst_attn_params* pp, void* stream) {
   using namespace pst;

@@ -224,12 +224,13 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
 // NST = 4 (64x64 tiles, the 768-row GEMMs of the sequential memory build): with only 8 MFMAs per K step those GEMMs
 // are bound by the global->LDS LATENCY of a one-deep prefetch, so three slabs are kept in flight and each step waits
 // with a COUNTED s_waitcnt vmcnt (raw s_barrier: __syncthreads() would drain the LDS-DMA queue).
+// the tile program: block (bx, by) of a launch of `ntiles` x batch workgroups (gemm_kernel: one problem per launch; gemm_pair_kernel: two)
 template <int FM, int FN, bool TRANS, int NST, bool F16>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in, const int ntiles, const int tiles_m, const int tiles_n) {
+__device__ __forceinline__ void gemm_tile(const pst_gemm_params& p_in, const int ntiles, const int tiles_m, const int tiles_n, const int bx, const int by) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
-  pst_gemm_params p = p_in;                 // strided batch: blockIdx.y selects the problem (all fields wave-uniform)
+  pst_gemm_params p = p_in;                 // strided batch: by selects the problem (all fields wave-uniform)
   if (p.batch > 1) {
-    const int64_t bi = blockIdx.y;
+    const int64_t bi = by;
     p.A = (const bf16_t*)p.A + bi * p.a_bs;
     p.W = (const bf16_t*)p.W + bi * p.w_bs;
     p.C = p.out_fp32 ? (void*)((float*)p.C + bi * p.c_bs) : (void*)((bf16_t*)p.C + bi * p.c_bs);
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p_in
   // ---- tile of this block: XCD-aware + grouped order
   int m0, n0;
   {
-    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int t = xcd_remap(bx, ntiles);
     const int grp = t / (GROUP_M * tiles_n);
     const int first_m = grp * GROUP_M;
     const int gm = min(GROUP_M, tiles_m - first_m);
@@ -495,6 +496,30 @@ static int num_cus() {
 }
 
 template <int FM, int FN, bool TRANS, int NST, bool F16>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
+  gemm_tile<FM, FN, TRANS, NST, F16>(p, ntiles, tiles_m, tiles_n, blockIdx.x, blockIdx.y);
+}
+
+// Two INDEPENDENT GEMMs in one launch: blocks [0, na) run problem a (row-major store), blocks [na, na + nb) problem b (transposed store) - the q|k and
+// V^T projections of one attention layer of the sequential memory build (768 rows: 288 + 144 tiles of 64 x 64).  Each problem alone fills half the chip
+// for ~7 us behind a ~2 us launch and a cold first operand fetch; together they share both (pst_gemm_pair).  Same tile program: same bits.
+template <int FM, int FN, int NST, bool F16>
+__global__ __launch_bounds__(256, 2) void gemm_pair_kernel(const pst_gemm_params pa, const int na, const int tma, const int tna,
+                                                           const pst_gemm_params pb, const int nb, const int tmb, const int tnb) {
+  if ((int)blockIdx.x < na) gemm_tile<FM, FN, false, NST, F16>(pa, na, tma, tna, blockIdx.x, 0);
+  else gemm_tile<FM, FN, true, NST, F16>(pb, nb, tmb, tnb, (int)blockIdx.x - na, 0);
+}
+
+template <int FM, int FN, int NST, bool F16>
+static int launch_pair_t(const pst_gemm_params& a, const pst_gemm_params& b, hipStream_t s) {
+  constexpr int BM = 32 * FM, BN = 32 * FN;
+  const int tma = (a.M + BM - 1) / BM, tna = (a.N + BN - 1) / BN, tmb = (b.M + BM - 1) / BM, tnb = (b.N + BN - 1) / BN;
+  const size_t lds = NST * (BM + BN) * 128 + BM * sizeof(float2);
+  hipLaunchKernelGGL((gemm_pair_kernel<FM, FN, NST, F16>), dim3(tma * tna + tmb * tnb), dim3(256), lds, s, a, tma * tna, tma, tna, b, tmb * tnb, tmb, tnb);
+  return check_launch("gemm_pair");
+}
+
+template <int FM, int FN, bool TRANS, int NST, bool F16>
 static int launch_t(const pst_gemm_params& p, hipStream_t s) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -619,6 +644,30 @@ extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
   if (c == 2) return gemm256_persistent_ok(p) ? launch_gemm256p(p, s, num_cus()) : launch_gemm256(p, s);
   if (p.trans_out) return c == 0 ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
   return c == 0 ? launch<2, 2, false, 4>(p, s) : launch<4, 4, false, 2>(p, s);
+}
+
+static bool pair_fusable(const pst_gemm_params& a, const pst_gemm_params& b) {
+  using namespace pst;
+  if (a.dtype16 == DT_F32 || a.dtype16 != b.dtype16 || a.trans_out || !b.trans_out || a.batch > 1 || b.batch > 1 || a.kernel || b.kernel) return false;
+  if (rowstream_class(a) || rowstream_class(b)) return false;
+  return gemm_choice(a) == 0 && gemm_choice(b) == 0;            // both on the 64 x 64 tiles: the small-M GEMMs of the memory build
+}
+
+extern "C" int pst_gemm_pair(const pst_gemm_params* pa, const pst_gemm_params* pb, void* stream) {
+  using namespace pst;
+  if (int rc = gemm_validate(pa)) return rc;
+  if (int rc = gemm_validate(pb)) return rc;
+  if (!pair_fusable(*pa, *pb)) {                                 // any other pair: two launches, same results
+    if (int rc = pst_gemm(pa, stream)) return rc;
+    return pst_gemm(pb, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  return pa->dtype16 == DT_F16 ? launch_pair_t<2, 2, 4, true>(*pa, *pb, s) : launch_pair_t<2, 2, 4, false>(*pa, *pb, s);
+}
+
+extern "C" const char* pst_gemm_pair_variant(const pst_gemm_params* pa, const pst_gemm_params* pb) {
+  if (gemm_validate(pa) || gemm_validate(pb)) return nullptr;
+  return pair_fusable(*pa, *pb) ? "gemm_pair_kernel<2,2>" : "";       // "": runs as two pst_gemm launches (ask pst_gemm_variant for each)
 }
 
 extern "C" int pst_tune(int knob, int value) {

@@ -39,7 +39,7 @@ class AttnParams(C.Structure):
                 ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64), ('dtype16', i32), ('prescaled', i32)]
 
 
-EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_tune', 'pst_debug_g2_trace', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_gemm_pair', 'pst_gemm_pair_variant', 'pst_tune', 'pst_debug_g2_trace', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
            'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
@@ -58,6 +58,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.pst_last_error.restype = C.c_char_p
     L.pst_gemm_variant.restype = C.c_char_p
+    L.pst_gemm_pair_variant.restype = C.c_char_p
     L.pst_attn_variant.restype = C.c_char_p
     L.pst_attn_workspace_bytes.restype = C.c_int64
     L.pst_qubo_workspace_floats.restype = C.c_int64
@@ -204,9 +205,10 @@ def _rowmajor(t):
 ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 
 
-def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
-         M=None, kernel=0, rope=None, batch=None, xcopy=None, stats_out=None, ln=None):
-    """out = epi(a @ w.T).  a [M,K] 16-bit (row-major view), w [N,K] 16-bit, out 16-bit / fp32 2-D view (or raw buffer for ps).
+def _gemm_params(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
+                 M=None, kernel=0, rope=None, batch=None, xcopy=None, stats_out=None, ln=None):
+    """pst_gemm_params of one hip.gemm call + (flops, shape tag) for the kernel timer.
+    out = epi(a @ w.T).  a [M,K] 16-bit (row-major view), w [N,K] 16-bit, out 16-bit / fp32 2-D view (or raw buffer for ps).
     a, w, out (and res) all fp32: the amp=False mode's fp32-FMA GEMM (same epilogues; no fused RoPE, no LayerNorm fold).
     LayerNorm fold (include/panst3r_hip.h): producer side `xcopy` (16-bit copy of an fp32 out) and `stats_out` (fp32 [M, N/64, 2]);
     consumer side `ln` = (stats [M, groups, 2], colsum [N], eps) with `a` the raw rows and `w` / `bias` folded at pack time."""
@@ -261,17 +263,44 @@ def gemm(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_
         assert st.dtype == torch.float32 and st.dim() == 3 and st.shape[2] == 2 and st.is_contiguous() and st.shape[1] * 64 >= K
         p.ln_stats, p.ln_groups, p.ln_colsum, p.ln_eps = _ptr(_dev(st)), K // 64, _ptr(_dev(cs, torch.float32)), float(eps)
         assert K % 64 == 0 and st.shape[1] == K // 64, 'LayerNorm fold: the statistics must cover exactly the K columns of A'
+    tag = (Mv, N, K, 'f32' if out.dtype == torch.float32 else '16', act or '', 'res' if res is not None else '',
+           'grp' if grp is not None else '', 'rope' if rope is not None else '', 'conv' if conv is not None else '', 'ps' if ps is not None else '')
+    return p, 2.0 * Mv * N * K * (batch[0] if batch else 1), tag
+
+
+def gemm(a, w, out, **kw):
+    """out = epi(a @ w.T): see _gemm_params for the arguments"""
+    p, flops, tag = _gemm_params(a, w, out, **kw)
     if TIMER is not None:
         name = lib().pst_gemm_variant(C.byref(p))          # the C side names the kernel it dispatches to (no re-derived rule here)
-        ev = TIMER.bracket(name.decode() if name else 'gemm?', 2.0 * Mv * N * K * (batch[0] if batch else 1),
-                           (Mv, N, K, 'f32' if out.dtype == torch.float32 else '16', act or '', 'res' if res is not None else '',
-                            'grp' if grp is not None else '', 'rope' if rope is not None else '', 'conv' if conv is not None else '', 'ps' if ps is not None else ''))
+        ev = TIMER.bracket(name.decode() if name else 'gemm?', flops, tag)
         ev[0].record()
         _check(lib().pst_gemm(C.byref(p), _stream()), 'pst_gemm')
         ev[1].record()
         return out
     _check(lib().pst_gemm(C.byref(p), _stream()), 'pst_gemm')
     return out
+
+
+def gemm_pair(first, second):
+    """Two independent GEMMs - `first` = (a, w, out, kwargs) with a row-major store, `second` with trans_out=True - through pst_gemm_pair: ONE launch
+    when both are small-M problems of the 64 x 64-tile kernel (the q|k and V^T projections of the memory build), else two; same bits either way."""
+    (a1, w1, o1, k1), (a2, w2, o2, k2) = first, second
+    p1, f1, t1 = _gemm_params(a1, w1, o1, **k1)
+    p2, f2, t2 = _gemm_params(a2, w2, o2, **k2)
+    if TIMER is not None:
+        name = lib().pst_gemm_pair_variant(C.byref(p1), C.byref(p2))
+        if not name:                                       # not fused: two attributed launches
+            gemm(a1, w1, o1, **k1)
+            gemm(a2, w2, o2, **k2)
+            return o1, o2
+        ev = TIMER.bracket(name.decode(), f1 + f2, t1 + t2)
+        ev[0].record()
+        _check(lib().pst_gemm_pair(C.byref(p1), C.byref(p2), _stream()), 'pst_gemm_pair')
+        ev[1].record()
+        return o1, o2
+    _check(lib().pst_gemm_pair(C.byref(p1), C.byref(p2), _stream()), 'pst_gemm_pair')
+    return o1, o2
 
 
 # ----------------------------------------------------------------------------------------------------------- attention
@@ -303,6 +332,14 @@ def auto_nsplit(B, H, Nq, Nk):
     blocks = ((Nq + 63) // 64) * H * B
     if blocks >= 256 or Nk < 1024:
         return 1
+    # long memories (the build's 768 queries x 12 heads against >= 6 144 keys): enough splits that 128-query blocks fill the chip - pst_attn_fwd
+    # takes its 128-query variant when blocks x splits >= 256, and every K / V fragment read then feeds two MFMAs (measured, tools/attn_split_bench.py:
+    # 11 520 keys 54.1 -> 48.3 us, 24 576 keys 103.4 -> 82.7 us; below 6 144 keys the 64-query blocks with 3 splits stay ahead)
+    blocks128 = ((Nq + 127) // 128) * H * B
+    if Nk >= 6144:
+        ns = min(768 // blocks128, Nk // 1024, 12)
+        if blocks128 * ns >= 256:
+            return ns
     return max(1, min(512 // blocks, Nk // 512, 32))
 
 

@@ -223,16 +223,15 @@ def self_attention(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
     qk = empty(lay.rows, 2 * D, adt(), dev)
     xn, lq = s.operand(w_qk)
     qs = qscale(D, 2 * D, hd, dev)                                          # softmax scale * log2(e) folded into q (linear: commutes with RoPE)
-    if rope is not None and hd == 64 and adt() != torch.float32:
-        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, gamma=qs, rope=(pos, rope), ln=lq)      # RoPE-2D applied in the GEMM's store phase
-    else:
-        hip.gemm(xn, w_qk.w, qk, bias=w_qk.b, gamma=qs, ln=lq)
-        if rope is not None:
-            hip.rope2d_(qk, pos, rope, 2 * H, hd)
     if vt is None:
         vt = torch.empty(D, lay.rows + 8, dtype=adt(), device=dev)
-    xn, lv = s.operand(w_v)
-    hip.gemm(xn, w_v.w, vt, bias=w_v.b, trans_out=True, ln=lv)
+    xv, lv = s.operand(w_v)                                                 # (the same LN(x) as xn: q|k and v share norm1)
+    fused_rope = rope is not None and hd == 64 and adt() != torch.float32   # RoPE-2D applied in the GEMM's store phase
+    # the two projections are independent: one launch for the small-M case (the memory build's 768 rows), two for the big ones - the C side decides
+    hip.gemm_pair((xn, w_qk.w, qk, dict(bias=w_qk.b, gamma=qs, ln=lq, **({'rope': (pos, rope)} if fused_rope else {}))),
+                  (xv, w_v.w, vt, dict(bias=w_v.b, trans_out=True, ln=lv)))
+    if rope is not None and not fused_rope:
+        hip.rope2d_(qk, pos, rope, 2 * H, hd)
     o = empty(lay.rows, D, adt(), dev)
     if lay.Tp != lay.N:
         o.view(lay.V, lay.Tp, D)[:, lay.N:].zero_()      # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite

@@ -224,9 +224,9 @@ class MUSt3R(HipModule):
                 # each image attends to the other image's layer input (norm_y folded into projk / projv, on the fly)
                 kk = empty(lay.rows, D, adt(), dev)
                 a, ln = s_in.operand(c['k_f'])
-                hip.gemm(a, c['k_f'].w, kk, bias=c['k_f'].b, ln=ln)
                 vt = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)
-                hip.gemm(a, c['v_f'].w, vt, bias=c['v_f'].b, trans_out=True, ln=ln if ln is None else ln_of(c['v_f'], s_in.st))
+                hip.gemm_pair((a, c['k_f'].w, kk, dict(bias=c['k_f'].b, ln=ln)),
+                              (a, c['v_f'].w, vt, dict(bias=c['v_f'].b, trans_out=True, ln=ln if ln is None else ln_of(c['v_f'], s_in.st))))
                 q = self._cross_q(s, bw)
                 ldv = vt.stride(0)
                 hip.attention(q, kk[lay.Tp:], vt[:, lay.Tp:], o, 2, H, T, T, hd,
@@ -273,9 +273,9 @@ class MUSt3R(HipModule):
                 lay, s_in = lays[i], S[i][l]
                 kk = empty(lay.rows, D, adt(), dev)
                 a, ln = s_in.operand(c['k_f'])
-                hip.gemm(a, c['k_f'].w, kk, bias=c['k_f'].b, ln=ln)
                 vt = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)
-                hip.gemm(a, c['v_f'].w, vt, bias=c['v_f'].b, trans_out=True, ln=ln if ln is None else ln_of(c['v_f'], s_in.st))
+                hip.gemm_pair((a, c['k_f'].w, kk, dict(bias=c['k_f'].b, ln=ln)),
+                              (a, c['v_f'].w, vt, dict(bias=c['v_f'].b, trans_out=True, ln=ln if ln is None else ln_of(c['v_f'], s_in.st))))
                 kvs.append((kk, vt))
             for i in range(2):
                 lay, s_in = lays[i], S[i][l]

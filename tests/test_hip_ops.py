@@ -970,3 +970,44 @@ def test_gemm256_ping_pong_loop_bit_identical_to_lock_step(M, N, K):
     for _ in range(20):
         assert all(torch.equal(x, y) for x, y in zip(pp, run(1)))
     assert hip.tune(hip.TUNE_G256_PP, 1) == 1 and hip.tune(99, 0) == -1
+
+
+@pytest.mark.parametrize('M,N1,N2,K', [(768, 1536, 768, 768), (768, 768, 768, 768), (441, 1536, 768, 768), (1536, 2048, 1024, 1024), (38400, 1536, 768, 768)])
+def test_gemm_pair_equals_two_launches(M, N1, N2, K):
+    """pst_gemm_pair: a row-major GEMM (q|k projection: fold consumer, q scale, fused RoPE) and a transposed one (V^T: fold consumer) sharing their A
+    operand, in ONE launch for the small-M shapes of the memory build and as two launches otherwise - bit-identical to two hip.gemm calls in both cases."""
+    from panst3r_amd import hip
+    x = rn(600, M, K).to(dev()) * 1.3 + 0.2
+    xb = torch.empty(M, K, dtype=d16(), device=dev())
+    st = torch.empty(M, K // 64, 2, device=dev())
+    hip.rowstats(x, xb, st)
+    w1, w2 = bf(rn(601, N1, K, scale=K ** -0.5)).to(dev()), bf(rn(602, N2, K, scale=K ** -0.5)).to(dev())
+    b1, b2 = rn(603, N1).to(dev()), rn(604, N2).to(dev())
+    gam = (1 + 0.1 * rn(605, N1)).to(dev())
+    T = 768
+    ys, xs = torch.meshgrid(torch.arange(24), torch.arange(32), indexing='ij')
+    pos = torch.stack([ys, xs], -1).reshape(T, 2).to(torch.int32).repeat(M // T + 1, 1)[:M].contiguous().to(dev())
+    table = hip.rope_table(32, 64, 100.0, dev())
+    ldc = (M + 7) // 8 * 8 + 8
+    k1 = dict(bias=b1, gamma=gam, rope=(pos, table), ln=(st, w1.float().sum(1).contiguous(), 1e-6))
+    k2 = dict(bias=b2, trans_out=True, ln=(st, w2.float().sum(1).contiguous(), 1e-6))
+    o1, o2 = torch.full((M, N1), float('nan'), dtype=d16(), device=dev()), torch.zeros(N2, ldc, dtype=d16(), device=dev())
+    hip.TIMER = hip.KernelTimer()
+    try:
+        hip.gemm(xb, w1, o1, **k1)
+        hip.gemm(xb, w2, o2, **k2)
+        single = [r[0] for r in hip.TIMER.records]
+        hip.TIMER = hip.KernelTimer()
+        p1, p2 = torch.full((M, N1), float('nan'), dtype=d16(), device=dev()), torch.zeros(N2, ldc, dtype=d16(), device=dev())
+        hip.gemm_pair((xb, w1, p1, k1), (xb, w2, p2, k2))
+        names = [r[0] for r in hip.TIMER.records]
+    finally:
+        hip.TIMER = None
+    small = single == ['gemm_kernel<2,2,false>', 'gemm_kernel<2,2,true>']          # both on the 64 x 64 tiles: fused, else two launches of the same kernels
+    assert names == (['gemm_pair_kernel<2,2>'] if small else single), (single, names)
+    assert small == (M <= 1536)
+    assert torch.equal(o1, p1) and torch.equal(o2, p2)
+    for _ in range(5):                      # untimed path
+        q1, q2 = torch.full((M, N1), float('nan'), dtype=d16(), device=dev()), torch.zeros(N2, ldc, dtype=d16(), device=dev())
+        hip.gemm_pair((xb, w1, q1, k1), (xb, w2, q2, k2))
+        assert torch.equal(o1, q1) and torch.equal(o2, q2)

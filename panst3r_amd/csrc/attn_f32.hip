@@ -2,8 +2,10 @@
 // (tools/demo_panst3r.py:88: torch SDPA / nn.MultiheadAttention in float32) on the GPU.  Selected by pst_attn_params.dtype16 == PST_F32;
 // same parameter block as the 16-bit kernel (strides in elements, V given transposed, optional uint8 mask shared by the heads, fully masked
 // rows -> zeros, `prescaled` queries), no split-K.  The PRECISION path: plain v_fma_f32, a block = 64 queries x one (batch, head), four threads
-// per query (each computes the scores of 16 of a tile's 64 keys with the whole query in registers, and owns hd / 4 output columns), K / V
-// tiles and the probabilities staged in LDS, online softmax in the exp2 domain with fp32 running maximum / sum.
+// per query (each computes the scores of 16 of a tile's 64 keys - keys 4 kk + part, so the four threads' K rows lie in different LDS banks - with
+// the whole query in registers, and owns hd / 4 output columns), K / V tiles and the probabilities staged in LDS with 16-byte-aligned row pitches
+// (every LDS read is a ds_read_b128: with scalar reads the kernel was LDS-issue bound at 21.7 TFLOP/s, now 29-37), online softmax in the exp2 domain
+// with fp32 running maximum / sum.
 #include "common.h"
 #include "../../include/panst3r_hip.h"
 
@@ -11,11 +13,11 @@ namespace pst {
 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const pst_attn_params p) {
-  constexpr int KT = 64, PITCH = HD + 1, PD = HD / 4;
+  constexpr int KT = 64, PITCH = HD + 4, PD = HD / 4, PP = KT + 4;      // row pitches in floats: multiples of 4 (16-byte rows: ds_read_b128)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Ks = (float*)smem_raw;                 // [KT][PITCH]
   float* Vs = Ks + KT * PITCH;                  // [KT][PITCH]   (V, not V^T: transposed while staging)
-  float* Ps = Vs + KT * PITCH;                  // [64 queries][KT + 1]
+  float* Ps = Vs + KT * PITCH;                  // [64 queries][PP]
   const int tid = threadIdx.x;
   const int ql = tid >> 2, part = tid & 3;
   const int qblocks = (p.Nq + 63) / 64;
@@ -50,8 +52,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const pst_attn_params p) 
       const int key = c / (HD / 4), d = (c - key * (HD / 4)) * 4;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (k0 + key < p.Nk) t = *(const float4*)(Kp + (int64_t)(k0 + key) * p.k_rs + d);
-      float* dst = Ks + key * PITCH + d;
-      dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+      *(float4*)(Ks + key * PITCH + d) = t;
     }
     for (int c = tid; c < KT * HD; c += 256) {
       const int key = c & 63, d = c >> 6;
@@ -63,11 +64,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const pst_attn_params p) 
     float tmax = -INFINITY;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-      const int key = part * 16 + kk;
-      const float* kr = Ks + key * PITCH;
+      const int key = kk * 4 + part;                 // the four threads of a query take interleaved keys: their K rows sit in different LDS banks
+      const float4* kr = (const float4*)(Ks + key * PITCH);
       float acc = 0.f;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) acc = fmaf(qv[d], kr[d], acc);
+      for (int d = 0; d < HD; d += 4) {
+        const float4 k4 = kr[d >> 2];
+        acc = fmaf(qv[d], k4.x, acc); acc = fmaf(qv[d + 1], k4.y, acc); acc = fmaf(qv[d + 2], k4.z, acc); acc = fmaf(qv[d + 3], k4.w, acc);
+      }
       acc *= c_exp;
       const bool dead = (k0 + key >= p.Nk) || (Mp && Mp[(int64_t)qc * p.m_rs + k0 + key] != 0);
       s[kk] = dead ? -INFINITY : acc;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const pst_attn_params p) 
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       const float pj = (s[kk] == -INFINITY) ? 0.f : exp2f(s[kk] - m_new);
-      Ps[ql * (KT + 1) + part * 16 + kk] = pj;
+      Ps[ql * PP + kk * 4 + part] = pj;
       psum += pj;
     }
     psum += __shfl_xor(psum, 1);
@@ -91,13 +95,20 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const pst_attn_params p) 
 #pragma unroll
     for (int d = 0; d < PD; ++d) o[d] *= alpha;
     __syncthreads();                            // the four threads of a query see each other's probabilities
-    const float* pr = Ps + ql * (KT + 1);
-#pragma unroll 4
-    for (int key = 0; key < KT; ++key) {
-      const float pj = pr[key];
-      const float* vr = Vs + key * PITCH + part * PD;
+    const float4* pr = (const float4*)(Ps + ql * PP);
+#pragma unroll 2
+    for (int k4 = 0; k4 < KT / 4; ++k4) {
+      const float4 p4 = pr[k4];
+      const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-      for (int d = 0; d < PD; ++d) o[d] = fmaf(pj, vr[d], o[d]);
+      for (int u = 0; u < 4; ++u) {
+        const float4* vr = (const float4*)(Vs + (4 * k4 + u) * PITCH + part * PD);
+#pragma unroll
+        for (int d = 0; d < PD; d += 4) {
+          const float4 v4 = vr[d >> 2];
+          o[d] = fmaf(pj[u], v4.x, o[d]); o[d + 1] = fmaf(pj[u], v4.y, o[d + 1]); o[d + 2] = fmaf(pj[u], v4.z, o[d + 2]); o[d + 3] = fmaf(pj[u], v4.w, o[d + 3]);
+        }
+      }
     }
   }
   if (q < p.Nq) {
@@ -120,9 +131,9 @@ int attn_f32_validate(const pst_attn_params& p) {
 
 template <int HD>
 static int launch_attn_f32_t(const pst_attn_params& p, hipStream_t s) {
-  constexpr int LDS = (2 * 64 * (HD + 1) + 64 * 65) * 4;
+  constexpr int LDS = (2 * 64 * (HD + 4) + 64 * 68) * 4;
   static unsigned long long seen = 0;
-  once_per_device(seen, [] { (void)hipFuncSetAttribute((const void*)attn_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 64 * (HD + 1) + 64 * 65) * 4); });
+  once_per_device(seen, [] { (void)hipFuncSetAttribute((const void*)attn_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 64 * (HD + 4) + 64 * 68) * 4); });
   const long grid = (long)((p.Nq + 63) / 64) * p.H * p.B;
   hipLaunchKernelGGL((attn_f32_kernel<HD>), dim3((unsigned)grid), dim3(256), LDS, s, p);
   return check_launch("attn_f32");

@@ -462,3 +462,41 @@ def test_scene_fp32_graph_replay_is_bit_identical(pair):
     assert torch.equal(s1['out_queries'], s2['out_queries'])
     for k in range(V):
         assert torch.equal(r1[k][0], r2[k][0]) and torch.equal(r1[k][1], r2[k][1])
+
+
+@pytest.mark.parametrize('H,W,V,K', [(112, 112, 5, 3), (80, 112, 4, 4)])
+def test_scene_fp32_odd_token_grids_and_graph_replay(pair, H, W, V, K):
+    """fp32 mode on token grids that are not multiples of 4 (7 x 7 and 5 x 7 tokens: the dense memory bank appends its fp32 V^T block at an unaligned
+    column, the query decoder's key count is odd) with V > K (heads-only views) - against the oracle, and a captured-graph replay gives the same bits."""
+    variant, o, h = pair
+    imgs = tiny.images(V, H, W)
+    ts = torch.tensor([[H, W]] * V)
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K)
+    pm_h, pan_h = h.forward_inference_multi_ar([d(i) for i in imgs], ts, tiny.NAMES, num_keyframes=K, amp=False)
+    for a, b in zip(pm_h, pm_o):
+        assert rel_l2(a.cpu(), b) < 1e-4
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 1e-4
+    for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
+        assert rel_l2(a.cpu(), b) < mask_tol(variant)
+    runner = h.scene_runner({i: d(im) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=False)
+    runner.run()
+    res, scene = runner.run()
+    assert torch.equal(scene['out_queries'], pan_h['out_queries'])
+    for i in range(V):
+        assert torch.equal(res[i][0], pm_h[i]) and torch.equal(res[i][1], pan_h['pred_masks'][i])
+
+
+def test_forward_fp32_224_padded_layout(pair):
+    """BASELINE config C1's shape (2 views, 224 x 224: 196 tokens in a 200-row padded layout per view) through the reference's same-shape entry point
+    `PanSt3R.forward` with its DEFAULT amp (False = fp32)"""
+    variant, o, h = pair
+    H = W = 224
+    imgs = tiny.images(2, H, W)
+    ts = torch.tensor([[H, W]] * 2)
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=2)
+    pan_h, pm_h = h.forward(d(torch.stack(imgs)[None]), ts[None], tiny.NAMES)
+    assert pm_h.dtype == F32 and pm_h.shape == (1, 2, H, W, 7)
+    for i in range(2):
+        assert rel_l2(pm_h[0, i].cpu(), pm_o[i][0]) < 1e-4
+        assert rel_l2(pan_h['pred_masks'][0, i].cpu(), pan_o['pred_masks'][i][0]) < mask_tol(variant)
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 1e-4

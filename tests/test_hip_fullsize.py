@@ -276,24 +276,22 @@ def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, k
         runners.append(S.SceneRunner(S.HipBackend(model), mine, V, H, W, K, names, rank=r, world=world, keyframes=keyframes, amp=amp, plan=plan))
     sends = []
     monkeypatch.setattr(S, '_all_gather_rows', lambda t, counts, w, g: [s[:c] for s, c in zip(sends, counts)])
-    with torch.no_grad():
+    from panst3r_amd.model.common import precision
+    with torch.no_grad(), precision(amp):          # (SceneRunner.run enters the runner's format around its stages; here the stages are stepped by hand)
         for rn in runners:
             rn.stage1()
         sends[:] = [rn.enc_send for rn in runners]
         for rn in runners:
             rn.gather1()
         if plan == 'broadcast':                # rank 0 builds, the others encode; the broadcast = a device copy of rank 0's banks
-            from panst3r_amd.model.common import precision
             for rn in runners:
-                with precision(amp):
-                    rn.stage2a()
+                rn.stage2a()
             src = runners[0].b.bank_payload(runners[0].bank)
             for rn in runners[1:]:
                 for d, t in zip(rn.b.bank_payload(rn.bank), src):
                     d.copy_(t)
             for rn in runners:
-                with precision(amp):
-                    rn.stage2b()
+                rn.stage2b()
         else:
             for rn in runners:
                 rn.stage2()
@@ -309,19 +307,20 @@ def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, k
     return res, scenes
 
 
-@pytest.mark.parametrize('V,K,world,plan', [(13, 4, 2, 'replicated'), (50, 16, 8, 'replicated'), (50, 16, 8, 'broadcast')])
-def test_full_size_sharded_equals_unsharded_on_one_gpu(full, monkeypatch, V, K, world, plan):
+@pytest.mark.parametrize('V,K,world,plan,amp', [(13, 4, 2, 'replicated', 'fp16'), (50, 16, 8, 'replicated', 'fp16'), (50, 16, 8, 'broadcast', 'fp16'),
+                                                 (9, 4, 4, 'broadcast', False)])
+def test_full_size_sharded_equals_unsharded_on_one_gpu(full, monkeypatch, V, K, world, plan, amp):
     """what `bench.py --gpus 8` computes (50 views, 16 keyframes, 6-7 views per rank) equals the 1-GPU scene BIT FOR BIT -
     every launch is row-independent and the smaller per-rank launches pick bit-compatible kernel variants (GEMM tile sizes, attention
-    split-K choice).  All ranks must also hold identical frozen queries / class logits."""
+    split-K choice).  All ranks must also hold identical frozen queries / class logits.  The last case: the fp32 mode (amp=False) on the broadcast plan."""
     from panst3r_amd.synthetic import synth_image
     model, _, names, _ = full
     dev = torch.device('cuda:0')
     H, W = 384, 512
     imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
     with torch.no_grad():
-        ref, sref = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=False, amp='fp16').run()
-    res, scenes = run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, plan=plan)
+        ref, sref = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=False, amp=amp).run()
+    res, scenes = run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, amp=amp, plan=plan)
     assert sorted(res) == list(range(V))
     for s in scenes:
         assert torch.equal(s['out_queries'], sref['out_queries']) and torch.equal(s['pred_logits'], sref['pred_logits'])

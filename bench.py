@@ -370,10 +370,10 @@ def main():
             out['alt_dtype'] = {'dtype': 'bf16' if alt == 'bf16' else 'f16', 'value': round(V * max(3, args.steps // 4) / e2, 3),
                                 'note': 'the other 16-bit format of the reference (--amp %s), same scene, %d timed steps' % (alt, max(3, args.steps // 4))}
         if host_legs and not args.no_alt_dtype:
-            try:          # the reference's default mode (amp=False: fp32 end to end) on the fp32-FMA kernels: the precision path, not the benchmark
+            try:          # the reference's default mode (amp=False: fp32 end to end) on the fp32 kernels: the precision path, not the benchmark
                 e3, _, _ = measure(False, 2, 1, False)
                 out['fp32_mode'] = {'dtype': 'f32', 'value': round(V * 2 / e3, 3), 'unit': 'frames/s',
-                                    'note': 'amp=False: float32 operands / activations, fp32-FMA GEMM + attention kernels (no MFMA), same scene, 2 timed steps'}
+                                    'note': 'amp=False: float32 operands / activations, fp32-input MFMA GEMMs + fp32 attention, same scene, 2 timed steps'}
             except Exception as e:
                 out['fp32_mode'] = {'error': repr(e)}
         if host_legs:

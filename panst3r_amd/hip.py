@@ -209,7 +209,7 @@ def _gemm_params(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None
                  M=None, kernel=0, rope=None, batch=None, xcopy=None, stats_out=None, ln=None):
     """pst_gemm_params of one hip.gemm call + (flops, shape tag) for the kernel timer.
     out = epi(a @ w.T).  a [M,K] 16-bit (row-major view), w [N,K] 16-bit, out 16-bit / fp32 2-D view (or raw buffer for ps).
-    a, w, out (and res) all fp32: the amp=False mode's fp32-FMA GEMM (same epilogues; no fused RoPE, no LayerNorm fold).
+    a, w, out (and res) all fp32: the amp=False mode's fp32-input-MFMA GEMM (same epilogues; no fused RoPE, no LayerNorm fold).
     LayerNorm fold (include/panst3r_hip.h): producer side `xcopy` (16-bit copy of an fp32 out) and `stats_out` (fp32 [M, N/64, 2]);
     consumer side `ln` = (stats [M, groups, 2], colsum [N], eps) with `a` the raw rows and `w` / `bias` folded at pack time."""
     _dev(a, *FMT); _dev(w, *FMT); _dev(out, *FMT)

@@ -373,7 +373,7 @@ def main():
             try:          # the reference's default mode (amp=False: fp32 end to end) on the fp32 kernels: the precision path, not the benchmark
                 e3, _, _ = measure(False, 2, 1, False)
                 out['fp32_mode'] = {'dtype': 'f32', 'value': round(V * 2 / e3, 3), 'unit': 'frames/s',
-                                    'note': 'amp=False: float32 operands / activations, fp32-input MFMA GEMMs + fp32 attention, same scene, 2 timed steps'}
+                                    'note': 'amp=False: float32 operands / activations, GEMMs and attention on the fp32-input MFMA, same scene, 2 timed steps'}
             except Exception as e:
                 out['fp32_mode'] = {'error': repr(e)}
         if host_legs:

@@ -17,7 +17,7 @@
  * fp32 mode (ABI 16; reference amp=False, tools/demo_panst3r.py:88: torch.float32 end to end): `dtype16` = PST_F32 is accepted by pst_gemm,
  * pst_attn_fwd, pst_rope2d, pst_patchify, pst_patch_rows, pst_l2norm_rows, pst_mean4, pst_resize_bilinear, pst_loftup_guidance_gn,
  * pst_groupnorm_apply and pst_loftup_lr_pe: the "16-bit" tensors of that call are then float (leading dimensions / strides still in
- * elements).  GEMM and attention run on fp32 kernels (gemm_f32.hip: the fp32-input MFMA; attn_f32.hip: fp32 FMAs; ~12x slower than 16-bit operands) with the same epilogues;
+ * elements).  GEMM and attention run on the fp32-input MFMA (gemm_f32.hip, attn_f32.hip: exact fp32 products, fp32 accumulation; 1 / 16 of the 16-bit matrix rate) with the same epilogues;
  * rejected in this mode: a 16-bit C / residual, fused RoPE, the LayerNorm-fold arguments, pst_gemm_params.kernel != 0, attention
  * split-K, pst_mask_head, pst_split3, pst_rowstats (16-bit precision devices with nothing to do in fp32).
  */

@@ -16,7 +16,7 @@ F16 = torch.float16
 class _Precision:
     """The storage / operand format of everything the HIP path computes: bfloat16 (amp='bf16') or IEEE half (amp='fp16'; reference
     tools/demo_panst3r.py:88, utils.py:206-215) on the MFMA kernels, or float32 (amp=False, the reference's default: fp32 end to end) on
-    the fp32 GEMM (fp32-input MFMA) / attention kernels - the precision path, ~12x slower.  Accumulation, residual streams, softmax and normalisation
+    the fp32-input-MFMA GEMM / attention kernels - the precision path, ~8x slower.  Accumulation, residual streams, softmax and normalisation
     statistics are fp32 in all three.  Process-wide, switched by the `precision(...)` context (a SceneRunner enters it around every
     stage, so graphs are captured - and weights packed - in the runner's format)."""
     dtype = torch.float16
@@ -45,12 +45,12 @@ def warn_once(key, msg):
 def amp_dtype(amp, quiet=False):
     """`amp` argument of the reference API (False | 'bf16' | 'fp16', utils.py:206-215) -> storage / operand dtype of the HIP path.
     amp=False is the reference's fp32 mode (tools/demo_panst3r.py:88 default): float32 activations and weights, the fp32-input-MFMA GEMM
-    (csrc/gemm_f32.hip) and fp32 attention (csrc/attn_f32.hip) kernels - the reference's arithmetic, at fp32 speed (1/16 of the 16-bit MFMA rate: ~12x the time of
+    (csrc/gemm_f32.hip) and attention (csrc/attn_f32.hip) kernels - the reference's arithmetic, at fp32 speed (1/16 of the 16-bit MFMA rate: ~8x the time of
     a 16-bit scene), said once per process.  ('fp32' is accepted as a synonym of False.)"""
     if amp is None or amp is False or amp == 'fp32' or amp is torch.float32:
         if not quiet:
-            warn_once('amp_false', "panst3r_amd: amp=False is the fp32 mode (float32 operands: fp32-input MFMA GEMMs, fp32 attention): exact to ~1e-5 but "
-                                   "~12x slower than amp='fp16' / 'bf16' - pass one of those for the fast path")
+            warn_once('amp_false', "panst3r_amd: amp=False is the fp32 mode (float32 operands on the fp32-input MFMA): exact to ~1e-5 but "
+                                   "~8x slower than amp='fp16' / 'bf16' - pass one of those for the fast path")
         return torch.float32
     if amp not in AMP_DTYPES:
         raise ValueError("amp must be False, 'bf16' or 'fp16' (got %r)" % (amp,))

@@ -12,8 +12,8 @@ Same call signatures and output structure; what changed is HOW the scene is exec
     one [Q,C]x[C,P] GEMM (the reference recomputes the heads per chunk, panoptic_decoder.py:71);
   * MinMaxScaler is per view (the demo's max_bs=1 convention), see SURVEY quirk 5.
 `amp` (False | 'bf16' | 'fp16', reference utils.py:206-215) selects the storage / operand format of the scene: 'bf16' and 'fp16' as in the
-reference's autocast (MFMA kernels); amp=False is the reference's fp32 mode: float32 weights and activations, GEMMs on the fp32-input MFMA and an fp32
-attention kernel (csrc/gemm_f32.hip, attn_f32.hip) - the reference's default arithmetic, ~12x slower, said once (RuntimeWarning).  Accumulation,
+reference's autocast (MFMA kernels); amp=False is the reference's fp32 mode: float32 weights and activations, GEMMs and attention on the fp32-input MFMA
+(csrc/gemm_f32.hip, attn_f32.hip) - the reference's default arithmetic, ~8x slower, said once (RuntimeWarning).  Accumulation,
 residual streams, softmax and normalisation statistics are fp32 always.
 """
 from argparse import Namespace

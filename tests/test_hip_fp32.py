@@ -1,6 +1,6 @@
 """The fp32 mode (reference `amp=False`, tools/demo_panst3r.py:88: torch.float32 end to end) of the HIP path.
 
-Operands and activations are float32; the GEMMs run on the fp32-input MFMA kernel (csrc/gemm_f32.hip), attention on csrc/attn_f32.hip, and the
+Operands and activations are float32; the GEMMs (csrc/gemm_f32.hip) and attention (csrc/attn_f32.hip) run on the fp32-input MFMA, and the
 streaming kernels read / write float32 rows (type code PST_F32).  Against a float64 evaluation of the same fp32 inputs only the summation
 order differs, so the bounds here are two to three orders of magnitude tighter than the 16-bit ones: ops rel-L2 <= 1e-5, tiny-model
 tokens / pointmaps / queries / mask logits rel-L2 <= 1e-4 (measured 1e-6 .. 2e-6) with >= 99.99 % sign agreement against the fp32 CPU

@@ -254,7 +254,7 @@ def main():
     model.to(dev)
 
     from panst3r_amd.scene import assign_views, resolve_plan
-    args.plan = resolve_plan(args.plan, world)
+    args.plan = resolve_plan(args.plan, world, min(K, V))
     _, order, owner = assign_views(V, K, world, plan=args.plan)
     mine = {order[i] for i in range(V) if owner[i] == rank}
     images = {i: synth_image(i, H, W).to(dev) for i in sorted(mine)}        # inputs resident in HBM before timing

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 16
+#define PST_ABI_VERSION 17
 
 /* element type codes: every `*_type` / `dtype16` argument below (and the former `*_fp32` flags: 0 and 1 keep their meaning) */
 #define PST_BF16 0   /* bfloat16, raw uint16 */
@@ -103,19 +103,10 @@ const char* pst_gemm_variant(const pst_gemm_params* p);
  * bit-identical to two pst_gemm calls either way.  pst_gemm_pair_variant: "gemm_pair_kernel<2,2>", or "" when the pair is not fused. */
 int pst_gemm_pair(const pst_gemm_params* a, const pst_gemm_params* b, void* stream);
 const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_params* b);
-/* Tuning knobs of the GEMM dispatch (process-wide; measurement tools and tests only - results never depend on them, every GEMM variant
- * is bit-identical):  PST_TUNE_G2_AUTO  1 = GEMMs of the persistent 256x256 kernel's classes go to the two-workgroups-per-CU kernel
- * (gemm2g.hip) when it is eligible, 0 = never (kernel == 2 still forces it);  PST_TUNE_G2_MODE  de-phasing of the CU's two workgroups:
- * bit 0 static priority for the first dispatch wave, bit 1 start delay of the second (bits 4-7 = delay in ~us), bits 8.. = timing ablation.
- * Returns the previous value, or -1 for an unknown knob.  Initial values: environment PST_G2_AUTO / PST_G2_MODE, else the defaults. */
-#define PST_TUNE_G2_AUTO 1
-#define PST_TUNE_G2_MODE 2
+/* Tuning knob of the GEMM dispatch (process-wide; measurement tools and tests only - results never depend on it, every GEMM variant
+ * is bit-identical).  Returns the previous value, or -1 for an unknown knob. */
 #define PST_TUNE_G256_PP 3      /* 1 (default): ping-pong K loop of the persistent 256x256 kernel, 0: the lock-step loop (A/B measurements) */
 int pst_tune(int knob, int value);
-/* Measurement only: phase trace of the two-workgroup GEMM.  `buf` = device int64 [workgroups][1 + 4 * tiles_per_workgroup] (NULL: off); every
- * workgroup writes its hardware id and, per tile it processes, four 100 MHz timestamps (tile start, main loop start, main loop end,
- * epilogue end).  tools/g2_trace.py turns them into phase durations and the overlap of the two workgroups of a CU. */
-int pst_debug_g2_trace(void* buf, int tiles_per_workgroup);
 
 /* ---------------------------------------------------------------- query x pixel mask einsum (HBM-bound streaming form)
  * pred_masks[v][q][p] = sum_c E[q][c] * F[v][p][c]  (reference mask_transformer.py:280 "bqc,bnchw->bnqhw" with pixel-major mask features):

@@ -26,8 +26,6 @@ bool gemm256_persistent_ok(const pst_gemm_params& p);
 int gemm256_persistent_class(const pst_gemm_params& p);
 int gemm_f32_validate(const pst_gemm_params& p);                          // gemm_f32.hip: fp32 operands (the reference's amp=False arithmetic)
 int launch_gemm_f32(const pst_gemm_params& p, hipStream_t s);
-int gemm2g_class(const pst_gemm_params& p);                               // gemm2g.hip: two workgroups per CU, 256 x 128 tiles
-int launch_gemm2g(const pst_gemm_params& p, hipStream_t s, int cus);
 int rowstream_class(const pst_gemm_params& p);                            // rowstream.hip
 int launch_rowstream(const pst_gemm_params& p, hipStream_t s, int cus);
 
@@ -546,10 +544,7 @@ static int gemm_validate(const pst_gemm_params* pp) {
     return pst::gemm_f32_validate(p);
   }
   if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("gemm: dtype16 must be PST_BF16, PST_F16 or PST_F32"); return PST_EINVAL; }
-  if (p.kernel != 0 && p.kernel != 128 && p.kernel != 256 && p.kernel != 2) { set_error("gemm: kernel must be 0 (auto), 128, 256 or 2 (two-workgroup persistent)"); return PST_EINVAL; }
-  if (p.kernel == 2 && (pst::gemm2g_class(p) == 0 || (int64_t)p.M * p.lda >= (1ll << 31) || (int64_t)p.N * p.ldw >= (1ll << 31))) {
-    set_error("gemm: the two-workgroup kernel takes the persistent kernel's classes only (plain 16-bit / fp32 residual stream / transposed 16-bit, N %% 64 == 0)"); return PST_EINVAL;
-  }
+  if (p.kernel != 0 && p.kernel != 128 && p.kernel != 256) { set_error("gemm: kernel must be 0 (auto), 128 or 256"); return PST_EINVAL; }
   if (p.kernel == 256 && (p.conv_c > 0 || (p.trans_out && pst::gemm256_persistent_class(p) != 3))) {
     set_error("gemm: the 256x256 kernel has no conv mode, and trans_out only in its persistent class (16-bit, ldc %% 8 == 0, N %% 64 == 0)"); return PST_EINVAL;
   }
@@ -589,24 +584,10 @@ static int gemm_validate(const pst_gemm_params* pp) {
   return PST_OK;
 }
 
-static int gemm_choice0(const pst_gemm_params& p);
-constexpr int G2_AUTO_DEFAULT = 0;
-namespace pst { int gemm2g_mode(int set); void gemm2g_trace(void* buf, int tiles); int gemm256_pp(int set); }
-// experiment switch: PST_G2_AUTO=1 sends every GEMM the persistent 256x256 kernel would take to the two-workgroup kernel instead
-static int g_g2_auto = -1;
-static bool g2_auto() {
-  if (g_g2_auto < 0) { const char* e = getenv("PST_G2_AUTO"); g_g2_auto = e ? (atoi(e) != 0) : G2_AUTO_DEFAULT; }
-  return g_g2_auto == 1;
-}
+namespace pst { int gemm256_pp(int set); }
 
-// the ONE dispatch rule, shared by the launch and by pst_gemm_variant: 0 = 64x64 tiles, 1 = 128x128, 2 = 256x256, 3 = two-workgroup 256x128
+// the ONE dispatch rule, shared by the launch and by pst_gemm_variant: 0 = 64x64 tiles, 1 = 128x128, 2 = 256x256
 static int gemm_choice(const pst_gemm_params& p) {
-  if (p.kernel == 2) return 3;
-  const int c0 = gemm_choice0(p);
-  if (c0 == 2 && g2_auto() && pst::gemm256_persistent_ok(p) && pst::gemm2g_class(p) != 0) return 3;
-  return c0;
-}
-static int gemm_choice0(const pst_gemm_params& p) {
   const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batch > 1 ? p.batch : 1);
   // fewer 128x128 tiles than about one per CU: 64x64 tiles fill the chip better.  Measured crossover (M = 1536 .. 5376, the
   // 2-7 views per rank of an 8-GPU scene): 192 tiles -> 64x64 wins for K = 1024 (348 vs 326 TFLOP/s) and loses for K = 4096
@@ -640,7 +621,6 @@ extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
   if (rowstream_class(p)) return launch_rowstream(p, s, num_cus());      // LoftUp's 384 x 384 GEMMs over ~10^6 rows: streamed, not tiled
   const int c = gemm_choice(p);
   // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
-  if (c == 3) return launch_gemm2g(p, s, num_cus());
   if (c == 2) return gemm256_persistent_ok(p) ? launch_gemm256p(p, s, num_cus()) : launch_gemm256(p, s);
   if (p.trans_out) return c == 0 ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
   return c == 0 ? launch<2, 2, false, 4>(p, s) : launch<4, 4, false, 2>(p, s);
@@ -671,15 +651,8 @@ extern "C" const char* pst_gemm_pair_variant(const pst_gemm_params* pa, const ps
 }
 
 extern "C" int pst_tune(int knob, int value) {
-  if (knob == PST_TUNE_G2_AUTO) { const int prev = g2_auto() ? 1 : 0; g_g2_auto = value != 0; return prev; }
-  if (knob == PST_TUNE_G2_MODE) return pst::gemm2g_mode(value);
   if (knob == PST_TUNE_G256_PP) return pst::gemm256_pp(value);
   return -1;
-}
-
-extern "C" int pst_debug_g2_trace(void* buf, int tiles_per_workgroup) {
-  pst::gemm2g_trace(buf, tiles_per_workgroup);
-  return PST_OK;
 }
 
 extern "C" const char* pst_gemm_variant(const pst_gemm_params* pp) {
@@ -687,7 +660,6 @@ extern "C" const char* pst_gemm_variant(const pst_gemm_params* pp) {
   if (pp->dtype16 == pst::DT_F32) return "gemm_f32_kernel";
   if (pst::rowstream_class(*pp)) return "rowgemm384_kernel";
   const int c = gemm_choice(*pp);
-  if (c == 3) return "gemm2g_kernel";
   if (pp->trans_out && c != 2) return c == 0 ? "gemm_kernel<2,2,true>" : "gemm_kernel<4,4,true>";
   return c == 2 ? (pst::gemm256_persistent_ok(*pp) ? "gemm256p_kernel" : "gemm256_kernel") : (c == 0 ? "gemm_kernel<2,2,false>" : "gemm_kernel<4,4,false>");
 }

@@ -55,6 +55,9 @@ def resize_recipe(size, patch_size, H, W):
         else:
             Hc, Wc = H, int(H * tr)
         return ((H - Hc) // 2, (W - Wc) // 2), (Hc, Wc), (Ho, Wo)
+    from ..model.common import warn_once
+    warn_once(('resize_recipe', size), 'panst3r_amd.load_images: image_size %d has no entry in the trained-resolution table (224, 512): the resize / crop rule '
+                                       'for it is this build\'s restatement of un-vendored must3r code and is not pinned against upstream' % size)
     scale = float(size) / max(H, W)
     Hr, Wr = max(int(round(H * scale)), patch_size), max(int(round(W * scale)), patch_size)
     Ho, Wo = Hr // patch_size * patch_size, Wr // patch_size * patch_size

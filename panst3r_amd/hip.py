@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PST_LIB') or os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')      # PST_LIB: A/B builds of the same ABI (measurement)
-ABI_VERSION = 16
+ABI_VERSION = 17
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -39,7 +39,7 @@ class AttnParams(C.Structure):
                 ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64), ('dtype16', i32), ('prescaled', i32)]
 
 
-EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_gemm_pair', 'pst_gemm_pair_variant', 'pst_tune', 'pst_debug_g2_trace', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_gemm_pair', 'pst_gemm_pair_variant', 'pst_tune', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
            'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
@@ -72,7 +72,7 @@ def lib():
     return L
 
 
-TUNE_G2_AUTO, TUNE_G2_MODE, TUNE_G256_PP = 1, 2, 3
+TUNE_G256_PP = 3
 
 
 def tune(knob, value):

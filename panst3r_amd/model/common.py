@@ -226,6 +226,9 @@ def self_attention(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
     if vt is None:
         vt = torch.empty(D, lay.rows + 8, dtype=adt(), device=dev)
     xv, lv = s.operand(w_v)                                                 # (the same LN(x) as xn: q|k and v share norm1)
+    # both operands are fetched before either GEMM is launched: in the non-fold modes operand() re-runs LayerNorm into the SHARED s.xb when the
+    # LayerNorm differs, which would overwrite xn under the q|k GEMM - q|k and v must be row slices of one folded qkv pack
+    assert xv is xn, 'self_attention: w_qk and w_v must share one LayerNorm (row slices of one qkv pack)'
     fused_rope = rope is not None and hd == 64 and adt() != torch.float32   # RoPE-2D applied in the GEMM's store phase
     # the two projections are independent: one launch for the small-M case (the memory build's 768 rows), two for the big ones - the C side decides
     hip.gemm_pair((xn, w_qk.w, qk, dict(bias=w_qk.b, gamma=qs, ln=lq, **({'rope': (pos, rope)} if fused_rope else {}))),

@@ -642,7 +642,10 @@ class TextEncoder(nn.Module):
         """unit-norm class embeddings as the bf16 [Ncls, 768] W operand of the class-logit GEMM (normalised on device)."""
         assert all(c in self.class_embeddings for c in classes), \
             "Missing classes in vocabulary. 'set_vocab' must be called if using fixed vocabulary"
-        key = (tuple(classes), str(device), adt(), getattr(self, '_cls_gen', 0))
+        # identity of the embeddings in use: vocabulary generation (set_vocab), plus per class the storage address and torch's in-place edit
+        # counter - an in-place edit or a direct dict assignment gets fresh device copies too (ADVICE r3)
+        ver = tuple((self.class_embeddings[c].data_ptr(), self.class_embeddings[c]._version) for c in classes)
+        key = (tuple(classes), str(device), adt(), getattr(self, '_cls_gen', 0), ver)
         cache = self.__dict__.setdefault('_cls_cache', {})     # keyed, entries never replaced: a captured graph may hold the address
         if not isinstance(cache, dict):
             cache = self.__dict__['_cls_cache'] = {}

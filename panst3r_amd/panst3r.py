@@ -224,6 +224,10 @@ class PanSt3R(nn.Module):
             # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: ONE fused flag over everything the
             # call returns (queries, class logits, pointmaps, mask logits), one host sync; raises, as the reference's "--amp fp16 might be
             # unstable" would show up.  (amp=False is fp32 and amp='bf16' has the fp32 range: neither can overflow this way.)
+            # COST: one extra read of every output incl. the mask logits (V x Q x H/2 x W/2 fp32 = 39 MB per 384x512 view, ~0.5 ms per 50-view
+            # scene at HBM speed) - the mask features that could overflow are just as large, so there is no cheaper exact proxy;
+            # check_finite=False skips it (SceneRunner.run, which bench.py times, never pays it).  The per-view mask tensors are VIEWS of one
+            # [n, Q, H/2, W/2] allocation per shape group (one mask-head launch writes them all): holding one keeps its group's block alive.
             ok = torch.isfinite(scene['out_queries']).all() & torch.isfinite(scene['pred_logits']).all()
             for i in range(V):
                 ok = ok & torch.isfinite(res[i][0]).all() & torch.isfinite(res[i][1]).all()
@@ -257,7 +261,7 @@ class PanSt3R(nn.Module):
         pver = sum(p._version for p in self.parameters())
         cver = tuple((c, te.class_embeddings[c].data_ptr(), te.class_embeddings[c]._version) if c in te.class_embeddings else (c,) for c in classes)
         key = (tuple(shapes), num_keyframes, None if keyframes is None else tuple(int(k) for k in keyframes), str(dev),
-               amp_dtype(amp, quiet=True), gens, pver, cver)
+               amp_dtype(amp, quiet=True), gens, pver, cver, getattr(te, '_cls_gen', 0))
         ent = self._runners.get(key)
         if ent is None:
             while len(self._runners) >= max(1, self.max_cached_runners):

@@ -27,12 +27,13 @@ from .schedule import select_keyframes, view_order
 PLANS = ('replicated', 'broadcast')
 
 
-def resolve_plan(plan, world):
+def resolve_plan(plan, world, K=None):
     """'auto' -> the plan the one-GPU projection favours (tools/shard_estimate.py, profiles/r3_shard_estimate.txt: 50 views / 16 keyframes, critical path
     replicated vs broadcast: 2 ranks 104.7 vs 123.4 ms, 4 ranks 71.3 vs 57.5 ms, 8 ranks 58.1 vs 44.5 ms with the 453 MB of banks at an ASSUMED 100 GB/s):
-    'broadcast' from 4 ranks on, 'replicated' below."""
+    'broadcast' from 4 ranks on, 'replicated' below - and 'replicated' whenever there are fewer keyframes than ranks (`K` given), which the
+    broadcast plan's deal cannot serve."""
     if plan in (None, 'auto'):
-        return 'broadcast' if world >= 4 else 'replicated'
+        return 'broadcast' if (world >= 4 and (K is None or K >= world)) else 'replicated'
     if plan not in PLANS:
         raise ValueError("plan must be 'auto' or one of %s (got %r)" % (PLANS, plan))
     return plan
@@ -144,11 +145,14 @@ class SceneRunner:
         self.K = K = len(keyframes) if keyframes is not None else (V if (K is None or K > V) else max(int(K), 2))
         if V < world:
             raise ValueError('need at least one view per rank (V=%d, world=%d)' % (V, world))
+        self.shapes = [tuple(sh) for sh in shapes] if shapes is not None else [(H, W)] * V      # per view id
+        self.plan = plan = resolve_plan(plan, world, K)
         if plan == 'broadcast' and world > 1 and K < world:
             raise ValueError("plan='broadcast' deals the keyframes over all ranks and the other views over ranks 1..: it needs K >= world (K=%d, world=%d)" % (K, world))
-        self.shapes = [tuple(sh) for sh in shapes] if shapes is not None else [(H, W)] * V      # per view id
-        self.plan = plan = resolve_plan(plan, world)
         self.keyframes, self.order, owner = assign_views(V, K, world, keyframes, plan)
+        empty = [r for r in range(world) if r not in owner]
+        if empty:           # every rank computes this from the same arguments: all of them raise, none is left waiting in a collective
+            raise ValueError('plan %r leaves rank(s) %s without a view (V=%d, K=%d, world=%d)' % (plan, empty, V, K, world))
         self.builder = plan == 'replicated' or rank == 0        # this rank runs the sequential memory build
         # the broadcast plan's split stage 2 also runs on a 1-rank process group (PST_FORCE_DIST=1: the collectives execute on RCCL at world = 1)
         self.split = plan == 'broadcast' and (world > 1 or (dist.is_available() and dist.is_initialized()))
@@ -400,8 +404,8 @@ def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=No
     Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
     {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W);
     `keyframes`: optional explicit keyframe list in memory-build order (overrides the linspace schedule of K)."""
-    Kc = V if (K is None or K > V) else max(int(K), 2)
-    plan = resolve_plan(plan, world)
+    Kc = len(keyframes) if keyframes is not None else (V if (K is None or K > V) else max(int(K), 2))
+    plan = resolve_plan(plan, world, Kc)
     _, order, owner = assign_views(V, Kc, world, keyframes, plan)
     images = {order[i]: get_image(order[i]) for i in range(V) if owner[i] == rank}
     return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes, amp=amp, plan=plan).run(outdevice)

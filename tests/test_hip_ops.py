@@ -818,88 +818,6 @@ def test_groupnorm_apply_streaming_16bit(C, G, P, relu):
     assert rel_l2(out.float().cpu(), ref) < (6e-3 if d16() == torch.bfloat16 else 1e-3)
 
 
-@pytest.mark.parametrize('M,N,K', [(3000, 1024, 1024), (40000, 768, 128), (2605, 256, 192), (9001, 320, 64), (70000, 128, 64), (5000, 4096, 256)])
-def test_gemm2g_bit_identical_to_gemm128(M, N, K):
-    """The two-workgroups-per-CU persistent kernel (gemm2g.hip: 256 x 128 tiles, BK = 32 three-stage ring) against the 128 x 128 kernel,
-    bit for bit, for every epilogue class it takes: plain 16-bit (bias / GELU / ReLU / LayerScale), fused RoPE-2D, LayerNorm-fold consumer,
-    fp32 residual stream + fold producer outputs (16-bit copy, statistics), transposed 16-bit store; ragged M (partial row tiles), N a
-    multiple of 64 only (clamped last column tile), many tiles per workgroup (70000 x 128: 274 row tiles on <= 512 workgroups; 40000 x 768:
-    942 tiles), and 20 repeated launches to screen the LDS-DMA ring for races."""
-    from panst3r_amd import hip
-    a, w = bf(rn(1200, M, K)).to(dev()), bf(rn(1201, N, K, scale=K ** -0.5)).to(dev())
-    bias, gamma = rn(1202, N).to(dev()), rn(1203, N).to(dev())
-    # class 1: plain 16-bit outputs
-    for kw in (dict(bias=bias, act='gelu'), dict(bias=bias, gamma=gamma), dict(), dict(bias=bias, act='relu')):
-        outs = []
-        for kern in (128, 2):
-            o = torch.full((M, N), float('nan'), dtype=d16(), device=dev())
-            hip.gemm(a, w, o, kernel=kern, **kw)
-            outs.append(o)
-        assert torch.equal(outs[0], outs[1]), sorted(kw.keys())
-    ref = None
-    for it in range(20):
-        o = torch.empty(M, N, dtype=d16(), device=dev())
-        hip.gemm(a, w, o, bias=bias, act='gelu', kernel=2)
-        ref = o if ref is None else ref
-        assert torch.equal(o, ref), it
-    # LayerNorm-fold consumer (raw rows + statistics in)
-    x = rn(1204, M, K).to(dev()) * 1.3 + 0.2
-    xb = torch.empty(M, K, dtype=d16(), device=dev())
-    st = torch.empty(M, K // 64, 2, device=dev())
-    hip.rowstats(x, xb, st)
-    cs = w.float().sum(1).contiguous()
-    if K // 64 in (16, 12, 6, 2):
-        outs = []
-        for kern in (128, 2):
-            o = torch.full((M, N), float('nan'), dtype=d16(), device=dev())
-            hip.gemm(xb, w, o, bias=bias, act='gelu', ln=(st, cs, 1e-6), kernel=kern)
-            outs.append(o)
-        assert torch.equal(outs[0], outs[1])
-    # class 3: transposed store
-    ldc = (M + 7) // 8 * 8 + 8
-    for kw in (dict(bias=bias), dict(bias=bias, act='gelu')):
-        outs = []
-        for kern in (128, 2):
-            o = torch.zeros(N, ldc, dtype=d16(), device=dev())
-            hip.gemm(a, w, o, trans_out=True, kernel=kern, **kw)
-            outs.append(o)
-        assert torch.equal(outs[0], outs[1])
-        assert float(outs[1][:, M:].abs().max()) == 0.0
-    # class 2: fp32 residual stream (+ fold producer outputs), N % 128 == 0
-    if N % 128 == 0:
-        res = rn(1205, M, N).to(dev())
-        for extra in (False, True):
-            ys = []
-            for kern in (128, 2):
-                y = res.clone()
-                xc = torch.full((M, N), float('nan'), dtype=d16(), device=dev()) if extra else None
-                s2 = torch.full((M, N // 64, 2), float('nan'), device=dev()) if extra else None
-                hip.gemm(a, w, y, bias=bias, gamma=gamma, res=y, xcopy=xc, stats_out=s2, kernel=kern)
-                ys.append((y, xc, s2))
-            assert torch.equal(ys[0][0], ys[1][0])
-            if extra:
-                assert torch.equal(ys[0][1], ys[1][1]) and torch.equal(ys[0][2], ys[1][2])
-
-
-@pytest.mark.parametrize('V', [6, 400])
-def test_gemm2g_fused_rope(V):
-    """q|k projection with RoPE-2D fused into the two-workgroup kernel's accumulator-layout epilogue == the 128 x 128 kernel's fused store
-    == GEMM followed by the stand-alone RoPE kernel (bit-exact)."""
-    from panst3r_amd import hip
-    gh, gw, H, hd, K = 8, 12, 4, 64, 128
-    T, D = gh * gw, H * hd
-    a, w, b = bf(rn(1210, V * T, K)).to(dev()), bf(rn(1211, 2 * D, K, scale=K ** -0.5)).to(dev()), rn(1212, 2 * D).to(dev())
-    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing='ij')
-    pos = torch.stack([ys, xs], -1).reshape(T, 2).to(torch.int32).repeat(V, 1).to(dev())
-    table = hip.rope_table(max(gh, gw), hd, 100.0, dev())
-    ref = torch.empty(V * T, 2 * D, dtype=d16(), device=dev())
-    hip.gemm(a, w, ref, bias=b, kernel=128)
-    hip.rope2d_(ref, pos, table, 2 * H, hd)
-    out = torch.empty_like(ref)
-    hip.gemm(a, w, out, bias=b, kernel=2, rope=(pos, table))
-    assert torch.equal(out, ref)
-
-
 @pytest.mark.parametrize('C', [256, 384])
 @pytest.mark.parametrize('Q,P,n', [(200, 49152, 3), (200, 640, 5), (24, 128, 2), (256, 1024, 1), (130, 64, 7)])
 def test_mask_head_streaming_kernel(C, Q, P, n):

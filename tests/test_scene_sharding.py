@@ -40,6 +40,20 @@ def test_assign_views():
         assign_views(50, 16, 8, plan='ring')
 
 
+def test_auto_plan_never_leaves_a_rank_without_views():
+    """plan='auto' resolves BEFORE the K >= world guard: with fewer keyframes than ranks it falls back to 'replicated' (every rank
+    owns >= 1 view), an explicit 'broadcast' in that situation raises on every rank, and no constructor returns a runner whose rank is idle."""
+    from panst3r_amd.scene import SceneRunner, resolve_plan
+    assert resolve_plan('auto', 8, 16) == 'broadcast' and resolve_plan('auto', 8, 4) == 'replicated' and resolve_plan('auto', 2, 16) == 'replicated'
+    model = tiny.build(tiny.OracleNS, 'v1')
+    imgs = {i: im for i, im in enumerate(tiny.images(9, H, W))}
+    for rank in range(8):
+        r = SceneRunner(OracleBackend(model), imgs, 9, H, W, 4, tiny.NAMES, rank=rank, world=8, plan='auto')
+        assert r.plan == 'replicated' and r.n_local >= 1
+        with pytest.raises(ValueError):
+            SceneRunner(OracleBackend(model), imgs, 9, H, W, 4, tiny.NAMES, rank=rank, world=8, plan='broadcast')
+
+
 @pytest.mark.parametrize('variant', ['v1', 'v2'])
 def test_plan_matches_reference_formulation(variant):
     """run_scene(world=1) with the oracle backend == the oracle pipeline that follows reference panst3r.py:169-284."""

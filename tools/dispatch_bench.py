@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Which GEMM variant should take the scene's big shapes?  Same-process comparison (GPU box): python tools/dispatch_bench.py [g2 mode]
+"""Which GEMM variant should take the scene's big shapes?  Same-process comparison (GPU box): python tools/dispatch_bench.py
 Methodology: the chip's clocks depend on the recent load (a burst measured right after host-side setup ran 10 % slower than the same kernel
 measured third), so every case is first brought to the sustained state (0.4 s of back-to-back launches) and the variants are then timed
 INTERLEAVED (A B C D A B C D ...), 7 rounds of 10 launches each, median per variant."""
@@ -7,10 +7,9 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from panst3r_amd import hip
-from tools.g2bench import case
+from tools.gemm_cases import case
 
 hip.lib()
-hip.tune(hip.TUNE_G2_MODE, int(sys.argv[1]) if len(sys.argv) > 1 else 4)
 
 
 def timed(fn, reps=10):
@@ -43,11 +42,11 @@ if __name__ == '__main__':
             if (M == 38400) != name.startswith('dec'):
                 continue
             a, w, out, kw = case(M, n, k, kind)
-            kerns = [0, 128, 256, 2]
+            kerns = [0, 128, 256]
             fns = [(lambda kern=kern: hip.gemm(a, w, out, kernel=kern, **kw)) for kern in kerns]
             ts = compare(fns)
             fl = 2.0 * M * n * k
-            best = min(range(1, 4), key=lambda i: ts[i])
-            print('%-10s %-22s auto %6.1f us %5.0f TF | 128: %6.1f  256: %6.1f  2g: %6.1f us   best %-3s (%+.1f %% vs auto)' %
-                  (name, (M, n, k), ts[0], fl / ts[0] / 1e6, ts[1], ts[2], ts[3], ('128', '256', '2g')[best - 1], 100 * (ts[best] / ts[0] - 1)))
+            best = min(range(1, 3), key=lambda i: ts[i])
+            print('%-10s %-22s auto %6.1f us %5.0f TF | 128: %6.1f  256: %6.1f us   best %-3s (%+.1f %% vs auto)' %
+                  (name, (M, n, k), ts[0], fl / ts[0] / 1e6, ts[1], ts[2], ('128', '256')[best - 1], 100 * (ts[best] / ts[0] - 1)))
             del a, w, out, kw, fns

@@ -1,11 +1,6 @@
 #!/usr/bin/env python
-"""Stand-alone comparison of the GEMM variants on the scene's big shapes (run on the GPU box):
-   auto dispatch of round 2 (persistent 256x256 / 128x128) vs the two-workgroups-per-CU kernel (gemm2g.hip) in its de-phasing modes.
-
-    python tools/g2bench.py [views=50] [modes=0,1,2+16*4,...]
-
-Every case is timed as `reps` back-to-back launches between two HIP events (median of 5 such bursts) with realistic epilogue arguments
-(LayerNorm fold consumer / producer outputs, fused RoPE, GELU, fp32 residual stream, transposed store)."""
+"""GEMM cases of the scene's big shapes with realistic epilogue arguments (LayerNorm fold consumer / producer outputs, fused RoPE, GELU,
+fp32 residual stream, transposed store), shared by the GEMM measurement tools (tools/dispatch_bench.py, pp_bench.py, ...).  GPU box only."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -69,36 +64,3 @@ def case(M, N, K, kind):
         kw['xcopy'] = torch.empty(M, N, dtype=DT, device=dev)
         kw['stats_out'] = torch.empty(M, N // 64, 2, device=dev)
     return a, w, out, kw
-
-
-def main():
-    V = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-    modes = [int(eval(m)) for m in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 1, 2 + 16 * 2, 2 + 16 * 4, 3 + 16 * 4]
-    M = V * 768
-    shapes = [('enc fc1+gelu', M, 4096, 1024, 'fc1'), ('enc qk+rope', M, 2048, 1024, 'qk'), ('enc v^T', M, 1024, 1024, 'vt'),
-              ('enc proj+res', M, 1024, 1024, 'res'), ('enc fc2+res', M, 1024, 4096, 'res'),
-              ('dec fc1+gelu', M, 3072, 768, 'fc1'), ('dec qk+rope', M, 1536, 768, 'qk'), ('dec v^T', M, 768, 768, 'vt'), ('dec q', M, 768, 768, 'q'),
-              ('dec proj+res', M, 768, 768, 'res'), ('dec fc2+res', M, 768, 3072, 'res')]
-    hip.lib()
-    print('M = %d rows (%d views), f16 operands; TFLOP/s (us)' % (M, V))
-    print('%-14s %-22s %16s %16s' % ('case', 'shape', 'auto (round 2)', '128x128') + ''.join('%16s' % ('2g mode %d' % m) for m in modes))
-    tot = {}
-    for name, m, n, k, kind in shapes:
-        a, w, out, kw = case(m, n, k, kind)
-        fl = 2.0 * m * n * k
-        row = []
-        hip.tune(hip.TUNE_G2_AUTO, 0)
-        variants = [('auto', 0, None), ('128', 128, None)] + [('2g%d' % md, 2, md) for md in modes]
-        for tag, kern, md in variants:
-            if md is not None:
-                hip.tune(hip.TUNE_G2_MODE, md)
-            t = burst(lambda: hip.gemm(a, w, out, kernel=kern, **kw))
-            row.append((fl / t / 1e12, t * 1e6))
-            tot[tag] = tot.get(tag, 0.0) + t
-        print('%-14s %-22s' % (name, (m, n, k)) + ''.join('%9.0f (%4.0f)' % r for r in row))
-        del a, w, out, kw
-    print('sum of the cases (us): ' + '  '.join('%s %.0f' % (k, v * 1e6) for k, v in tot.items()))
-
-
-if __name__ == '__main__':
-    main()

@@ -5,7 +5,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from panst3r_amd import hip
-from tools.g2bench import case
+from tools.gemm_cases import case
 from tools.dispatch_bench import compare
 
 hip.lib()

@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from panst3r_amd import hip
-from tools.g2bench import case
+from tools.gemm_cases import case
 M, N, K, kind, pp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
 n = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 hip.lib()

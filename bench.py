@@ -73,7 +73,7 @@ def cpu_baseline(variant, H, W, state, names, emb, threads, V=2, K=2, sharp=None
     mt.forward_prediction_heads = recording_heads
     t0 = time.perf_counter()
     with torch.no_grad():
-        ref = model.forward_inference_multi_ar(imgs, ts, names, num_keyframes=K)
+        ref = model.forward_inference_multi_ar(imgs, ts, names, num_keyframes=K, max_bs=1)       # the demo's max_bs=1 (per-view MinMaxScaler), as the timed runner
     dt = time.perf_counter() - t0
     mt.forward_prediction_heads = heads
     ref = (ref[0], dict(ref[1], attn_masks=amasks[:mt.num_layers]))
@@ -129,7 +129,7 @@ def full_size_parity(model, dev, ref, imgs, ts, names, amp='fp16', K=2):
     with torch.no_grad():
         log = []
         with mt.instrument(log=log):       # (forward_inference_multi_ar runs eagerly unless cache_graphs=True: nothing is captured here)
-            pm_h, pan_h = model.forward_inference_multi_ar(inp, ts, names, num_keyframes=K, amp=amp)
+            pm_h, pan_h = model.forward_inference_multi_ar(inp, ts, names, num_keyframes=K, amp=amp, max_bs=1)
     torch.cuda.synchronize()
     res = {'scene': '%d views / %d keyframes, full-size weights (the cpu_baseline sample)' % (len(imgs), K), 'amp': amp if amp else 'False (fp32 mode)'}
     res.update(_scene_errors(pm_h, pan_h, pm_o, pan_o))
@@ -140,7 +140,7 @@ def full_size_parity(model, dev, ref, imgs, ts, names, amp='fp16', K=2):
         res['attention_mask_bit_agreement'] = round(min(float((a.cpu() == b).float().mean()) for a, b in zip(log, om)), 5)
         with torch.no_grad():
             with mt.instrument(forced=[m.to(dev) for m in om]):
-                pm_f, pan_f = model.forward_inference_multi_ar(inp, ts, names, num_keyframes=K, amp=amp)
+                pm_f, pan_f = model.forward_inference_multi_ar(inp, ts, names, num_keyframes=K, amp=amp, max_bs=1)
         torch.cuda.synchronize()
         dm = _scene_errors(pm_f, pan_f, pm_o, pan_o)
         dm['within_tolerance_every_view'] = _within(dm, worst=True)
@@ -200,6 +200,47 @@ def hbm_stage_table(timer, V, H, W, variant):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): re-execute this command line under torch.distributed.run, one rank per
+    GPU of this node (rendezvous on 127.0.0.1, a free port), pass rank 0's JSON line through and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env, stdout=REAL_STDOUT, stderr=2).returncode
+
+
+def launch_selftest(args):
+    """--launch-selftest: the launch / rendezvous / one-line-output plumbing of `--gpus N` without any model work - N ranks (RCCL when every rank
+    has a GPU, else gloo on the CPU), one barrier and one all_gather; rank 0 prints the JSON line.  tests/test_bench_launch.py runs it with 2
+    ranks on gloo in the CPU container."""
+    import torch.distributed as dist
+    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    if gpu:
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda', local) if gpu else torch.device('cpu')
+    t = torch.full((4,), float(rank), device=dev)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.barrier()
+    dist.all_gather(outs, t)
+    ok = all(float(o[0]) == r for r, o in enumerate(outs))
+    dist.barrier()
+    if rank == 0:
+        os.write(REAL_STDOUT, (json.dumps({'launch_selftest': True, 'n_gpus': world, 'world_size_seen': dist.get_world_size(), 'backend': dist.get_backend(),
+                                           'all_gather_ok': ok, 'gpus_requested': args.gpus}) + '\n').encode())
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -223,7 +264,14 @@ def main():
     ap.add_argument('--plan', default='auto', choices=['auto', 'replicated', 'broadcast'],
                     help="multi-GPU plan (panst3r_amd/scene.py): every rank repeats the memory build | rank 0 builds and broadcasts the banks; "
                          "auto = broadcast from 4 ranks on (projection: profiles/r3_shard_estimate.txt)")
+    ap.add_argument('--launch-selftest', action='store_true', help='only exercise the rank launch / rendezvous / output plumbing (no model work; CPU + gloo when there is no GPU per rank)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started the way the driver starts `--gpus 1` (plain `python bench.py --gpus N`): become the launcher of N ranks
+        raise SystemExit(spawn_ranks(args.gpus))
+    if args.launch_selftest:
+        return launch_selftest(args)
 
     import torch.distributed as dist
     from panst3r_amd import hip
@@ -271,6 +319,8 @@ def main():
             runner.run(copy=False)
         timer = None
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        if use_dist:
+            runner.coll_events = []          # HIP events around every eager collective of the timed steps (2 events per collective, no sync)
         fence()
         t0 = time.perf_counter()
         for s in range(steps):
@@ -292,10 +342,21 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t)
         per = sorted(marks[s].elapsed_time(marks[s + 1]) for s in range(steps - (1 if instrument else 0)))      # graph-replay steps only
+        coll = None
+        if use_dist:
+            # per collective: median over the timed steps on this rank, then the max over ranks (a collective ends when its slowest rank does;
+            # the time a rank WAITS for a late peer is inside its own measurement, so this is transfer + skew, an upper bound on the transfer)
+            med = {k: sorted(v)[len(v) // 2] for k, v in runner.collective_ms().items()}
+            cnames = sorted(med)
+            t = torch.tensor([med[k] for k in cnames], device=dev, dtype=torch.float64)
+            lo = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            coll = {k: {'max_over_ranks_ms': round(float(a), 3), 'min_over_ranks_ms': round(float(b), 3)} for k, a, b in zip(cnames, t, lo)}
         del runner
-        return elapsed, (per[len(per) // 2] if per else None), timer
+        return elapsed, (per[len(per) // 2] if per else None), timer, coll
 
-    elapsed, median_ms, timer = measure(args.amp, args.steps, args.warmup, not args.no_kernel_timing)
+    elapsed, median_ms, timer, coll_ms = measure(args.amp, args.steps, args.warmup, not args.no_kernel_timing)
 
     if rank == 0:
         fps = V * args.steps / elapsed
@@ -318,6 +379,15 @@ def main():
                        'scene_algorithmic_tflop': round(scene_flops / 1e12, 2),
                        'scene_mfma_frac': round(scene_flops / (elapsed / args.steps) / world / (PEAK_BF16_TFLOPS * 1e12), 4)},
         }
+        if use_dist:
+            # what the transport did, measured, next to the one-GPU projection of the same plan (profiles/r3_shard_estimate.txt: every rank's stage
+            # graphs replayed on ONE GPU, all-gathers counted as zero, the 453 MB bank broadcast ASSUMED at 100 GB/s)
+            proj = {('replicated', 2): 102.2, ('replicated', 4): 69.2, ('replicated', 8): 52.3, ('broadcast', 2): 121.9, ('broadcast', 4): 56.2, ('broadcast', 8): 42.5}
+            out['multi_gpu'] = {'backend': dist.get_backend(), 'rccl_world_size': dist.get_world_size(), 'plan': args.plan,
+                                'collectives_measured': coll_ms,
+                                'projected_ms_per_scene_one_gpu_estimate': proj.get((args.plan, world)) if (V, K, args.variant) == (50, 16, 'v2') else None,
+                                'measured_ms_per_scene': round(1e3 * elapsed / args.steps, 3),
+                                'bank_bytes': (2 * 12 * K * (H // 16) * (W // 16) * 768 * 2) if args.plan == 'broadcast' else 0}
         if timer is not None and os.environ.get('PST_SHAPE_PROFILE') == '1':      # per-shape table of the instrumented step (stderr)
             rows = sorted(timer.by_tag().items(), key=lambda kv: -kv[1]['ms'])
             for (name, tag), d in rows[:48]:
@@ -366,12 +436,12 @@ def main():
                 out['hbm_stages_standalone'] = {'error': repr(e)}
         if host_legs and not args.no_alt_dtype:
             alt = 'bf16' if args.amp == 'fp16' else 'fp16'
-            e2, m2, _ = measure(alt, max(3, args.steps // 4), 1, False)
+            e2, m2, _, _ = measure(alt, max(3, args.steps // 4), 1, False)
             out['alt_dtype'] = {'dtype': 'bf16' if alt == 'bf16' else 'f16', 'value': round(V * max(3, args.steps // 4) / e2, 3),
                                 'note': 'the other 16-bit format of the reference (--amp %s), same scene, %d timed steps' % (alt, max(3, args.steps // 4))}
         if host_legs and not args.no_alt_dtype:
             try:          # the reference's default mode (amp=False: fp32 end to end) on the fp32 kernels: the precision path, not the benchmark
-                e3, _, _ = measure(False, 2, 1, False)
+                e3, _, _, _ = measure(False, 2, 1, False)
                 out['fp32_mode'] = {'dtype': 'f32', 'value': round(V * 2 / e3, 3), 'unit': 'frames/s',
                                     'note': 'amp=False: float32 operands / activations, GEMMs and attention on the fp32-input MFMA, same scene, 2 timed steps'}
             except Exception as e:

@@ -247,9 +247,16 @@ int pst_attn_mask_from_logits(const float* logits, int64_t ldl, uint8_t* mask, i
 /* guidance_gn: the same features followed by GroupNorm(1 group, affine) WITHOUT materialising them: a statistics pass and a
  *   normalise-and-store pass both recompute the features per pixel (no fp32 feature round trip through HBM).
  *   y bf16 [nimg*P, ldy], columns [10*nf+3, ldy) zero; scratch >= nimg*(3*P + 6) floats; stats as for pst_loftup_guidance.
- *   (loftup.py:117-124: fourier_feat -> first GroupNorm of first_conv) */
+ *   (loftup.py:117-124: fourier_feat -> first GroupNorm of first_conv)
+ *   mm_ext (ABI 17): NULL = every view is scaled with its OWN per-channel min / max (the demo's max_bs=1 convention, tools/demo_panst3r.py:201); else
+ *   fp32 [nimg][3][2] (min, max) per (view, channel) to scale with - the reference's MinMaxScaler takes min / max over the whole chunk of views it is
+ *   handed (loftup.py:14-19; panoptic_decoder.py:50-62 chunks by max_bs): pst_loftup_minmax gives the per-view table, pst_minmax_merge pools it
+ *   over the views of a chunk (scope[v] = chunk id of view v; out of place). */
 int pst_loftup_guidance_gn(const float* img, const float* biases, const float* gamma, const float* beta, float eps,
-                           float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, int dtype16, void* stream);
+                           float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, int dtype16,
+                           const float* mm_ext, void* stream);
+int pst_loftup_minmax(const float* img, float* mm, int nimg, int H, int W, void* stream);
+int pst_minmax_merge(const float* mm, const int32_t* scope, float* out, int nviews, void* stream);
 int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float* stats, int nimg, int P, int C, int G,
                         void* stream);
 int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma,

@@ -1,7 +1,7 @@
 """Oracle restatement of the PanSt3R scene orchestration (TEST INFRASTRUCTURE; CPU, fp32, plain torch).
 
-Follows reference panst3r.py:169-296 with the demo's conventions (max_bs=1 => every stack holds one view, MinMaxScaler
-per view; amp=False => fp32 everywhere).  The must3r engine helpers it calls (encoder_multi_ar, inference_multi_ar,
+Follows reference panst3r.py:169-296 (amp=False => fp32 everywhere; `max_bs` decides which views share LoftUp's MinMaxScaler
+statistics: None = the reference's default, 1 = the demo's per-view convention).  The must3r engine helpers it calls (encoder_multi_ar, inference_multi_ar,
 stack_views) are restated in oracle/must3r.py ([3P-recalled], parity unpinned).
 """
 import numpy as np
@@ -20,10 +20,13 @@ class PanSt3R(nn.Module):
         self.dino_encoder, self.panoptic_decoder = dino_encoder, panoptic_decoder
 
     @torch.no_grad()
-    def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=1,
+    def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=None,
                                    outdevice=None, amp=False, keyframes=None):
         """`keyframes`: the list `_get_keyframes_retrieval` would return (:179-180, use_retrieval=True; the ASMK retriever itself is
-        not restated) - an explicit keyframe list in memory-build order; otherwise the linspace / all-views choice of :183-186."""
+        not restated) - an explicit keyframe list in memory-build order; otherwise the linspace / all-views choice of :183-186.
+        `max_bs` (reference default None; the demo passes 1, tools/demo_panst3r.py:201): `stack_views` groups same-shape views into stacks of
+        <= max_bs (keyframes :212-216 and the other views :257-261 separately) and the panoptic decoder's mixer + upscaler runs once per
+        stack (panoptic_decoder.py:50-62) - which is the scope of LoftUp's MinMaxScaler (loftup.py:14-19).  Everything else is per view."""
         assert not amp and (not use_retrieval or keyframes is not None)
         N = len(imgs)
         x_enc, pos = encoder_multi_ar(self.must3r_encoder, imgs, true_shape)                       # :174-175
@@ -48,14 +51,25 @@ class PanSt3R(nn.Module):
             x_dino = self.dino_encoder(imgs[i][None], ts)
             return pm[0], out[0], x_dino
         pd = self.panoptic_decoder
-        pointmaps, feats = [], []
+        pointmaps, cats = [], []
         for i in range(N):
             pm, y, xd = render(i)
             pointmaps.append(pm)
-            cat = torch.cat([x_enc[i][None], y, xd], dim=-1)[None]                                  # [1,1,T,2816]
-            ts = torch.tensor([[shapes[i]]])
-            fpn, mf = pd.features(cat, imgs[i][None, None], pos[i][None, None], ts, max_bs=1)
-            feats.append((fpn, mf, ts))
+            cats.append(torch.cat([x_enc[i][None], y, xd], dim=-1)[0])                              # [T,2816]
+        feats = [None] * N
+        for lo, hi in ((0, K), (K, N)):                                                            # stack_views: same-shape stacks of <= max_bs
+            by_shape = {}
+            for i in range(lo, hi):
+                by_shape.setdefault(tuple(shapes[i]), []).append(i)
+            for sh, idx in by_shape.items():
+                bs = len(idx) if max_bs is None else int(max_bs)
+                for c0 in range(0, len(idx), bs):
+                    ch = idx[c0:c0 + bs]
+                    ts = torch.tensor([[list(sh)] * len(ch)])
+                    fpn, mf = pd.features(torch.stack([cats[i] for i in ch])[None], torch.stack([imgs[i] for i in ch])[None],
+                                          torch.stack([pos[i] for i in ch])[None], ts, max_bs=None)
+                    for j, i in enumerate(ch):
+                        feats[i] = (fpn[:, j:j + 1], mf[:, j:j + 1], torch.tensor([[list(sh)]]))
         cls_emb = pd.text_encoder(classes)
         mt = pd.mask_transformer
         out = mt([[f[0] for f in feats[:K]]], [f[1] for f in feats[:K]], [f[2] for f in feats[:K]], cls_emb, multi_ar=True)  # :244
@@ -68,10 +82,10 @@ class PanSt3R(nn.Module):
         return [pointmaps[i] for i in inv], panout
 
     @torch.no_grad()
-    def forward(self, imgs, true_shape, classes, max_bs=1, outdevice=None):
+    def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):
         """panst3r.py:286-296 for one scene: all n views are memory views and all are rendered."""
         n = imgs.shape[1]
-        pms, panout = self.forward_inference_multi_ar(list(imgs[0]), true_shape[0], classes, num_keyframes=n)
+        pms, panout = self.forward_inference_multi_ar(list(imgs[0]), true_shape[0], classes, num_keyframes=n, max_bs=max_bs)
         panout = dict(panout)
         panout['pred_masks'] = torch.stack([m[0] for m in panout['pred_masks']])[None]
         return panout, torch.stack([p[0] for p in pms])[None]

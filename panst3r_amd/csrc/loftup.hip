@@ -77,7 +77,7 @@ __global__ __launch_bounds__(1024) void down2_minmax_kernel(const float* img, fl
     const float2 a = *(const float2*)(src + (int64_t)(2 * y) * W + 2 * x);
     const float2 b = *(const float2*)(src + (int64_t)(2 * y + 1) * W + 2 * x);
     const float v = 0.25f * (a.x + a.y + b.x + b.y);
-    dst[i] = v;
+    if (img2) dst[i] = v;
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);
   }
@@ -90,6 +90,19 @@ __global__ __launch_bounds__(1024) void down2_minmax_kernel(const float* img, fl
     mm[2 * vc] = lo;
     mm[2 * vc + 1] = hi;
   }
+}
+
+// MinMaxScaler over a SET of views (loftup.py:14-19 takes min / max over the whole batch it is handed): out[v][c] = (min, max) over the views u with
+// scope[u] == scope[v] of the per-view values.  min / max are exact and order-independent: any evaluation order gives the reference's bits.
+__global__ void minmax_merge_kernel(const float* mm, const int* scope, float* out, int nviews) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nviews * 3) return;
+  const int v = i / 3, c = i - v * 3, sv = scope[v];
+  float lo = 3.4e38f, hi = -3.4e38f;
+  for (int u = 0; u < nviews; ++u)
+    if (scope[u] == sv) { lo = fminf(lo, mm[2 * (u * 3 + c)]); hi = fmaxf(hi, mm[2 * (u * 3 + c) + 1]); }
+  out[2 * i] = lo;
+  out[2 * i + 1] = hi;
 }
 
 // ------------------------------------------------------------------ fused guidance front end: features -> GroupNorm(1) -> bf16
@@ -318,8 +331,21 @@ __global__ void lr_pe_kernel(const float* biases, void* out, int64_t ld, int col
 
 using namespace pst;
 
+extern "C" int pst_loftup_minmax(const float* img, float* mm, int nimg, int H, int W, void* stream) {
+  if (!img || !mm || nimg <= 0 || H % 2 || W % 2 || H <= 0 || W <= 0) { set_error("loftup_minmax: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(1024), 0, (hipStream_t)stream, img, (float*)nullptr, mm, H, W);
+  return check_launch("loftup_minmax");
+}
+
+extern "C" int pst_minmax_merge(const float* mm, const int32_t* scope, float* out, int nviews, void* stream) {
+  if (!mm || !scope || !out || nviews <= 0 || mm == out) { set_error("minmax_merge: bad argument (out of place only)"); return PST_EINVAL; }
+  hipLaunchKernelGGL(minmax_merge_kernel, dim3((nviews * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, mm, scope, out, nviews);
+  return check_launch("minmax_merge");
+}
+
 extern "C" int pst_loftup_guidance_gn(const float* img, const float* biases, const float* gamma, const float* beta, float eps,
-                                      float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, int dtype16, void* stream) {
+                                      float* scratch, float* stats, void* y, int64_t ldy, int nimg, int H, int W, int nf, int dtype16,
+                                      const float* mm_ext, void* stream) {
   const int CHc = 10 * nf + 3;
   if ((dtype16 != DT_BF16 && dtype16 != DT_F16 && dtype16 != DT_F32) || !img || !biases || !gamma || !beta || !scratch || !stats || !y || nimg <= 0 || H % 2 || W % 2 || nf < 2 || nf > 64 || ldy < CHc ||
       ldy % 8 || ldy > 512 || ((uintptr_t)y & 15)) {
@@ -330,14 +356,15 @@ extern "C" int pst_loftup_guidance_gn(const float* img, const float* biases, con
   float* img2 = scratch;                                 // [nimg][3][P]
   float* mm = img2 + (int64_t)nimg * 3 * P;              // [nimg][3][2]
   hipLaunchKernelGGL(down2_minmax_kernel, dim3(nimg * 3), dim3(1024), 0, s, img, img2, mm, H, W);
+  const float* mmu = mm_ext ? mm_ext : mm;               // the scale table in use: the caller's (a scope wider than one view) or the per-view one
   const int ntile = (P + 63) / 64;
   const int gx = ntile < PST_STATS_BLOCKS ? ntile : PST_STATS_BLOCKS;
   float* part = stats + 2 * nimg;                        // [nimg][gx][2] partial sums behind the result
   const size_t lds0 = ((nf + 4 + 3) & ~3) * sizeof(float);
-  hipLaunchKernelGGL((guidance_px_kernel<false>), dim3(gx, nimg), dim3(256), lds0, s, img2, mm, biases, part, (const float*)nullptr,
+  hipLaunchKernelGGL((guidance_px_kernel<false>), dim3(gx, nimg), dim3(256), lds0, s, img2, mmu, biases, part, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, 0.f, (bf16_t*)nullptr, ldy, H2, W2, nf, dtype16);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((nimg * 2 + 3) / 4), dim3(256), 0, s, part, stats, nimg, gx, 2);
-  hipLaunchKernelGGL((guidance_px_kernel<true>), dim3(ntile, nimg), dim3(256), lds0 + 64 * (ldy + 8) * sizeof(bf16_t), s, img2, mm, biases,
+  hipLaunchKernelGGL((guidance_px_kernel<true>), dim3(ntile, nimg), dim3(256), lds0 + 64 * (ldy + 8) * sizeof(bf16_t), s, img2, mmu, biases,
                      (float*)nullptr, stats, gamma, beta, eps, (bf16_t*)y, ldy, H2, W2, nf, dtype16);
   return check_launch("loftup_guidance_gn");
 }

@@ -42,7 +42,7 @@ class AttnParams(C.Structure):
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_gemm_pair', 'pst_gemm_pair_variant', 'pst_tune', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
            'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
-           'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
+           'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_loftup_minmax', 'pst_minmax_merge', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize', 'pst_pointmap_activate', 'pst_focal_weiszfeld', 'pst_rigid_moments',
            'pst_qubo_upsample', 'pst_qubo_workspace_floats', 'pst_qubo_overlap', 'pst_qubo_argmax']
 
@@ -557,15 +557,37 @@ def stats_buffer(nimg, G, device):
     return torch.empty(nimg * G * 2 * (1 + STATS_BLOCKS), dtype=torch.float32, device=device)
 
 
-@hbm_timed('loftup_guidance_gn', lambda img, biases, gamma, beta, eps, scratch, stats, out, nf: img.numel() * 4 + out.numel() * 2)
-def loftup_guidance_gn(img, biases, gamma, beta, eps, scratch, stats, out, nf):
-    """Fourier guidance features + GroupNorm(1) straight to bf16 `out` [nimg*P, ld] (zero-padded columns); no fp32 feature buffer."""
+@hbm_timed('loftup_guidance_gn', lambda img, biases, gamma, beta, eps, scratch, stats, out, nf, mm=None: img.numel() * 4 + out.numel() * 2)
+def loftup_guidance_gn(img, biases, gamma, beta, eps, scratch, stats, out, nf, mm=None):
+    """Fourier guidance features + GroupNorm(1) straight to bf16 `out` [nimg*P, ld] (zero-padded columns); no fp32 feature buffer.
+    mm: None = MinMaxScaler per view; else fp32 [nimg, 3, 2] (min, max) to scale with (loftup_minmax / minmax_merge: a scope of several views)."""
     _dev(img, torch.float32); _dev(biases, torch.float32); _dev(scratch, torch.float32); _dev(stats, torch.float32); _dev(out, *FMT)
     n, _, h, w = img.shape
     assert img.is_contiguous() and scratch.numel() >= n * (3 * (h // 2) * (w // 2) + 6)
+    if mm is not None:
+        _dev(mm, torch.float32)
+        assert mm.is_contiguous() and tuple(mm.shape) == (n, 3, 2)
     _check(lib().pst_loftup_guidance_gn(_ptr(img), _ptr(biases), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)), f32(eps),
-                                        _ptr(scratch), _ptr(stats), _ptr(out), i64(_rowmajor(out)), n, h, w, nf, _tc(out), _stream()),
+                                        _ptr(scratch), _ptr(stats), _ptr(out), i64(_rowmajor(out)), n, h, w, nf, _tc(out), _ptr(mm), _stream()),
            'pst_loftup_guidance_gn')
+    return out
+
+
+def loftup_minmax(img, mm):
+    """per (view, channel) (min, max) of the 2x2-mean (= bilinear x0.5) image: img fp32 [n, 3, H, W] -> mm fp32 [n, 3, 2]"""
+    _dev(img, torch.float32); _dev(mm, torch.float32)
+    n, c, h, w = img.shape
+    assert c == 3 and img.is_contiguous() and mm.is_contiguous() and tuple(mm.shape) == (n, 3, 2)
+    _check(lib().pst_loftup_minmax(_ptr(img), _ptr(mm), n, h, w, _stream()), 'pst_loftup_minmax')
+    return mm
+
+
+def minmax_merge(mm, scope, out):
+    """out[v] = (min, max) over the views u with scope[u] == scope[v] of mm[u] (the reference's MinMaxScaler over a chunk of views, loftup.py:14-19)"""
+    _dev(mm, torch.float32); _dev(scope, torch.int32); _dev(out, torch.float32)
+    n = scope.numel()
+    assert mm.is_contiguous() and out.is_contiguous() and tuple(mm.shape) == (n, 3, 2) and tuple(out.shape) == (n, 3, 2) and mm.data_ptr() != out.data_ptr()
+    _check(lib().pst_minmax_merge(_ptr(mm), _ptr(scope), _ptr(out), n, _stream()), 'pst_minmax_merge')
     return out
 
 

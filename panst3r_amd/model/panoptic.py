@@ -197,11 +197,13 @@ class LoftUpUpscaler(HipModule):
         return ceil_to(self.input_dim + 20, 64)
 
     @torch.no_grad()
-    def guidance_tokens(self, imgs, h, w):
+    def guidance_tokens(self, imgs, h, w, mm=None):
         """Guidance branch (loftup.py:154-156,117-130): Fourier features -> GN(1) -> conv3x3 -> GN(8)+ReLU -> conv3x3 -> GN(8)+ReLU.
         imgs fp32 [V,3,H,W] -> bf16 [V*P, dim] pixel-major, P = H/2 * W/2.  It depends on the IMAGES only (not on the memory, the
         decoder or the mixer), so the scene runner computes it with the other memory-independent work (SceneRunner._encode_rest).
-        A tall token grid (h > w) takes the image transposed (loftup.py:147-149)."""
+        A tall token grid (h > w) takes the image transposed (loftup.py:147-149).
+        mm: None = MinMaxScaler per view (the demo's max_bs=1); else fp32 [V,3,2] (min, max) per (view, channel) pooled over the chunk of views the
+        reference would have scaled together (loftup.py:14-19: min / max over the batch it is handed; `minmax_tables`)."""
         dev = imgs.device
         pk = self.packed(dev)
         C = self.dim
@@ -219,7 +221,7 @@ class LoftUpUpscaler(HipModule):
             g0 = empty(n * P, pk['c0'], adt(), dev)
             scratch = torch.empty(n * (3 * P + 6) + 16, dtype=torch.float32, device=dev)
             hip.loftup_guidance_gn(imgs[v0:v0 + n].contiguous(), pk['ff_bias'], pk['gn0'][0], pk['gn0'][1], pk['gn0'][2], scratch, st0, g0,
-                                   self.n_freqs)
+                                   self.n_freqs, mm=None if mm is None else mm[v0:v0 + n].contiguous())
             del scratch
             c1 = empty(n * P, C, adt(), dev)
             hip.gemm(g0, pk['conv1'].w, c1, bias=pk['conv1'].b, conv=(pk['c0'], H2, W2))
@@ -234,7 +236,7 @@ class LoftUpUpscaler(HipModule):
         return out
 
     @torch.no_grad()
-    def upscale_tokens(self, lr, imgs, V, h, w, fpn_out, mask_out, guidance=None):
+    def upscale_tokens(self, lr, imgs, V, h, w, fpn_out, mask_out, guidance=None, mm=None):
         """lr bf16 [V*T, lr_width()] with the mixer tokens in columns [0, input_dim) (the rest is filled here);
         imgs fp32 [V,3,H,W] -> fpn_out bf16 [V*T, input_dim] (h x w raster), mask_out bf16 [V, H/2, W/2, dim].
         A tall token grid (h > w) takes the guidance image transposed (loftup.py:147-149): the mask features then come
@@ -249,7 +251,7 @@ class LoftUpUpscaler(HipModule):
         assert tuple(mask_out.shape) == (V, H2, W2, C), (tuple(mask_out.shape), (V, H2, W2, C))
         P = H2 * W2
         if guidance is None:
-            guidance = self.guidance_tokens(imgs, h, w)
+            guidance = self.guidance_tokens(imgs, h, w, mm=mm)
         assert tuple(guidance.shape) == (V * P, C)
         hip.gemm(lr[:, :D], pk['pe'].w, fpn_out, bias=pk['pe'].b)
         lr[:, D:].zero_()
@@ -685,13 +687,40 @@ class PanopticDecoder(HipModule):
         return ((w, h) if portrait else (h, w)), portrait
 
     @torch.no_grad()
-    def guidance_tokens(self, imgs, h, w):
+    def guidance_tokens(self, imgs, h, w, mm=None):
         """Image-only part of the upscaler (LoftUp's guidance branch) or None: can run before / beside anything token-dependent."""
         up = self.upscaler
-        return up.guidance_tokens(imgs, h, w) if isinstance(up, LoftUpUpscaler) else None
+        return up.guidance_tokens(imgs, h, w, mm=mm) if isinstance(up, LoftUpUpscaler) else None
+
+    def minmax_scaled(self):
+        """True when the upscaler scales its guidance image with batch statistics (LoftUp's MinMaxScaler): results then depend on which views are
+        scaled together; the pixel-shuffle upscaler is batch-invariant."""
+        return isinstance(self.upscaler, LoftUpUpscaler)
 
     @torch.no_grad()
-    def features_tokens(self, cat, imgs, V, h, w, guidance=None):
+    def minmax_tables(self, img_stacks, scope):
+        """MinMaxScaler statistics for scaling scopes wider than one view: img_stacks = list of fp32 [n_i,3,H_i,W_i] stacks, scope = int32 device tensor
+        [sum n_i] of scope ids (views with equal ids are scaled together, as one chunk of the reference's batched_map, panoptic_decoder.py:50-62).
+        Returns one [n_i,3,2] (min, max) table per stack, or None per stack for a batch-invariant upscaler."""
+        if not self.minmax_scaled():
+            return [None] * len(img_stacks)
+        dev = img_stacks[0].device
+        n = sum(int(t.shape[0]) for t in img_stacks)
+        assert scope.numel() == n
+        per_view = torch.empty(n, 3, 2, dtype=torch.float32, device=dev)
+        o = 0
+        for t in img_stacks:
+            hip.loftup_minmax(t.float().contiguous(), per_view[o:o + t.shape[0]])
+            o += t.shape[0]
+        pooled = hip.minmax_merge(per_view, scope, torch.empty_like(per_view))
+        out, o = [], 0
+        for t in img_stacks:
+            out.append(pooled[o:o + t.shape[0]])
+            o += t.shape[0]
+        return out
+
+    @torch.no_grad()
+    def features_tokens(self, cat, imgs, V, h, w, guidance=None, mm=None):
         """cat bf16 [V*T, 2816] (enc | dec | dino) -> (fpn bf16 [V*T, d], mask_feats bf16 [V, Hm, Wm, C]).
         Portrait views (h > w) with landscape_only=True follow `transpose_to_landscape(upscaler, dims=(2,3))`
         (panoptic_decoder.py:26,56): the upscaler runs on the tall grid and both results are handed back transposed --
@@ -709,7 +738,7 @@ class PanopticDecoder(HipModule):
                 lr[:, :up.input_dim] = cat
             H2, W2 = imgs.shape[2] // 2, imgs.shape[3] // 2
             mf = torch.empty(V, min(H2, W2) if h > w else H2, max(H2, W2) if h > w else W2, up.mask_dim, dtype=adt(), device=dev)
-            up.upscale_tokens(lr, imgs, V, h, w, fpn, mf, guidance=guidance)
+            up.upscale_tokens(lr, imgs, V, h, w, fpn, mf, guidance=guidance, mm=mm)
         else:
             x = cat
             if self.input_mixer is not None:
@@ -722,23 +751,39 @@ class PanopticDecoder(HipModule):
             mf = mf.transpose(1, 2).contiguous()
         return fpn, mf
 
-    def forward(self, in_feats, in_imgs, pos, true_shape, classes, max_bs=None, outdevice=None, memory_queries=None, multi_ar=False):
+    def forward(self, in_feats, in_imgs, pos, true_shape, classes, max_bs=None, outdevice=None, memory_queries=None, multi_ar=False, _mm=None):
         """Reference signature (panoptic_decoder.py:41), images in native orientation.
         multi_ar=False: in_feats = (x_enc, y_dec, x_dino) each [B,n,T,*], in_imgs [B,n,3,H,W], true_shape [B,n,2]
             -> pred_logits [B,Q,Ncls], pred_masks [B,n,Q,H/2,W/2], out_queries [Q,B,d]; scenes of a batch are independent.
         multi_ar=True (panoptic_decoder.py:45-47, panst3r.py:248-249): every argument is a LIST of same-shape stacks ([1,n_i,...]);
             the queries are decoded against the tokens of ALL stacks, pred_masks is the list of per-stack [1,n_i,Q,h_i,w_i].
-        MinMaxScaler is applied per view (the demo's max_bs=1 convention); `max_bs` only chunks work in the
-        reference and is accepted for signature compatibility."""
+        `max_bs` as in the reference (panoptic_decoder.py:50-62, utils.py batched_map): the views of a stack (flattened over B and n) are processed
+        in chunks of max_bs, None = the whole stack at once.  All the work here is batched regardless - what the chunking CHANGES is LoftUp's
+        MinMaxScaler, which takes min / max over the chunk it is handed (loftup.py:14-19): views of one chunk share their scale
+        (max_bs=1, the demo's setting: per view).  The pixel-shuffle variant is chunk-invariant."""
         feats = in_feats if multi_ar else tuple([f] for f in in_feats)
         imgs = in_imgs if multi_ar else [in_imgs]
         shapes = true_shape if multi_ar else [true_shape]
         B = feats[0][0].shape[0]
+        # MinMaxScaler scopes: chunk ids over the flattened (B, n) views of every stack
+        mms = _mm
+        if mms is None and self.minmax_scaled() and max_bs != 1:
+            ids, nxt = [], 0
+            for im in imgs:
+                tot = int(im.shape[0]) * int(im.shape[1])
+                bs = tot if max_bs is None else int(max_bs)
+                ids += [nxt + i // bs for i in range(tot)]
+                nxt = ids[-1] + 1
+            if len(set(ids)) < len(ids):
+                scope = torch.tensor(ids, dtype=torch.int32).to(imgs[0].device)
+                mms = self.minmax_tables([im.flatten(0, 1) for im in imgs], scope)
         if B != 1:
             if multi_ar:
                 raise NotImplementedError('multi_ar stacks carry one scene (B == 1), as in the reference call site panst3r.py:248')
-            outs = [self.forward(tuple(f[b:b + 1] for f in in_feats), in_imgs[b:b + 1], None, true_shape[b:b + 1], classes, max_bs, outdevice,
-                                 None if memory_queries is None else memory_queries[:, b:b + 1], False) for b in range(B)]
+            n = int(in_imgs.shape[1])
+            outs = [self.forward(tuple(f[b:b + 1] for f in in_feats), in_imgs[b:b + 1], None, true_shape[b:b + 1], classes, 1, outdevice,
+                                 None if memory_queries is None else memory_queries[:, b:b + 1], False,
+                                 _mm=None if mms is None else [mms[0][b * n:(b + 1) * n]]) for b in range(B)]
             res = {'pred_logits': torch.cat([o['pred_logits'] for o in outs]), 'pred_masks': torch.cat([o['pred_masks'] for o in outs])}
             if memory_queries is None:
                 res['out_queries'] = torch.cat([o['out_queries'] for o in outs], dim=1)
@@ -754,7 +799,7 @@ class PanopticDecoder(HipModule):
             H, W = [int(v) for v in shapes[si].reshape(-1, 2)[0].tolist()]
             h, w = H // p, W // p
             cat = torch.cat([f[si].reshape(n * T, -1) for f in feats], dim=-1).to(adt()).contiguous()
-            fpn, mf = self.features_tokens(cat, imgs[si][0].float().contiguous(), n, h, w)
+            fpn, mf = self.features_tokens(cat, imgs[si][0].float().contiguous(), n, h, w, mm=None if mms is None else mms[si])
             grid, portrait = self.fpn_grid(h, w)
             fpns.append(fpn); mfs.append(mf); grids += [grid] * n; portraits += [portrait] * n
             if memory_queries is None:

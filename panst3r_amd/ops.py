@@ -138,8 +138,19 @@ def attn_mask_from_logits(logits: Tensor, mask: Tensor) -> None:
 
 
 @_op('loftup_guidance_gn', ('scratch', 'stats', 'out'))
-def loftup_guidance_gn(img: Tensor, biases: Tensor, gamma: Tensor, beta: Tensor, eps: float, scratch: Tensor, stats: Tensor, out: Tensor, nf: int) -> None:
-    hip.loftup_guidance_gn(img, biases, gamma, beta, eps, scratch, stats, out, nf)
+def loftup_guidance_gn(img: Tensor, biases: Tensor, gamma: Tensor, beta: Tensor, eps: float, scratch: Tensor, stats: Tensor, out: Tensor, nf: int,
+                       mm: Optional[Tensor] = None) -> None:
+    hip.loftup_guidance_gn(img, biases, gamma, beta, eps, scratch, stats, out, nf, mm)
+
+
+@_op('loftup_minmax', ('mm',))
+def loftup_minmax(img: Tensor, mm: Tensor) -> None:
+    hip.loftup_minmax(img, mm)
+
+
+@_op('minmax_merge', ('out',))
+def minmax_merge(mm: Tensor, scope: Tensor, out: Tensor) -> None:
+    hip.minmax_merge(mm, scope, out)
 
 
 @_op('groupnorm_stats', ('stats',))

@@ -10,7 +10,8 @@ Same call signatures and output structure; what changed is HOW the scene is exec
   * the keyframe memory is built once as projected K / V^T caches (model/must3r.py);
   * decoder_norm -> class logits -> mask_embed of the frozen queries is computed once per scene, each view then costs
     one [Q,C]x[C,P] GEMM (the reference recomputes the heads per chunk, panoptic_decoder.py:71);
-  * MinMaxScaler is per view (the demo's max_bs=1 convention), see SURVEY quirk 5.
+  * MinMaxScaler's scope follows `max_bs` as in the reference (None: same-shape keyframes / other views pooled; 1: per view, the demo's setting and
+    the scene_runner / bench default), see SURVEY quirk 5.
 `amp` (False | 'bf16' | 'fp16', reference utils.py:206-215) selects the storage / operand format of the scene: 'bf16' and 'fp16' as in the
 reference's autocast (MFMA kernels); amp=False is the reference's fp32 mode: float32 weights and activations, GEMMs and attention on the fp32-input MFMA
 (csrc/gemm_f32.hip, attn_f32.hip) - the reference's default arithmetic, ~8x slower, said once (RuntimeWarning).  Accumulation,
@@ -206,6 +207,9 @@ class PanSt3R(nn.Module):
         V x V image-similarity matrix as `sim_matrix` - the ASMK retriever that produces it in the reference needs asmk / faiss and
         is outside this build - and applies the reference's selection (schedule.keyframes_from_similarity: farthest-point sampling
         on 1 - sim, then the greedy overlap ordering of panst3r.py:105-123).  `keyframes=` passes an explicit list instead.
+        `max_bs` (reference default None; the demo passes 1): the reference stacks same-shape views in chunks of max_bs and LoftUp's MinMaxScaler
+        pools min / max over each chunk (loftup.py:14-19, panst3r.py:212-216,257-261) - None scales all same-shape keyframes
+        together and all same-shape other views together, 1 scales every view on its own.  Everything else is chunk-invariant and batched here.
         `cache_graphs=True` (not in the reference) keeps the scene's runner: repeated calls with the same signature replay captured HIP
         graphs (see _runner_for; `clear_runners()` frees them).  Default: one eager pass, nothing kept."""
         if use_retrieval and keyframes is None:
@@ -218,7 +222,7 @@ class PanSt3R(nn.Module):
         shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
         H, W = shapes[0]
         fmt = amp_dtype(amp)                    # tells (once) that amp=False is the slow fp32 mode
-        runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs)
+        runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs)
         res, scene = runner.run(outdevice)
         if check_finite and fmt == torch.float16:
             # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: ONE fused flag over everything the
@@ -242,7 +246,7 @@ class PanSt3R(nn.Module):
             runner.release()                    # a one-off scene keeps no intermediates (stacked inputs, features, mask features) alive
         return pms, panout
 
-    def _runner_for(self, imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs):
+    def _runner_for(self, imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs=1):
         """The SceneRunner of a call.  Default: a fresh eager runner, dropped after the call (what the reference's per-call execution
         costs in memory).  cache_graphs=True: runners are kept per scene SIGNATURE - everything a captured graph depends on: shapes,
         keyframe schedule, class list, device, format, and the version of every weight and class embedding (module generations bumped
@@ -254,20 +258,20 @@ class PanSt3R(nn.Module):
         H, W = shapes[0]
         if not cache_graphs:
             return SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
-                               keyframes=keyframes, amp=amp)
+                               keyframes=keyframes, amp=amp, minmax_bs=max_bs)
         from .model.common import HipModule
         te = self.panoptic_decoder.text_encoder
         gens = tuple(m.generation for m in self.modules() if isinstance(m, HipModule))
         pver = sum(p._version for p in self.parameters())
         cver = tuple((c, te.class_embeddings[c].data_ptr(), te.class_embeddings[c]._version) if c in te.class_embeddings else (c,) for c in classes)
         key = (tuple(shapes), num_keyframes, None if keyframes is None else tuple(int(k) for k in keyframes), str(dev),
-               amp_dtype(amp, quiet=True), gens, pver, cver, getattr(te, '_cls_gen', 0))
+               amp_dtype(amp, quiet=True), gens, pver, cver, getattr(te, '_cls_gen', 0), max_bs)
         ent = self._runners.get(key)
         if ent is None:
             while len(self._runners) >= max(1, self.max_cached_runners):
                 self._runners.pop(next(iter(self._runners)))
             runner = SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
-                                 keyframes=keyframes, amp=amp)
+                                 keyframes=keyframes, amp=amp, minmax_bs=max_bs)
             ent = self._runners[key] = [0, runner]
         else:
             ent[1].set_images(imgs)
@@ -290,16 +294,17 @@ class PanSt3R(nn.Module):
         return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice, amp=amp, plan=plan)
 
     def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None, keyframes=None, amp=False,
-                     plan='replicated'):
+                     plan='replicated', max_bs=1):
         """Static-shape scene runner (panst3r_amd/scene.py): `images` = {view_id: [3,H,W] device tensor} of the views
         this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True.
         `overlap=True` runs the memory build beside the bulk encoder work on a second stream (faster, NOT reproducible on this
-        platform - scene.OVERLAP_DEFAULT); the default runs them back to back."""
+        platform - scene.OVERLAP_DEFAULT); the default runs them back to back.  `max_bs`: MinMaxScaler scope as in forward_inference_multi_ar,
+        default 1 = per view (the demo's convention, SURVEY 8(d) synthetic inputs; what bench.py times)."""
         import torch.distributed as dist
         from .scene import SceneRunner, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
         return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes, amp=amp,
-                           plan=plan)
+                           plan=plan, minmax_bs=max_bs)
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False):
@@ -308,6 +313,11 @@ class PanSt3R(nn.Module):
         runs this entry point under the caller's autocast)."""
         B, n = imgs.shape[:2]
         Ht, Wt = int(imgs.shape[-2]), int(imgs.shape[-1])
+        if B > 1 and self.panoptic_decoder.minmax_scaled() and (max_bs is None or n % int(max_bs)):
+            # the reference flattens (B, n) before it chunks by max_bs (panoptic_decoder.py:56-62): LoftUp's MinMaxScaler would pool min / max ACROSS the
+            # scenes of the batch.  The scenes run one after another here, so only chunkings that stay inside a scene are reproduced.
+            raise NotImplementedError('PanSt3R.forward with B > 1 and the LoftUp upscaler: max_bs=%r makes MinMaxScaler chunks span scenes of the batch '
+                                      '(reference semantics); pass max_bs dividing n=%d (1 = per view, the demo\'s convention) or one scene per call' % (max_bs, n))
         outs = []
         for b in range(B):                      # the scenes of a batch are independent (own memory, own queries)
             # DUSt3R storage convention (utils.py:8-61 transpose_to_landscape): a same-shape batch may hold PORTRAIT views stored transposed, marked
@@ -324,7 +334,7 @@ class PanSt3R(nn.Module):
                 else:
                     raise ValueError('view %d: true_shape %s matches neither the tensor shape (%d, %d) nor its transpose' % (i, (th, tw), Ht, Wt))
             ts = torch.tensor([list(v.shape[-2:]) for v in views])
-            pms, panout = self.forward_inference_multi_ar(views, ts, classes, num_keyframes=n, outdevice=outdevice, amp=amp)
+            pms, panout = self.forward_inference_multi_ar(views, ts, classes, num_keyframes=n, outdevice=outdevice, amp=amp, max_bs=max_bs)
             masks = list(panout['pred_masks'])
             for i in stored:
                 pms[i] = pms[i].transpose(1, 2)

@@ -116,7 +116,7 @@ DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a calla
 
 class _Group:
     """The views of one image shape owned by this rank (keyframes first)."""
-    __slots__ = ('H', 'W', 'h', 'w', 'T', 'idx', 'k', 'imgs', 'cat', 'pointmaps', 'fpn', 'mf', 'guid')
+    __slots__ = ('H', 'W', 'h', 'w', 'T', 'idx', 'k', 'imgs', 'cat', 'pointmaps', 'fpn', 'mf', 'guid', 'mm')
 
 
 class SceneRunner:
@@ -133,8 +133,15 @@ class SceneRunner:
     (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
     def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None,
-                 amp=None, plan='replicated'):
+                 amp=None, plan='replicated', minmax_bs=1):
         self.b, self.V, self.classes = backend, V, classes
+        # LoftUp's MinMaxScaler scope (loftup.py:14-19 pools min / max over the chunk of views it is handed; the reference chunks by max_bs):
+        # 1 = per view (the demo's max_bs=1, tools/demo_panst3r.py:201 - the default here and what bench.py times); k = same-shape keyframes /
+        # same-shape other views in chunks of k, None = all of them together (the reference with max_bs=None: stack_views + batched_map,
+        # panst3r.py:212-216,244,257-270).  Pooling over views of OTHER ranks would need a collective the path does not have.
+        self.minmax_bs = minmax_bs
+        if minmax_bs != 1 and world > 1 and getattr(backend, 'minmax_scaled', lambda: False)():
+            raise NotImplementedError('a MinMaxScaler scope wider than one view (max_bs != 1) is not sharded: use max_bs=1 or one rank')
         self.amp = amp                # False | 'bf16' | 'fp16' (reference utils.py:206-215): 16-bit format of this runner, fixed for its lifetime
         self._refs = None             # packed weights / tables the captured graphs point into (kept alive with the runner)
         self.rank, self.world, self.group = rank, world, group
@@ -186,9 +193,22 @@ class SceneRunner:
         for g in self.groups:
             for r, j in enumerate(g.idx):
                 self.where[j] = (g, r)
+        self.mm_scope = None                  # per group: scope id of every row (views with equal ids share one min-max scale), or None = per view
+        if minmax_bs != 1 and getattr(backend, 'minmax_scaled', lambda: False)():
+            ids, nxt = [], 0
+            for g in self.groups:             # rows of a group: its keyframes (schedule order) first, then its other views (ascending)
+                row = []
+                for lo, hi in ((0, g.k), (g.k, len(g.idx))):
+                    bs = max(hi - lo, 1) if minmax_bs is None else int(minmax_bs)
+                    row += [nxt + i // bs for i in range(hi - lo)]
+                    nxt = (row[-1] + 1) if row else nxt
+                ids.append(row)
+            if any(len(set(r)) < len(r) for r in ids):
+                self.mm_scope = backend.scope_ids(ids, self.groups[0].imgs.device)
         self.use_graphs = use_graphs
         self.serial = not (OVERLAP_DEFAULT if overlap is None else overlap)      # True: the two branches of stage 2 run back-to-back
         self.graphs = None
+        self.coll_events = None       # bench.py: [] -> every eager collective is bracketed by HIP events (collective_ms)
         self.enc_kf = self.both_kf = None
         self.out = self.bank = None
 
@@ -221,8 +241,10 @@ class SceneRunner:
             if len(g.idx) > g.k:
                 b.encode_enc(g.imgs[g.k:], g.cat[g.k * g.T:])
             b.encode_dino(g.imgs, g.cat)
-        for g in self.groups:         # image-only part of the upscaler (LoftUp guidance convs, SURVEY 8(e) phase A): memory-independent,
-            g.guid = b.guidance(g.imgs, g.h, g.w)     # so it belongs to this branch (with overlap=True it fills the tail of the memory build)
+        mms = b.minmax_tables([g.imgs for g in self.groups], self.mm_scope) if self.mm_scope is not None else [None] * len(self.groups)
+        for g, mm in zip(self.groups, mms):     # image-only part of the upscaler (LoftUp guidance convs, SURVEY 8(e) phase A): memory-independent,
+            g.mm = mm                         # so it belongs to this branch (with overlap=True it fills the tail of the memory build)
+            g.guid = b.guidance(g.imgs, g.h, g.w, mm)
 
     def gather1(self):
         kf = gather_keyframe_rows(self.enc_send, self.K, self.kf_T, rank=self.rank, world=self.world, group=self.group)
@@ -284,8 +306,8 @@ class SceneRunner:
         for g in self.groups:
             n = len(g.idx)
             g.pointmaps = b.render(g.cat, n, g.h, g.w, bank)
-            g.fpn, g.mf = b.features(g.cat, g.imgs, n, g.h, g.w, g.guid)
-            g.guid = None
+            g.fpn, g.mf = b.features(g.cat, g.imgs, n, g.h, g.w, g.guid, g.mm)
+            g.guid = g.mm = None
             fm = b.attn_feats(g.mf, g.k, b.fpn_grid(g.h, g.w)[0])
             self.d = g.fpn.shape[1]
             rows.append(torch.cat([g.fpn[:g.k * g.T], fm], dim=1) if g.k else g.fpn.new_zeros(0, self.d + b.mask_dim))
@@ -316,17 +338,35 @@ class SceneRunner:
             return [(self.stage1, self.gather1), (self.stage2a, self.bank_exchange), (self.stage2b, self.gather2), (self.stage3, None)]
         return [(self.stage1, self.gather1), (self.stage2, self.gather2), (self.stage3, None)]
 
+    def _collective(self, coll):
+        """run one eager collective; with `coll_events` set (bench.py) it is bracketed by HIP events on the launch stream"""
+        if self.coll_events is None or not torch.cuda.is_available():
+            return coll()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        coll()
+        b.record()
+        self.coll_events.append((coll.__name__, a, b))
+
+    def collective_ms(self):
+        """{collective name: [ms per recorded call]} of the calls recorded since `coll_events = []` (synchronises)"""
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.coll_events or []:
+            out.setdefault(name, []).append(a.elapsed_time(b))
+        return out
+
     def _eager(self):
         for stage, coll in self._segments():
             stage()
             if coll is not None:
-                coll()
+                self._collective(coll)
 
     def release(self):
         """Drop everything the runner holds on the device (stacked inputs, feature / mask-feature buffers, gathered keyframe rows, captured
         graphs).  Outputs already handed out by results() stay valid: they are tensors of their own."""
         for g in self.groups:
-            g.imgs = g.cat = g.pointmaps = g.fpn = g.mf = g.guid = None
+            g.imgs = g.cat = g.pointmaps = g.fpn = g.mf = g.guid = g.mm = None
         self.enc_kf = self.both_kf = self.enc_send = self.both_send = self.out = self.graphs = self._refs = self.bank = None
 
     def set_images(self, images):
@@ -377,7 +417,7 @@ class SceneRunner:
                     for g, (_, coll) in zip(self.graphs, self._segments()):
                         g.replay()
                         if coll is not None:
-                            coll()
+                            self._collective(coll)
             else:
                 self._eager()
         return self.results(outdevice, copy=copy)
@@ -399,7 +439,8 @@ class SceneRunner:
 
 
 @torch.no_grad()
-def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None, keyframes=None, amp=None, plan='replicated'):
+def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None, keyframes=None, amp=None, plan='replicated',
+              minmax_bs=1):
     """Run one scene eagerly.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
     Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
     {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W);
@@ -408,7 +449,8 @@ def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=No
     plan = resolve_plan(plan, world, Kc)
     _, order, owner = assign_views(V, Kc, world, keyframes, plan)
     images = {order[i]: get_image(order[i]) for i in range(V) if owner[i] == rank}
-    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes, amp=amp, plan=plan).run(outdevice)
+    return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes, amp=amp, plan=plan,
+                       minmax_bs=minmax_bs).run(outdevice)
 
 
 class HipBackend:
@@ -466,11 +508,21 @@ class HipBackend:
     def render(self, cat, n, h, w, bank):
         return self.m.render_views(cat, n, h, w, bank)
 
-    def guidance(self, imgs, h, w):
-        return self.m.panoptic_decoder.guidance_tokens(imgs, h, w)
+    def minmax_scaled(self):
+        return self.m.panoptic_decoder.minmax_scaled()
 
-    def features(self, cat, imgs, n, h, w, guidance=None):
-        return self.m.panoptic_decoder.features_tokens(cat, imgs, n, h, w, guidance=guidance)
+    def scope_ids(self, ids, device):
+        """per-group scope-id lists -> one static int32 device tensor (made once, outside any graph capture)"""
+        return torch.tensor([i for row in ids for i in row], dtype=torch.int32).to(device)
+
+    def minmax_tables(self, img_stacks, scope):
+        return self.m.panoptic_decoder.minmax_tables(img_stacks, scope)
+
+    def guidance(self, imgs, h, w, mm=None):
+        return self.m.panoptic_decoder.guidance_tokens(imgs, h, w, mm=mm)
+
+    def features(self, cat, imgs, n, h, w, guidance=None, mm=None):
+        return self.m.panoptic_decoder.features_tokens(cat, imgs, n, h, w, guidance=guidance, mm=mm)
 
     def fpn_grid(self, h, w):
         return self.m.panoptic_decoder.fpn_grid(h, w)

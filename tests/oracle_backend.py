@@ -73,15 +73,31 @@ class OracleBackend:
             pms.append(pm[0][0])
         return torch.stack(pms)
 
-    def guidance(self, imgs, h, w):
+    def minmax_scaled(self):
+        return type(self.m.panoptic_decoder.upscaler).__name__ == 'LoftUpUpscaler'
+
+    def scope_ids(self, ids, device):
+        return ids             # per-group lists of scope ids; features() chunks by them
+
+    def minmax_tables(self, img_stacks, scope):
+        return scope           # the oracle's MinMaxScaler pools over the chunk it is handed: hand it the chunks
+
+    def guidance(self, imgs, h, w, mm=None):
         return None            # the oracle computes the guidance branch inside features()
 
-    def features(self, cat, imgs, n, h, w, guidance=None):
+    def features(self, cat, imgs, n, h, w, guidance=None, mm=None):
         T, p = h * w, self.patch_size
-        ts = torch.tensor([[[h * p, w * p]] * n])
-        pos = self._pos(h, w)[None].expand(1, n, -1, -1)
-        fpn, mf = self.m.panoptic_decoder.features(cat.reshape(1, n, T, -1), imgs[None], pos, ts, max_bs=1)
-        return fpn[0].flatten(2).transpose(1, 2).reshape(n * T, -1).contiguous(), mf[0]          # tokens, [n,C,Hm,Wm]
+        pos1 = self._pos(h, w)[None]
+        chunks = [[i] for i in range(n)] if mm is None else [[i for i in range(n) if mm[i] == s] for s in sorted(set(mm))]
+        fpns, mfs = [None] * n, [None] * n
+        for ch in chunks:           # one MinMaxScaler scope per chunk (mm is None: per view, the demo's max_bs=1)
+            ts = torch.tensor([[[h * p, w * p]] * len(ch)])
+            c = torch.stack([cat[i * T:(i + 1) * T] for i in ch])[None]
+            fpn, mf = self.m.panoptic_decoder.features(c, torch.stack([imgs[i] for i in ch])[None], pos1.expand(1, len(ch), -1, -1), ts, max_bs=None)
+            for j, i in enumerate(ch):
+                fpns[i], mfs[i] = fpn[0, j], mf[0, j]
+        fpn, mf = torch.stack(fpns), torch.stack(mfs)
+        return fpn.flatten(2).transpose(1, 2).reshape(n * T, -1).contiguous(), mf          # tokens, [n,C,Hm,Wm]
 
     def fpn_grid(self, h, w):
         portrait = bool(self.m.panoptic_decoder.landscape_only and h > w)

@@ -124,7 +124,10 @@ def test_reference_stage_methods(variant):
         _, pm_o, f_o = o.must3r_decoder(xo[None, :n], po[None, :n], ts[:1], mem_o, render=True, return_feats=True)
         assert pm.shape == (1, n, H, W, 7) and rel_l2(pm.cpu(), pm_o) < 2e-2 and rel_l2(y.cpu(), f_o[-1]) < 2e-2
         # full forward, B = 2 (two independent scenes)
-        pan, pms = h(imgs.to(DEV), ts, tiny.NAMES)
+        if variant == 'v2':        # LoftUp: the reference's max_bs=None pools MinMaxScaler statistics ACROSS the scenes of a batch - refused, not approximated
+            with pytest.raises(NotImplementedError):
+                h(imgs.to(DEV), ts, tiny.NAMES)
+        pan, pms = h(imgs.to(DEV), ts, tiny.NAMES, max_bs=n)      # one MinMaxScaler chunk per scene
         assert pms.shape == (2, n, H, W, 7) and pan['pred_masks'].shape == (2, n, 24, H // 2, W // 2) and pan['out_queries'].shape[1] == 2
         for b in range(2):
             pm_ob, pan_ob = o.forward_inference_multi_ar(list(imgs[b]), ts[b], tiny.NAMES, num_keyframes=n)

@@ -478,7 +478,7 @@ def test_scene_fp32_odd_token_grids_and_graph_replay(pair, H, W, V, K):
     assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 1e-4
     for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
         assert rel_l2(a.cpu(), b) < mask_tol(variant)
-    runner = h.scene_runner({i: d(im) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=False)
+    runner = h.scene_runner({i: d(im) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=False, max_bs=None)
     runner.run()
     res, scene = runner.run()
     assert torch.equal(scene['out_queries'], pan_h['out_queries'])

@@ -158,7 +158,7 @@ def test_scene_keyframes_by_retrieval(pair):
     assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 2e-2
     for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
         assert rel_l2(a.cpu(), b) < mask_tol(h)
-    runner = h.scene_runner({i: im.to(DEV) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, keyframes=kf, use_graphs=True, amp=h.amp)
+    runner = h.scene_runner({i: im.to(DEV) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, keyframes=kf, use_graphs=True, amp=h.amp, max_bs=None)     # (the entry point's default scope)
     assert runner.keyframes == kf and runner.order[:K] == kf
     runner.run()
     res, scene = runner.run()
@@ -235,6 +235,39 @@ def test_scene_multi_aspect_ratio(pair, K):
         assert rel_l2(pm_h[i].cpu(), pm_o[i]) < 2e-2
         assert rel_l2(pan_h['pred_masks'][i].cpu(), pan_o['pred_masks'][i]) < mask_tol(h)
     assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 2e-2
+
+
+@pytest.mark.parametrize('max_bs', [None, 2, 1])
+def test_minmax_scope_follows_max_bs(pair, max_bs):
+    """LoftUp's MinMaxScaler pools min / max over the chunk of views the reference hands it (loftup.py:14-19; chunks = same-shape keyframes / other
+    views in stacks of max_bs, panst3r.py:212-216,257-261): forward_inference_multi_ar(max_bs=...) against the oracle with the same
+    max_bs on a multi-aspect-ratio scene, PanopticDecoder.forward(max_bs=...) against the oracle's (whose chunking is pinned by the reference-generated
+    golden panoptic_decoder_v2_tiny), and - v2 only - pooled scaling must NOT equal per-view scaling (the scope is really applied)."""
+    variant, o, h = pair
+    shapes = [(64, 96), (32, 96), (64, 96), (64, 96), (32, 96), (64, 96), (64, 96)]
+    V, K = len(shapes), 4
+    imgs = [tiny.synth_image(i, a, b, 7) for i, (a, b) in enumerate(shapes)]
+    ts = torch.tensor(shapes)
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K, max_bs=max_bs)
+    pm_h, pan_h = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K, amp=h.amp, max_bs=max_bs)
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 2e-2
+    for i in range(V):
+        assert rel_l2(pan_h['pred_masks'][i].cpu(), pan_o['pred_masks'][i]) < mask_tol(h), i
+    if variant == 'v2' and max_bs != 1:
+        _, pan_1 = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, num_keyframes=K, amp=h.amp, max_bs=1)
+        assert max(rel_l2(a, b) for a, b in zip(pan_h['pred_masks'], pan_1['pred_masks'])) > 5e-2
+    # the decoder entry point on a same-shape stack of 5 views: chunks [0,1] [2,3] [4] for max_bs=2
+    H, W, n, T = 64, 96, 5, 24
+    g = torch.Generator().manual_seed(3)
+    feats = tuple(torch.randn(1, n, T, 128, generator=g) for _ in range(3))
+    im = torch.stack(tiny.images(n, H, W))[None]
+    pos = grid_pos(4, 6)[None].expand(1, n, -1, -1).contiguous()
+    t5 = torch.tensor([[[H, W]] * n])
+    with torch.no_grad():
+        ro = o.panoptic_decoder(feats, im, pos, t5, tiny.NAMES, max_bs=max_bs)
+        rh = h.panoptic_decoder(tuple(f.to(DEV) for f in feats), im.to(DEV), pos.to(DEV), t5, tiny.NAMES, max_bs=max_bs)
+    assert rel_l2(rh['pred_masks'].cpu(), ro['pred_masks']) < 3e-2
+    assert rel_l2(rh['out_queries'].cpu(), ro['out_queries']) < 2e-2
 
 
 @pytest.mark.parametrize('K', [2, 5])
@@ -373,7 +406,7 @@ def test_scene_odd_token_grids(pair, H, W, V, K):
     assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 0.05
     for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
         assert rel_l2(a.cpu(), b) < mask_tol(h)
-    runner = h.scene_runner({i: im.to(DEV) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=h.amp)
+    runner = h.scene_runner({i: im.to(DEV) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=h.amp, max_bs=None)
     runner.run()
     res, scene = runner.run()
     assert torch.equal(scene['out_queries'], pan_h['out_queries'])
@@ -423,11 +456,11 @@ def test_forward_batch_and_dust3r_storage_convention(pair):
     stored = [b[0], b[1].transpose(-1, -2).contiguous(), b[2]]
     imgs = torch.stack([torch.stack(a), torch.stack(stored)]).to(DEV)
     ts = torch.tensor([[[H, W]] * n, [[H, W], [W, H], [H, W]]])
-    pan, pm = h.forward(imgs, ts, tiny.NAMES, amp=h.amp)
+    pan, pm = h.forward(imgs, ts, tiny.NAMES, amp=h.amp, max_bs=1)          # (max_bs=None would pool LoftUp's MinMaxScaler over the batch: refused for B > 1)
     assert pm.shape == (2, n, H, W, 7) and pan['pred_masks'].shape == (2, n, 24, H // 2, W // 2) and pan['out_queries'].shape[1] == 2
     for s, views in enumerate((a, b)):
         t2 = torch.tensor([list(v.shape[-2:]) for v in views])
-        pm_n, pan_n = h.forward_inference_multi_ar([v.to(DEV) for v in views], t2, tiny.NAMES, num_keyframes=n, amp=h.amp)
+        pm_n, pan_n = h.forward_inference_multi_ar([v.to(DEV) for v in views], t2, tiny.NAMES, num_keyframes=n, amp=h.amp, max_bs=1)
         assert torch.equal(pan['out_queries'][:, s], pan_n['out_queries'][:, 0])
         for i in range(n):
             back = views[i].shape[-2] != H
@@ -437,4 +470,4 @@ def test_forward_batch_and_dust3r_storage_convention(pair):
                 mk = mk.transpose(-1, -2)
             assert torch.equal(pan['pred_masks'][s, i], mk), (s, i)
     with pytest.raises(ValueError):
-        h.forward(imgs, torch.tensor([[[H, W]] * n, [[H, W], [W + 16, H], [H, W]]]), tiny.NAMES, amp=h.amp)
+        h.forward(imgs, torch.tensor([[[H, W]] * n, [[H, W], [W + 16, H], [H, W]]]), tiny.NAMES, amp=h.amp, max_bs=1)

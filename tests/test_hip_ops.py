@@ -929,3 +929,24 @@ def test_gemm_pair_equals_two_launches(M, N1, N2, K):
         q1, q2 = torch.full((M, N1), float('nan'), dtype=d16(), device=dev()), torch.zeros(N2, ldc, dtype=d16(), device=dev())
         hip.gemm_pair((xb, w1, q1, k1), (xb, w2, q2, k2))
         assert torch.equal(o1, q1) and torch.equal(o2, q2)
+
+
+def test_loftup_minmax_and_merge():
+    """the MinMaxScaler statistics for scopes wider than one view (loftup.py:14-19 pools min / max over the batch it is handed): per-view table of
+    the 2x2-mean image, pooled over scope ids - exact (min / max are order-independent), and the guidance kernel scaled with the pooled table
+    equals the reference formulation applied to the chunk."""
+    from panst3r_amd import hip
+    import torch.nn.functional as F
+    n, H, W = 5, 32, 48
+    img = torch.stack([rn(1300 + i, 3, H, W) * (0.3 + 0.2 * i) for i in range(n)]).clamp(-1, 1).contiguous()
+    d2 = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+    mm = torch.empty(n, 3, 2, device=dev())
+    hip.loftup_minmax(img.to(dev()), mm)
+    close = lambda a, b: torch.allclose(a, b, rtol=0, atol=3e-7)          # (2x2 mean: one association of four adds, torch's lerp another)
+    assert close(mm[..., 0].cpu(), d2.amin(dim=(2, 3))) and close(mm[..., 1].cpu(), d2.amax(dim=(2, 3)))
+    scope = torch.tensor([0, 0, 1, 0, 1], dtype=torch.int32, device=dev())
+    out = hip.minmax_merge(mm, scope, torch.empty_like(mm))
+    for v in range(n):
+        grp = [u for u in range(n) if int(scope[u]) == int(scope[v])]
+        assert torch.equal(out[v, :, 0], mm[grp][:, :, 0].amin(0)) and torch.equal(out[v, :, 1], mm[grp][:, :, 1].amax(0))          # pooling itself is exact
+        assert close(out[v, :, 0].cpu(), d2[grp].amin(dim=(0, 2, 3))) and close(out[v, :, 1].cpu(), d2[grp].amax(dim=(0, 2, 3)))

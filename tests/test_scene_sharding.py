@@ -60,7 +60,7 @@ def test_plan_matches_reference_formulation(variant):
     V, K = 4, 3
     model = tiny.build(tiny.OracleNS, variant)
     imgs = tiny.images(V, H, W)
-    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor([[H, W]] * V), tiny.NAMES, num_keyframes=K)
+    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor([[H, W]] * V), tiny.NAMES, num_keyframes=K, max_bs=1)
     res, scene = _scene(variant, V, K)
     assert rel_l2(scene['out_queries'], pan_ref['out_queries']) < 1e-4
     assert rel_l2(scene['pred_logits'], pan_ref['pred_logits']) < 1e-4
@@ -69,20 +69,42 @@ def test_plan_matches_reference_formulation(variant):
         assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
 
 
+@pytest.mark.parametrize('max_bs', [None, 2])
+def test_minmax_scope_follows_max_bs(max_bs):
+    """LoftUp's MinMaxScaler pools min / max over the chunk of views the reference hands it (loftup.py:14-19; stack_views + batched_map chunk by
+    max_bs, panst3r.py:212-216,257-261): run_scene(minmax_bs=...) == the oracle pipeline with the same max_bs, on a multi-aspect-ratio scene
+    (scopes never cross shapes, nor the keyframe / other-view boundary) - and it is NOT what per-view scaling gives."""
+    shapes = [(64, 96), (32, 96), (64, 96), (64, 96), (32, 96), (64, 96), (64, 96)]
+    V, K = len(shapes), 4
+    model = tiny.build(tiny.OracleNS, 'v2')
+    imgs = [tiny.synth_image(i, a, b, 7) for i, (a, b) in enumerate(shapes)]
+    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor(shapes), tiny.NAMES, num_keyframes=K, max_bs=max_bs)
+    per_view = model.forward_inference_multi_ar(imgs, torch.tensor(shapes), tiny.NAMES, num_keyframes=K, max_bs=1)[1]
+    with torch.no_grad():
+        res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], V, None, None, K, tiny.NAMES, shapes=shapes, minmax_bs=max_bs)
+    assert rel_l2(scene['out_queries'], pan_ref['out_queries']) < 1e-4
+    for i in range(V):
+        assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4, i
+    assert max(rel_l2(res[i][1], per_view['pred_masks'][i]) for i in range(V)) > 1e-2          # the scope matters (SURVEY quirk 5)
+    with pytest.raises(NotImplementedError):                                                   # pooling across ranks is not sharded
+        from panst3r_amd.scene import SceneRunner
+        SceneRunner(OracleBackend(model), {i: im for i, im in enumerate(imgs)}, V, None, None, K, tiny.NAMES, rank=0, world=2, shapes=shapes, minmax_bs=max_bs)
+
+
 @pytest.mark.parametrize('variant', ['v1', 'v2'])
 def test_explicit_keyframe_order_matches_reference_formulation(variant):
     """Keyframes as the reference's retrieval mode hands them over (panst3r.py:179-180): an unsorted list in memory-build order."""
     V, kf = 5, [3, 0, 4]
     model = tiny.build(tiny.OracleNS, variant)
     imgs = tiny.images(V, H, W)
-    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor([[H, W]] * V), tiny.NAMES, num_keyframes=3, use_retrieval=True, keyframes=kf)
+    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor([[H, W]] * V), tiny.NAMES, num_keyframes=3, use_retrieval=True, keyframes=kf, max_bs=1)
     with torch.no_grad():
         res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], V, H, W, 3, tiny.NAMES, keyframes=kf)
     assert rel_l2(scene['out_queries'], pan_ref['out_queries']) < 1e-4
     for i in range(V):
         assert rel_l2(res[i][0], pm_ref[i]) < 1e-5
         assert rel_l2(res[i][1], pan_ref['pred_masks'][i]) < 1e-4
-    lin = model.forward_inference_multi_ar(imgs, torch.tensor([[H, W]] * V), tiny.NAMES, num_keyframes=3)[1]
+    lin = model.forward_inference_multi_ar(imgs, torch.tensor([[H, W]] * V), tiny.NAMES, num_keyframes=3, max_bs=1)[1]
     assert rel_l2(lin['out_queries'], pan_ref['out_queries']) > 1e-3            # a different memory than the linspace choice [0, 2, 4]
     kfs, order, owner = assign_views(V, 3, 2, kf)
     assert kfs == kf and order == [3, 0, 4, 1, 2] and owner == [0, 1, 0, 1, 0]
@@ -105,7 +127,7 @@ def test_multi_aspect_ratio_scene_matches_reference_formulation(variant, K):
     V = len(MULTI_AR)
     model = tiny.build(tiny.OracleNS, variant)
     imgs = _multi_ar_images()
-    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor(MULTI_AR), tiny.NAMES, num_keyframes=K)
+    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor(MULTI_AR), tiny.NAMES, num_keyframes=K, max_bs=1)
     with torch.no_grad():
         res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], V, None, None, K, tiny.NAMES, shapes=MULTI_AR)
     assert rel_l2(scene['out_queries'], pan_ref['out_queries']) < 1e-4
@@ -127,7 +149,7 @@ def test_portrait_scene_matches_reference_formulation(variant, K):
     V = len(PORTRAIT_AR)
     model = tiny.build(tiny.OracleNS, variant)
     imgs = [tiny.synth_image(i, h, w, 11) for i, (h, w) in enumerate(PORTRAIT_AR)]
-    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor(PORTRAIT_AR), tiny.NAMES, num_keyframes=K)
+    pm_ref, pan_ref = model.forward_inference_multi_ar(imgs, torch.tensor(PORTRAIT_AR), tiny.NAMES, num_keyframes=K, max_bs=1)
     with torch.no_grad():
         res, scene = run_scene(OracleBackend(model), lambda i: imgs[i], V, None, None, K, tiny.NAMES, shapes=PORTRAIT_AR)
     assert rel_l2(scene['out_queries'], pan_ref['out_queries']) < 1e-4

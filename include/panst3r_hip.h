@@ -97,10 +97,16 @@ int pst_gemm(const pst_gemm_params* p, void* stream);
 /* name of the kernel variant pst_gemm dispatches `p` to ("gemm_kernel<4,4,false>", "gemm256_kernel", ...), without launching:
  * what a profiler row of this call is called (bench.py attributes its HIP-event timings with it). NULL for a rejected argument. */
 const char* pst_gemm_variant(const pst_gemm_params* p);
-/* Two INDEPENDENT GEMMs, `a` with a row-major store and `b` with trans_out (the q|k and V^T projections of an attention layer: croco Attention's
- * qkv Linear, models/blocks.py - same A operand, different epilogues), in ONE launch when both resolve to the 64 x 64-tile kernel (the 768-row GEMMs of
- * the sequential memory build: launch latency and the cold first operand fetch are shared); any other pair runs as two pst_gemm launches.  Results are
- * bit-identical to two pst_gemm calls either way.  pst_gemm_pair_variant: "gemm_pair_kernel<2,2>", or "" when the pair is not fused. */
+/* Two INDEPENDENT GEMMs in ONE launch where that pays; any other pair runs as two pst_gemm launches.  Results are bit-identical to two pst_gemm
+ * calls either way.  Fused cases:
+ *   - `a` with a row-major store and `b` with trans_out (the q|k and V^T projections of an attention layer: croco Attention's qkv Linear, models/blocks.py -
+ *     same A operand, different epilogues) when both resolve to the 64 x 64-tile kernel (the 768-row GEMMs of the sequential memory build: launch latency
+ *     and the cold first operand fetch are shared);  variant "gemm_pair_kernel<2,2>"
+ *   - (ABI 17) two big problems of the SAME persistent-kernel class (both plain 16-bit / both fp32 residual stream / both transposed) - the same layer of
+ *     two independent ViTs, e.g. the CroCo encoder of the views that are not keyframes and DINOv2 of all views (panst3r.py:174-175,229-230): the chip's
+ *     workgroups are split between the two tile lists so that both finish in the same number of rounds (tile quantisation: 408 + 608 tiles of 256 x 256
+ *     cost 2 + 3 rounds of 256 CUs on their own, 4 side by side);  variant "gemm256p_kernel"
+ * pst_gemm_pair_variant: the fused kernel's name, or "" when the pair is not fused. */
 int pst_gemm_pair(const pst_gemm_params* a, const pst_gemm_params* b, void* stream);
 const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_params* b);
 /* Tuning knob of the GEMM dispatch (process-wide; measurement tools and tests only - results never depend on it, every GEMM variant

@@ -22,6 +22,8 @@ namespace pst {
 
 int launch_gemm256(const pst_gemm_params& p, hipStream_t s);   // gemm256.hip
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus);
+int gemm256p_pair_split(const pst_gemm_params& a, const pst_gemm_params& b, int cus);      // workgroups of problem a when a and b share one persistent launch (0: two launches)
+int launch_gemm256p_pair(const pst_gemm_params& a, const pst_gemm_params& b, hipStream_t s, int cus, int g0);
 bool gemm256_persistent_ok(const pst_gemm_params& p);
 int gemm256_persistent_class(const pst_gemm_params& p);
 int gemm_f32_validate(const pst_gemm_params& p);                          // gemm_f32.hip: fp32 operands (the reference's amp=False arithmetic)
@@ -633,20 +635,31 @@ static bool pair_fusable(const pst_gemm_params& a, const pst_gemm_params& b) {
   return gemm_choice(a) == 0 && gemm_choice(b) == 0;            // both on the 64 x 64 tiles: the small-M GEMMs of the memory build
 }
 
+// two big problems of the SAME persistent class side by side in one launch (gemm256.hip gemm256p2_kernel): workgroups of problem a, or 0
+static int pair_split_256p(const pst_gemm_params& a, const pst_gemm_params& b) {
+  using namespace pst;
+  if (a.dtype16 == DT_F32 || a.dtype16 != b.dtype16 || a.batch > 1 || b.batch > 1 || a.kernel || b.kernel) return 0;
+  if (rowstream_class(a) || rowstream_class(b)) return 0;
+  if (gemm_choice(a) != 2 || gemm_choice(b) != 2 || !gemm256_persistent_ok(a) || !gemm256_persistent_ok(b)) return 0;
+  return gemm256p_pair_split(a, b, num_cus());
+}
+
 extern "C" int pst_gemm_pair(const pst_gemm_params* pa, const pst_gemm_params* pb, void* stream) {
   using namespace pst;
   if (int rc = gemm_validate(pa)) return rc;
   if (int rc = gemm_validate(pb)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (const int g0 = pair_split_256p(*pa, *pb)) return launch_gemm256p_pair(*pa, *pb, s, num_cus(), g0);
   if (!pair_fusable(*pa, *pb)) {                                 // any other pair: two launches, same results
     if (int rc = pst_gemm(pa, stream)) return rc;
     return pst_gemm(pb, stream);
   }
-  hipStream_t s = (hipStream_t)stream;
   return pa->dtype16 == DT_F16 ? launch_pair_t<2, 2, 4, true>(*pa, *pb, s) : launch_pair_t<2, 2, 4, false>(*pa, *pb, s);
 }
 
 extern "C" const char* pst_gemm_pair_variant(const pst_gemm_params* pa, const pst_gemm_params* pb) {
   if (gemm_validate(pa) || gemm_validate(pb)) return nullptr;
+  if (pair_split_256p(*pa, *pb)) return "gemm256p_kernel";          // two problems side by side in one persistent launch
   return pair_fusable(*pa, *pb) ? "gemm_pair_kernel<2,2>" : "";       // "": runs as two pst_gemm launches (ask pst_gemm_variant for each)
 }
 

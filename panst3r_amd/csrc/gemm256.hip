@@ -10,6 +10,7 @@
 // everything but the two newest half-tiles (B(t+2)) has landed, i.e. all of tile t+1.  A(t+1) goes to buffer b^1, whose
 // last reads (tile t-1, phase 2) are two barriers old; B(t+2) goes to buffer b after its last B read (phase 1 of tile t).
 // Each output element accumulates its K products in the same order as the 128x128 kernel => bit-identical results.
+#include <algorithm>
 #include "common.h"
 #include "../../include/panst3r_hip.h"
 
@@ -393,9 +394,10 @@ __device__ __forceinline__ float mul_add_2r(float a, float b, float c) {
 // L2's four pieces = all of tile t+1, followed by two barriers before any wave reads it.  Slot table (global slots between barriers):
 //   group 0:  L0 M0 L1 M1 L2 M2 L3 M3 | L0' ...          L0: A(m0) B(n0)   L1: B(n1)   L2: A(m1) + DMA B(t+2)   L3: vmcnt + DMA A(t+2)
 //   group 1:     L0 M0 L1 M1 L2 M2 L3 | M3 L0' ...       M0: (m0,n0)  M1: (m0,n1)  M2: (m1,n1)  M3: (m1,n0)      -- same K order: same bits
+// The kernel body: workgroup `bid` of the `nblk` workgroups that walk problem `p` (its `ntiles` tiles).  One problem per launch: (blockIdx.x, gridDim.x);
+// two problems per launch (gemm256p2_kernel below): each problem gets a contiguous range of the launch's workgroups.
 template <bool F16, bool RES, bool TRANS, bool PP>
-__global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const int ntiles, const int tiles_m, const int tiles_n, const int bid, const int nblk, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
     __builtin_amdgcn_s_setprio(0);
   };
 
-  int slot = blockIdx.x;
+  int slot = bid;
   int m0, n0;
   tile_origin(xcd_remap(slot, ntiles), m0, n0);
   describe(m0, n0);
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
     }
 
     const int cm0 = m0, cn0 = n0;
-    slot += gridDim.x;
+    slot += nblk;
     const bool more = slot < ntiles;
     // request the next tile's first operand tiles: the buffers are free.  Loads issued after this point queue BEHIND that DMA in the
     // in-order vmcnt, so the plain epilogue issues none at all and the residual epilogue requests its first half before it.
@@ -803,6 +805,31 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params 
   }
 }
 
+template <bool F16, bool RES, bool TRANS, bool PP>
+__global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm256p_body<F16, RES, TRANS, PP>(p, ntiles, tiles_m, tiles_n, blockIdx.x, gridDim.x, smem);
+}
+
+// TWO independent problems of the same class in one launch (pst_gemm_pair): workgroups [0, g0) walk problem 0, [g0, gridDim.x) problem 1.  Tile
+// quantisation is what this buys: a problem of t tiles costs ceil(t / 256) rounds on its own (38800 x 1024: 608 tiles = 2.375 -> 3 rounds, 79 %), two
+// problems side by side cost max(ceil(t0 / g0), ceil(t1 / g1)) rounds (the non-keyframe encoder's 408 tiles + DINOv2's 608 on 103 + 153 workgroups:
+// 4 rounds instead of 2 + 3).  Per tile nothing changes: bit-identical to two launches.  The problem is picked by a dynamic index into the
+// by-value argument (a wave-uniform offset into the kernarg segment: the fields stay scalar loads).
+struct gemm256p2_args {
+  pst_gemm_params p[2];
+  int ntiles[2], tiles_m[2], tiles_n[2];
+  int g0;
+};
+template <bool F16, bool RES, bool TRANS, bool PP>
+__global__ __launch_bounds__(512, 1) void gemm256p2_kernel(const gemm256p2_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int which = (int)blockIdx.x >= a.g0 ? 1 : 0;
+  const int bid = which ? (int)blockIdx.x - a.g0 : (int)blockIdx.x;
+  const int nblk = which ? (int)gridDim.x - a.g0 : a.g0;
+  gemm256p_body<F16, RES, TRANS, PP>(a.p[which], a.ntiles[which], a.tiles_m[which], a.tiles_n[which], bid, nblk, smem);
+}
+
 constexpr int LDS256 = 2 * BUF_BYTES + 256 * (int)sizeof(float2);      // operand buffers + the LayerNorm-fold row table
 constexpr int LDS256P = LDS256P_TABLES + 2 * 256 * 8 + 64 * 32 * 4;      // + row positions (two sets) + the RoPE table (<= 64 positions)
 
@@ -863,6 +890,62 @@ static void launch_256p_c(const pst_gemm_params& p, hipStream_t s, int grid, int
     if (h) launch_256p_t<true, RES, TRANS, false>(p, s, grid, tiles, tiles_m, tiles_n);
     else launch_256p_t<false, RES, TRANS, false>(p, s, grid, tiles, tiles_m, tiles_n);
   }
+}
+
+// cost of one output tile in K-tile units: the K loop plus a prologue / epilogue that is worth ~8 K tiles (profiles/r3_gemm_pp_ablation.txt: at K = 1024 the
+// loop is 60 % of the kernel)
+static inline long tile_cost(const pst_gemm_params& p) { return p.K / 64 + 8; }
+
+// workgroups of problem 0 when two problems share one launch of `cus` workgroups, or 0 when two launches are at least as good: minimises
+// max(rounds0 * cost0, rounds1 * cost1) over the split and compares with rounds0(cus) * cost0 + rounds1(cus) * cost1
+int gemm256p_pair_split(const pst_gemm_params& a, const pst_gemm_params& b, int cus) {
+  if (a.dtype16 != b.dtype16) return 0;
+  const int ca = gemm256_persistent_class(a), cb = gemm256_persistent_class(b);
+  if (ca == 0 || ca != cb) return 0;
+  const long ta = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), tb = (long)((b.M + 255) / 256) * ((b.N + 255) / 256);
+  const long ka = tile_cost(a), kb = tile_cost(b);
+  if (ta < 64 || tb < 64) return 0;
+  const long separate = ((ta + cus - 1) / cus) * ka + ((tb + cus - 1) / cus) * kb;
+  long best = separate;
+  int g0 = 0;
+  for (int g = 8; g <= cus - 8; ++g) {
+    const long t = std::max(((ta + g - 1) / g) * ka, ((tb + (cus - g) - 1) / (cus - g)) * kb);
+    if (t < best) { best = t; g0 = g; }
+  }
+  return (best * 100 <= separate * 97) ? g0 : 0;          // worth it from 3 % on
+}
+
+template <bool F16, bool RES, bool TRANS, bool PP>
+static void launch_256p2_t(const gemm256p2_args& a, hipStream_t s, int grid) {
+  static unsigned long long attr_seen = 0;
+  once_per_device(attr_seen, [] { (void)hipFuncSetAttribute((const void*)gemm256p2_kernel<F16, RES, TRANS, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P); });
+  hipLaunchKernelGGL((gemm256p2_kernel<F16, RES, TRANS, PP>), dim3(grid), dim3(512), LDS256P, s, a);
+}
+template <bool RES, bool TRANS>
+static void launch_256p2_c(const gemm256p2_args& a, hipStream_t s, int grid) {
+  const bool h = a.p[0].dtype16 == DT_F16;
+  if (g_g256_pp) {
+    if (h) launch_256p2_t<true, RES, TRANS, true>(a, s, grid); else launch_256p2_t<false, RES, TRANS, true>(a, s, grid);
+  } else {
+    if (h) launch_256p2_t<true, RES, TRANS, false>(a, s, grid); else launch_256p2_t<false, RES, TRANS, false>(a, s, grid);
+  }
+}
+
+int launch_gemm256p_pair(const pst_gemm_params& pa, const pst_gemm_params& pb, hipStream_t s, int cus, int g0) {
+  gemm256p2_args a;
+  a.p[0] = pa; a.p[1] = pb;
+  const pst_gemm_params* ps[2] = {&pa, &pb};
+  for (int i = 0; i < 2; ++i) {
+    a.tiles_m[i] = (ps[i]->M + 255) / 256;
+    a.tiles_n[i] = (ps[i]->N + 255) / 256;
+    a.ntiles[i] = a.tiles_m[i] * a.tiles_n[i];
+  }
+  a.g0 = g0;
+  const int cls = gemm256_persistent_class(pa);
+  if (cls == 3) launch_256p2_c<false, true>(a, s, cus);
+  else if (cls == 2) launch_256p2_c<true, false>(a, s, cus);
+  else launch_256p2_c<false, false>(a, s, cus);
+  return check_launch("gemm256p (pair)");
 }
 
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus) {

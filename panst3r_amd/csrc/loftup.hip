@@ -76,7 +76,10 @@ __global__ __launch_bounds__(1024) void down2_minmax_kernel(const float* img, fl
     const int y = i / W2, x = i - y * W2;
     const float2 a = *(const float2*)(src + (int64_t)(2 * y) * W + 2 * x);
     const float2 b = *(const float2*)(src + (int64_t)(2 * y + 1) * W + 2 * x);
-    const float v = 0.25f * (a.x + a.y + b.x + b.y);
+    // torch's bilinear x0.5 (align_corners=False) is wh0 (ww0 a00 + ww1 a01) + wh1 (ww0 a10 + ww1 a11) with all weights 0.5 (exact scalings): the two
+    // ROW sums first, then their sum.  ((a + b) + c) + d differs from it by one ulp in 30 % of the pixels - and the Fourier featurizer multiplies the scaled
+    // value by frequencies up to e^10: that ulp was the fp32 mode's 2e-4 mask-logit residue at full size (tests/diag/fp32_bisect.py)
+    const float v = 0.25f * ((a.x + a.y) + (b.x + b.y));
     if (img2) dst[i] = v;
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);

@@ -283,8 +283,9 @@ def gemm(a, w, out, **kw):
 
 
 def gemm_pair(first, second):
-    """Two independent GEMMs - `first` = (a, w, out, kwargs) with a row-major store, `second` with trans_out=True - through pst_gemm_pair: ONE launch
-    when both are small-M problems of the 64 x 64-tile kernel (the q|k and V^T projections of the memory build), else two; same bits either way."""
+    """Two independent GEMMs, each (a, w, out, kwargs), through pst_gemm_pair: ONE launch when both are small-M problems of the 64 x 64-tile kernel
+    (`first` row-major, `second` trans_out: the q|k and V^T projections of the memory build) or two big problems of the same persistent-kernel class
+    whose tile lists fill the chip better side by side (the same layer of two independent ViTs), else two launches; same bits either way."""
     (a1, w1, o1, k1), (a2, w2, o2, k2) = first, second
     p1, f1, t1 = _gemm_params(a1, w1, o1, **k1)
     p2, f2, t2 = _gemm_params(a2, w2, o2, **k2)

@@ -215,9 +215,10 @@ def empty(rows, cols, dtype, device):
     return torch.empty(rows, cols, dtype=dtype, device=device)
 
 
-def self_attention(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
-    """q,k projection (+RoPE) / transposed v projection / flash attention of LN(stream s) with the folded weights w_qk / w_v.
-    `vt`: optional caller-owned V^T scratch [D, >= lay.rows + 8] (saves an allocation per layer)."""
+def self_attention_parts(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
+    """The self-attention of LN(stream s) with the folded weights w_qk / w_v as (q|k projection call, V^T projection call, finish): the two calls are
+    (a, w, out, kwargs) tuples for hip.gemm / hip.gemm_pair, finish() runs what follows them (stand-alone RoPE where it is not fused, flash attention)
+    and returns the attention output.  Split like this so that the SAME layer of two independent ViTs can share launches (vit_block_pair)."""
     dev = s.x.device
     D = H * hd
     qk = empty(lay.rows, 2 * D, adt(), dev)
@@ -230,19 +231,30 @@ def self_attention(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
     # LayerNorm differs, which would overwrite xn under the q|k GEMM - q|k and v must be row slices of one folded qkv pack
     assert xv is xn, 'self_attention: w_qk and w_v must share one LayerNorm (row slices of one qkv pack)'
     fused_rope = rope is not None and hd == 64 and adt() != torch.float32   # RoPE-2D applied in the GEMM's store phase
+    qk_call = (xn, w_qk.w, qk, dict(bias=w_qk.b, gamma=qs, ln=lq, **({'rope': (pos, rope)} if fused_rope else {})))
+    vt_call = (xv, w_v.w, vt, dict(bias=w_v.b, trans_out=True, ln=lv))
+
+    def finish():
+        if rope is not None and not fused_rope:
+            hip.rope2d_(qk, pos, rope, 2 * H, hd)
+        o = empty(lay.rows, D, adt(), dev)
+        if lay.Tp != lay.N:
+            o.view(lay.V, lay.Tp, D)[:, lay.N:].zero_()      # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
+        ldq, ldv = qk.stride(0), vt.stride(0)
+        hip.attention(qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd,
+                      q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq),
+                      v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D), prescaled=True)
+        return o
+    return qk_call, vt_call, finish
+
+
+def self_attention(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
+    """q,k projection (+RoPE) / transposed v projection / flash attention of LN(stream s) with the folded weights w_qk / w_v.
+    `vt`: optional caller-owned V^T scratch [D, >= lay.rows + 8] (saves an allocation per layer)."""
+    qk_call, vt_call, finish = self_attention_parts(s, lay, H, hd, w_qk, w_v, pos, rope, vt)
     # the two projections are independent: one launch for the small-M case (the memory build's 768 rows), two for the big ones - the C side decides
-    hip.gemm_pair((xn, w_qk.w, qk, dict(bias=w_qk.b, gamma=qs, ln=lq, **({'rope': (pos, rope)} if fused_rope else {}))),
-                  (xv, w_v.w, vt, dict(bias=w_v.b, trans_out=True, ln=lv)))
-    if rope is not None and not fused_rope:
-        hip.rope2d_(qk, pos, rope, 2 * H, hd)
-    o = empty(lay.rows, D, adt(), dev)
-    if lay.Tp != lay.N:
-        o.view(lay.V, lay.Tp, D)[:, lay.N:].zero_()      # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
-    ldq, ldv = qk.stride(0), vt.stride(0)
-    hip.attention(qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd,
-                  q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq),
-                  v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D), prescaled=True)
-    return o
+    hip.gemm_pair(qk_call, vt_call)
+    return finish()
 
 
 class BlockW:
@@ -328,14 +340,18 @@ class Stream:
             self.dirty, self.eps = False, lid
         return self.xb, None
 
-    def residual(self, a, w, gamma=None, res=None):
-        """x = (res or x) + gamma * (a W^T + b); in fold mode the epilogue also refreshes xb / st"""
+    def residual_call(self, a, w, gamma=None, res=None):
+        """the (a, w, out, kwargs) call of `residual` for hip.gemm / hip.gemm_pair; the caller launches it (and nothing may read the stream before)"""
         r = self.x if res is None else res
         if self.fold:
-            hip.gemm(a, w.w, self.x, bias=w.b, gamma=gamma, res=r, xcopy=None if self.xb is self.x else self.xb, stats_out=self.st)
-        else:
-            hip.gemm(a, w.w, self.x, bias=w.b, gamma=gamma, res=r)
-            self.dirty = True
+            return (a, w.w, self.x, dict(bias=w.b, gamma=gamma, res=r, xcopy=None if self.xb is self.x else self.xb, stats_out=self.st))
+        self.dirty = True
+        return (a, w.w, self.x, dict(bias=w.b, gamma=gamma, res=r))
+
+    def residual(self, a, w, gamma=None, res=None):
+        """x = (res or x) + gamma * (a W^T + b); in fold mode the epilogue also refreshes xb / st"""
+        a_, w_, o_, kw = self.residual_call(a, w, gamma, res)
+        hip.gemm(a_, w_, o_, **kw)
 
 
 def vit_block(s, bw, lay, H, hd, pos=None, rope=None):
@@ -349,6 +365,24 @@ def vit_block(s, bw, lay, H, hd, pos=None, rope=None):
     hip.gemm(a, bw.fc1.w, h, bias=bw.fc1.b, act='gelu', ln=ln)
     s.residual(h, bw.fc2, gamma=bw.ls2)
     return s
+
+
+def vit_block_pair(a, b):
+    """The same layer of TWO independent pre-LN ViTs in lock-step (a, b = (stream, BlockW, Layout, H, hd, pos, rope)): every GEMM of the layer is
+    issued through hip.gemm_pair, so the two problems of a kind share ONE launch of the persistent kernel when that beats two (tile quantisation:
+    panst3r_hip.h pst_gemm_pair).  Same kernels on the same tiles as two vit_block calls: bit-identical results."""
+    (sa, wa, la, Ha, hda, pa, ra), (sb, wb, lb, Hb, hdb, pb, rb) = a, b
+    qa, va, fa = self_attention_parts(sa, la, Ha, hda, wa.qk, wa.v, pa, ra)
+    qb, vb, fb = self_attention_parts(sb, lb, Hb, hdb, wb.qk, wb.v, pb, rb)
+    hip.gemm_pair(qa, qb)
+    hip.gemm_pair(va, vb)
+    oa, ob = fa(), fb()
+    hip.gemm_pair(sa.residual_call(oa, wa.proj, gamma=wa.ls1), sb.residual_call(ob, wb.proj, gamma=wb.ls1))
+    ha, hb = empty(la.rows, wa.fc1.n, adt(), sa.x.device), empty(lb.rows, wb.fc1.n, adt(), sb.x.device)
+    xa, lna = sa.operand(wa.fc1)
+    xb, lnb = sb.operand(wb.fc1)
+    hip.gemm_pair((xa, wa.fc1.w, ha, dict(bias=wa.fc1.b, act='gelu', ln=lna)), (xb, wb.fc1.w, hb, dict(bias=wb.fc1.b, act='gelu', ln=lnb)))
+    hip.gemm_pair(sa.residual_call(ha, wa.fc2, gamma=wa.ls2), sb.residual_call(hb, wb.fc2, gamma=wb.ls2))
 
 
 class ParamLinear(nn.Linear):

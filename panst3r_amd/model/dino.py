@@ -132,17 +132,14 @@ class DinoV2Encoder(HipModule):
     def patch_width(self, device):
         return self.packed(device)['patch'].k
 
-    def encode_tokens(self, img, out, col0=0, patches=None, transposed=False):
-        """img fp32 [V,3,H,W] in [-1,1] -> 16-bit tokens written to out[:, col0:col0+D].  `transposed`: DINOv2 runs on the TRANSPOSED image
-        (portrait views with landscape_only, model/dino.py:15-47) - sampled with swapped axes, no transposed copy.  ImageNet
-        normalisation + bilinear resize to the 14-pixel grid + 14x14 patch rows are one kernel (hip.patch_rows); `patches` when the
-        caller already produced them together with the encoder's."""
+    def begin_tokens(self, img, patches=None, transposed=False):
+        """embeddings + everything the layers need, as a state dict (see Dust3rEncoder.begin_tokens: the lock-step form of encode_tokens)"""
         dev = img.device
         pk = self.packed(dev)
         V, _, H, W = img.shape
         if transposed:
             H, W = W, H
-        p, D, Hh = self.patch_size, self.embed_dim, self.num_heads
+        p, D = self.patch_size, self.embed_dim
         gh, gw = H // self.output_stride, W // self.output_stride
         lay = Layout(V, gh * gw, extra=1)
         if patches is None:
@@ -154,13 +151,28 @@ class DinoV2Encoder(HipModule):
         hip.gemm(patches, pk['patch'].w, x, bias=pk['patch'].b, res=pospatch, res_mod=lay.T, grp=lay.grp)
         if TAPS is not None:
             TAPS.append(('patches', patches.clone())); TAPS.append(('embed', x.clone()))
-        s = Stream(x).refresh()
-        for i, bw in enumerate(pk['blocks']):
-            vit_block(s, bw, lay, Hh, D // Hh)
-            if TAPS is not None:
-                TAPS.append(('block %d' % i, x.clone()))
-        hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, col0:col0 + D], pk['norm'][2], rows=V * lay.T, grp=lay.grp)
+        return dict(pk=pk, x=x, s=Stream(x).refresh(), lay=lay, V=V)
+
+    def blocks(self, st):
+        D, Hh = self.embed_dim, self.num_heads
+        return [(st['s'], bw, st['lay'], Hh, D // Hh, None, None) for bw in st['pk']['blocks']]
+
+    def finish_tokens(self, st, out, col0=0):
+        pk, lay, D = st['pk'], st['lay'], self.embed_dim
+        hip.layernorm(st['x'], pk['norm'][0], pk['norm'][1], out[:, col0:col0 + D], pk['norm'][2], rows=st['V'] * lay.T, grp=lay.grp)
         return out
+
+    def encode_tokens(self, img, out, col0=0, patches=None, transposed=False):
+        """img fp32 [V,3,H,W] in [-1,1] -> 16-bit tokens written to out[:, col0:col0+D].  `transposed`: DINOv2 runs on the TRANSPOSED image
+        (portrait views with landscape_only, model/dino.py:15-47) - sampled with swapped axes, no transposed copy.  ImageNet
+        normalisation + bilinear resize to the 14-pixel grid + 14x14 patch rows are one kernel (hip.patch_rows); `patches` when the
+        caller already produced them together with the encoder's."""
+        st = self.begin_tokens(img, patches, transposed)
+        for i, args in enumerate(self.blocks(st)):
+            vit_block(*args)
+            if TAPS is not None:
+                TAPS.append(('block %d' % i, st['x'].clone()))
+        return self.finish_tokens(st, out, col0)
 
     def forward(self, image, true_shape):
         """Reference signature (model/dino.py:59-71): [b,3,H,W], true_shape [b,2] -> [b,T,1024] (CLS dropped)."""

@@ -38,10 +38,9 @@ class Dust3rEncoder(HipModule):
         return grow_table(pk['rope'], n, lambda m: hip.rope_table(m, hd, self.rope_base, device))
 
     @torch.no_grad()
-    def encode_tokens(self, img, out=None, patches=None):
-        """img fp32 [V,3,H,W] (one shape) -> 16-bit tokens [V*T, out_ld] written into `out[:, :D]` (or a new buffer),
-        plus int32 positions [V*T, 2].  `patches`: the 16x16 patch rows when the caller already produced them (hip.patch_rows makes the
-        rows of both ViTs in one launch)."""
+    def begin_tokens(self, img, patches=None):
+        """patch embedding + everything the blocks need, as a state dict; `blocks(state)` yields one vit_block argument tuple per layer and
+        `finish_tokens` applies the final norm - split so that PanSt3R.encode_views can run this ViT in lock-step with DINOv2 (vit_block_pair)."""
         dev = img.device
         pk = self.packed(dev)
         V, _, H, W = img.shape
@@ -55,14 +54,29 @@ class Dust3rEncoder(HipModule):
         hip.gemm(patches, pk['patch'].w, x, bias=pk['patch'].b, grp=lay.grp)
         pos = grid_pos(V, gh, gw, lay.Tp, 0, dev)
         rope = self.rope_table(pk, max(gh, gw), D // Hh, dev)
-        s = Stream(x).refresh()
-        for bw in pk['blocks']:
-            vit_block(s, bw, lay, Hh, D // Hh, pos, rope)
+        return dict(pk=pk, x=x, s=Stream(x).refresh(), lay=lay, pos=pos, rope=rope, V=V, gh=gh, gw=gw, dev=dev)
+
+    def blocks(self, st):
+        D, Hh = self.embed_dim, self.num_heads
+        return [(st['s'], bw, st['lay'], Hh, D // Hh, st['pos'], st['rope']) for bw in st['pk']['blocks']]
+
+    def finish_tokens(self, st, out=None):
+        pk, lay, D = st['pk'], st['lay'], self.embed_dim
         if out is None:
-            out = empty(V * lay.T, D, adt(), dev)
-        hip.layernorm(x, pk['norm'][0], pk['norm'][1], out[:, :D] if out.shape[1] != D else out, pk['norm'][2],
-                      rows=V * lay.T, grp=lay.grp)
-        return out, grid_pos(V, gh, gw, lay.T, 0, dev)
+            out = empty(st['V'] * lay.T, D, adt(), st['dev'])
+        hip.layernorm(st['x'], pk['norm'][0], pk['norm'][1], out[:, :D] if out.shape[1] != D else out, pk['norm'][2],
+                      rows=st['V'] * lay.T, grp=lay.grp)
+        return out, grid_pos(st['V'], st['gh'], st['gw'], lay.T, 0, st['dev'])
+
+    @torch.no_grad()
+    def encode_tokens(self, img, out=None, patches=None):
+        """img fp32 [V,3,H,W] (one shape) -> 16-bit tokens [V*T, out_ld] written into `out[:, :D]` (or a new buffer),
+        plus int32 positions [V*T, 2].  `patches`: the 16x16 patch rows when the caller already produced them (hip.patch_rows makes the
+        rows of both ViTs in one launch)."""
+        st = self.begin_tokens(img, patches)
+        for args in self.blocks(st):
+            vit_block(*args)
+        return self.finish_tokens(st, out)
 
     def forward(self, img, true_shape=None):
         V = img.shape[0]

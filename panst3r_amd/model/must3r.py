@@ -42,17 +42,21 @@ class _HeadP(nn.Module):
 class MemoryBank:
     """Per-layer projected memory: K[l] bf16 [cap, D], Vt[l] bf16 [D, cap+8]; `n` tokens are valid."""
 
-    def __init__(self, L, D, cap, device):
+    def __init__(self, L, D, cap, device, dtype=None, f32=False):
         self.L, self.D, self.cap, self.n = L, D, cap, 0
+        self.dtype = adt() if dtype is None else dtype
         self._alloc(cap, device)
         self.labels = []          # image id of every T-token slot
         self.nimgs = 0
+        # the SAME entries projected in fp32 (reference AMP placement, panst3r.py:268: the views that are not keyframes are rendered OUTSIDE
+        # autocast, i.e. in fp32, against the memory the autocast build left behind): a second bank the append keeps in step
+        self.f32 = MemoryBank(L, D, cap, device, dtype=torch.float32) if (f32 and self.dtype != torch.float32) else None
 
     def _alloc(self, cap, device):
         # one allocation per kind: the L per-layer caches are equally strided slices, so an append projects the new
         # entries of all layers with ONE strided-batch GEMM launch for K and one for V^T
-        self.K_all = torch.zeros(self.L, cap, self.D, dtype=adt(), device=device)
-        self.Vt_all = torch.zeros(self.L, self.D, (cap + 7) // 8 * 8 + 8, dtype=adt(), device=device)      # 16-byte rows
+        self.K_all = torch.zeros(self.L, cap, self.D, dtype=self.dtype, device=device)
+        self.Vt_all = torch.zeros(self.L, self.D, (cap + 7) // 8 * 8 + 8, dtype=self.dtype, device=device)      # 16-byte rows
         self.K = [self.K_all[l] for l in range(self.L)]
         self.Vt = [self.Vt_all[l] for l in range(self.L)]
 
@@ -65,6 +69,8 @@ class MemoryBank:
         self.K_all[:, :self.n] = K_old[:, :self.n]
         self.Vt_all[:, :, :self.n] = Vt_old[:, :, :self.n]
         self.cap = cap
+        if self.f32 is not None:
+            self.f32.reserve(n_tokens)
 
     # list-like face expected by the reference glue (engine/must3r.py:76-80 reads mem_vals[-1].shape)
     def __len__(self):
@@ -126,8 +132,8 @@ class MUSt3R(HipModule):
     def _rope(self, pk, n, device):
         return grow_table(pk['rope'], n, lambda m: hip.rope_table(m, self.embed_dim // self.num_heads, self.rope_base, device))
 
-    def new_bank(self, device, cap_tokens):
-        return MemoryBank(self.depth, self.embed_dim, cap_tokens, device)
+    def new_bank(self, device, cap_tokens, f32=False):
+        return MemoryBank(self.depth, self.embed_dim, cap_tokens, device, f32=f32)
 
     # ------------------------------------------------------------------ core
     def _embed(self, pk, x_enc, lay, first_is_ref, out=None):
@@ -302,7 +308,7 @@ class MUSt3R(HipModule):
         out = empty(lay.rows, D, torch.float32, dev)
         hip.layernorm(hs[-1], pk['norm'][0], pk['norm'][1], out, pk['norm'][2])
         fb = None
-        if self.feedback_type:
+        if self.feedback_type and not getattr(self, '_test_skip_feedback', False):      # (_test_skip_feedback: tests/test_hip_negative.py's deliberately wrong bank)
             fbn = empty(lay.rows, D, adt(), dev)
             hip.layernorm(out, pk['fb_norm'][0], pk['fb_norm'][1], fbn, pk['fb_norm'][2])
             hh = empty(lay.rows, pk['fb1'].n, adt(), dev)
@@ -334,10 +340,35 @@ class MUSt3R(HipModule):
             hip.gemm(y[0], pk['mem_vw'][0], tmp[0], bias=pk['mem_vb'][0], trans_out=True,
                      batch=(L, rows * D, pk['mem_vw'].stride(0), tmp.stride(0), D))
             bank.Vt_all[:, :, bank.n:bank.n + rows].copy_(tmp[:, :, :rows])
+        if bank.f32 is not None:
+            self._append_f32(bank, hs, hs_all, fb, lay, rows)
         bank.n += n * T
         bank.labels += list(range(bank.nimgs, bank.nimgs + n))
         bank.nimgs += n
         return out
+
+    def _append_f32(self, bank, hs, hs_all, fb, lay, rows):
+        """the fp32 twin of the append: norm_y(h_l + feedback) and projk / projv in float32 (fp32 weights, fp32-input MFMA) from the SAME streams the
+        16-bit build produced - what the reference's fp32 render of the other views reads out of the autocast-built memory (panst3r.py:268)."""
+        from .common import precision
+        b32, dev, D, L = bank.f32, hs[0].device, self.embed_dim, self.depth
+        with precision(torch.float32):
+            pk = self.packed(dev)
+            y = torch.empty(L, rows, D, dtype=torch.float32, device=dev)
+            if hs_all is not None:
+                hip.layernorm_batch(hs_all[:L], pk['mem_ng'], pk['mem_nb'], y, pk['blocks'][0].cross['norm_y'][2], rows=rows, grp=lay.grp, add=fb)
+            else:
+                for l, bw in enumerate(pk['blocks']):
+                    c = bw.cross
+                    hip.layernorm(hs[l], c['norm_y'][0], c['norm_y'][1], y[l], c['norm_y'][2], rows=rows, grp=lay.grp, add=fb)
+            hip.gemm(y[0], pk['mem_kw'][0], b32.K_all[0, bank.n: bank.n + rows], bias=pk['mem_kb'][0],
+                     batch=(L, rows * D, pk['mem_kw'].stride(0), b32.K_all.stride(0), D))
+            tmp = torch.empty(L, D, (rows + 7) // 8 * 8 + 8, dtype=torch.float32, device=dev)
+            hip.gemm(y[0], pk['mem_vw'][0], tmp[0], bias=pk['mem_vb'][0], trans_out=True,
+                     batch=(L, rows * D, pk['mem_vw'].stride(0), tmp.stride(0), D))
+            b32.Vt_all[:, :, bank.n:bank.n + rows].copy_(tmp[:, :, :rows])
+        b32.n = bank.n + rows
+        b32.labels, b32.nimgs = bank.labels, bank.nimgs
 
     # ------------------------------------------------------------------ reference-signature wrapper
     def forward(self, x, pos, true_shape, mem=None, render=False, return_feats=False):

@@ -30,6 +30,16 @@ from .schedule import mem_batches
 ENC_CHUNK = 64        # views per encoder / DINOv2 / render pass (M = views*T rows through every GEMM)
 
 
+def pan_amp_of(amp, panoptic_precision):
+    """`panoptic_precision` -> the `amp` value of the panoptic decoder (+ the other views' render): None / 'amp' = the scene's format, 'reference' = fp32
+    (the reference runs those parts outside torch.autocast, panst3r.py:236-245,268)"""
+    if panoptic_precision in (None, 'amp'):
+        return None
+    if panoptic_precision != 'reference':
+        raise ValueError("panoptic_precision must be None, 'amp' or 'reference' (got %r)" % (panoptic_precision,))
+    return False
+
+
 class PanSt3R(nn.Module):
     def __init__(self, must3r_encoder, must3r_decoder, dino_encoder, panoptic_decoder, retrieval=None, preserve_gpu_mem=False,
                  postprocess_default='standard_v2', qubo_enabled=True, must3r_encoder_requires_grad=False,
@@ -134,6 +144,34 @@ class PanSt3R(nn.Module):
             mks.append(mk)
         return (pms, mks) if multi_ar else (pms[0], mks[0])
 
+    @torch.no_grad()
+    def encode_views_paired(self, imgs_enc, cat_enc, imgs_dino, cat_dino):
+        """CroCo encoder of `imgs_enc` and DINOv2 of `imgs_dino` (two independent ViT-L towers, panst3r.py:174-175 and :229-230) layer by layer in
+        LOCK-STEP: the GEMMs of layer l of both towers go through hip.gemm_pair and share one persistent launch where the two tile lists fill the chip
+        better side by side (model/common.py vit_block_pair).  Results are bit-identical to encode_views(enc only) + encode_views(dino only).
+        Falls back to the two sequential passes when a tower needs more than one chunk of views."""
+        from .model.common import vit_block, vit_block_pair
+        Ve, Vd = imgs_enc.shape[0], imgs_dino.shape[0]
+        if Ve == 0 or Vd == 0 or Ve > ENC_CHUNK or Vd > ENC_CHUNK or tuple(imgs_enc.shape[1:]) != tuple(imgs_dino.shape[1:]):
+            if Ve:
+                self.encode_views(imgs_enc, cat_enc, dino=False)
+            if Vd:
+                self.encode_views(imgs_dino, cat_dino, enc=False)
+            return
+        H, W = imgs_dino.shape[-2:]
+        De, Dd = self.must3r_encoder.embed_dim, self.must3r_decoder.embed_dim
+        tr = bool(H > W and self.dino_encoder.landscape_only)
+        se = self.must3r_encoder.begin_tokens(imgs_enc.contiguous())
+        sd = self.dino_encoder.begin_tokens(imgs_dino.contiguous(), transposed=tr)
+        be, bd = self.must3r_encoder.blocks(se), self.dino_encoder.blocks(sd)
+        n = min(len(be), len(bd))
+        for l in range(n):
+            vit_block_pair(be[l], bd[l])
+        for args in be[n:] + bd[n:]:
+            vit_block(*args)
+        self.must3r_encoder.finish_tokens(se, cat_enc)
+        self.dino_encoder.finish_tokens(sd, cat_dino, col0=De + Dd)
+
     # ------------------------------------------------------------------ scene stages (token level)
     def _cat_width(self):
         return self.must3r_encoder.embed_dim + self.must3r_decoder.embed_dim + self.dino_encoder.embed_dim
@@ -161,7 +199,7 @@ class PanSt3R(nn.Module):
                 self.dino_encoder.encode_tokens(im, cat[sl], col0=De + Dd, patches=pdn, transposed=tr)
 
     @torch.no_grad()
-    def build_memory(self, enc_kf, K, h=None, w=None, grids=None):
+    def build_memory(self, enc_kf, K, h=None, w=None, grids=None, f32_bank=False):
         """Sequential keyframe memory build, batches [2,1,1,...] (panst3r.py:65-70,205-210).
         enc_kf: bf16 rows of the K keyframes' encoder tokens, concatenated in schedule order; `grids` = per-keyframe (h, w)
         token grids for multi-aspect-ratio scenes (default: all (h, w))."""
@@ -170,7 +208,7 @@ class PanSt3R(nn.Module):
         offs = [0]
         for T in Ts:
             offs.append(offs[-1] + T)
-        bank = self.must3r_decoder.new_bank(enc_kf.device, offs[-1])
+        bank = self.must3r_decoder.new_bank(enc_kf.device, offs[-1], f32=f32_bank)        # f32_bank: fp32 twin for the reference's AMP placement
         De = self.must3r_encoder.embed_dim
         start = 0
         for nb in self.get_must3r_mem_batches(K):
@@ -185,22 +223,25 @@ class PanSt3R(nn.Module):
         return bank
 
     @torch.no_grad()
-    def render_views(self, cat, V, h, w, bank):
-        """Render V views against the memory: decoder features -> cat[:, De:De+Dd]; returns pointmaps fp32 [V,H,W,7]."""
+    def render_views(self, cat, V, h, w, bank, enc=None):
+        """Render V views against the memory: decoder features -> cat[:, De:De+Dd]; returns pointmaps fp32 [V,H,W,7].
+        enc: the views' encoder tokens [V*T, >= De] in the format in effect when `cat` is kept in another one (reference AMP placement)."""
         T = h * w
         De, Dd = self.must3r_encoder.embed_dim, self.must3r_decoder.embed_dim
         pms = []
         for v0 in range(0, V, ENC_CHUNK):
             n = min(ENC_CHUNK, V - v0)
             rows = cat[v0 * T:(v0 + n) * T]
-            pm, _ = self.must3r_decoder.render_tokens(rows[:, :De], n, h, w, bank, feat_out=rows[:, De:De + Dd])
+            xe = rows[:, :De] if enc is None else enc[v0 * T:(v0 + n) * T, :De]
+            pm, _ = self.must3r_decoder.render_tokens(xe, n, h, w, bank, feat_out=rows[:, De:De + Dd])
             pms.append(pm)
         return torch.cat(pms) if len(pms) > 1 else pms[0]
 
     # ------------------------------------------------------------------ reference API
     @torch.no_grad()
     def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=None,
-                                   outdevice=None, amp=False, sim_matrix=None, keyframes=None, check_finite=True, cache_graphs=False):
+                                   outdevice=None, amp=False, sim_matrix=None, keyframes=None, check_finite=True, cache_graphs=False,
+                                   panoptic_precision=None):
         """imgs: list[V] of [3,H,W] in [-1,1]; true_shape [V,2]; returns (pointmaps list[V] of [1,H,W,7],
         {'pred_logits' [1,Q,Ncls], 'pred_masks' list[V] of [1,Q,H/2,W/2], 'out_queries' [Q,1,768]}).
         Keyframes: linspace over the views (panst3r.py:183-186) by default.  `use_retrieval=True` (panst3r.py:179-180) takes the
@@ -210,6 +251,11 @@ class PanSt3R(nn.Module):
         `max_bs` (reference default None; the demo passes 1): the reference stacks same-shape views in chunks of max_bs and LoftUp's MinMaxScaler
         pools min / max over each chunk (loftup.py:14-19, panst3r.py:212-216,257-261) - None scales all same-shape keyframes
         together and all same-shape other views together, 1 scales every view on its own.  Everything else is chunk-invariant and batched here.
+        `panoptic_precision` (not in the reference): None = everything in the format `amp` names (the fast default: InputMixer, upscaler, query decoder and
+        mask head on 16-bit operands as well - SURVEY 8(d) sanctions it against the stated tolerances).  'reference' = the reference's own placement
+        under --amp (panst3r.py:174-175,204-234 autocast the encoder, the memory build and the keyframes' render + DINOv2 only; the WHOLE panoptic
+        decoder :236-245 and the render + DINOv2 + heads of the views that are not keyframes :268 run outside autocast): those parts run on the fp32
+        kernels here too (~2.5x the scene time; the encoder tokens of every view stay 16-bit-computed, as in the reference).
         `cache_graphs=True` (not in the reference) keeps the scene's runner: repeated calls with the same signature replay captured HIP
         graphs (see _runner_for; `clear_runners()` frees them).  Default: one eager pass, nothing kept."""
         if use_retrieval and keyframes is None:
@@ -222,7 +268,7 @@ class PanSt3R(nn.Module):
         shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
         H, W = shapes[0]
         fmt = amp_dtype(amp)                    # tells (once) that amp=False is the slow fp32 mode
-        runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs)
+        runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs, panoptic_precision)
         res, scene = runner.run(outdevice)
         if check_finite and fmt == torch.float16:
             # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: ONE fused flag over everything the
@@ -246,7 +292,7 @@ class PanSt3R(nn.Module):
             runner.release()                    # a one-off scene keeps no intermediates (stacked inputs, features, mask features) alive
         return pms, panout
 
-    def _runner_for(self, imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs=1):
+    def _runner_for(self, imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs=1, panoptic_precision=None):
         """The SceneRunner of a call.  Default: a fresh eager runner, dropped after the call (what the reference's per-call execution
         costs in memory).  cache_graphs=True: runners are kept per scene SIGNATURE - everything a captured graph depends on: shapes,
         keyframe schedule, class list, device, format, and the version of every weight and class embedding (module generations bumped
@@ -258,20 +304,20 @@ class PanSt3R(nn.Module):
         H, W = shapes[0]
         if not cache_graphs:
             return SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
-                               keyframes=keyframes, amp=amp, minmax_bs=max_bs)
+                               keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pan_amp_of(amp, panoptic_precision))
         from .model.common import HipModule
         te = self.panoptic_decoder.text_encoder
         gens = tuple(m.generation for m in self.modules() if isinstance(m, HipModule))
         pver = sum(p._version for p in self.parameters())
         cver = tuple((c, te.class_embeddings[c].data_ptr(), te.class_embeddings[c]._version) if c in te.class_embeddings else (c,) for c in classes)
         key = (tuple(shapes), num_keyframes, None if keyframes is None else tuple(int(k) for k in keyframes), str(dev),
-               amp_dtype(amp, quiet=True), gens, pver, cver, getattr(te, '_cls_gen', 0), max_bs)
+               amp_dtype(amp, quiet=True), gens, pver, cver, getattr(te, '_cls_gen', 0), max_bs, panoptic_precision)
         ent = self._runners.get(key)
         if ent is None:
             while len(self._runners) >= max(1, self.max_cached_runners):
                 self._runners.pop(next(iter(self._runners)))
             runner = SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
-                                 keyframes=keyframes, amp=amp, minmax_bs=max_bs)
+                                 keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pan_amp_of(amp, panoptic_precision))
             ent = self._runners[key] = [0, runner]
         else:
             ent[1].set_images(imgs)
@@ -294,7 +340,7 @@ class PanSt3R(nn.Module):
         return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice, amp=amp, plan=plan)
 
     def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None, keyframes=None, amp=False,
-                     plan='replicated', max_bs=1):
+                     plan='replicated', max_bs=1, panoptic_precision=None):
         """Static-shape scene runner (panst3r_amd/scene.py): `images` = {view_id: [3,H,W] device tensor} of the views
         this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True.
         `overlap=True` runs the memory build beside the bulk encoder work on a second stream (faster, NOT reproducible on this
@@ -304,7 +350,7 @@ class PanSt3R(nn.Module):
         from .scene import SceneRunner, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
         return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes, amp=amp,
-                           plan=plan, minmax_bs=max_bs)
+                           plan=plan, minmax_bs=max_bs, pan_amp=pan_amp_of(amp, panoptic_precision))
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False):

@@ -116,7 +116,7 @@ DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a calla
 
 class _Group:
     """The views of one image shape owned by this rank (keyframes first)."""
-    __slots__ = ('H', 'W', 'h', 'w', 'T', 'idx', 'k', 'imgs', 'cat', 'pointmaps', 'fpn', 'mf', 'guid', 'mm')
+    __slots__ = ('H', 'W', 'h', 'w', 'T', 'idx', 'k', 'imgs', 'cat', 'pointmaps', 'fpn', 'mf', 'guid', 'mm', 'enc')
 
 
 class SceneRunner:
@@ -133,8 +133,13 @@ class SceneRunner:
     (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
     def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None,
-                 amp=None, plan='replicated', minmax_bs=1):
+                 amp=None, plan='replicated', minmax_bs=1, pan_amp=None):
         self.b, self.V, self.classes = backend, V, classes
+        # reference AMP placement (panst3r.py:174-175,204-245,268): `amp` names the format of the encoder, the memory build and the keyframes' render +
+        # DINOv2; `pan_amp` (None = the same format) that of the panoptic decoder AND of the render + DINOv2 of the views that are not keyframes.
+        # With two formats in play (`mixed`) the feature concat is kept in the panoptic format and the encoder tokens additionally in the scene's.
+        self.pan_amp = amp if pan_amp is None else pan_amp
+        self.mixed = pan_amp is not None and not backend.same_format(amp, pan_amp)
         # LoftUp's MinMaxScaler scope (loftup.py:14-19 pools min / max over the chunk of views it is handed; the reference chunks by max_bs):
         # 1 = per view (the demo's max_bs=1, tools/demo_panst3r.py:201 - the default here and what bench.py times); k = same-shape keyframes /
         # same-shape other views in chunks of k, None = all of them together (the reference with max_bs=None: stack_views + batched_map,
@@ -228,23 +233,37 @@ class SceneRunner:
         b = self.b
         rows = []
         for g in self.groups:
-            g.cat = b.alloc_cat(len(g.idx) * g.T, g.imgs.device)
+            with b.precision(self.pan_amp):
+                g.cat = b.alloc_cat(len(g.idx) * g.T, g.imgs.device)
+            g.enc = b.alloc_enc(len(g.idx) * g.T, g.imgs.device) if self.mixed else None       # encoder tokens in the scene's format (mixed: cat is not)
             if g.k:
-                b.encode_enc(g.imgs[:g.k], g.cat[:g.k * g.T])
-            rows.append(b.enc_rows(g.cat, g.k * g.T))
+                b.encode_enc(g.imgs[:g.k], g.cat[:g.k * g.T], None if g.enc is None else g.enc[:g.k * g.T])
+            rows.append(b.enc_rows(g.cat if g.enc is None else g.enc, g.k * g.T))
         self.enc_send = self._kf_rows(rows)
 
     def _encode_rest(self):
         """Everything the build does not depend on: encoder of the non-keyframe views + DINOv2 of every view."""
         b = self.b
         for g in self.groups:
+            if not self.mixed and len(g.idx) > g.k and hasattr(b, 'encode_rest_paired'):
+                # the encoder of the views that are not keyframes and DINOv2 of all views, layer by layer in lock-step (shared launches)
+                b.encode_rest_paired(g.imgs[g.k:], g.cat[g.k * g.T:], g.imgs, g.cat)
+                continue
             if len(g.idx) > g.k:
-                b.encode_enc(g.imgs[g.k:], g.cat[g.k * g.T:])
-            b.encode_dino(g.imgs, g.cat)
-        mms = b.minmax_tables([g.imgs for g in self.groups], self.mm_scope) if self.mm_scope is not None else [None] * len(self.groups)
-        for g, mm in zip(self.groups, mms):     # image-only part of the upscaler (LoftUp guidance convs, SURVEY 8(e) phase A): memory-independent,
-            g.mm = mm                         # so it belongs to this branch (with overlap=True it fills the tail of the memory build)
-            g.guid = b.guidance(g.imgs, g.h, g.w, mm)
+                b.encode_enc(g.imgs[g.k:], g.cat[g.k * g.T:], None if g.enc is None else g.enc[g.k * g.T:])
+            if not self.mixed:
+                b.encode_dino(g.imgs, g.cat)
+            else:               # reference placement: DINOv2 of the keyframes under autocast (panst3r.py:229-230), of the other views outside it (:150 via :268)
+                if g.k:
+                    b.encode_dino(g.imgs[:g.k], g.cat[:g.k * g.T])
+                if len(g.idx) > g.k:
+                    with b.precision(self.pan_amp):
+                        b.encode_dino(g.imgs[g.k:], g.cat[g.k * g.T:])
+        with b.precision(self.pan_amp):
+            mms = b.minmax_tables([g.imgs for g in self.groups], self.mm_scope) if self.mm_scope is not None else [None] * len(self.groups)
+            for g, mm in zip(self.groups, mms):     # image-only part of the upscaler (LoftUp guidance convs, SURVEY 8(e) phase A): memory-independent,
+                g.mm = mm                         # so it belongs to this branch (with overlap=True it fills the tail of the memory build)
+                g.guid = b.guidance(g.imgs, g.h, g.w, mm)
 
     def gather1(self):
         kf = gather_keyframe_rows(self.enc_send, self.K, self.kf_T, rank=self.rank, world=self.world, group=self.group)
@@ -268,16 +287,16 @@ class SceneRunner:
         dev = self.groups[0].imgs.device
         if self.split:
             if self.builder:
-                self.bank = b.build_memory(self.enc_kf, self.K, self.kf_grids)
+                self.bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.mixed)
             else:
                 self._encode_rest()
-                self.bank = b.bank_alloc(self.K, self.kf_grids, dev)
+                self.bank = b.bank_alloc(self.K, self.kf_grids, dev, self.mixed)
             return
         # (measured +5 % frames/s at 50 views, but unsafe on this platform - see OVERLAP_DEFAULT - hence only when asked for)
         side = b.side_stream(dev) if not self.serial else None
         if side is None:
             self._encode_rest()
-            bank = b.build_memory(self.enc_kf, self.K, self.kf_grids)
+            bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.mixed)
         else:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
@@ -286,9 +305,9 @@ class SceneRunner:
             if DIAG_CONCURRENT is not None:        # diagnostics only (tests/diag/dino_taps.py): some other workload beside the side branch
                 DIAG_CONCURRENT()
                 main.wait_stream(side)
-                bank = b.build_memory(self.enc_kf, self.K, self.kf_grids)
+                bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.mixed)
             else:
-                bank = b.build_memory(self.enc_kf, self.K, self.kf_grids)
+                bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.mixed)
                 main.wait_stream(side)
         self.bank = bank
 
@@ -305,10 +324,19 @@ class SceneRunner:
         rows = []
         for g in self.groups:
             n = len(g.idx)
-            g.pointmaps = b.render(g.cat, n, g.h, g.w, bank)
-            g.fpn, g.mf = b.features(g.cat, g.imgs, n, g.h, g.w, g.guid, g.mm)
-            g.guid = g.mm = None
-            fm = b.attn_feats(g.mf, g.k, b.fpn_grid(g.h, g.w)[0])
+            if not self.mixed:
+                g.pointmaps = b.render(g.cat, n, g.h, g.w, bank)
+            else:               # reference placement: keyframes rendered in the scene's format (panst3r.py:221-227), the other views in the panoptic one (:268)
+                kT = g.k * g.T
+                pms = [b.render(g.cat[:kT], g.k, g.h, g.w, bank, g.enc[:kT])] if g.k else []
+                if n > g.k:
+                    with b.precision(self.pan_amp):
+                        pms.append(b.render(g.cat[kT:], n - g.k, g.h, g.w, b.bank_f32(bank)))
+                g.pointmaps = torch.cat(pms) if len(pms) > 1 else pms[0]
+            with b.precision(self.pan_amp):
+                g.fpn, g.mf = b.features(g.cat, g.imgs, n, g.h, g.w, g.guid, g.mm)
+                g.guid = g.mm = None
+                fm = b.attn_feats(g.mf, g.k, b.fpn_grid(g.h, g.w)[0])
             self.d = g.fpn.shape[1]
             rows.append(torch.cat([g.fpn[:g.k * g.T], fm], dim=1) if g.k else g.fpn.new_zeros(0, self.d + b.mask_dim))
         self.both_send = self._kf_rows(rows)
@@ -322,14 +350,15 @@ class SceneRunner:
 
     def stage3(self):
         b = self.b
-        outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.kf_fpn_grids,
-                              self.classes, self.kf_portrait)
-        masks = [None] * self.n_local
-        for g in self.groups:
-            gm = b.masks_group(head, g.mf)          # [n, Q, Hm, Wm]: all views of the shape group in one launch where the backend can
-            for r, j in enumerate(g.idx):
-                masks[j] = gm[r]
-        self.out = (outq, b.logits(head), masks)
+        with b.precision(self.pan_amp):
+            outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.kf_fpn_grids,
+                                  self.classes, self.kf_portrait)
+            masks = [None] * self.n_local
+            for g in self.groups:
+                gm = b.masks_group(head, g.mf)          # [n, Q, Hm, Wm]: all views of the shape group in one launch where the backend can
+                for r, j in enumerate(g.idx):
+                    masks[j] = gm[r]
+            self.out = (outq, b.logits(head), masks)
 
     def _segments(self):
         """[(stage, collective run eagerly behind it | None)]: the replicated plan has three stages, the broadcast plan splits stage 2 around the
@@ -366,7 +395,7 @@ class SceneRunner:
         """Drop everything the runner holds on the device (stacked inputs, feature / mask-feature buffers, gathered keyframe rows, captured
         graphs).  Outputs already handed out by results() stay valid: they are tensors of their own."""
         for g in self.groups:
-            g.imgs = g.cat = g.pointmaps = g.fpn = g.mf = g.guid = g.mm = None
+            g.imgs = g.cat = g.pointmaps = g.fpn = g.mf = g.guid = g.mm = g.enc = None
         self.enc_kf = self.both_kf = self.enc_send = self.both_send = self.out = self.graphs = self._refs = self.bank = None
 
     def set_images(self, images):
@@ -474,12 +503,31 @@ class HipBackend:
                 refs.extend(m.pack_refs())
         return refs
 
+    def same_format(self, a, b):
+        from .model.common import amp_dtype
+        return amp_dtype(a, quiet=True) == amp_dtype(b, quiet=True)
+
     def alloc_cat(self, rows, device):
         from .model.common import adt
         return torch.empty(rows, self.m._cat_width(), dtype=adt(), device=device)
 
-    def encode_enc(self, imgs, cat_rows):
+    def alloc_enc(self, rows, device):
+        from .model.common import adt
+        return torch.empty(rows, self.De, dtype=adt(), device=device)
+
+    def encode_enc(self, imgs, cat_rows, enc_rows=None):
+        """enc_rows: additionally the tokens in the format in effect when `cat_rows` is kept in another one (the final LayerNorm's fp32 result rounded once,
+        exactly what the LayerNorm kernel stores when it writes that format itself)"""
         self.m.encode_views(imgs, cat_rows, dino=False)
+        if enc_rows is not None:
+            from . import hip
+            hip.add_cast(cat_rows[:, :self.De], enc_rows)
+
+    def bank_f32(self, bank):
+        return bank.f32
+
+    def encode_rest_paired(self, imgs_enc, cat_enc, imgs_dino, cat_dino):
+        self.m.encode_views_paired(imgs_enc, cat_enc, imgs_dino, cat_dino)
 
     def encode_dino(self, imgs, cat_rows):
         self.m.encode_views(imgs, cat_rows, enc=False)
@@ -492,21 +540,23 @@ class HipBackend:
     def enc_rows(self, cat, rows):
         return cat[:rows, :self.De].contiguous()
 
-    def build_memory(self, enc_kf, K, grids):
-        return self.m.build_memory(enc_kf, K, grids=grids)
+    def build_memory(self, enc_kf, K, grids, f32_bank=False):
+        return self.m.build_memory(enc_kf, K, grids=grids, f32_bank=f32_bank)
 
     def bank_payload(self, bank):
-        return [bank.K_all, bank.Vt_all]
+        return [bank.K_all, bank.Vt_all] + ([bank.f32.K_all, bank.f32.Vt_all] if bank.f32 is not None else [])
 
-    def bank_alloc(self, K, grids, device):
+    def bank_alloc(self, K, grids, device, f32_bank=False):
         """an empty memory bank of the shape build_memory leaves behind (plan='broadcast': filled by the broadcast from rank 0)"""
         n = sum(a * c for a, c in grids)
-        bank = self.m.must3r_decoder.new_bank(device, n)
-        bank.n, bank.labels, bank.nimgs = n, list(range(K)), K
+        bank = self.m.must3r_decoder.new_bank(device, n, f32=f32_bank)
+        for bk in (bank, bank.f32):
+            if bk is not None:
+                bk.n, bk.labels, bk.nimgs = n, list(range(K)), K
         return bank
 
-    def render(self, cat, n, h, w, bank):
-        return self.m.render_views(cat, n, h, w, bank)
+    def render(self, cat, n, h, w, bank, enc=None):
+        return self.m.render_views(cat, n, h, w, bank, enc=enc)
 
     def minmax_scaled(self):
         return self.m.panoptic_decoder.minmax_scaled()

@@ -25,13 +25,19 @@ class OracleBackend:
         ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
         return torch.stack([ys, xs], -1).reshape(1, -1, 2)
 
+    def same_format(self, a, b):
+        return True            # the oracle computes in fp32 whatever `amp` says
+
+    def alloc_enc(self, rows, device):
+        return None
+
     def alloc_cat(self, rows, device):
         return torch.zeros(rows, self.De + self.Dd + self.m.dino_encoder.embed_dim)
 
     def _ts(self, imgs):
         return torch.tensor([list(imgs.shape[-2:])] * imgs.shape[0])
 
-    def encode_enc(self, imgs, cat_rows):
+    def encode_enc(self, imgs, cat_rows, enc_rows=None):
         x, _ = self.m.must3r_encoder(imgs, self._ts(imgs))
         cat_rows[:, :self.De] = x.reshape(cat_rows.shape[0], -1)
 
@@ -45,7 +51,7 @@ class OracleBackend:
     def enc_rows(self, cat, rows):
         return cat[:rows, :self.De].contiguous()
 
-    def build_memory(self, enc_kf, K, grids):
+    def build_memory(self, enc_kf, K, grids, f32_bank=False):
         from oracle.must3r import build_memory, mem_batches_for
         p = self.patch_size
         xs, o = [], 0
@@ -58,12 +64,12 @@ class OracleBackend:
     def bank_payload(self, bank):
         return list(bank[0]) + [bank[1]]
 
-    def bank_alloc(self, K, grids, device):
+    def bank_alloc(self, K, grids, device, f32_bank=False):
         n = sum(a * c for a, c in grids)
         vals = [torch.zeros(1, n, self.Dd) for _ in range(self.m.must3r_decoder.depth)]
         return (vals, torch.zeros(1, n, dtype=torch.long), K, 0, 0)
 
-    def render(self, cat, n, h, w, bank):
+    def render(self, cat, n, h, w, bank, enc=None):
         T, p = h * w, self.patch_size
         pms = []
         for i in range(n):

@@ -931,6 +931,83 @@ def test_gemm_pair_equals_two_launches(M, N1, N2, K):
         assert torch.equal(o1, q1) and torch.equal(o2, q2)
 
 
+@pytest.mark.parametrize('kind', ['plain', 'rope_vs_plain', 'res', 'trans'])
+@pytest.mark.parametrize('Ma,Mb', [(26112, 38800), (12288, 38400), (6200, 9000)])
+def test_gemm_pair_two_problems_one_persistent_launch(kind, Ma, Mb):
+    """pst_gemm_pair, second fused case: two INDEPENDENT big problems of one persistent-kernel class (the same layer of the CroCo encoder and of DINOv2)
+    side by side in one launch with the workgroups split between the tile lists - bit-identical to two hip.gemm calls for every class (plain 16-bit with
+    GELU / fold consumer, fused RoPE on one side only, fp32 residual stream + fold producer outputs with LayerScale on one side only, transposed V^T),
+    ragged M, and unfused (two launches, same bits) when the split does not pay or a problem is too small for the persistent kernel."""
+    from panst3r_amd import hip
+    N, K = (1024, 2048) if kind == 'res' else (1024, 1024)
+
+    def problem(seed, M, side):
+        x = rn(seed, M, K).to(dev()) * 1.1 + 0.1
+        xb = torch.empty(M, K, dtype=d16(), device=dev())
+        st = torch.empty(M, K // 64, 2, device=dev())
+        hip.rowstats(x, xb, st)
+        w = bf(rn(seed + 1, N, K, scale=K ** -0.5)).to(dev())
+        b = rn(seed + 2, N).to(dev())
+        ln = (st, w.float().sum(1).contiguous(), 1e-6)
+        if kind == 'plain':
+            return xb, w, (lambda: torch.full((M, N), float('nan'), dtype=d16(), device=dev())), dict(bias=b, act='gelu', ln=ln)
+        if kind == 'rope_vs_plain':
+            kw = dict(bias=b, ln=ln, gamma=(1 + 0.1 * rn(seed + 3, N)).to(dev()))
+            if side == 0:
+                T = 768
+                ys, xs = torch.meshgrid(torch.arange(24), torch.arange(32), indexing='ij')
+                pos = torch.stack([ys, xs], -1).reshape(T, 2).to(torch.int32).repeat(M // T + 1, 1)[:M].contiguous().to(dev())
+                kw['rope'] = (pos, hip.rope_table(32, 64, 100.0, dev()))
+            return xb, w, (lambda: torch.full((M, N), float('nan'), dtype=d16(), device=dev())), kw
+        if kind == 'trans':
+            ldc = (M + 7) // 8 * 8 + 8
+            return xb, w, (lambda: torch.zeros(N, ldc, dtype=d16(), device=dev())), dict(bias=b, trans_out=True, ln=ln)
+        res = rn(seed + 4, M, N).to(dev())
+        kw = dict(bias=b, res=res)
+        if side == 1:
+            kw['gamma'] = (1 + 0.1 * rn(seed + 3, N)).to(dev())
+        return xb, w, (lambda: dict(out=torch.full((M, N), float('nan'), device=dev()), xcopy=torch.zeros(M, N, dtype=d16(), device=dev()),
+                                    stats=torch.zeros(M, N // 64, 2, device=dev()))), kw
+
+    def run(pair):
+        calls, outs = [], []
+        for (a, w, mk, kw) in probs:
+            o = mk()
+            if isinstance(o, dict):
+                calls.append((a, w, o['out'], dict(kw, xcopy=o['xcopy'], stats_out=o['stats'])))
+                outs.append([o['out'], o['xcopy'], o['stats']])
+            else:
+                calls.append((a, w, o, kw))
+                outs.append([o])
+        hip.TIMER = hip.KernelTimer()
+        try:
+            if pair:
+                hip.gemm_pair(calls[0], calls[1])
+            else:
+                for c in calls:
+                    hip.gemm(c[0], c[1], c[2], **c[3])
+            names = [r[0] for r in hip.TIMER.records]
+        finally:
+            hip.TIMER = None
+        return outs, names
+    probs = [problem(2000, Ma, 0), problem(2100, Mb, 1)]
+    ref, single = run(False)
+    got, names = run(True)
+    big = all(nm == 'gemm256p_kernel' for nm in single)
+    if (Ma, Mb) == (26112, 38800):
+        assert big and names == ['gemm256p_kernel'], (single, names)           # 408 + 608 tiles: 4 rounds side by side instead of 2 + 3
+    if not big:
+        assert names == single                                                  # e.g. 6200 / 9000 rows: not the persistent kernel's shapes - two launches
+    for r, g in zip(ref, got):
+        for a, b in zip(r, g):
+            assert torch.equal(a, b)
+    for _ in range(3):
+        again, _ = run(True)
+        for r, g in zip(ref, again):
+            for a, b in zip(r, g):
+                assert torch.equal(a, b)
+
+
 def test_loftup_minmax_and_merge():
     """the MinMaxScaler statistics for scopes wider than one view (loftup.py:14-19 pools min / max over the batch it is handed): per-view table of
     the 2x2-mean image, pooled over scope ids - exact (min / max are order-independent), and the guidance kernel scaled with the pooled table

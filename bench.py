@@ -267,6 +267,7 @@ def main():
     ap.add_argument('--plan', default='auto', choices=['auto', 'replicated', 'broadcast'],
                     help="multi-GPU plan (panst3r_amd/scene.py): every rank repeats the memory build | rank 0 builds and broadcasts the banks; "
                          "auto = broadcast from 4 ranks on (projection: profiles/r3_shard_estimate.txt)")
+    ap.add_argument('--tune', action='append', default=[], metavar='KNOB=VALUE', help='pst_tune knob for A/B measurements (G256_PP, PAIR, PAIR_RES); results never depend on a knob')
     ap.add_argument('--launch-selftest', action='store_true', help='only exercise the rank launch / rendezvous / output plumbing (no model work; CPU + gloo when there is no GPU per rank)')
     args = ap.parse_args()
 
@@ -294,6 +295,9 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     hip.lib()      # fail loudly if the HIP library is missing
+    for kv in args.tune:
+        k, v = kv.split('=')
+        hip.tune(getattr(hip, 'TUNE_' + k.upper()), int(v))
 
     V, K, H, W = args.views, args.keyframes, args.height, args.width
     model = build_from_config(CONFIG_V2 if args.variant == 'v2' else CONFIG_V1).eval()

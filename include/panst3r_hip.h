@@ -112,6 +112,8 @@ const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_param
 /* Tuning knob of the GEMM dispatch (process-wide; measurement tools and tests only - results never depend on it, every GEMM variant
  * is bit-identical).  Returns the previous value, or -1 for an unknown knob. */
 #define PST_TUNE_G256_PP 3      /* 1 (default): ping-pong K loop of the persistent 256x256 kernel, 0: the lock-step loop (A/B measurements) */
+#define PST_TUNE_PAIR 4         /* 1 (default): pst_gemm_pair may put two big problems side by side in one persistent launch, 0: never */
+#define PST_TUNE_PAIR_RES 5     /* 1 (default): ... including fp32 residual-stream problems at K >= 1024 that would run on the 128x128 kernel on their own */
 int pst_tune(int knob, int value);
 
 /* ---------------------------------------------------------------- query x pixel mask einsum (HBM-bound streaming form)

@@ -106,6 +106,24 @@ class PixelShuffleUpscaler(nn.Module):
         return [f16], m2
 
 
+# Operation order of the guidance image's x0.5 bilinear down-sampling (loftup.py:154 F.interpolate(..., scale_factor=0.5, mode='bilinear')).
+# All four weights are 0.5, so the result is a quarter of a sum of four pixels - in ONE of two association orders, one ulp apart in ~30 % of the
+# pixels, and LoftUp's Fourier featurizer multiplies the (min-max scaled) value by frequencies up to e^10: that ulp is 1e-4 on the features.
+#   'nested'  0.5 (0.5 a00 + 0.5 a01) + 0.5 (0.5 a10 + 0.5 a11): the CUDA kernel the reference runs (ATen UpSampleBilinear2d.cu) and torch's generic
+#             CPU kernel (large images) - row sums first.  The oracle's default and what the HIP path implements, at EVERY size.
+#   'torch'   whatever F.interpolate does on this host: for small images / one thread torch's CPU dispatch takes its vectorised 4-tap kernel,
+#             ((a00 + a01) + a10) + a11.  Used by tests/test_oracle_golden.py, whose goldens were generated by the reference's code on the CPU.
+HALF_BILINEAR = 'nested'
+
+
+def half_bilinear(img):
+    H, W = img.shape[-2:]
+    if HALF_BILINEAR == 'torch' or H % 2 or W % 2:
+        return F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+    a, b = img[..., 0::2, :], img[..., 1::2, :]
+    return 0.5 * (0.5 * a[..., 0::2] + 0.5 * a[..., 1::2]) + 0.5 * (0.5 * b[..., 0::2] + 0.5 * b[..., 1::2])
+
+
 class MinMaxScaler(nn.Module):
     def forward(self, x):
         lo = x.amin(dim=(0, 2, 3), keepdim=True)
@@ -172,7 +190,9 @@ class LoftUpUpscaler(nn.Module):
         fpn = self.patch_embed(lr)
         if H > W:
             img = img.transpose(2, 3)
-        if self.output_stride != 1:
+        if self.output_stride == 2:
+            img = half_bilinear(img)
+        elif self.output_stride != 1:
             img = F.interpolate(img, scale_factor=1.0 / self.output_stride, mode='bilinear', align_corners=False)
         g = self.first_conv(self.fourier_feat(img))
         _, C, Ho, Wo = g.shape

@@ -179,6 +179,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
 #endif
     const char* vb_ = kb_ + C::K_BYTES;
     const int k0 = kt * KT;
+    // a wave whose query rows all lie beyond Nq (DINOv2's 769 = 6 x 128 + 1 queries: three of the four waves of every 7th block) takes part in the
+    // staging and the barriers only - its MFMAs would compete with the co-resident blocks' for nothing (wave-uniform branch; q_wave0 is scalar)
+    if (q_wave0 >= p.Nq) continue;
 
     // ---- S^T - m = K Q^T - m
     f32x4 s[4][QF];

@@ -22,7 +22,8 @@ namespace pst {
 
 int launch_gemm256(const pst_gemm_params& p, hipStream_t s);   // gemm256.hip
 int launch_gemm256p(const pst_gemm_params& p, hipStream_t s, int cus);
-int gemm256p_pair_split(const pst_gemm_params& a, const pst_gemm_params& b, int cus);      // workgroups of problem a when a and b share one persistent launch (0: two launches)
+int gemm256p_pair_split(const pst_gemm_params& a, const pst_gemm_params& b, int cus, double separate_us, double* pair_us);      // workgroups of problem a when a and b share one persistent launch (0: two launches)
+double gemm256p_single_us(const pst_gemm_params& p, int cus);
 int launch_gemm256p_pair(const pst_gemm_params& a, const pst_gemm_params& b, hipStream_t s, int cus, int g0);
 bool gemm256_persistent_ok(const pst_gemm_params& p);
 int gemm256_persistent_class(const pst_gemm_params& p);
@@ -635,13 +636,26 @@ static bool pair_fusable(const pst_gemm_params& a, const pst_gemm_params& b) {
   return gemm_choice(a) == 0 && gemm_choice(b) == 0;            // both on the 64 x 64 tiles: the small-M GEMMs of the memory build
 }
 
-// two big problems of the SAME persistent class side by side in one launch (gemm256.hip gemm256p2_kernel): workgroups of problem a, or 0
+// two big problems of the SAME persistent class side by side in one launch (gemm256.hip gemm256p2_kernel): workgroups of problem a, or 0.
+// A problem qualifies when the dispatch sends it to the persistent kernel anyway, or - fp32 residual-stream class at K >= 1024 (the attention output
+// projections: 128 x 128 tiles at 450-500 TFLOP/s on their own, profiles/r3_shape_profile.txt) - when sharing the launch beats that (PST_TUNE_PAIR_RES).
+static int g_pair_res = 1;
+static int g_pair = 1;          // PST_TUNE_PAIR: 0 = never share a persistent launch (A/B measurements)
 static int pair_split_256p(const pst_gemm_params& a, const pst_gemm_params& b) {
   using namespace pst;
-  if (a.dtype16 == DT_F32 || a.dtype16 != b.dtype16 || a.batch > 1 || b.batch > 1 || a.kernel || b.kernel) return 0;
+  if (!g_pair || a.dtype16 == DT_F32 || a.dtype16 != b.dtype16 || a.batch > 1 || b.batch > 1 || a.kernel || b.kernel) return 0;
   if (rowstream_class(a) || rowstream_class(b)) return 0;
-  if (gemm_choice(a) != 2 || gemm_choice(b) != 2 || !gemm256_persistent_ok(a) || !gemm256_persistent_ok(b)) return 0;
-  return gemm256p_pair_split(a, b, num_cus());
+  const int cus = num_cus();
+  double sep = 0.0;
+  const pst_gemm_params* ps[2] = {&a, &b};
+  for (const pst_gemm_params* p : ps) {
+    const bool fits32 = (int64_t)p->M * p->lda < (1ll << 31) && (int64_t)p->N * p->ldw < (1ll << 31);
+    if (gemm_choice(*p) == 2 && gemm256_persistent_ok(*p)) { sep += gemm256p_single_us(*p, cus); continue; }
+    const long tiles256 = (long)((p->M + 255) / 256) * ((p->N + 255) / 256);
+    if (!(g_pair_res && gemm256_persistent_class(*p) == 2 && fits32 && p->conv_c == 0 && p->K >= 1024 && tiles256 >= 128)) return 0;
+    sep += 2.0 * p->M * p->N * p->K / 470e6;          // the 128 x 128 kernel on this class: ~470 TFLOP/s -> microseconds
+  }
+  return gemm256p_pair_split(a, b, cus, sep, nullptr);
 }
 
 extern "C" int pst_gemm_pair(const pst_gemm_params* pa, const pst_gemm_params* pb, void* stream) {
@@ -665,6 +679,8 @@ extern "C" const char* pst_gemm_pair_variant(const pst_gemm_params* pa, const ps
 
 extern "C" int pst_tune(int knob, int value) {
   if (knob == PST_TUNE_G256_PP) return pst::gemm256_pp(value);
+  if (knob == PST_TUNE_PAIR_RES) { const int prev = g_pair_res; g_pair_res = value != 0; return prev; }
+  if (knob == PST_TUNE_PAIR) { const int prev = g_pair; g_pair = value != 0; return prev; }
   return -1;
 }
 

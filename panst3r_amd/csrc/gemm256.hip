@@ -892,27 +892,35 @@ static void launch_256p_c(const pst_gemm_params& p, hipStream_t s, int grid, int
   }
 }
 
-// cost of one output tile in K-tile units: the K loop plus a prologue / epilogue that is worth ~8 K tiles (profiles/r3_gemm_pp_ablation.txt: at K = 1024 the
-// loop is 60 % of the kernel)
-static inline long tile_cost(const pst_gemm_params& p) { return p.K / 64 + 8; }
+// Time model of the persistent kernel (microseconds; fitted to profiles/r3_shape_profile.txt and r3_gemm_pp_ablation.txt): a 256 x 256 tile costs
+// 1.94 us per K tile of 64 in the loop plus a prologue / epilogue worth ~8 K tiles for the 16-bit classes (at K = 1024 the loop is 60 % of the kernel) and
+// ~15 for the fp32 residual-stream class (its epilogue moves 5 x the bytes: 29 us per round at N = 1024 against 31 us of loop).
+static inline double tile_us(const pst_gemm_params& p, int cls) { return 1.94 * (p.K / 64 + (cls == 2 ? 15 : 8)); }
 
-// workgroups of problem 0 when two problems share one launch of `cus` workgroups, or 0 when two launches are at least as good: minimises
-// max(rounds0 * cost0, rounds1 * cost1) over the split and compares with rounds0(cus) * cost0 + rounds1(cus) * cost1
-int gemm256p_pair_split(const pst_gemm_params& a, const pst_gemm_params& b, int cus) {
+// Two problems of one persistent class side by side in one launch of `cus` workgroups: the number of workgroups problem `a` gets (the split that
+// minimises max(rounds_a * tile_a, rounds_b * tile_b)), or 0 when that is not at least 5 % better than `separate_us`, the caller's estimate of the two
+// launches on their own dispatch.  *pair_us: the estimate of the shared launch.
+int gemm256p_pair_split(const pst_gemm_params& a, const pst_gemm_params& b, int cus, double separate_us, double* pair_us) {
   if (a.dtype16 != b.dtype16) return 0;
   const int ca = gemm256_persistent_class(a), cb = gemm256_persistent_class(b);
   if (ca == 0 || ca != cb) return 0;
   const long ta = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), tb = (long)((b.M + 255) / 256) * ((b.N + 255) / 256);
-  const long ka = tile_cost(a), kb = tile_cost(b);
   if (ta < 64 || tb < 64) return 0;
-  const long separate = ((ta + cus - 1) / cus) * ka + ((tb + cus - 1) / cus) * kb;
-  long best = separate;
+  const double ka = tile_us(a, ca), kb = tile_us(b, cb);
+  double best = 1e30;
   int g0 = 0;
   for (int g = 8; g <= cus - 8; ++g) {
-    const long t = std::max(((ta + g - 1) / g) * ka, ((tb + (cus - g) - 1) / (cus - g)) * kb);
+    const double t = std::max(((ta + g - 1) / g) * ka, ((tb + (cus - g) - 1) / (cus - g)) * kb);
     if (t < best) { best = t; g0 = g; }
   }
-  return (best * 100 <= separate * 97) ? g0 : 0;          // worth it from 3 % on
+  if (pair_us) *pair_us = best;
+  return best <= 0.95 * separate_us ? g0 : 0;
+}
+
+// estimate of ONE problem on the persistent kernel by itself
+double gemm256p_single_us(const pst_gemm_params& p, int cus) {
+  const long t = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  return ((t + cus - 1) / cus) * tile_us(p, gemm256_persistent_class(p));
 }
 
 template <bool F16, bool RES, bool TRANS, bool PP>

@@ -72,7 +72,7 @@ def lib():
     return L
 
 
-TUNE_G256_PP = 3
+TUNE_G256_PP, TUNE_PAIR, TUNE_PAIR_RES = 3, 4, 5
 
 
 def tune(knob, value):

@@ -294,7 +294,8 @@ def test_loftup_guidance_and_groupnorm_f32():
     feat = ImplicitFeaturizer(True, n_freqs=nf, learn_bias=True)
     with torch.no_grad():
         feat.biases.copy_(rn(81, 2, 5, nf))
-    small = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+    from oracle.panoptic import half_bilinear
+    small = half_bilinear(img)           # the x0.5 bilinear in the CUDA kernel's operation order (oracle/panoptic.py HALF_BILINEAR; torch's CPU kernel picks by size)
     with torch.no_grad():
         ref = torch.stack([feat(MinMaxScaler()(small[i:i + 1]))[0] for i in range(2)])
     P, CH = (H // 2) * (W // 2), 10 * nf + 3

@@ -127,9 +127,36 @@ def _pd(tag):
     return fill_module_(d.eval(), seed=13)
 
 
+@pytest.fixture
+def torch_half_bilinear(monkeypatch):
+    """the goldens were generated by the reference's code on the CPU, where F.interpolate's x0.5 picks torch's 4-tap association for these small images
+    (oracle/panoptic.py HALF_BILINEAR): compare the oracle in that mode"""
+    import oracle.panoptic as OPm
+    monkeypatch.setattr(OPm, 'HALF_BILINEAR', 'torch')
+
+
+def test_half_bilinear_orders():
+    """the two association orders of the x0.5 bilinear (oracle/panoptic.py): equal to within one ulp, NOT bit-equal - and 'nested' is what torch's generic
+    kernel computes (checked here on a large image, where torch's CPU dispatch uses it) as does the CUDA kernel the reference runs"""
+    import torch.nn.functional as F
+    import oracle.panoptic as OPm
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(1, 3, 64, 96, generator=g) * 2 - 1
+    a = OPm.half_bilinear(img)
+    four = 0.25 * (((img[..., 0::2, 0::2] + img[..., 0::2, 1::2]) + img[..., 1::2, 0::2]) + img[..., 1::2, 1::2])
+    assert float((a - four).abs().max()) <= 1.2e-7 and not torch.equal(a, four)
+    t = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+    assert torch.equal(t, a) or torch.equal(t, four)          # torch takes one of the two, depending on size / threads
+    big = torch.rand(2, 3, 384, 512, generator=g) * 2 - 1
+    tb = F.interpolate(big, scale_factor=0.5, mode='bilinear', align_corners=False)
+    nested = OPm.half_bilinear(big)
+    four_b = 0.25 * (((big[..., 0::2, 0::2] + big[..., 0::2, 1::2]) + big[..., 1::2, 0::2]) + big[..., 1::2, 1::2])
+    assert torch.equal(tb, nested) or torch.equal(tb, four_b)
+
+
 @pytest.mark.parametrize('tag', ['v1', 'v2'])
 @torch.no_grad()
-def test_panoptic_decoder_tiny(golden, tag):
+def test_panoptic_decoder_tiny(golden, tag, torch_half_bilinear):
     g = golden('panoptic_decoder_%s_tiny' % tag)
     d = _pd(tag)
     names = ['c%d' % i for i in range(5)]

@@ -105,7 +105,7 @@ const char* pst_gemm_variant(const pst_gemm_params* p);
  *   - (ABI 17) two big problems of the SAME persistent-kernel class (both plain 16-bit / both fp32 residual stream / both transposed) - the same layer of
  *     two independent ViTs, e.g. the CroCo encoder of the views that are not keyframes and DINOv2 of all views (panst3r.py:174-175,229-230): the chip's
  *     workgroups are split between the two tile lists so that both finish in the same number of rounds (tile quantisation: 408 + 608 tiles of 256 x 256
- *     cost 2 + 3 rounds of 256 CUs on their own, 4 side by side);  variant "gemm256p_kernel"
+ *     cost 2 + 3 rounds of 256 CUs on their own, 4 side by side);  variant "gemm256p2_kernel"
  * pst_gemm_pair_variant: the fused kernel's name, or "" when the pair is not fused. */
 int pst_gemm_pair(const pst_gemm_params* a, const pst_gemm_params* b, void* stream);
 const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_params* b);
@@ -113,6 +113,7 @@ const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_param
  * is bit-identical).  Returns the previous value, or -1 for an unknown knob. */
 #define PST_TUNE_G256_PP 3      /* 1 (default): ping-pong K loop of the persistent 256x256 kernel, 0: the lock-step loop (A/B measurements) */
 #define PST_TUNE_PAIR 4         /* 1 (default): pst_gemm_pair may put two big problems side by side in one persistent launch, 0: never */
+#define PST_TUNE_PAIR_DELAY 6   /* start delay of the second problem of a shared launch in % of a tile period (default 0 = none; measured slower): de-phases its epilogues from the first's */
 #define PST_TUNE_PAIR_RES 5     /* 1 (default): ... including fp32 residual-stream problems at K >= 1024 that would run on the 128x128 kernel on their own */
 int pst_tune(int knob, int value);
 

@@ -587,7 +587,7 @@ static int gemm_validate(const pst_gemm_params* pp) {
   return PST_OK;
 }
 
-namespace pst { int gemm256_pp(int set); }
+namespace pst { int gemm256_pp(int set); int gemm256p_pair_delay(int set); }
 
 // the ONE dispatch rule, shared by the launch and by pst_gemm_variant: 0 = 64x64 tiles, 1 = 128x128, 2 = 256x256
 static int gemm_choice(const pst_gemm_params& p) {
@@ -673,13 +673,14 @@ extern "C" int pst_gemm_pair(const pst_gemm_params* pa, const pst_gemm_params* p
 
 extern "C" const char* pst_gemm_pair_variant(const pst_gemm_params* pa, const pst_gemm_params* pb) {
   if (gemm_validate(pa) || gemm_validate(pb)) return nullptr;
-  if (pair_split_256p(*pa, *pb)) return "gemm256p_kernel";          // two problems side by side in one persistent launch
+  if (pair_split_256p(*pa, *pb)) return "gemm256p2_kernel";         // two problems side by side in one persistent launch
   return pair_fusable(*pa, *pb) ? "gemm_pair_kernel<2,2>" : "";       // "": runs as two pst_gemm launches (ask pst_gemm_variant for each)
 }
 
 extern "C" int pst_tune(int knob, int value) {
   if (knob == PST_TUNE_G256_PP) return pst::gemm256_pp(value);
   if (knob == PST_TUNE_PAIR_RES) { const int prev = g_pair_res; g_pair_res = value != 0; return prev; }
+  if (knob == PST_TUNE_PAIR_DELAY) return pst::gemm256p_pair_delay(value);
   if (knob == PST_TUNE_PAIR) { const int prev = g_pair; g_pair = value != 0; return prev; }
   return -1;
 }

@@ -820,6 +820,7 @@ struct gemm256p2_args {
   pst_gemm_params p[2];
   int ntiles[2], tiles_m[2], tiles_n[2];
   int g0;
+  int delay_ticks;        // start delay of problem 1's workgroups in 100 MHz ticks (0: none), see gemm256p_pair_delay_us
 };
 template <bool F16, bool RES, bool TRANS, bool PP>
 __global__ __launch_bounds__(512, 1) void gemm256p2_kernel(const gemm256p2_args a) {
@@ -827,6 +828,14 @@ __global__ __launch_bounds__(512, 1) void gemm256p2_kernel(const gemm256p2_args 
   const int which = (int)blockIdx.x >= a.g0 ? 1 : 0;
   const int bid = which ? (int)blockIdx.x - a.g0 : (int)blockIdx.x;
   const int nblk = which ? (int)gridDim.x - a.g0 : a.g0;
+  // DE-PHASING: every workgroup of a persistent launch alternates a K loop (matrix pipe, operands from L2) with an epilogue (HBM: stores, residual
+  // loads), and with equal tile costs the whole chip does so in step - the epilogue bursts meet a saturated HBM while the matrix cores idle, then the
+  // reverse (profiles/r3_gemm_pp_ablation.txt: 92 us of loop + 86 us of epilogue traffic that do not overlap).  With two problems in the launch, the
+  // second one's workgroups start half a tile period late: its epilogues fall into the first one's K loops for the rest of the launch.
+  if (which && a.delay_ticks > 0) {
+    const uint64_t t0 = wall_clock64();
+    while ((int64_t)(wall_clock64() - t0) < (int64_t)a.delay_ticks) __builtin_amdgcn_s_sleep(32);
+  }
   gemm256p_body<F16, RES, TRANS, PP>(a.p[which], a.ntiles[which], a.tiles_m[which], a.tiles_n[which], bid, nblk, smem);
 }
 
@@ -939,8 +948,30 @@ static void launch_256p2_c(const gemm256p2_args& a, hipStream_t s, int grid) {
   }
 }
 
+// PST_TUNE_PAIR_DELAY: start delay of the second problem of a shared launch in % of a tile period (0 = off, the default).  Applied when the model says
+// it could pay: the delayed problem ends `delay` later, each of its rounds overlaps about half an epilogue - worth it when rounds x epilogue / 2 > delay.
+// MEASURED (profiles/r4_pair_ab.txt, same box, 10 graph-replayed scenes each, twice): 0 % 304.1 / 303.7 frames/s, 25 % 303.2, 50 % 302.0 / 302.8,
+// 75 % 301.7 - the delay costs more at the end of the launch than the de-phased epilogues give back (tried, negative, kept as a knob).
+static int g_pair_delay_pct = 0;
+int gemm256p_pair_delay(int set) {
+  const int prev = g_pair_delay_pct;
+  if (set >= 0 && set <= 200) g_pair_delay_pct = set;
+  return prev;
+}
+static int pair_delay_ticks(const pst_gemm_params& pa, const pst_gemm_params& pb, int cus, int g0) {
+  if (g_pair_delay_pct <= 0) return 0;
+  const int cls = gemm256_persistent_class(pb);
+  const double tile = tile_us(pb, cls), epi = 1.94 * (cls == 2 ? 15 : 8), delay = tile * g_pair_delay_pct / 100.0;
+  const long tb = (long)((pb.M + 255) / 256) * ((pb.N + 255) / 256);
+  const long rounds = (tb + (cus - g0) - 1) / (cus - g0);
+  if (rounds * epi * 0.5 <= delay * 1.2) return 0;
+  (void)pa;
+  return (int)(delay * 100.0);          // microseconds -> 100 MHz ticks
+}
+
 int launch_gemm256p_pair(const pst_gemm_params& pa, const pst_gemm_params& pb, hipStream_t s, int cus, int g0) {
   gemm256p2_args a;
+  a.delay_ticks = pair_delay_ticks(pa, pb, cus, g0);
   a.p[0] = pa; a.p[1] = pb;
   const pst_gemm_params* ps[2] = {&pa, &pb};
   for (int i = 0; i < 2; ++i) {

@@ -62,7 +62,10 @@ __device__ __forceinline__ void store4(void* base, int64_t idx, int tc, const fl
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row, row in registers
-template <int NIT>
+// RPW rows per wave: the loads of all of a wave's rows are issued before the first reduction, so a wave keeps RPW x (row bytes) in flight instead
+// of one short row (LoftUp's final norms: 786 432 rows of 384 16-bit values = 768 B per row: 2.8 TB/s with one row per wave; the arithmetic of a row is
+// untouched, so results do not depend on RPW)
+template <int NIT, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t ldx, int in_fp32, void* y, int64_t ldy,
                                                         int out_fp32, const float* gamma, const float* beta, int rows,
                                                         int D, float eps, int grp_in, int grp_out, int grp_off,
@@ -75,45 +78,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t l
     beta += bi * w_bs;
   }
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int irow = grp_in > 0 ? (row / grp_in) * grp_out + grp_off + row % grp_in : row;
-  float v[NIT][4];
-  float s = 0.f;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= rows) return;
+  float v[RPW][NIT][4];
+  float s[RPW];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int c = it * 256 + lane * 4;
-    if (c < D) {
-      load4(x, (int64_t)irow * ldx + c, in_fp32, v[it]);
-      if (add) {
-        const float4 a4 = *(const float4*)(add + (int64_t)irow * ld_add + c);
-        v[it][0] += a4.x; v[it][1] += a4.y; v[it][2] += a4.z; v[it][3] += a4.w;
+  for (int j = 0; j < RPW; ++j) {
+    const int row = min(row0 + j, rows - 1);
+    const int irow = grp_in > 0 ? (row / grp_in) * grp_out + grp_off + row % grp_in : row;
+    s[j] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < D) {
+        load4(x, (int64_t)irow * ldx + c, in_fp32, v[j][it]);
+        if (add) {
+          const float4 a4 = *(const float4*)(add + (int64_t)irow * ld_add + c);
+          v[j][it][0] += a4.x; v[j][it][1] += a4.y; v[j][it][2] += a4.z; v[j][it][3] += a4.w;
+        }
+        s[j] += v[j][it][0] + v[j][it][1] + v[j][it][2] + v[j][it][3];
+      } else {
+        v[j][it][0] = v[j][it][1] = v[j][it][2] = v[j][it][3] = 0.f;
       }
-      s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
-    } else {
-      v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f;
     }
   }
-  const float mean = wave_sum(s) / D;
-  float q = 0.f;
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int c = it * 256 + lane * 4;
-    if (c < D) {
+  for (int j = 0; j < RPW; ++j) {
+    const int row = row0 + j;
+    if (row >= rows) break;
+    const float mean = wave_sum(s[j]) / D;
+    float q = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float d = v[it][r] - mean; q += d * d; }
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < D) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = v[j][it][r] - mean; q += d * d; }
+      }
     }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int c = it * 256 + lane * 4;
-    if (c < D) {
-      const float4 gm = *(const float4*)(gamma + c);
-      const float4 bt = *(const float4*)(beta + c);
-      float o[4] = {(v[it][0] - mean) * rstd * gm.x + bt.x, (v[it][1] - mean) * rstd * gm.y + bt.y,
-                    (v[it][2] - mean) * rstd * gm.z + bt.z, (v[it][3] - mean) * rstd * gm.w + bt.w};
-      store4(y, (int64_t)row * ldy + c, out_fp32, o);
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < D) {
+        const float4 gm = *(const float4*)(gamma + c);
+        const float4 bt = *(const float4*)(beta + c);
+        float o[4] = {(v[j][it][0] - mean) * rstd * gm.x + bt.x, (v[j][it][1] - mean) * rstd * gm.y + bt.y,
+                      (v[j][it][2] - mean) * rstd * gm.z + bt.z, (v[j][it][3] - mean) * rstd * gm.w + bt.w};
+        store4(y, (int64_t)row * ldy + c, out_fp32, o);
+      }
     }
   }
 }
@@ -371,11 +384,14 @@ static int launch_layernorm(const void* x, int64_t ldx, int in_fp32, const float
   if ((in_fp32 != DT_BF16 && in_fp32 != DT_F32 && in_fp32 != DT_F16) || (out_fp32 != DT_BF16 && out_fp32 != DT_F32 && out_fp32 != DT_F16)) { set_error("layernorm: bad element type code"); return PST_EINVAL; }
   if (D <= 0 || D % 4 || D > 4096 || ldx % 4 || ldy % 4 || (add && ld_add % 4)) { set_error("layernorm: need D%%4==0, D<=4096, ld%%4==0 (D=%d)", D); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((rows + 3) / 4, nbatch), block(256);
   const int nit = (D + 255) / 256;
-#define PST_LN(N) hipLaunchKernelGGL((layernorm_kernel<N>), grid, block, 0, s, x, ldx, in_fp32, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, add, ld_add, x_bs, y_bs, w_bs)
-  if (nit <= 1) PST_LN(1); else if (nit <= 2) PST_LN(2); else if (nit <= 3) PST_LN(3); else if (nit <= 4) PST_LN(4);
-  else if (nit <= 8) PST_LN(8); else PST_LN(16);
+  const bool many = nit <= 4 && rows >= 32768;              // long launches of short rows: 4 rows per wave in flight
+  const dim3 grid(many ? (rows + 15) / 16 : (rows + 3) / 4, nbatch), block(256);
+#define PST_LN(N, R) hipLaunchKernelGGL((layernorm_kernel<N, R>), grid, block, 0, s, x, ldx, in_fp32, y, ldy, out_fp32, gamma, beta, rows, D, eps, grp_in, grp_out, grp_off, add, ld_add, x_bs, y_bs, w_bs)
+  if (many) {
+    if (nit <= 1) PST_LN(1, 4); else if (nit <= 2) PST_LN(2, 4); else if (nit <= 3) PST_LN(3, 4); else PST_LN(4, 4);
+  } else if (nit <= 1) PST_LN(1, 1); else if (nit <= 2) PST_LN(2, 1); else if (nit <= 3) PST_LN(3, 1); else if (nit <= 4) PST_LN(4, 1);
+  else if (nit <= 8) PST_LN(8, 1); else PST_LN(16, 1);
 #undef PST_LN
   return check_launch("layernorm");
 }

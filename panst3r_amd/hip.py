@@ -72,7 +72,7 @@ def lib():
     return L
 
 
-TUNE_G256_PP, TUNE_PAIR, TUNE_PAIR_RES = 3, 4, 5
+TUNE_G256_PP, TUNE_PAIR, TUNE_PAIR_RES, TUNE_PAIR_DELAY = 3, 4, 5, 6
 
 
 def tune(knob, value):

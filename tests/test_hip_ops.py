@@ -996,7 +996,7 @@ def test_gemm_pair_two_problems_one_persistent_launch(kind, Ma, Mb):
     got, names = run(True)
     big = all(nm == 'gemm256p_kernel' for nm in single)
     if (Ma, Mb) == (26112, 38800):
-        assert big and names == ['gemm256p_kernel'], (single, names)           # 408 + 608 tiles: 4 rounds side by side instead of 2 + 3
+        assert big and names == ['gemm256p2_kernel'], (single, names)           # 408 + 608 tiles: 4 rounds side by side instead of 2 + 3
     if not big:
         assert names == single                                                  # e.g. 6200 / 9000 rows: not the persistent kernel's shapes - two launches
     for r, g in zip(ref, got):

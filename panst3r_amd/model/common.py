@@ -242,14 +242,10 @@ def self_attention_parts(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None)
             o.view(lay.V, lay.Tp, D)[:, lay.N:].zero_()      # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
         ldq, ldv = qk.stride(0), vt.stride(0)
         st = dict(q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq), v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D), prescaled=True)
-        if lay.extra == 1 and (lay.N - 1) % 128 == 0 and lay.V * H >= 256:
-            # a CLS row in front of a multiple of 128 patch rows (DINOv2 at 384 x 512: 1 + 768): as ONE launch the 769th query costs every (view, head) a
-            # 7th 128-query block that walks all 13 key tiles for one row - a seventh of the launch.  Two launches instead: the patch queries in full
-            # blocks, the CLS queries of all (view, head) pairs in one round of one-row blocks.  Rows are independent: same bits.
-            hip.attention(qk[1:], qk[:, D:], vt, o[1:], lay.V, H, lay.N - 1, lay.N, hd, **st)
-            hip.attention(qk, qk[:, D:], vt, o, lay.V, H, 1, lay.N, hd, **st)
-        else:
-            hip.attention(qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd, **st)
+        # (tried in round 4: DINOv2's 769 queries as two launches - 768 patch queries in full 128-row blocks + the CLS queries of all (view, head) pairs in
+        # one-row blocks - to save every 7th block's walk over 13 key tiles: 4.58 + 0.97 ms against 5.05 ms for the one launch, i.e. slower; the one-row
+        # launch is a 40 us latency chain of its own)
+        hip.attention(qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd, **st)
         return o
     return qk_call, vt_call, finish
 

@@ -293,6 +293,12 @@ def main():
     use_dist = world > 1 or os.environ.get('PST_FORCE_DIST') == '1'       # PST_FORCE_DIST=1: exercise the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if world == 1 and 'MASTER_ADDR' not in os.environ:      # PST_FORCE_DIST=1 without a launcher: a one-rank rendezvous of its own
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+            os.environ['MASTER_ADDR'] = '127.0.0.1'
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     hip.lib()      # fail loudly if the HIP library is missing
     for kv in args.tune:

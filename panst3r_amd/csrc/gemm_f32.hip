@@ -32,8 +32,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const pst_gemm_params p_i
     p.C = (float*)p.C + bi * p.c_bs;
     if (p.bias) p.bias += bi * p.bias_bs;
   }
-  __shared__ __attribute__((aligned(16))) float As[F32_BK][PAD];
-  __shared__ __attribute__((aligned(16))) float Ws[F32_BK][PAD];
+  // double buffered (round 4): the global loads of K step s + 1 are in flight while step s is multiplied, one barrier per step (the round-3 kernel
+  // loaded, barrier, stored, barrier, multiplied: every step waited a full memory round trip with only the co-resident blocks to cover it)
+  __shared__ __attribute__((aligned(16))) float As[2][F32_BK][PAD];
+  __shared__ __attribute__((aligned(16))) float Ws[2][F32_BK][PAD];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const pst_gemm_params p_i
 #pragma unroll
     for (int j = 0; j < FR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < p.K; k0 += F32_BK) {
-    float4 av[NH], wv[NH];
+  float4 av[NH], wv[NH];
+  auto fetch = [&](int k0) {               // this thread's share of K step k0 into registers
     const int k = k0 + lk;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -85,27 +87,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const pst_gemm_params p_i
       }
       wv[h] = *(const float4*)(w_row[h] + k);
     }
-    __syncthreads();                       // everybody is done with the previous K step's tiles
+  };
+  auto put = [&](int buf) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int r = lr + 64 * h;
-      As[lk + 0][r] = av[h].x; As[lk + 1][r] = av[h].y; As[lk + 2][r] = av[h].z; As[lk + 3][r] = av[h].w;
-      Ws[lk + 0][r] = wv[h].x; Ws[lk + 1][r] = wv[h].y; Ws[lk + 2][r] = wv[h].z; Ws[lk + 3][r] = wv[h].w;
+      As[buf][lk + 0][r] = av[h].x; As[buf][lk + 1][r] = av[h].y; As[buf][lk + 2][r] = av[h].z; As[buf][lk + 3][r] = av[h].w;
+      Ws[buf][lk + 0][r] = wv[h].x; Ws[buf][lk + 1][r] = wv[h].y; Ws[buf][lk + 2][r] = wv[h].z; Ws[buf][lk + 3][r] = wv[h].w;
     }
-    __syncthreads();
+  };
+  fetch(0);
+  put(0);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < p.K; k0 += F32_BK) {
+    const bool more = k0 + F32_BK < p.K;
+    if (more) fetch(k0 + F32_BK);          // lands while this step is multiplied
 #pragma unroll
     for (int ks = 0; ks < F32_BK; ks += 4) {
       float af[FR], wf[FR];
 #pragma unroll
       for (int i = 0; i < FR; ++i) {
-        af[i] = As[ks + g][wm * 16 * FR + i * 16 + l16];
-        wf[i] = Ws[ks + g][wn * 16 * FR + i * 16 + l16];
+        af[i] = As[cur][ks + g][wm * 16 * FR + i * 16 + l16];
+        wf[i] = Ws[cur][ks + g][wn * 16 * FR + i * 16 + l16];
       }
 #pragma unroll
       for (int i = 0; i < FR; ++i)
 #pragma unroll
         for (int j = 0; j < FR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
+    if (more) put(cur ^ 1);                // the other buffer: its last readers passed the barrier that ended the previous step
+    __syncthreads();
+    cur ^= 1;
   }
 
   // ---- epilogue: lane (g, l16) owns row l16 of row fragment i and columns 4g .. 4g + 3 of column fragment j

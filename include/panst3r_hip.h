@@ -113,6 +113,7 @@ const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_param
  * is bit-identical).  Returns the previous value, or -1 for an unknown knob. */
 #define PST_TUNE_G256_PP 3      /* 1 (default): ping-pong K loop of the persistent 256x256 kernel, 0: the lock-step loop (A/B measurements) */
 #define PST_TUNE_PAIR 4         /* 1 (default): pst_gemm_pair may put two big problems side by side in one persistent launch, 0: never */
+#define PST_TUNE_PAIR_ATTN 7    /* 1 (default): pst_attn_pair may put two attention problems into one launch, 0: never */
 #define PST_TUNE_PAIR_DELAY 6   /* start delay of the second problem of a shared launch in % of a tile period (default 0 = none; measured slower): de-phases its epilogues from the first's */
 #define PST_TUNE_PAIR_RES 5     /* 1 (default): ... including fp32 residual-stream problems at K >= 1024 that would run on the 128x128 kernel on their own */
 int pst_tune(int knob, int value);
@@ -156,6 +157,12 @@ int64_t pst_attn_workspace_bytes(int B, int H, int Nq, int hd, int nsplit);
 
 int pst_attn_fwd(const pst_attn_params* p, void* stream);
 const char* pst_attn_variant(const pst_attn_params* p);   /* as pst_gemm_variant */
+/* (ABI 17) Two INDEPENDENT attention problems in ONE launch when both take the same 128-query kernel variant (same format, head dim, softmax mode, no key
+ * split) - the self-attentions of the two ViT towers that run in lock-step (see pst_gemm_pair): one grid over both block lists, so the last partial round of
+ * resident blocks is shared; any other pair runs as two pst_attn_fwd launches.  Bit-identical either way.  pst_attn_pair_variant: "attn2_kernel<64,2>" /
+ * "attn2_kernel<96,2>", or "" when not fused. */
+int pst_attn_pair(const pst_attn_params* a, const pst_attn_params* b, void* stream);
+const char* pst_attn_pair_variant(const pst_attn_params* a, const pst_attn_params* b);
 
 /* ---------------------------------------------------------------- LayerNorm
  * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dim D (D % 4 == 0, D <= 4096), fp32 statistics.

@@ -50,12 +50,12 @@ __device__ __forceinline__ float max_rows(float v) {
   return m;
 }
 
+// the kernel body for block `bidx` of problem `p` (one problem per launch: blockIdx.x; two per launch: attn2_kernel below)
 template <int HD, int QF, bool F16, bool PRE>
-__global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
+__device__ __forceinline__ void attn_body(const pst_attn_params& p, const int bidx, char* smem) {
   using C = AttnCfg<HD>;
   constexpr int NKK = HD / 32;      // K-steps of the QK^T contraction
   constexpr int NHF = HD / 16;      // output fragments along head dim
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
 
   const int qblocks = (p.Nq + 64 * QF - 1) / (64 * QF);
   const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
-  const int split = blockIdx.x % nsplit;          // key-range split (flash-decoding): consecutive blocks share the queries
-  const int bid = blockIdx.x / nsplit;
+  const int split = bidx % nsplit;                // key-range split (flash-decoding): consecutive blocks share the queries
+  const int bid = bidx / nsplit;
   const int qb = bid % qblocks, bh = bid / qblocks;
   const int h = bh % p.H, b = bh / p.H;
 
@@ -336,6 +336,27 @@ __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
   }
 }
 
+template <int HD, int QF, bool F16, bool PRE>
+__global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_body<HD, QF, F16, PRE>(p, (int)blockIdx.x, smem);
+}
+
+// TWO independent attention problems of one kernel variant in one launch (pst_attn_pair): blocks [0, nblk0) belong to problem 0, the rest to problem 1.
+// A launch of n equal blocks costs ceil(n / resident blocks) rounds of the chip: the self-attentions of the two ViT-L towers that run in lock-step
+// (non-keyframe encoder 34 x 16 heads x 6 query blocks = 3 264 blocks, DINOv2 50 x 16 x 7 = 5 600) are 4 + 6 rounds of 1 024 resident blocks on their
+// own and 9 together.  Per block nothing changes: bit-identical to two launches.
+struct attn2_args {
+  pst_attn_params p[2];
+  int nblk0;
+};
+template <int HD, int QF, bool F16, bool PRE>
+__global__ __launch_bounds__(256) void attn2_kernel(const attn2_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int which = (int)blockIdx.x >= a.nblk0 ? 1 : 0;
+  attn_body<HD, QF, F16, PRE>(a.p[which], which ? (int)blockIdx.x - a.nblk0 : (int)blockIdx.x, smem);
+}
+
 // merge the nsplit partial results of one (b, h, q) row: O = sum_s O_s 2^((m_s-m)c) / sum_s l_s 2^((m_s-m)c)
 __global__ void attn_combine_kernel(const pst_attn_params p, int hd) {
   const int64_t rows = (int64_t)p.B * p.H * p.Nq;
@@ -383,6 +404,16 @@ static int launch_attn4(const pst_attn_params& p, hipStream_t s) {
 template <int HD, int QF, bool F16>
 static int launch_attn(const pst_attn_params& p, hipStream_t s) {
   return p.prescaled ? launch_attn4<HD, QF, F16, true>(p, s) : launch_attn4<HD, QF, F16, false>(p, s);
+}
+
+template <int HD, int QF, bool F16, bool PRE>
+static int launch_attn2_t(const pst_attn_params& pa, const pst_attn_params& pb, hipStream_t s) {
+  attn2_args a;
+  a.p[0] = pa; a.p[1] = pb;
+  const long ga = (long)((pa.Nq + 64 * QF - 1) / (64 * QF)) * pa.H * pa.B, gb = (long)((pb.Nq + 64 * QF - 1) / (64 * QF)) * pb.H * pb.B;
+  a.nblk0 = (int)ga;
+  hipLaunchKernelGGL((attn2_kernel<HD, QF, F16, PRE>), dim3((unsigned)(ga + gb)), dim3(256), 2 * AttnCfg<HD>::BUF, s, a);
+  return check_launch("attn_fwd (pair)");
 }
 
 int attn_f32_validate(const pst_attn_params& p);          // attn_f32.hip: fp32 operands (the reference's amp=False arithmetic)
@@ -441,6 +472,40 @@ extern "C" int pst_attn_fwd(const pst_attn_params* pp, void* stream) {
   }
   if (big) return h ? launch_attn<96, 2, true>(p, s) : launch_attn<96, 2, false>(p, s);
   return h ? launch_attn<96, 1, true>(p, s) : launch_attn<96, 1, false>(p, s);
+}
+
+// PST_TUNE_PAIR_ATTN: 1 (default) = pst_attn_pair may share a launch, 0 = never (A/B measurements)
+static int g_attn_pair = 1;
+namespace pst { int attn_pair_enable(int set) { const int prev = g_attn_pair; if (set == 0 || set == 1) g_attn_pair = set; return prev; } }
+
+// two problems in one launch: both 16-bit, same format, head dim, softmax mode and block size, no key split
+static bool attn_pair_fusable(const pst_attn_params& a, const pst_attn_params& b) {
+  if (!g_attn_pair) return false;
+  if (a.dtype16 == pst::DT_F32 || a.dtype16 != b.dtype16 || a.hd != b.hd || a.prescaled != b.prescaled || a.nsplit > 1 || b.nsplit > 1) return false;
+  if (!a.prescaled && a.scale != b.scale) return false;
+  return attn_big(a) && attn_big(b);
+}
+
+extern "C" int pst_attn_pair(const pst_attn_params* pa, const pst_attn_params* pb, void* stream) {
+  using namespace pst;
+  if (int rc = attn_validate(pa)) return rc;
+  if (int rc = attn_validate(pb)) return rc;
+  if (!attn_pair_fusable(*pa, *pb)) {
+    if (int rc = pst_attn_fwd(pa, stream)) return rc;
+    return pst_attn_fwd(pb, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const bool h = pa->dtype16 == DT_F16, pre = pa->prescaled != 0;
+#define PST_A2(HD) (h ? (pre ? launch_attn2_t<HD, 2, true, true>(*pa, *pb, s) : launch_attn2_t<HD, 2, true, false>(*pa, *pb, s)) \
+                      : (pre ? launch_attn2_t<HD, 2, false, true>(*pa, *pb, s) : launch_attn2_t<HD, 2, false, false>(*pa, *pb, s)))
+  return pa->hd == 64 ? PST_A2(64) : PST_A2(96);
+#undef PST_A2
+}
+
+extern "C" const char* pst_attn_pair_variant(const pst_attn_params* pa, const pst_attn_params* pb) {
+  if (attn_validate(pa) || attn_validate(pb)) return nullptr;
+  if (!attn_pair_fusable(*pa, *pb)) return "";
+  return pa->hd == 64 ? "attn2_kernel<64,2>" : "attn2_kernel<96,2>";
 }
 
 extern "C" const char* pst_attn_variant(const pst_attn_params* pp) {

@@ -39,7 +39,7 @@ class AttnParams(C.Structure):
                 ('scale', f32), ('zeros', vp), ('nsplit', i32), ('ws', vp), ('ws_bytes', i64), ('dtype16', i32), ('prescaled', i32)]
 
 
-EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_gemm_pair', 'pst_gemm_pair_variant', 'pst_tune', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
+EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_gemm_pair', 'pst_gemm_pair_variant', 'pst_tune', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_pair', 'pst_attn_pair_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
            'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_loftup_minmax', 'pst_minmax_merge', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
@@ -60,6 +60,7 @@ def lib():
     L.pst_gemm_variant.restype = C.c_char_p
     L.pst_gemm_pair_variant.restype = C.c_char_p
     L.pst_attn_variant.restype = C.c_char_p
+    L.pst_attn_pair_variant.restype = C.c_char_p
     L.pst_attn_workspace_bytes.restype = C.c_int64
     L.pst_qubo_workspace_floats.restype = C.c_int64
     L.pst_qubo_workspace_floats.argtypes = [C.c_int, C.c_int64]
@@ -72,7 +73,7 @@ def lib():
     return L
 
 
-TUNE_G256_PP, TUNE_PAIR, TUNE_PAIR_RES, TUNE_PAIR_DELAY = 3, 4, 5, 6
+TUNE_G256_PP, TUNE_PAIR, TUNE_PAIR_RES, TUNE_PAIR_DELAY, TUNE_PAIR_ATTN = 3, 4, 5, 6, 7
 
 
 def tune(knob, value):
@@ -347,10 +348,9 @@ def auto_nsplit(B, H, Nq, Nk):
 LOG2E = 1.4426950408889634
 
 
-def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale=None, mask=None,
-              mask_strides=(0, 0), nsplit=None, ws=None, prescaled=False):
-    """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row).
-    prescaled: q was produced with scale * LOG2E folded in (see `qscale`): softmax in the exp2 domain without a per-score multiply."""
+def _attn_params(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale=None, mask=None,
+                 mask_strides=(0, 0), nsplit=None, ws=None, prescaled=False):
+    """pst_attn_params of one hip.attention call (+ the tensors it must keep alive, flops, shape tag)"""
     _dev(q, *FMT); _dev(k, *FMT); _dev(vt, *FMT); _dev(out, *FMT)
     p = AttnParams()
     p.dtype16 = _fmt(q, k, vt, out)
@@ -374,15 +374,43 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
             ws = torch.empty(n, dtype=torch.float32, device=q.device)
         assert ws.dtype == torch.float32 and ws.numel() >= n
         p.nsplit, p.ws, p.ws_bytes = ns, _ptr(ws), ws.numel() * 4
+    return p, ws, 4.0 * B * H * Nq * Nk * hd, (B, H, Nq, Nk, hd)
+
+
+def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale=None, mask=None,
+              mask_strides=(0, 0), nsplit=None, ws=None, prescaled=False):
+    """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row).
+    prescaled: q was produced with scale * LOG2E folded in (see `qscale`): softmax in the exp2 domain without a per-score multiply."""
+    p, ws, flops, tag = _attn_params(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale, mask, mask_strides, nsplit, ws, prescaled)
     if TIMER is not None:
         name = lib().pst_attn_variant(C.byref(p))
-        ev = TIMER.bracket(name.decode() if name else 'attn?', 4.0 * B * H * Nq * Nk * hd, (B, H, Nq, Nk, hd))
+        ev = TIMER.bracket(name.decode() if name else 'attn?', flops, tag)
         ev[0].record()
         _check(lib().pst_attn_fwd(C.byref(p), _stream()), 'pst_attn_fwd')
         ev[1].record()
         return out
     _check(lib().pst_attn_fwd(C.byref(p), _stream()), 'pst_attn_fwd')
     return out
+
+
+def attention_pair(first, second):
+    """Two independent attention calls, each (args tuple, kwargs dict) of hip.attention, through pst_attn_pair: ONE launch over both block lists when both
+    take the same 128-query kernel variant (the self-attentions of two ViT towers in lock-step), else two launches; same bits either way."""
+    (a1, k1), (a2, k2) = first, second
+    p1, w1, f1, t1 = _attn_params(*a1, **k1)
+    p2, w2, f2, t2 = _attn_params(*a2, **k2)
+    if TIMER is not None:
+        name = lib().pst_attn_pair_variant(C.byref(p1), C.byref(p2))
+        if not name:
+            attention(*a1, **k1)
+            attention(*a2, **k2)
+            return
+        ev = TIMER.bracket(name.decode(), f1 + f2, t1 + t2)
+        ev[0].record()
+        _check(lib().pst_attn_pair(C.byref(p1), C.byref(p2), _stream()), 'pst_attn_pair')
+        ev[1].record()
+        return
+    _check(lib().pst_attn_pair(C.byref(p1), C.byref(p2), _stream()), 'pst_attn_pair')
 
 
 def attn_workspace_floats(B, H, Nq, Nk, hd, nsplit=None):

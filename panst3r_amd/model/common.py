@@ -234,7 +234,8 @@ def self_attention_parts(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None)
     qk_call = (xn, w_qk.w, qk, dict(bias=w_qk.b, gamma=qs, ln=lq, **({'rope': (pos, rope)} if fused_rope else {})))
     vt_call = (xv, w_v.w, vt, dict(bias=w_v.b, trans_out=True, ln=lv))
 
-    def finish():
+    def finish(launch=True):
+        """launch=False: everything but the attention launch; returns (output buffer, hip.attention args, kwargs) for hip.attention_pair"""
         if rope is not None and not fused_rope:
             hip.rope2d_(qk, pos, rope, 2 * H, hd)
         o = empty(lay.rows, D, adt(), dev)
@@ -245,7 +246,10 @@ def self_attention_parts(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None)
         # (tried in round 4: DINOv2's 769 queries as two launches - 768 patch queries in full 128-row blocks + the CLS queries of all (view, head) pairs in
         # one-row blocks - to save every 7th block's walk over 13 key tiles: 4.58 + 0.97 ms against 5.05 ms for the one launch, i.e. slower; the one-row
         # launch is a 40 us latency chain of its own)
-        hip.attention(qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd, **st)
+        args = (qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd)
+        if not launch:
+            return o, args, st
+        hip.attention(*args, **st)
         return o
     return qk_call, vt_call, finish
 
@@ -378,7 +382,8 @@ def vit_block_pair(a, b):
     qb, vb, fb = self_attention_parts(sb, lb, Hb, hdb, wb.qk, wb.v, pb, rb)
     hip.gemm_pair(qa, qb)
     hip.gemm_pair(va, vb)
-    oa, ob = fa(), fb()
+    (oa, aa, ka), (ob, ab, kb) = fa(launch=False), fb(launch=False)
+    hip.attention_pair((aa, ka), (ab, kb))              # one grid over both towers' query blocks (pst_attn_pair)
     hip.gemm_pair(sa.residual_call(oa, wa.proj, gamma=wa.ls1), sb.residual_call(ob, wb.proj, gamma=wb.ls1))
     ha, hb = empty(la.rows, wa.fc1.n, adt(), sa.x.device), empty(lb.rows, wb.fc1.n, adt(), sb.x.device)
     xa, lna = sa.operand(wa.fc1)

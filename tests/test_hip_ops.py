@@ -1029,3 +1029,40 @@ def test_loftup_minmax_and_merge():
         grp = [u for u in range(n) if int(scope[u]) == int(scope[v])]
         assert torch.equal(out[v, :, 0], mm[grp][:, :, 0].amin(0)) and torch.equal(out[v, :, 1], mm[grp][:, :, 1].amax(0))          # pooling itself is exact
         assert close(out[v, :, 0].cpu(), d2[grp].amin(dim=(0, 2, 3))) and close(out[v, :, 1].cpu(), d2[grp].amax(dim=(0, 2, 3)))
+
+
+@pytest.mark.parametrize('shape_a,shape_b,fused', [((34, 16, 768, 64), (50, 16, 769, 64), True), ((3, 4, 200, 64), (5, 4, 130, 64), False),
+                                                    ((20, 8, 300, 96), (24, 8, 257, 96), True)])
+def test_attention_pair_equals_two_launches(shape_a, shape_b, fused):
+    """pst_attn_pair: the self-attentions of two independent towers in ONE launch (one grid over both lists of 128-query blocks) when both take the
+    128-query kernel variant, two launches otherwise - bit-identical to two hip.attention calls, padded per-view layouts included."""
+    from panst3r_amd import hip
+
+    def problem(seed, B, H, N, hd):
+        D = H * hd
+        Np = (N + 7) // 8 * 8
+        q = (rn(seed, B * Np, 2 * D) * (hd ** -0.5 * hip.LOG2E) ** 0.5).to(d16()).to(dev())
+        vt = rn(seed + 1, D, B * Np + 8).to(d16()).to(dev())
+        mk = lambda: torch.zeros(B * Np, D, dtype=d16(), device=dev())
+        ldq, ldv = q.stride(0), vt.stride(0)
+        kw = dict(q_strides=(Np * ldq, hd, ldq), k_strides=(Np * ldq, hd, ldq), v_strides=(Np, hd * ldv, ldv), o_strides=(Np * D, hd, D), prescaled=True)
+        return (lambda o: (q, q[:, D:], vt, o, B, H, N, N, hd)), kw, mk
+    A, Bp = problem(3000, *shape_a), problem(3100, *shape_b)
+    ref = []
+    for mkargs, kw, mk in (A, Bp):
+        o = mk()
+        hip.attention(*mkargs(o), **kw)
+        ref.append(o)
+    hip.TIMER = hip.KernelTimer()
+    try:
+        oa, ob = A[2](), Bp[2]()
+        hip.attention_pair((A[0](oa), A[1]), (Bp[0](ob), Bp[1]))
+        names = [r[0] for r in hip.TIMER.records]
+    finally:
+        hip.TIMER = None
+    assert (len(names) == 1 and names[0].startswith('attn2_kernel')) == fused, names
+    assert torch.equal(oa, ref[0]) and torch.equal(ob, ref[1])
+    for _ in range(3):
+        oa, ob = A[2](), Bp[2]()
+        hip.attention_pair((A[0](oa), A[1]), (Bp[0](ob), Bp[1]))
+        assert torch.equal(oa, ref[0]) and torch.equal(ob, ref[1])

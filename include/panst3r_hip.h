@@ -113,6 +113,7 @@ const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_param
  * is bit-identical).  Returns the previous value, or -1 for an unknown knob. */
 #define PST_TUNE_G256_PP 3      /* 1 (default): ping-pong K loop of the persistent 256x256 kernel, 0: the lock-step loop (A/B measurements) */
 #define PST_TUNE_PAIR 4         /* 1 (default): pst_gemm_pair may put two big problems side by side in one persistent launch, 0: never */
+#define PST_TUNE_DEEP_RING 8    /* LDS slabs of the 64x64-tile GEMM when a launch has at most one tile per CU: 4 (the ring of every other launch), 6 or 8 */
 #define PST_TUNE_PAIR_ATTN 7    /* 1 (default): pst_attn_pair may put two attention problems into one launch, 0: never */
 #define PST_TUNE_PAIR_DELAY 6   /* start delay of the second problem of a shared launch in % of a tile period (default 0 = none; measured slower): de-phases its epilogues from the first's */
 #define PST_TUNE_PAIR_RES 5     /* 1 (default): ... including fp32 residual-stream problems at K >= 1024 that would run on the 128x128 kernel on their own */

@@ -329,7 +329,7 @@ __device__ __forceinline__ void gemm_tile(const pst_gemm_params& p_in, const int
   const int b_off = b_row * 128 + ((g ^ ((b_row >> 1) & 7)) << 4);
 
   const int nk = p.K / BK;
-  static_assert(NST == 2 || ((NST == 3 || NST == 4) && FM + FN == 4), "counted waits below assume 4 LDS-DMA ops per slab when NST > 2");
+  static_assert(NST == 2 || ((NST == 3 || NST == 4 || NST == 6 || NST == 8) && FM + FN == 4), "counted waits below assume 4 LDS-DMA ops per slab when NST > 2");
 #pragma unroll
   for (int st = 0; st < NST - 1; ++st)
     if (st < nk) stage(st, st);
@@ -341,7 +341,11 @@ __device__ __forceinline__ void gemm_tile(const pst_gemm_params& p_in, const int
   for (int kt = 0; kt < nk; ++kt) {
     // slab kt has landed once at most `newer` younger slabs (4 LDS-DMA ops each) are still in flight
     const int newer = min(NST - 2, nk - 1 - kt);
-    if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (NST > 4 && newer >= 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (NST > 4 && newer == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (NST > 4 && newer == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (NST > 4 && newer == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else wait_vm0();
     __builtin_amdgcn_s_barrier();   // ... for every wave, and everybody is done reading the buffer that is refilled next
@@ -526,6 +530,10 @@ static int launch_t(const pst_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
   const size_t lds = NST * (BM + BN) * 128 + BM * sizeof(float2);      // operand slabs + the LayerNorm-fold row table
+  if constexpr (NST > 4) {
+    static unsigned long long attr_seen = 0;
+    once_per_device(attr_seen, [] { (void)hipFuncSetAttribute((const void*)gemm_kernel<FM, FN, TRANS, NST, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * (BM + BN) * 128 + BM * (int)sizeof(float2)); });
+  }
   hipLaunchKernelGGL((gemm_kernel<FM, FN, TRANS, NST, F16>), dim3(tiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, tiles, tiles_m, tiles_n);
   return check_launch("gemm");
 }
@@ -587,6 +595,7 @@ static int gemm_validate(const pst_gemm_params* pp) {
   return PST_OK;
 }
 
+static int g_deep_ring = 4;          // PST_TUNE_DEEP_RING
 namespace pst { int gemm256_pp(int set); int gemm256p_pair_delay(int set); int attn_pair_enable(int set); }
 
 // the ONE dispatch rule, shared by the launch and by pst_gemm_variant: 0 = 64x64 tiles, 1 = 128x128, 2 = 256x256
@@ -626,6 +635,12 @@ extern "C" int pst_gemm(const pst_gemm_params* pp, void* stream) {
   // measured (K = 16 memory build, graph replay): NST 2 / 3 / 4 -> 42.2 / 34.8 / 33.8 ms
   if (c == 2) return gemm256_persistent_ok(p) ? launch_gemm256p(p, s, num_cus()) : launch_gemm256(p, s);
   if (p.trans_out) return c == 0 ? launch<2, 2, true, 4>(p, s) : launch<4, 4, true, 2>(p, s);
+  if (c == 0 && g_deep_ring > 4 && p.batch <= 1) {
+    // at most one 64 x 64 tile per CU (the 768-row projections of the memory build: 144 tiles): the CU's whole LDS can be ring - K steps of such a tile
+    // are latency-bound (0.25 us each with 3 slabs in flight), twice the slabs in flight halve that (PST_TUNE_DEEP_RING: 4 = off, 6, 8)
+    const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (tiles <= num_cus() && p.K >= 512) return g_deep_ring >= 8 ? launch<2, 2, false, 8>(p, s) : launch<2, 2, false, 6>(p, s);
+  }
   return c == 0 ? launch<2, 2, false, 4>(p, s) : launch<4, 4, false, 2>(p, s);
 }
 
@@ -682,6 +697,7 @@ extern "C" int pst_tune(int knob, int value) {
   if (knob == PST_TUNE_PAIR_RES) { const int prev = g_pair_res; g_pair_res = value != 0; return prev; }
   if (knob == PST_TUNE_PAIR_DELAY) return pst::gemm256p_pair_delay(value);
   if (knob == PST_TUNE_PAIR_ATTN) return pst::attn_pair_enable(value);
+  if (knob == PST_TUNE_DEEP_RING) { const int prev = g_deep_ring; if (value == 4 || value == 6 || value == 8) g_deep_ring = value; return prev; }
   if (knob == PST_TUNE_PAIR) { const int prev = g_pair; g_pair = value != 0; return prev; }
   return -1;
 }

@@ -80,6 +80,20 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(const float* img, void*
       const int ty = t / gw, tx = t - ty * gw;
       const float* s = im + ((int64_t)c * H + ty * pe + dy) * W + tx * pe;
       const int64_t d = orow + (c * pe + dy) * pe;
+      if (pe == 16 && tc != DT_F32 && (W & 3) == 0 && (ld_enc & 7) == 0 && ((uintptr_t)enc & 15) == 0 && ((uintptr_t)img & 15) == 0) {
+        // the usual case (round 4): a thread's 16 pixels are 64 contiguous bytes in and 32 contiguous bytes out - four 16-byte loads, two 16-byte stores
+        // instead of 16 scalar loads and 16 two-byte stores (patch_rows ran at 0.63 TB/s)
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 t4 = *(const float4*)(s + 4 * q); v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w; }
+        uint4 o[2];
+        uint32_t* ow = (uint32_t*)o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ow[q] = pack2(v[2 * q], v[2 * q + 1], tc);
+        uint4* dp = (uint4*)((bf16_t*)enc + d);
+        dp[0] = o[0]; dp[1] = o[1];
+        continue;
+      }
       for (int dx = 0; dx < pe; ++dx) store1(enc, d + dx, tc, s[dx]);
       continue;
     }
@@ -97,6 +111,8 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(const float* img, void*
     const float* pl = im + (int64_t)c * H * W;
     auto px = [&](int y, int x) { const float v = transposed ? pl[(int64_t)x * W + y] : pl[(int64_t)y * W + x]; return ((v * 0.5f + 0.5f) - mean) / stdv; };
     const int64_t d = orow + (c * pd + dy) * pd;
+    const bool pairs = tc != DT_F32 && (pd & 1) == 0 && (ld_dino & 1) == 0 && ((uintptr_t)dino & 3) == 0;      // 14 values = 7 four-byte stores instead of 14 two-byte ones
+    float prev = 0.f;
     for (int dx = 0; dx < pd; ++dx) {
       const int ox = tx * pd + dx;
       const float fx = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
@@ -105,7 +121,10 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(const float* img, void*
       const float lx = fx - x0;
       const float topv = px(y0, x0) * (1.f - lx) + px(y0, x1) * lx;
       const float botv = px(y1, x0) * (1.f - lx) + px(y1, x1) * lx;
-      store1(dino, d + dx, tc, topv * (1.f - ly) + botv * ly);
+      const float val = topv * (1.f - ly) + botv * ly;
+      if (!pairs) store1(dino, d + dx, tc, val);
+      else if (dx & 1) *(uint32_t*)((bf16_t*)dino + d + dx - 1) = pack2(prev, val, tc);
+      else prev = val;
     }
   }
 }

@@ -255,7 +255,7 @@ class PanSt3R(nn.Module):
         mask head on 16-bit operands as well - SURVEY 8(d) sanctions it against the stated tolerances).  'reference' = the reference's own placement
         under --amp (panst3r.py:174-175,204-234 autocast the encoder, the memory build and the keyframes' render + DINOv2 only; the WHOLE panoptic
         decoder :236-245 and the render + DINOv2 + heads of the views that are not keyframes :268 run outside autocast): those parts run on the fp32
-        kernels here too (measured 4.9x the scene time at 50 views / 16 keyframes; the encoder tokens of every view stay 16-bit-computed, as in the reference).
+        kernels here too (measured 4.7x the scene time at 50 views / 16 keyframes; the encoder tokens of every view stay 16-bit-computed, as in the reference).
         `cache_graphs=True` (not in the reference) keeps the scene's runner: repeated calls with the same signature replay captured HIP
         graphs (see _runner_for; `clear_runners()` frees them).  Default: one eager pass, nothing kept."""
         if use_retrieval and keyframes is None:

@@ -336,10 +336,16 @@ __device__ __forceinline__ void attn_body(const pst_attn_params& p, const int bi
   }
 }
 
+// Block order (`xcd` != 0, the default): the hardware places workgroup i on XCD i % 8, so with the plain order the 6 - 7 query blocks that share one
+// (view, head)'s K / V^T land on 6 - 7 different XCDs and each of their L2s fetches the same 196 KB from the fabric - PMC of the two ViT-L towers' paired
+// self-attention: 1.96 GB of FETCH_SIZE per launch for 0.53 GB of unique Q / K / V (profiles/r4_pmc_summary.md), i.e. the 768-key self-attentions ran at
+// the fabric's ~6.5 TB/s, not at the matrix pipe's rate.  xcd_remap gives every XCD a CONTIGUOUS range of logical blocks: the query blocks of one head
+// run on one XCD at the same time and share each K / V tile through its L2 (the render's 300 blocks per head: one 3.1 MB head per 4 MB L2).
+// Which block computes what is unchanged: bit-identical outputs (tests/test_hip_ops.py::test_attention_block_order_is_bit_identical).
 template <int HD, int QF, bool F16, bool PRE>
-__global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p) {
+__global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p, const int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  attn_body<HD, QF, F16, PRE>(p, (int)blockIdx.x, smem);
+  attn_body<HD, QF, F16, PRE>(p, xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x, smem);
 }
 
 // TWO independent attention problems of one kernel variant in one launch (pst_attn_pair): blocks [0, nblk0) belong to problem 0, the rest to problem 1.
@@ -351,10 +357,11 @@ struct attn2_args {
   int nblk0;
 };
 template <int HD, int QF, bool F16, bool PRE>
-__global__ __launch_bounds__(256) void attn2_kernel(const attn2_args a) {
+__global__ __launch_bounds__(256) void attn2_kernel(const attn2_args a, const int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int which = (int)blockIdx.x >= a.nblk0 ? 1 : 0;
-  attn_body<HD, QF, F16, PRE>(a.p[which], which ? (int)blockIdx.x - a.nblk0 : (int)blockIdx.x, smem);
+  const int blk = xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;        // one remap over the whole launch: an XCD's range may span both problems
+  const int which = blk >= a.nblk0 ? 1 : 0;
+  attn_body<HD, QF, F16, PRE>(a.p[which], which ? blk - a.nblk0 : blk, smem);
 }
 
 // merge the nsplit partial results of one (b, h, q) row: O = sum_s O_s 2^((m_s-m)c) / sum_s l_s 2^((m_s-m)c)
@@ -386,12 +393,16 @@ __global__ void attn_combine_kernel(const pst_attn_params p, int hd) {
   }
 }
 
+// PST_TUNE_ATTN_XCD: 1 (default) = XCD-contiguous block order, 0 = the plain order (A/B measurements; bit-identical)
+static int g_attn_xcd = 1;
+int attn_xcd_order(int set) { const int prev = g_attn_xcd; if (set == 0 || set == 1) g_attn_xcd = set; return prev; }
+
 template <int HD, int QF, bool F16, bool PRE>
 static int launch_attn4(const pst_attn_params& p, hipStream_t s) {
   const int qblocks = (p.Nq + 64 * QF - 1) / (64 * QF);
   const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
   const long grid = (long)qblocks * p.H * p.B * nsplit;
-  hipLaunchKernelGGL((attn_kernel<HD, QF, F16, PRE>), dim3((unsigned)grid), dim3(256), 2 * AttnCfg<HD>::BUF, s, p);
+  hipLaunchKernelGGL((attn_kernel<HD, QF, F16, PRE>), dim3((unsigned)grid), dim3(256), 2 * AttnCfg<HD>::BUF, s, p, attn_xcd_order(-1));
   if (nsplit > 1) {
     const int64_t total = (int64_t)p.B * p.H * p.Nq * (HD / 4);
     int64_t g = (total + 255) / 256;
@@ -412,7 +423,7 @@ static int launch_attn2_t(const pst_attn_params& pa, const pst_attn_params& pb, 
   a.p[0] = pa; a.p[1] = pb;
   const long ga = (long)((pa.Nq + 64 * QF - 1) / (64 * QF)) * pa.H * pa.B, gb = (long)((pb.Nq + 64 * QF - 1) / (64 * QF)) * pb.H * pb.B;
   a.nblk0 = (int)ga;
-  hipLaunchKernelGGL((attn2_kernel<HD, QF, F16, PRE>), dim3((unsigned)(ga + gb)), dim3(256), 2 * AttnCfg<HD>::BUF, s, a);
+  hipLaunchKernelGGL((attn2_kernel<HD, QF, F16, PRE>), dim3((unsigned)(ga + gb)), dim3(256), 2 * AttnCfg<HD>::BUF, s, a, attn_xcd_order(-1));
   return check_launch("attn_fwd (pair)");
 }
 

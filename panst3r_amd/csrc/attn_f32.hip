@@ -17,7 +17,7 @@ namespace pst {
 //                 keys does not see; lane (g, l16) ends up with output dims 16 df + 4 g + r of query l16: float4 stores.
 // K and V tiles are staged key-major with a pitch of hd + 4 floats: the fragment reads above are conflict-free ds_read_b32 (bank = 4 l16 + g / 16 g + l16).
 template <int HD>
-__global__ __launch_bounds__(256) void attn_f32_kernel(const pst_attn_params p) {
+__global__ __launch_bounds__(256) void attn_f32_kernel(const pst_attn_params p, const int xcd) {
   constexpr int KT = 64, PITCH = HD + 4, NKS = HD / 4, NDF = HD / 16;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Ks = (float*)smem_raw;                 // [KT][PITCH]
@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const pst_attn_params p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l16 = lane & 15;
   const int qblocks = (p.Nq + 63) / 64;
-  const int qb = blockIdx.x % qblocks, bh = blockIdx.x / qblocks;
+  const int blk = xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;      // XCD-contiguous block order (attention.hip): one head's K / V in one L2
+  const int qb = blk % qblocks, bh = blk / qblocks;
   const int h = bh % p.H, b = bh / p.H;
   const float* Qp = (const float*)p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs;
   const float* Kp = (const float*)p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
@@ -135,13 +136,15 @@ int attn_f32_validate(const pst_attn_params& p) {
   return PST_OK;
 }
 
+int attn_xcd_order(int set);          // attention.hip (PST_TUNE_ATTN_XCD)
+
 template <int HD>
 static int launch_attn_f32_t(const pst_attn_params& p, hipStream_t s) {
   constexpr int LDS = 2 * 64 * (HD + 4) * 4;
   static unsigned long long seen = 0;
   once_per_device(seen, [] { (void)hipFuncSetAttribute((const void*)attn_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (HD + 4) * 4); });
   const long grid = (long)((p.Nq + 63) / 64) * p.H * p.B;
-  hipLaunchKernelGGL((attn_f32_kernel<HD>), dim3((unsigned)grid), dim3(256), LDS, s, p);
+  hipLaunchKernelGGL((attn_f32_kernel<HD>), dim3((unsigned)grid), dim3(256), LDS, s, p, attn_xcd_order(-1));
   return check_launch("attn_f32");
 }
 

@@ -114,6 +114,27 @@ __device__ __forceinline__ void lgkm_wait(bf16x8& x) {           // at most N LD
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N));
 }
 __device__ __forceinline__ void lds_tie(bf16x8& x) { asm volatile("" : "+v"(x)); }      // x may not be consumed before the preceding wait
+// LDS TABLE reads next to an LDS-DMA in flight.  hipcc cannot tell what a global_load_lds writes, so it puts an s_waitcnt vmcnt(...) that covers every
+// pending LDS-DMA in front of ANY LDS access it schedules behind one - in the persistent GEMM that was a full round trip of the next tile's first
+// operand tile at the first table read of every epilogue (s_waitcnt vmcnt(0) right after request_next(): all matrix pipes and all stores idle).  Reads
+// issued as inline asm are not modelled: no wait is inserted, the caller orders them by hand - lds_ld* (issue, program order), lds_wait (all returned),
+// lds_use (ties a destination to the wait: its consumers cannot be hoisted above it).  The tables live outside the operand buffers; nothing aliases.
+__device__ __forceinline__ void lds_ld(f32x4& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); }
+template <int OFF>
+__device__ __forceinline__ void lds_ldo(f32x4& d, uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is 16 bit");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_ld(f32x2_t& d, uint32_t addr) { asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"(addr)); }
+template <int OFF>
+__device__ __forceinline__ void lds_ldo(f32x2_t& d, uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is 16 bit");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)"); }
+template <typename T>
+__device__ __forceinline__ void lds_use(T& x) { asm volatile("" : "+v"(x)); }
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -212,6 +233,16 @@ __device__ __forceinline__ void ln_row_sums(const float2* st, float& s, float& q
 #pragma unroll
   for (int g = 0; g < NG / 2; ++g) { s += v[g].x; q += v[g].y; s += v[g].z; q += v[g].w; }     // index order, as the generic loop
 }
+// (rstd, -mean rstd) of a row from its (sum, sum of squares) over K elements.  The variance is ONE explicit fma, -mean * mean + (q / K): every kernel
+// that turns partials into a fold entry must round identically, and `q * inv_d - mean * mean` left to the compiler contracts either product
+// (the persistent kernel's table commit picked the other one: 1-ulp entries, one 16-bit output in 10^5 off by an ulp).
+__device__ __forceinline__ float2 ln_fold_entry(float s, float q, int K, float eps) {
+  const float inv_d = 1.0f / (float)K;
+  const float mean = s * inv_d;
+  const float t = q * inv_d;
+  const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, t), 0.f) + eps);
+  return make_float2(rstd, -mean * rstd);
+}
 __device__ __forceinline__ void ln_fold_prologue(const pst_gemm_params& p, float2* lnst, int tid, int m0, int BM) {
   if (tid < BM) {
     const int m = min(m0 + tid, p.M - 1);
@@ -222,10 +253,7 @@ __device__ __forceinline__ void ln_fold_prologue(const pst_gemm_params& p, float
     else if (p.ln_groups == 6) ln_row_sums<6>(st, s, q);         // D = 384 (LoftUp)
     else if (p.ln_groups == 2) ln_row_sums<2>(st, s, q);
     else for (int g = 0; g < p.ln_groups; ++g) { const float2 t = st[g]; s += t.x; q += t.y; }
-    const float inv_d = 1.0f / (float)p.K;
-    const float mean = s * inv_d;
-    const float rstd = rsqrtf(fmaxf(q * inv_d - mean * mean, 0.f) + p.ln_eps);
-    lnst[tid] = make_float2(rstd, -mean * rstd);
+    lnst[tid] = ln_fold_entry(s, q, p.K, p.ln_eps);
   }
 }
 

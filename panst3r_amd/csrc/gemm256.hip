@@ -396,7 +396,7 @@ __device__ __forceinline__ float mul_add_2r(float a, float b, float c) {
 //   group 1:     L0 M0 L1 M1 L2 M2 L3 | M3 L0' ...       M0: (m0,n0)  M1: (m0,n1)  M2: (m1,n1)  M3: (m1,n0)      -- same K order: same bits
 // The kernel body: workgroup `bid` of the `nblk` workgroups that walk problem `p` (its `ntiles` tiles).  One problem per launch: (blockIdx.x, gridDim.x);
 // two problems per launch (gemm256p2_kernel below): each problem gets a contiguous range of the launch's workgroups.
-template <bool F16, bool RES, bool TRANS, bool PP>
+template <bool F16, bool RES, bool TRANS, bool PP, bool ROPE>
 __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const int ntiles, const int tiles_m, const int tiles_n, const int bid, const int nblk, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -452,7 +452,7 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
   // fused RoPE-2D (q|k projections): the positions of the tile's rows per tile, the whole (cos, sin) table [npos][16][2] once
   int2* postab_all = (int2*)(smem + LDS256P_TABLES);                      // [2][256]
   float* ropetab = (float*)(smem + LDS256P_TABLES + 2 * 256 * 8);         // [npos <= 64][32]
-  const bool rope = !RES && p.rope_hd == 64;
+  const bool rope = ROPE && p.rope_hd == 64;          // ROPE: the variant that can rotate (plain class only; a problem without positions runs in it unrotated)
   if (rope)
     for (int i = tid; i < p.rope_npos * 32; i += 512) ropetab[i] = p.rope_cs[i];
   int par = 0;
@@ -507,23 +507,93 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
     __builtin_amdgcn_s_setprio(0);
   };
 
+  // ---- the per-tile tables, fetched ONE TILE AHEAD.  Rounds 2-4 filled them at the top of every tile: three to five global loads in a row (bias, LayerScale,
+  // fold column sums, the 16 fold partials of the row, the row's RoPE position), each in its own conditional block and therefore each behind its own
+  // s_waitcnt vmcnt(0) - which, the counter being in order, also drained every store of the previous epilogue - with all eight waves parked at the
+  // barrier meanwhile.  Now threads < 256 REQUEST the next tile's entries inside the epilogue of the current one (plain global loads into registers, no
+  // wait) and COMMIT them to the other parity's tables at its end: the round trips overlap the epilogue's stores, one wait instead of up to five.
+  // The rows' fold partials (ln_groups (sum, sumsq) pairs per row: 32 KB per tile at D = 1024) are too many for registers next to the accumulators:
+  // they travel by LDS-DMA into the A halves of operand buffer 1, which are free from the end of the K loop until K tile 1 of the next tile is staged.
+  // Layout: 128 B per row (8 slots of 16 B = two groups each; ln_groups / 2 of them used), 1 KB units of 8 rows.  Unit u is requested by wave u % 8,
+  // reduced by the same wave (lanes 0..31: one row each) and overwritten by that wave's own share of K tile 1's A halves (stage(): wave w fills the
+  // KB w, 8 + w, 16 + w, 24 + w) - no other wave ever touches it: no barrier, the wave's program order is the only ordering needed.  Slot c of row r holds
+  // chunk c ^ key(r, u) (the DMA takes a per-lane SOURCE address, so the permutation is free): the 32 reading lanes - rows 128 B apart - spread over
+  // all 16 bank quads instead of two.
+  struct tile_tables { float b, g, c; int2 pos; };
+  char* const raw_lds = smem + BUF_BYTES;                                  // buffer 1, A-lo | A-hi: 32 KB
+  auto raw_key = [&](int rr, int u) { return (rr >> 1) | (((u >> 3) & 1) << 2); };
+  // (`opaque`: the lane-derived addresses of these once-per-tile steps are recomputed where they are used - hoisted out of the tile loop they would sit
+  // in registers, or in scratch, through the K loop and the epilogue)
+  auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+  auto opaque_s = [](int x) { asm volatile("" : "+v"(x)); return __builtin_amdgcn_readfirstlane(x); };      // ... a wave-uniform value, back in a scalar
+  auto tables_request = [&](tile_tables& t, int tm0, int tn0) {          // column constants and position: registers of threads < 256
+    if (tid < 256) {
+      const int tid_ = opaque(tid);
+      const int nc = min(tn0 + tid_, p.N - 1);
+      t.b = p.bias ? p.bias[nc] : 0.f;
+      t.g = p.gamma ? p.gamma[nc] : 1.f;
+      t.c = p.ln_stats ? p.ln_colsum[nc] : 0.f;
+      if constexpr (ROPE) { if (rope) t.pos = *(const int2*)(p.rope_pos + 2 * min(tm0 + tid_, p.M - 1)); }
+    }
+  };
+  auto stats_request = [&](int tm0) {                                      // every wave: its four units
+    if constexpr (!RES) {
+      if (p.ln_stats) {
+        const int nq = opaque_s(p.ln_groups >> 1);                         // ln_groups is even and <= 16 here (gemm256_persistent_class)
+        const int lane_ = opaque(lane);
+        const int rr = lane_ >> 3, c = lane_ & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int u = wave + 8 * j;
+          const int m = min(tm0 + u * 8 + rr, p.M - 1);
+          const int q = min(c ^ raw_key(rr, u), nq - 1);                  // (unused slots of a short row re-read its last chunk)
+          glds16((const char*)p.ln_stats + ((int64_t)m * p.ln_groups * 8 + q * 16), raw_lds + (u << 10));
+        }
+      }
+    }
+  };
+  auto tables_commit = [&](const tile_tables& t, int parity) {
+    if (tid < 256) {
+      const int tid_ = opaque(tid);
+      float* ct = coltab_all + parity * 768;
+      ct[tid_] = t.b;
+      ct[256 + tid_] = t.g;
+      ct[512 + tid_] = t.c;
+      if constexpr (ROPE) { if (rope) (postab_all + parity * 256)[tid_] = t.pos; }
+    }
+    if constexpr (!RES) {
+      if (p.ln_stats && lane < 32) {   // the sums of ln_row_sums / ln_fold_prologue (common.h), group by group in index order: same bits
+        const int lane_ = opaque(lane);
+        const int rr = lane_ & 7, u = wave + 8 * (lane_ >> 3), key = raw_key(rr, u);
+        const char* row = raw_lds + (u << 10) + rr * 128;
+        const int nq = opaque_s(p.ln_groups >> 1);
+        f32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *(const f32x4*)(row + ((min(q, nq - 1) ^ key) << 4));
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < nq) { sm += v[q][0]; sq += v[q][1]; sm += v[q][2]; sq += v[q][3]; }
+        (lnst_all + parity * 256)[u * 8 + rr] = ln_fold_entry(sm, sq, p.K, p.ln_eps);
+      }
+    }
+  };
+
   int slot = bid;
   int m0, n0;
   tile_origin(xcd_remap(slot, ntiles), m0, n0);
   describe(m0, n0);
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  {
+    tile_tables t0;               // the first tile's tables: their round trip runs beside the operand DMA just issued
+    tables_request(t0, m0, n0);
+    stats_request(m0);
+    tables_commit(t0, 0);
+  }
   for (;;) {
     float2* lnst = lnst_all + par * 256;
     float* coltab = coltab_all + par * 768;
-    if (p.ln_stats) ln_fold_prologue(p, lnst, tid, m0, 256);
     int2* postab = postab_all + par * 256;
-    if (rope && tid < 256) postab[tid] = *(const int2*)(p.rope_pos + 2 * min(m0 + tid, p.M - 1));
-    if (tid < 256) {
-      const int nc = min(n0 + tid, p.N - 1);
-      coltab[tid] = p.bias ? p.bias[nc] : 0.f;
-      coltab[256 + tid] = p.gamma ? p.gamma[nc] : 1.f;
-      coltab[512 + tid] = p.ln_stats ? p.ln_colsum[nc] : 0.f;
-    }
     if constexpr (PP) {
       // ---- all of K tile 1 behind K tile 0: with the in-order vmcnt, "all but the 8 newest" = everything of K tile 0 (and every older store)
       stage(2, 1); stage(3, 1); stage(0, 1); stage(1, 1);
@@ -618,105 +688,135 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
     const int cm0 = m0, cn0 = n0;
     slot += nblk;
     const bool more = slot < ntiles;
-    // request the next tile's first operand tiles: the buffers are free.  Loads issued after this point queue BEHIND that DMA in the
-    // in-order vmcnt, so the plain epilogue issues none at all and the residual epilogue requests its first half before it.
+    if (more) tile_origin(xcd_remap(slot, ntiles), m0, n0);        // (m0, n0): the NEXT tile from here on
+    // request the next tile's first operand tiles: the buffers are free.  From here to the end of the epilogue no LDS access may be left to the
+    // compiler's scheduling (common.h, lds_ld): the tables are read before this point or by lds_ld* / lds_wait.
     auto request_next = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
       if (more) {
-        tile_origin(xcd_remap(slot, ntiles), m0, n0);
         describe(m0, n0);
         stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+        stats_request(m0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     };
+    tile_tables nt;
     const bool fold = p.ln_stats != nullptr;
     if constexpr (RES) {
+      // The residual tile goes through registers ONE ROW FRAGMENT at a time (16 rows x the wave's 64 columns = 4 x 16 B per lane = 16 registers),
+      // RES_LA fragments ahead of the one being finished: the loads of fragment i + RES_LA are in flight while fragment i is scaled, added, stored.
+      // (Rounds 3-4 loaded four fragments = 64 registers at once, twice per tile: with the 128 accumulators live that is past the 256-register file -
+      // the allocator spilled five of the sixteen loads, each behind its own s_waitcnt vmcnt(0): five serialised HBM round trips per tile and no
+      // store overlap.  vgpr_spill_count 33 -> 0 (1 in the two-problem kernel, outside the tile loop's hot part); proj + residual at K = 1024, both towers in
+      // one launch: 262 -> 251 us, fc2 + residual at K = 4096: 584 -> 568 us, same box (profiles/r4_epi_ab_kernels.txt).)
+      // No LayerNorm-fold consumer and no activation in this class (gemm256_persistent_class): the epilogue is acc + bias, x LayerScale, + residual.
+      constexpr int RES_LA = 2;
       float* Cf = (float*)p.C;
       const int grp64 = (cn0 + wn * 64) >> 6;
-      float4 rv[4][2][2];
-      auto load_res = [&](int i0) {
+      const uint32_t ct_a = lds_addr(coltab) + (uint32_t)(wn * 64 + g * 8) * 4u;
+      float4 rv[8][2][2];
+      auto load_row = [&](auto i) {
+        const int m = min(cm0 + wm * 128 + i * 16 + l16, p.M - 1);
+        const float* rp = p.res + (int64_t)m * p.ldr + cn0 + wn * 64 + g * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = min(cm0 + wm * 128 + (i0 + i) * 16 + l16, p.M - 1);
-          const float* rp = p.res + (int64_t)m * p.ldr + cn0 + wn * 64 + g * 8;
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) rv[i][h][u] = *(const float4*)(rp + h * 32 + 4 * u);
-        }
+          for (int u = 0; u < 2; ++u) rv[i][h][u] = *(const float4*)(rp + h * 32 + 4 * u);
       };
-      auto finish = [&](int i0) {
+      auto finish_row = [&](auto i) {
+        const int r = wm * 128 + i * 16 + l16;
+        const int m = cm0 + r;
+        f32x4 bias4[2][2], gam4[2][2];
+        static_for<0, 2>([&](auto h) {
+          static_for<0, 2>([&](auto u) {
+            lds_ldo<(h * 32 + 4 * u) * 4>(bias4[h][u], ct_a);
+            lds_ldo<1024 + (h * 32 + 4 * u) * 4>(gam4[h][u], ct_a);
+          });
+        });
+        if constexpr (i + RES_LA < 8) load_row(std::integral_constant<int, i + RES_LA>{});      // its address arithmetic covers the LDS latency
+        lds_wait();
+        static_for<0, 2>([&](auto h) { static_for<0, 2>([&](auto u) { lds_use(bias4[h][u]); lds_use(gam4[h][u]); }); });
+        float osum[2], osq[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = wm * 128 + (i0 + i) * 16 + l16;
-          const int m = cm0 + r;
-          const float2 st = fold ? lnst[r] : make_float2(1.f, 0.f);
-          float osum[2], osq[2];
+        for (int h = 0; h < 2; ++h) {
+          const int cl = wn * 64 + h * 32 + g * 8;
+          float4 f[2];
+          float cs_[2], cq_[2];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int cl = wn * 64 + h * 32 + g * 8;
-            float4 f[2];
-            float cs_[2], cq_[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const float4 bias4 = *(const float4*)(coltab + cl + 4 * u), gam4 = *(const float4*)(coltab + 256 + cl + 4 * u), cs4 = *(const float4*)(coltab + 512 + cl + 4 * u);
-              const f32x4 a = acc[i0 + i][2 * h + u];
-              float v[4] = {fmaf(a[0], st.x, fmaf(st.y, cs4.x, bias4.x)), fmaf(a[1], st.x, fmaf(st.y, cs4.y, bias4.y)),
-                            fmaf(a[2], st.x, fmaf(st.y, cs4.z, bias4.z)), fmaf(a[3], st.x, fmaf(st.y, cs4.w, bias4.w))};
-              if (p.act == 1) {
-                gelu_erf4(v);
-              } else if (p.act == 2) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-              }
-              // two roundings (scale, then add), as in the row-phase epilogues where an LDS round trip separates them: no fma contraction
-              const float4 q4 = rv[i][h][u];
-              f[u] = make_float4(mul_add_2r(v[0], gam4.x, q4.x), mul_add_2r(v[1], gam4.y, q4.y), mul_add_2r(v[2], gam4.z, q4.z), mul_add_2r(v[3], gam4.w, q4.w));
-              ln_acc4(f[u], cs_[u], cq_[u]);
-            }
-            if (m < p.M) {
-              float* dst = Cf + (int64_t)m * p.ldc + cn0 + cl;
-              *(float4*)dst = f[0];
-              *(float4*)(dst + 4) = f[1];
-              if (p.xcopy)
-                *(uint4*)((bf16_t*)p.xcopy + (int64_t)m * p.ldxc + cn0 + cl) =
-                    make_uint4(H16<F16>::pack(f[0].x, f[0].y), H16<F16>::pack(f[0].z, f[0].w), H16<F16>::pack(f[1].x, f[1].y), H16<F16>::pack(f[1].z, f[1].w));
-            }
-            // chunk pair -> quad (lane ^ 16) -> octet (lane ^ 32): the butterfly of row_sum<16>, same association
-            osum[h] = add_lane32(add_lane16(cs_[0] + cs_[1]));
-            osq[h] = add_lane32(add_lane16(cq_[0] + cq_[1]));
+          for (int u = 0; u < 2; ++u) {
+            const f32x4 a = acc[i][2 * h + u], b4 = bias4[h][u], g4 = gam4[h][u];
+            // (the fold consumer's fmaf(acc, rstd, fmaf(-mean rstd, colsum, bias)) with rstd = 1, mean = 0: acc + bias in one rounding, same bits)
+            const float v[4] = {fmaf(a[0], 1.f, b4[0]), fmaf(a[1], 1.f, b4[1]), fmaf(a[2], 1.f, b4[2]), fmaf(a[3], 1.f, b4[3])};
+            // two roundings (scale, then add), as in the row-phase epilogues where an LDS round trip separates them: no fma contraction
+            const float4 q4 = rv[i][h][u];
+            f[u] = make_float4(mul_add_2r(v[0], g4[0], q4.x), mul_add_2r(v[1], g4[1], q4.y), mul_add_2r(v[2], g4[2], q4.z), mul_add_2r(v[3], g4[3], q4.w));
+            ln_acc4(f[u], cs_[u], cq_[u]);
           }
-          if (p.stats_out && g == 0 && m < p.M) *((float2*)p.stats_out + (int64_t)m * p.stats_ld + grp64) = make_float2(osum[0] + osum[1], osq[0] + osq[1]);
+          if (m < p.M) {
+            float* dst = Cf + (int64_t)m * p.ldc + cn0 + cl;
+            *(float4*)dst = f[0];
+            *(float4*)(dst + 4) = f[1];
+            if (p.xcopy)
+              *(uint4*)((bf16_t*)p.xcopy + (int64_t)m * p.ldxc + cn0 + cl) =
+                  make_uint4(H16<F16>::pack(f[0].x, f[0].y), H16<F16>::pack(f[0].z, f[0].w), H16<F16>::pack(f[1].x, f[1].y), H16<F16>::pack(f[1].z, f[1].w));
+          }
+          // chunk pair -> quad (lane ^ 16) -> octet (lane ^ 32): the butterfly of row_sum<16>, same association
+          osum[h] = add_lane32(add_lane16(cs_[0] + cs_[1]));
+          osq[h] = add_lane32(add_lane16(cq_[0] + cq_[1]));
         }
+        if (p.stats_out && g == 0 && m < p.M) *((float2*)p.stats_out + (int64_t)m * p.stats_ld + grp64) = make_float2(osum[0] + osum[1], osq[0] + osq[1]);
       };
-      load_res(0);
-      __builtin_amdgcn_sched_barrier(0);
-      request_next();
-      __builtin_amdgcn_sched_barrier(0);
-      finish(0);
-      load_res(4);
-      finish(4);
+      static_for<0, RES_LA>(load_row);
+      if (more) tables_request(nt, m0, n0);        // three scalars per thread, ahead of the DMA in the in-order queue
+      request_next();                              // behind the first residual loads, ahead of every store
+      static_for<0, 8>([&](auto i) {
+        finish_row(i);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if (more) tables_commit(nt, par ^ 1);
       par ^= 1;
       if (!more) break;
       continue;
     }
-    request_next();
 
     if constexpr (TRANS) {
       // lane (g, l16): column l16 of each column fragment; per pair of row fragments the 8 consecutive rows (sub-block, half, g*8 ..)
       bf16_t* Ct = (bf16_t*)p.C;
+      // the column constants are read BEFORE the operand request; the rows' fold entries (8 consecutive rows = 64 B per (jj, ip) step) by lds_ld, one
+      // step ahead of their use
+      float bcol[4], ccol[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int nl = wn * 64 + jj * 16 + l16;
+        bcol[jj] = coltab[nl];
+        ccol[jj] = coltab[512 + nl];
+      }
+      const uint32_t st_a = lds_addr(lnst) + (uint32_t)(wm * 128 + g * 8) * 8u;
+      f32x4 sq[4];                         // (rstd, -mean rstd) of rows r8 .. r8 + 7, two rows per register quad
+      auto st_issue = [&](auto step) {     // step = jj * 4 + ip: rows depend on ip only
+        constexpr int ip = step & 3;
+        static_for<0, 4>([&](auto q) { lds_ldo<((ip >> 1) * 64 + (ip & 1) * 32) * 8 + q * 16>(sq[q], st_a); });
+      };
+      if (fold) st_issue(std::integral_constant<int, 0>{});
+      lds_wait();
+      request_next();
+      static_for<0, 4>([&](auto jj) {
+        const int nl = wn * 64 + jj * 16 + l16;
         const int n = cn0 + nl;
-        const float b = coltab[nl], cs = coltab[512 + nl];
-#pragma unroll
-        for (int ip = 0; ip < 4; ++ip) {
+        const float b = bcol[jj], cs = ccol[jj];
+        static_for<0, 4>([&](auto ip) {
+          constexpr int step = jj * 4 + ip;
           const int r8 = wm * 128 + (ip >> 1) * 64 + (ip & 1) * 32 + g * 8;           // tile-local first row of the lane's run
+          if constexpr (step > 0) lds_wait();
+          static_for<0, 4>([&](auto q) { lds_use(sq[q]); });
           float v[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const float2 st = fold ? lnst[r8 + k] : make_float2(1.f, 0.f);
-            v[k] = fmaf(acc[2 * ip + (k >> 2)][jj][k & 3], st.x, fmaf(st.y, cs, b));
+            const float sx = fold ? sq[k >> 1][2 * (k & 1)] : 1.f, sy = fold ? sq[k >> 1][2 * (k & 1) + 1] : 0.f;
+            v[k] = fmaf(acc[2 * ip + (k >> 2)][jj][k & 3], sx, fmaf(sy, cs, b));
           }
+          static_for<0, 8>([&](auto k) { lds_use(v[k]); });          // the rows' entries are consumed: the same registers take the next step's
+          if constexpr (step + 1 < 16) { if (fold) st_issue(std::integral_constant<int, step + 1>{}); }
           if (p.act == 1) {
             gelu_erf4(*(float (*)[4])v);
             gelu_erf4(*(float (*)[4])(v + 4));
@@ -733,8 +833,13 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
               for (int k = 0; k < 8 && m + k < p.M; ++k) dst[k] = H16<F16>::from_f(v[k]);
             }
           }
-        }
-      }
+        });
+        // the next tile's table entries ride in the registers of the accumulator columns that are done
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (jj == 2) { if (more) tables_request(nt, m0, n0); }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if (more) tables_commit(nt, par ^ 1);
       par ^= 1;
       if (!more) break;
       continue;
@@ -744,6 +849,8 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
     // Row fragment outer, half inner: the two 64-byte halves of a row leave in consecutive store instructions and meet in the same 128-byte line
     // on their way out (measured on fc1, M = 38800: 380 -> 352 us against half-outer order; an exchange of halves between lanes l16 and l16 ^ 8 so
     // that ONE instruction writes 8 whole 128-byte rows was slower, 403 us: profiles/r3_gemm_pp_ablation.txt).
+    // Column constants, the rows' fold entries and RoPE positions: read before the operand request; only the RoPE (cos, sin) rows, which depend on
+    // the positions and would not fit the registers, are fetched per row fragment behind it (lds_ld).
     float4 bias4[2][2], gam4[2][2], cs4[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -754,15 +861,35 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
         gam4[h][u] = *(const float4*)(coltab + 256 + cl);
         cs4[h][u] = *(const float4*)(coltab + 512 + cl);
       }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    // per row fragment: (rstd, -mean rstd) of the lane's row and its (y, x) position, read one fragment ahead by lds_ld
+    const uint32_t st_a = lds_addr(lnst) + (uint32_t)(wm * 128 + l16) * 8u, pp_a = lds_addr(postab) + (uint32_t)(wm * 128 + l16) * 8u;
+    const uint32_t rt_a = lds_addr(ropetab) + (uint32_t)(g & 1) * 64u;
+    f32x2_t stq[2], ppq[ROPE ? 2 : 1];
+    auto row_issue = [&](auto i) {
+      if (fold) lds_ldo<i * 16 * 8>(stq[i & 1], st_a);
+      if constexpr (ROPE) { if (rope) lds_ldo<i * 16 * 8>(ppq[i & 1], pp_a); }
+    };
+    row_issue(std::integral_constant<int, 0>{});
+    lds_wait();
+    request_next();
+    static_for<0, 8>([&](auto i) {
       const int r = wm * 128 + i * 16 + l16;
-      const float2 st = fold ? lnst[r] : make_float2(1.f, 0.f);
-      uint4 val[2];
+      lds_use(stq[i & 1]);
+      const float2 st = fold ? make_float2(stq[i & 1][0], stq[i & 1][1]) : make_float2(1.f, 0.f);
+      f32x4 rc[4];                           // the (cos, sin) rows of one half (y, then x position)
+      uint32_t ax = 0;
+      if constexpr (ROPE) {
+        lds_use(ppq[i & 1]);
+        if (rope) {
+          const uint32_t ay = rt_a + (uint32_t)__float_as_int(ppq[i & 1][0]) * 128u;
+          ax = rt_a + (uint32_t)__float_as_int(ppq[i & 1][1]) * 128u;
+          static_for<0, 4>([&](auto q) { lds_ldo<q * 16>(rc[q], ay); });
+        }
+      }
+      if constexpr (i + 1 < 8) row_issue(std::integral_constant<int, i + 1>{});
+      uint32_t w[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int nn = cn0 + wn * 64 + h * 32 + g * 8;
-        uint32_t w[4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const f32x4 a = acc[i][2 * h + u];
@@ -775,40 +902,54 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
             for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
           }
           if (p.gamma) { v[0] *= gam4[h][u].x; v[1] *= gam4[h][u].y; v[2] *= gam4[h][u].z; v[3] *= gam4[h][u].w; }      // (x 1.0f is exact: skipping it changes no bit)
-          w[2 * u] = H16<F16>::pack(v[0], v[1]);
-          w[2 * u + 1] = H16<F16>::pack(v[2], v[3]);
+          w[h][2 * u] = H16<F16>::pack(v[0], v[1]);
+          w[h][2 * u + 1] = H16<F16>::pack(v[2], v[3]);
         }
-        val[h] = make_uint4(w[0], w[1], w[2], w[3]);
-        if (rope) {
-          // the wave's 64 columns are one head: half h rotates with the row's y (h = 0) / x (h = 1) position, pairs are 16 columns apart,
-          // i.e. the partner chunk lives in lane ^ 32 (g ^ 2).  The 16-bit-rounded values are rotated, as in the LDS store phases.
+      }
+      uint4 val[2] = {make_uint4(w[0][0], w[0][1], w[0][2], w[0][3]), make_uint4(w[1][0], w[1][1], w[1][2], w[1][3])};
+      lds_wait();                            // this row's first (cos, sin) rows and the next row's table entries have arrived
+      if constexpr (ROPE) if (rope) {
+        // the wave's 64 columns are one head: half h rotates with the row's y (h = 0) / x (h = 1) position, pairs are 16 columns apart,
+        // i.e. the partner chunk lives in lane ^ 32 (g ^ 2).  The 16-bit-rounded values are rotated, as in the LDS store phases.
+        static_for<0, 2>([&](auto h) {
+          static_for<0, 4>([&](auto q) { lds_use(rc[q]); });
+          const int nn = cn0 + wn * 64 + h * 32 + g * 8;
           uint32_t pw[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(w[q], w[q], false, false);
+            const auto sw = __builtin_amdgcn_permlane32_swap(w[h][q], w[h][q], false, false);
             pw[q] = lane < 32 ? sw[1] : sw[0];
           }
-          const int2 pp = postab[r];
-          const float4* t = (const float4*)(ropetab + (h == 0 ? pp.x : pp.y) * 32 + (g & 1) * 16);
-          const float4 cs[4] = {t[0], t[1], t[2], t[3]};
+          const float4 cs[4] = {make_float4(rc[0][0], rc[0][1], rc[0][2], rc[0][3]), make_float4(rc[1][0], rc[1][1], rc[1][2], rc[1][3]),
+                                make_float4(rc[2][0], rc[2][1], rc[2][2], rc[2][3]), make_float4(rc[3][0], rc[3][1], rc[3][2], rc[3][3])};
           val[h] = rope_rotate<F16>(val[h], make_uint4(pw[0], pw[1], pw[2], pw[3]), cs, nn);
-        }
+          if constexpr (h == 0) {            // the x rows into the same registers
+            lds_use(val[0].x); lds_use(val[0].y); lds_use(val[0].z); lds_use(val[0].w);
+            static_for<0, 4>([&](auto q) { lds_ldo<q * 16>(rc[q], ax); });
+            lds_wait();
+          }
+        });
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int m = cm0 + r, nn = cn0 + wn * 64 + h * 32 + g * 8;
         if (!(PST_ABL_E & 16) && m < p.M && nn < p.N) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = val[h];
       }
-    }
+      // the next tile's table entries ride in the registers of the accumulator rows that are done
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i == (ROPE ? 5 : 3)) { if (more) tables_request(nt, m0, n0); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (more) tables_commit(nt, par ^ 1);
     par ^= 1;
     if (!more) break;
   }
 }
 
-template <bool F16, bool RES, bool TRANS, bool PP>
+template <bool F16, bool RES, bool TRANS, bool PP, bool ROPE>
 __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm256p_body<F16, RES, TRANS, PP>(p, ntiles, tiles_m, tiles_n, blockIdx.x, gridDim.x, smem);
+  gemm256p_body<F16, RES, TRANS, PP, ROPE>(p, ntiles, tiles_m, tiles_n, blockIdx.x, gridDim.x, smem);
 }
 
 // TWO independent problems of the same class in one launch (pst_gemm_pair): workgroups [0, g0) walk problem 0, [g0, gridDim.x) problem 1.  Tile
@@ -822,7 +963,7 @@ struct gemm256p2_args {
   int g0;
   int delay_ticks;        // start delay of problem 1's workgroups in 100 MHz ticks (0: none), see gemm256p_pair_delay_us
 };
-template <bool F16, bool RES, bool TRANS, bool PP>
+template <bool F16, bool RES, bool TRANS, bool PP, bool ROPE>
 __global__ __launch_bounds__(512, 1) void gemm256p2_kernel(const gemm256p2_args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int which = (int)blockIdx.x >= a.g0 ? 1 : 0;
@@ -836,7 +977,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p2_kernel(const gemm256p2_args 
     const uint64_t t0 = wall_clock64();
     while ((int64_t)(wall_clock64() - t0) < (int64_t)a.delay_ticks) __builtin_amdgcn_s_sleep(32);
   }
-  gemm256p_body<F16, RES, TRANS, PP>(a.p[which], a.ntiles[which], a.tiles_m[which], a.tiles_n[which], bid, nblk, smem);
+  gemm256p_body<F16, RES, TRANS, PP, ROPE>(a.p[which], a.ntiles[which], a.tiles_m[which], a.tiles_n[which], bid, nblk, smem);
 }
 
 constexpr int LDS256 = 2 * BUF_BYTES + 256 * (int)sizeof(float2);      // operand buffers + the LayerNorm-fold row table
@@ -859,14 +1000,16 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
 // 2 = fp32 residual stream (C = res + ..., optional 16-bit copy + fold statistics); 0 = not eligible
 int gemm256_persistent_class(const pst_gemm_params& p) {
   if (p.ps_p || p.grp_in || p.res_mod || p.N % 64 || p.conv_c || p.batch > 1) return 0;
+  // fold consumers: the partials travel as 16-byte pairs of groups into 128-byte LDS rows (tables_commit): an even number of groups, at most 16 (D <= 1024)
+  if (p.ln_stats && ((p.ln_groups & 1) || p.ln_groups < 2 || p.ln_groups > 16 || ((uintptr_t)p.ln_stats & 15))) return 0;
   if (p.trans_out)        // class 3: transposed 16-bit store (bias / activation / fold consumer)
     return (p.out_fp32 || p.res || p.gamma || p.rope_hd || p.stats_out || p.xcopy || (p.ldc & 7) || ((uintptr_t)p.C & 15) || (int64_t)p.N * p.ldc >= (1ll << 31)) ? 0 : 3;
   if (p.rope_hd && (p.rope_hd != 64 || p.rope_npos <= 0 || p.rope_npos > 64 || p.out_fp32)) return 0;
-  if (p.ln_stats && p.ln_groups != 16 && p.ln_groups != 12 && p.ln_groups != 6 && p.ln_groups != 2) return 0;
   if (!p.out_fp32) {
     if (p.res || p.stats_out || p.xcopy || (p.ldc & 7) || ((uintptr_t)p.C & 15) || (int64_t)p.M * p.ldc >= (1ll << 31)) return 0;
     return 1;
   }
+  if (p.act || p.ln_stats) return 0;      // the residual-stream GEMMs (attention output projection, fc2) carry no activation and read no LayerNorm-ed operand
   if (p.N % 256 || !p.res || p.res_bf16 || (p.ldc & 3) || (p.ldr & 3) || (((uintptr_t)p.C | (uintptr_t)p.res) & 15)) return 0;
   if (p.xcopy && ((p.ldxc & 7) || ((uintptr_t)p.xcopy & 15))) return 0;
   if (p.stats_out && ((uintptr_t)p.stats_out & 7)) return 0;
@@ -882,11 +1025,18 @@ int gemm256_pp(int set) {
   return prev;
 }
 
+template <bool F16, bool RES, bool TRANS, bool PP, bool ROPE>
+static void launch_256p_r(const pst_gemm_params& p, hipStream_t s, int grid, int tiles, int tiles_m, int tiles_n) {
+  static unsigned long long attr_seen = 0;
+  once_per_device(attr_seen, [] { (void)hipFuncSetAttribute((const void*)gemm256p_kernel<F16, RES, TRANS, PP, ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P); });
+  hipLaunchKernelGGL((gemm256p_kernel<F16, RES, TRANS, PP, ROPE>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+}
 template <bool F16, bool RES, bool TRANS, bool PP>
 static void launch_256p_t(const pst_gemm_params& p, hipStream_t s, int grid, int tiles, int tiles_m, int tiles_n) {
-  static unsigned long long attr_seen = 0;
-  once_per_device(attr_seen, [] { (void)hipFuncSetAttribute((const void*)gemm256p_kernel<F16, RES, TRANS, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P); });
-  hipLaunchKernelGGL((gemm256p_kernel<F16, RES, TRANS, PP>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+  if constexpr (!RES && !TRANS) {
+    if (p.rope_hd == 64) { launch_256p_r<F16, RES, TRANS, PP, true>(p, s, grid, tiles, tiles_m, tiles_n); return; }
+  }
+  launch_256p_r<F16, RES, TRANS, PP, false>(p, s, grid, tiles, tiles_m, tiles_n);
 }
 
 template <bool RES, bool TRANS>
@@ -932,11 +1082,18 @@ double gemm256p_single_us(const pst_gemm_params& p, int cus) {
   return ((t + cus - 1) / cus) * tile_us(p, gemm256_persistent_class(p));
 }
 
+template <bool F16, bool RES, bool TRANS, bool PP, bool ROPE>
+static void launch_256p2_r(const gemm256p2_args& a, hipStream_t s, int grid) {
+  static unsigned long long attr_seen = 0;
+  once_per_device(attr_seen, [] { (void)hipFuncSetAttribute((const void*)gemm256p2_kernel<F16, RES, TRANS, PP, ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P); });
+  hipLaunchKernelGGL((gemm256p2_kernel<F16, RES, TRANS, PP, ROPE>), dim3(grid), dim3(512), LDS256P, s, a);
+}
 template <bool F16, bool RES, bool TRANS, bool PP>
 static void launch_256p2_t(const gemm256p2_args& a, hipStream_t s, int grid) {
-  static unsigned long long attr_seen = 0;
-  once_per_device(attr_seen, [] { (void)hipFuncSetAttribute((const void*)gemm256p2_kernel<F16, RES, TRANS, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P); });
-  hipLaunchKernelGGL((gemm256p2_kernel<F16, RES, TRANS, PP>), dim3(grid), dim3(512), LDS256P, s, a);
+  if constexpr (!RES && !TRANS) {          // the rotating variant when either problem carries positions
+    if (a.p[0].rope_hd == 64 || a.p[1].rope_hd == 64) { launch_256p2_r<F16, RES, TRANS, PP, true>(a, s, grid); return; }
+  }
+  launch_256p2_r<F16, RES, TRANS, PP, false>(a, s, grid);
 }
 template <bool RES, bool TRANS>
 static void launch_256p2_c(const gemm256p2_args& a, hipStream_t s, int grid) {

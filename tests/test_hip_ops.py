@@ -775,7 +775,7 @@ def test_rowstream_gemm_bit_identical_to_tiled(M):
         assert torch.equal(o, ref)
 
 
-@pytest.mark.parametrize('M,N,K', [(3000, 1024, 1024), (40000, 768, 128), (2605, 256, 192), (9001, 320, 64)])
+@pytest.mark.parametrize('M,N,K', [(3000, 1024, 1024), (40000, 768, 128), (2605, 256, 192), (9001, 320, 64), (1500, 512, 768), (700, 256, 256)])
 def test_gemm256_persistent_transposed_store_bit_identical(M, N, K):
     """V^T projections on the persistent 256 x 256 kernel (swapped MFMA operands, a lane owns 8 consecutive rows of one output column):
     bit-identical to the 128 x 128 transposed kernel, incl. ragged M (scalar tail), ragged N (multiple of 64) and the fold consumer."""
@@ -783,7 +783,7 @@ def test_gemm256_persistent_transposed_store_bit_identical(M, N, K):
     a, w, b = bf(rn(980, M, K)).to(dev()), bf(rn(981, N, K, scale=K ** -0.5)).to(dev()), rn(982, N).to(dev())
     ldc = (M + 7) // 8 * 8 + 8
     cases = [dict(bias=b), dict(bias=b, act='gelu'), dict()]
-    if K % 64 == 0:
+    if K % 128 == 0:          # fold consumer: the persistent kernel takes an even number of 64-column groups (16-byte pairs of partials)
         x = rn(983, M, K).to(dev()) * 1.3 + 0.2
         xb = torch.empty(M, K, dtype=d16(), device=dev())
         st = torch.empty(M, K // 64, 2, device=dev())
@@ -1066,3 +1066,38 @@ def test_attention_pair_equals_two_launches(shape_a, shape_b, fused):
         oa, ob = A[2](), Bp[2]()
         hip.attention_pair((A[0](oa), A[1]), (Bp[0](ob), Bp[1]))
         assert torch.equal(oa, ref[0]) and torch.equal(ob, ref[1])
+
+
+@pytest.mark.parametrize('B,H,N,Nk,hd,ns', [(5, 16, 769, 769, 64, None), (3, 12, 768, 768, 64, None), (1, 12, 768, 5000, 64, 4), (2, 4, 1100, 300, 96, None), (1, 3, 70, 130, 64, None)])
+def test_attention_block_order_is_bit_identical(B, H, N, Nk, hd, ns):
+    """PST_TUNE_ATTN_XCD: the XCD-contiguous block order (default) only changes WHICH workgroup computes a (view, head, query block, key split) -
+    every output bit equals the plain order's, single launches, key splits and the two-problem launch alike (grids that are not multiples of 8)."""
+    from panst3r_amd import hip
+    D = H * hd
+    q = (rn(4000, B * N, D) * (hd ** -0.5 * hip.LOG2E)).to(d16()).to(dev())
+    k = rn(4001, B * Nk, D).to(d16()).to(dev())
+    Nkp = (Nk + 7) // 8 * 8
+    vt = rn(4002, D, B * Nkp + 8).to(d16()).to(dev())
+    kw = dict(q_strides=(N * D, hd, D), k_strides=(Nk * D, hd, D), v_strides=(Nkp, hd * vt.stride(0), vt.stride(0)), o_strides=(N * D, hd, D), prescaled=True, nsplit=ns)
+
+    def run():
+        o = torch.zeros(B * N, D, dtype=d16(), device=dev())
+        hip.attention(q, k, vt, o, B, H, N, Nk, hd, **kw)
+        o2 = None
+        if ns is None and N == Nk:
+            oa, ob = torch.zeros_like(o), torch.zeros_like(o)
+            kw2 = {k_: v for k_, v in kw.items() if k_ != 'nsplit'}
+            hip.attention_pair(((q, k, vt, oa, B, H, N, Nk, hd), kw2), ((k, q, vt, ob, B, H, N, Nk, hd), kw2))
+            o2 = (oa, ob)
+        return o, o2
+    prev = hip.tune(hip.TUNE_ATTN_XCD, 0)
+    try:
+        assert prev == 1                                   # the XCD-contiguous order is the default
+        plain, plain2 = run()
+        hip.tune(hip.TUNE_ATTN_XCD, 1)
+        xcd, xcd2 = run()
+    finally:
+        hip.tune(hip.TUNE_ATTN_XCD, prev)
+    assert torch.isfinite(plain.float()).all() and torch.equal(plain, xcd)
+    if plain2 is not None:
+        assert torch.equal(plain2[0], xcd2[0]) and torch.equal(plain2[1], xcd2[1]) and torch.equal(plain2[0], plain)

@@ -608,8 +608,11 @@ static int gemm_choice(const pst_gemm_params& p) {
   // large plain GEMMs: 256x256 tiles, 8 waves, counted-vmcnt pipeline (>= 3 full rounds of the 256 CUs, or forced)
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool fits32 = (int64_t)p.M * p.lda < (1ll << 31) && (int64_t)p.N * p.ldw < (1ll << 31);
+  // ONE nearly full round of one 256 x 256 tile per CU also goes to the persistent kernel (the 16 keyframes' encoder: 12 288 rows x 1024 columns = 192
+  // tiles; same box, profiles/r4_dispatch_bench.txt: V^T 39.3 -> 33.1 us, proj + residual 53.2 -> 46.7, fc2 + residual 122.5 -> 107.7 against 128 x 128 tiles)
+  const bool one_round = tiles256 >= 176 && tiles256 <= 256;
   if (p.trans_out) {       // V^T projections: the persistent kernel's transposed class from 1.5 rounds of tiles on, else the 128 / 64 tiles
-    const bool p3 = pst::gemm256_persistent_class(p) == 3 && fits32 && p.batch <= 1 && (p.kernel == 256 || (p.kernel == 0 && tiles256 >= 384 && p.K >= 512));
+    const bool p3 = pst::gemm256_persistent_class(p) == 3 && fits32 && p.batch <= 1 && (p.kernel == 256 || (p.kernel == 0 && (tiles256 >= 384 || one_round) && p.K >= 512));
     return p3 ? 2 : (small ? 0 : 1);
   }
   // measured on MI355X: the 256^2 kernel wins for deep K / wide N (v1 MLPs +10 %, 8192^3 +20 %), loses for K < 1024 or ragged N
@@ -619,7 +622,9 @@ static int gemm_choice(const pst_gemm_params& p) {
   // its residual-stream class (fp32 out + residual + fold producer) pays the epilogue's HBM burst with every CU at once: it only wins
   // for deep K (1024 x 4096: 480 vs 497 us, 768 x 3072: 277 vs 308; 1024 x 1024: 202 vs 185 -- stays on the 128x128 kernel)
   const int pclass = pst::gemm256_persistent_class(p);
-  const bool shape256p = tiles256 >= 384 && ((pclass == 1 && p.K >= 512) || (pclass == 2 && p.K >= 2048));
+  // (round 4, with the spill-free residual epilogue: K < 2048 too when the tile list is at most two rounds - 38400 x 768 x 768: 92.4 -> 87.2 us,
+  // 26112 x 1024 x 1024: 100.7 -> 97.4; 38800 x 1024 x 1024 = 2.4 rounds stays on the 128 x 128 kernel, 159.9 vs 171.8 us)
+  const bool shape256p = (tiles256 >= 384 || one_round) && ((pclass == 1 && p.K >= 512) || (pclass == 2 && (p.K >= 2048 || (p.K >= 768 && tiles256 <= 512))));
   if (p.conv_c == 0 && fits32 && p.batch <= 1 && (p.kernel == 256 || (p.kernel == 0 && (shape256 || shape256p)))) return 2;
   return small ? 0 : 1;
 }

@@ -632,32 +632,44 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
         lgkm_wait<0>(bfr[ni][0][0]);
         static_for<0, 2>([&](auto j) { static_for<0, 2>([&](auto kk) { lds_tie(bfr[ni][j][kk]); }); });
       };
-      if (wm == 1) seg_end();              // group 1 runs one barrier behind group 0
-      for (int kt = 0; kt < nk; ++kt) {
-        const uint32_t buf = lds0 + (uint32_t)((kt & 1) * BUF_BYTES);
-        read_b_l(buf, c0);                   // L0
+      // One K tile; F = the n half its FIRST quadrant takes (S = the other).  The B fragments of that half are already in bfr[F]: they were read in slot L3 of the
+      // previous K tile (bfr[F] of this tile = bfr[S] of that one, dead since its M2) - the L segments read 8 / 4 / 8 / 4 fragments instead of 12 / 4 / 8 / 0,
+      // none longer than an M segment (16 MFMAs = 256 cycles against 4 waves x 8 KB = 256 cycles of LDS).  Consecutive K tiles alternate F; every accumulator
+      // still receives its K products in ascending order: same bits.  For that early read, B(kt + 1) must have landed at the END of L2 (counted wait: all but
+      // A(kt + 1) and the B(kt + 2) pieces just issued; the barriers that end L2 and M2 carry the other waves' shares), A(kt + 1) at L3 as before.
+      auto ktile = [&](int kt, auto F) {
+        constexpr std::integral_constant<int, 1 - F> S{};
+        const uint32_t buf = lds0 + (uint32_t)((kt & 1) * BUF_BYTES), nbuf = lds0 + (uint32_t)(((kt + 1) & 1) * BUF_BYTES);
+        if (kt == 0) read_b_l(buf, F);       // L0 (the first K tile of an output tile has nothing preloaded)
         read_a_l(buf, c0);
         reads_done_a();
-        reads_done_b(c0);
+        if (kt == 0) reads_done_b(F);
         seg_end();
-        mma_l(c0, c0);                     // M0
+        mma_l(c0, F);                      // M0
         seg_end();
-        read_b_l(buf, c1);                   // L1
-        reads_done_b(c1);
+        read_b_l(buf, S);                    // L1
+        reads_done_b(S);
         seg_end();
-        mma_l(c0, c1);                     // M1
+        mma_l(c0, S);                      // M1
         seg_end();
         read_a_l(buf, c1);                   // L2: the B halves of this buffer are dead (both groups' B reads retired two barriers ago)
         stage_l(2, kt + 2); stage_l(3, kt + 2);
         reads_done_a();
+        if (kt + 2 < nk) PST_VMCNT(8); else if (kt + 1 < nk) PST_VMCNT(4);
         seg_end();
-        mma_l(c1, c1);                     // M2
+        mma_l(c1, S);                      // M2
         seg_end();
         if (kt + 2 < nk) PST_VMCNT(4); else PST_VMCNT(0);      // L3: K tile kt + 1 has landed (this wave's share); A of this buffer is dead
         stage_l(0, kt + 2); stage_l(1, kt + 2);
+        if (kt + 1 < nk) { read_b_l(nbuf, S); reads_done_b(S); }     // the next K tile's first half
         seg_end();
-        mma_l(c1, c0);                     // M3
+        mma_l(c1, F);                      // M3
         seg_end();
+      };
+      if (wm == 1) seg_end();              // group 1 runs one barrier behind group 0
+      for (int kt = 0; kt < nk; kt += 2) {
+        ktile(kt, c0);
+        if (kt + 1 < nk) ktile(kt + 1, c1);
       }
       if (wm == 0) seg_end();              // re-align the groups for the epilogue
     } else
@@ -845,12 +857,82 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
       continue;
     }
 
+    if constexpr (ROPE) {
+      // The rotating variant (q | k projections of the CroCo towers) keeps the round-3 order: operand request first, then the row fragments with the
+      // table reads - column constants, fold entry, position, (cos, sin) rows: 2 x 64 B per row fragment and half - left to the compiler.  Its first LDS
+      // read waits for the request (common.h, lds_ld), but the hand-ordered form of the plain class needs 40 registers more than this epilogue has:
+      // measured 298 -> 311 us on the two towers' paired q | k launch with it, 283 us with this order (profiles/r4_epi_ab_kernels.txt).
+      request_next();
+      float4 bias4[2][2], gam4[2][2], cs4[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int cl = wn * 64 + h * 32 + g * 8 + 4 * u;               // tile-local column
+          bias4[h][u] = *(const float4*)(coltab + cl);
+          gam4[h][u] = *(const float4*)(coltab + 256 + cl);
+          cs4[h][u] = *(const float4*)(coltab + 512 + cl);
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = wm * 128 + i * 16 + l16;
+        const float2 st = fold ? lnst[r] : make_float2(1.f, 0.f);
+        uint4 val[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int nn = cn0 + wn * 64 + h * 32 + g * 8;
+          uint32_t w[4];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x4 a = acc[i][2 * h + u];
+            float v[4] = {fmaf(a[0], st.x, fmaf(st.y, cs4[h][u].x, bias4[h][u].x)), fmaf(a[1], st.x, fmaf(st.y, cs4[h][u].y, bias4[h][u].y)),
+                          fmaf(a[2], st.x, fmaf(st.y, cs4[h][u].z, bias4[h][u].z)), fmaf(a[3], st.x, fmaf(st.y, cs4[h][u].w, bias4[h][u].w))};
+            if (p.act == 1) {
+              gelu_erf4(v);
+            } else if (p.act == 2) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            if (p.gamma) { v[0] *= gam4[h][u].x; v[1] *= gam4[h][u].y; v[2] *= gam4[h][u].z; v[3] *= gam4[h][u].w; }      // (x 1.0f is exact: skipping it changes no bit)
+            w[2 * u] = H16<F16>::pack(v[0], v[1]);
+            w[2 * u + 1] = H16<F16>::pack(v[2], v[3]);
+          }
+          val[h] = make_uint4(w[0], w[1], w[2], w[3]);
+          if (rope) {
+            // the wave's 64 columns are one head: half h rotates with the row's y (h = 0) / x (h = 1) position, pairs are 16 columns apart,
+            // i.e. the partner chunk lives in lane ^ 32 (g ^ 2).  The 16-bit-rounded values are rotated, as in the LDS store phases.
+            uint32_t pw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(w[q], w[q], false, false);
+              pw[q] = lane < 32 ? sw[1] : sw[0];
+            }
+            const int2 pp = postab[r];
+            const float4* t = (const float4*)(ropetab + (h == 0 ? pp.x : pp.y) * 32 + (g & 1) * 16);
+            const float4 cs[4] = {t[0], t[1], t[2], t[3]};
+            val[h] = rope_rotate<F16>(val[h], make_uint4(pw[0], pw[1], pw[2], pw[3]), cs, nn);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = cm0 + r, nn = cn0 + wn * 64 + h * 32 + g * 8;
+          if (m < p.M && nn < p.N) *(uint4*)((bf16_t*)p.C + ((int64_t)m * p.ldc + nn)) = val[h];
+        }
+      }
+      if (more) {
+        tables_request(nt, m0, n0);
+        tables_commit(nt, par ^ 1);
+      }
+      par ^= 1;
+      if (!more) break;
+      continue;
+    }
+
     // ---- epilogue from the accumulators: lane (g, l16) owns row l16 of each row fragment and, per 32-column half, columns g*8 .. g*8+7.
     // Row fragment outer, half inner: the two 64-byte halves of a row leave in consecutive store instructions and meet in the same 128-byte line
     // on their way out (measured on fc1, M = 38800: 380 -> 352 us against half-outer order; an exchange of halves between lanes l16 and l16 ^ 8 so
     // that ONE instruction writes 8 whole 128-byte rows was slower, 403 us: profiles/r3_gemm_pp_ablation.txt).
-    // Column constants, the rows' fold entries and RoPE positions: read before the operand request; only the RoPE (cos, sin) rows, which depend on
-    // the positions and would not fit the registers, are fetched per row fragment behind it (lds_ld).
+    // The column constants are read before the operand request, the rows' fold entries behind it by lds_ld (common.h).
     float4 bias4[2][2], gam4[2][2], cs4[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -861,13 +943,11 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
         gam4[h][u] = *(const float4*)(coltab + 256 + cl);
         cs4[h][u] = *(const float4*)(coltab + 512 + cl);
       }
-    // per row fragment: (rstd, -mean rstd) of the lane's row and its (y, x) position, read one fragment ahead by lds_ld
-    const uint32_t st_a = lds_addr(lnst) + (uint32_t)(wm * 128 + l16) * 8u, pp_a = lds_addr(postab) + (uint32_t)(wm * 128 + l16) * 8u;
-    const uint32_t rt_a = lds_addr(ropetab) + (uint32_t)(g & 1) * 64u;
-    f32x2_t stq[2], ppq[ROPE ? 2 : 1];
+    // per row fragment: (rstd, -mean rstd) of the lane's row, read one fragment ahead by lds_ld
+    const uint32_t st_a = lds_addr(lnst) + (uint32_t)(wm * 128 + l16) * 8u;
+    f32x2_t stq[2];
     auto row_issue = [&](auto i) {
       if (fold) lds_ldo<i * 16 * 8>(stq[i & 1], st_a);
-      if constexpr (ROPE) { if (rope) lds_ldo<i * 16 * 8>(ppq[i & 1], pp_a); }
     };
     row_issue(std::integral_constant<int, 0>{});
     lds_wait();
@@ -876,16 +956,6 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
       const int r = wm * 128 + i * 16 + l16;
       lds_use(stq[i & 1]);
       const float2 st = fold ? make_float2(stq[i & 1][0], stq[i & 1][1]) : make_float2(1.f, 0.f);
-      f32x4 rc[4];                           // the (cos, sin) rows of one half (y, then x position)
-      uint32_t ax = 0;
-      if constexpr (ROPE) {
-        lds_use(ppq[i & 1]);
-        if (rope) {
-          const uint32_t ay = rt_a + (uint32_t)__float_as_int(ppq[i & 1][0]) * 128u;
-          ax = rt_a + (uint32_t)__float_as_int(ppq[i & 1][1]) * 128u;
-          static_for<0, 4>([&](auto q) { lds_ldo<q * 16>(rc[q], ay); });
-        }
-      }
       if constexpr (i + 1 < 8) row_issue(std::integral_constant<int, i + 1>{});
       uint32_t w[2][4];
 #pragma unroll
@@ -907,29 +977,7 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
         }
       }
       uint4 val[2] = {make_uint4(w[0][0], w[0][1], w[0][2], w[0][3]), make_uint4(w[1][0], w[1][1], w[1][2], w[1][3])};
-      lds_wait();                            // this row's first (cos, sin) rows and the next row's table entries have arrived
-      if constexpr (ROPE) if (rope) {
-        // the wave's 64 columns are one head: half h rotates with the row's y (h = 0) / x (h = 1) position, pairs are 16 columns apart,
-        // i.e. the partner chunk lives in lane ^ 32 (g ^ 2).  The 16-bit-rounded values are rotated, as in the LDS store phases.
-        static_for<0, 2>([&](auto h) {
-          static_for<0, 4>([&](auto q) { lds_use(rc[q]); });
-          const int nn = cn0 + wn * 64 + h * 32 + g * 8;
-          uint32_t pw[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(w[h][q], w[h][q], false, false);
-            pw[q] = lane < 32 ? sw[1] : sw[0];
-          }
-          const float4 cs[4] = {make_float4(rc[0][0], rc[0][1], rc[0][2], rc[0][3]), make_float4(rc[1][0], rc[1][1], rc[1][2], rc[1][3]),
-                                make_float4(rc[2][0], rc[2][1], rc[2][2], rc[2][3]), make_float4(rc[3][0], rc[3][1], rc[3][2], rc[3][3])};
-          val[h] = rope_rotate<F16>(val[h], make_uint4(pw[0], pw[1], pw[2], pw[3]), cs, nn);
-          if constexpr (h == 0) {            // the x rows into the same registers
-            lds_use(val[0].x); lds_use(val[0].y); lds_use(val[0].z); lds_use(val[0].w);
-            static_for<0, 4>([&](auto q) { lds_ldo<q * 16>(rc[q], ax); });
-            lds_wait();
-          }
-        });
-      }
+      lds_wait();                            // the next row's fold entry has arrived
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int m = cm0 + r, nn = cn0 + wn * 64 + h * 32 + g * 8;
@@ -937,7 +985,7 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
       }
       // the next tile's table entries ride in the registers of the accumulator rows that are done
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (i == (ROPE ? 5 : 3)) { if (more) tables_request(nt, m0, n0); }
+      if constexpr (i == 3) { if (more) tables_request(nt, m0, n0); }
       __builtin_amdgcn_sched_barrier(0);
     });
     if (more) tables_commit(nt, par ^ 1);

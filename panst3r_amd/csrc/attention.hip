@@ -342,6 +342,8 @@ __device__ __forceinline__ void attn_body(const pst_attn_params& p, const int bi
 // the fabric's ~6.5 TB/s, not at the matrix pipe's rate.  xcd_remap gives every XCD a CONTIGUOUS range of logical blocks: the query blocks of one head
 // run on one XCD at the same time and share each K / V tile through its L2 (the render's 300 blocks per head: one 3.1 MB head per 4 MB L2).
 // Which block computes what is unchanged: bit-identical outputs (tests/test_hip_ops.py::test_attention_block_order_is_bit_identical).
+// (Occupancy: 140 registers at head dim 64 = three blocks per CU.  Holding the kernel to 128 = four blocks costs two scratch reloads per key tile and was
+// measured SLOWER, same box: render 884 -> 828 TFLOP/s, DINOv2 self-attention 609 -> 530, scene 304.5 -> 297.1 frames/s; profiles/r4_attn_occ_ab.txt.)
 template <int HD, int QF, bool F16, bool PRE>
 __global__ __launch_bounds__(256) void attn_kernel(const pst_attn_params p, const int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -131,6 +131,63 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t l
   }
 }
 
+// LayerNorm of 384-wide 16-bit rows -> 16-bit rows (LoftUp's per-pixel norms: 786 432 rows per 16 views, 4 launches per scene).  The generic kernel gives
+// a 768-byte row one wave: 8-byte accesses, half of the wave idle in its second 256-column pass, two 6-step ds_bpermute reductions per row - 3.1 TB/s.
+// Here 16 lanes share a row (three 16-byte chunks each, chunk = lane + 16 j: every load instruction covers 256 contiguous bytes per row), a wave takes
+// 4 rows per pass and keeps two passes (6 loads per lane) in flight; the two reductions are DPP butterflies inside the 16-lane row (VALU only).
+// Always taken for this (width, types) combination, whatever the row count: a view's result never depends on how many rows the launch has.
+template <bool F16>
+__global__ __launch_bounds__(256) void layernorm384_kernel(const bf16_t* x, int64_t ldx, bf16_t* y, int64_t ldy, const float* gamma, const float* beta, int rows, float eps) {
+  constexpr int PASSES = 2, D = 384;
+  const int lane = threadIdx.x & 63, q = lane >> 4, l16 = lane & 15;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (4 * PASSES) + q;
+  if (row0 - q >= rows) return;
+  uint4 raw[PASSES][3];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int64_t row = min(row0 + 4 * ps, (int64_t)rows - 1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) raw[ps][j] = *(const uint4*)(x + row * ldx + (l16 + 16 * j) * 8);
+  }
+  float gm[3][8], bt[3][8];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float4 g0 = *(const float4*)(gamma + (l16 + 16 * j) * 8), g1 = *(const float4*)(gamma + (l16 + 16 * j) * 8 + 4);
+    const float4 b0 = *(const float4*)(beta + (l16 + 16 * j) * 8), b1 = *(const float4*)(beta + (l16 + 16 * j) * 8 + 4);
+    gm[j][0] = g0.x; gm[j][1] = g0.y; gm[j][2] = g0.z; gm[j][3] = g0.w; gm[j][4] = g1.x; gm[j][5] = g1.y; gm[j][6] = g1.z; gm[j][7] = g1.w;
+    bt[j][0] = b0.x; bt[j][1] = b0.y; bt[j][2] = b0.z; bt[j][3] = b0.w; bt[j][4] = b1.x; bt[j][5] = b1.y; bt[j][6] = b1.z; bt[j][7] = b1.w;
+  }
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int64_t row = row0 + 4 * ps;
+    float v[3][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const uint32_t w[4] = {raw[ps][j].x, raw[ps][j].y, raw[ps][j].z, raw[ps][j].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[j][2 * k] = H16<F16>::lo(w[k]); v[j][2 * k + 1] = H16<F16>::hi(w[k]); s += v[j][2 * k] + v[j][2 * k + 1]; }
+    }
+    const float mean = row_sum<16>(s) / D;
+    float qq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = v[j][k] - mean; qq += d * d; }
+    const float rstd = rsqrtf(row_sum<16>(qq) / D + eps);
+    if (row < rows) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          o[k] = H16<F16>::pack((v[j][2 * k] - mean) * rstd * gm[j][2 * k] + bt[j][2 * k], (v[j][2 * k + 1] - mean) * rstd * gm[j][2 * k + 1] + bt[j][2 * k + 1]);
+        *(uint4*)(y + row * ldy + (l16 + 16 * j) * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm-fold producer outputs of an fp32 stream
 // One 16-lane group per (row, 64-column group): lane = 4 columns.  16-bit copy + (sum, sumsq) of the group (fixed shuffle tree).
 __global__ __launch_bounds__(256) void rowstats_kernel(const void* x, int64_t ldx, int x_tc, bf16_t* xc, int64_t ldxc, float2* stats, int stats_ld,
@@ -384,6 +441,13 @@ static int launch_layernorm(const void* x, int64_t ldx, int in_fp32, const float
   if ((in_fp32 != DT_BF16 && in_fp32 != DT_F32 && in_fp32 != DT_F16) || (out_fp32 != DT_BF16 && out_fp32 != DT_F32 && out_fp32 != DT_F16)) { set_error("layernorm: bad element type code"); return PST_EINVAL; }
   if (D <= 0 || D % 4 || D > 4096 || ldx % 4 || ldy % 4 || (add && ld_add % 4)) { set_error("layernorm: need D%%4==0, D<=4096, ld%%4==0 (D=%d)", D); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
+  if (D == 384 && in_fp32 == out_fp32 && in_fp32 != DT_F32 && !add && grp_in <= 0 && nbatch == 1 && ldx % 8 == 0 && ldy % 8 == 0 && !(((uintptr_t)x | (uintptr_t)y) & 15) &&
+      !(((uintptr_t)gamma | (uintptr_t)beta) & 15)) {
+    const dim3 grid384((rows + 31) / 32);
+    if (in_fp32 == DT_F16) hipLaunchKernelGGL(layernorm384_kernel<true>, grid384, dim3(256), 0, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, gamma, beta, rows, eps);
+    else hipLaunchKernelGGL(layernorm384_kernel<false>, grid384, dim3(256), 0, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, gamma, beta, rows, eps);
+    return check_launch("layernorm");
+  }
   const int nit = (D + 255) / 256;
   const bool many = nit <= 4 && rows >= 32768;              // long launches of short rows: 4 rows per wave in flight
   const dim3 grid(many ? (rows + 15) / 16 : (rows + 3) / 4, nbatch), block(256);

@@ -1101,3 +1101,16 @@ def test_attention_block_order_is_bit_identical(B, H, N, Nk, hd, ns):
     assert torch.isfinite(plain.float()).all() and torch.equal(plain, xcd)
     if plain2 is not None:
         assert torch.equal(plain2[0], xcd2[0]) and torch.equal(plain2[1], xcd2[1]) and torch.equal(plain2[0], plain)
+
+
+@pytest.mark.parametrize('rows', [1, 31, 33, 5003])
+def test_layernorm_384_wide_16bit_rows(rows):
+    """the 16-lanes-per-row kernel of LoftUp's per-pixel norms (16-bit in and out, D = 384): ragged row counts, strided output rows"""
+    from panst3r_amd import hip
+    D = 384
+    x, g, b = bf(rn(4400, rows, D) * 2 + 0.5), 1 + 0.1 * rn(4401, D), 0.1 * rn(4402, D)
+    ref = F.layer_norm(x.float(), (D,), g, b, 1e-5)
+    out = torch.full((rows + 2, D + 8), 7.0, dtype=d16(), device=dev())
+    hip.layernorm(x.to(dev()), g.to(dev()), b.to(dev()), out[:rows, :D], 1e-5)
+    assert rel_l2(out[:rows, :D].float().cpu(), ref) < 5e-3
+    assert float((out[rows:].float() - 7.0).abs().max()) == 0.0 and float((out[:, D:].float() - 7.0).abs().max()) == 0.0      # nothing written outside

@@ -15,10 +15,7 @@
 //     source address) so that those keys are exactly the 8-key K-slot the lane must supply to the second MFMA.
 //   * V arrives already transposed ([hd, Nk], key contiguous; produced by the GEMM's trans_out epilogue) so both
 //     LDS tiles are filled by 16-B LDS-DMA and read back with conflict-free XOR-swizzled ds_read_b128.
-//   * K/V tiles are double buffered (DMA of tile t+1 overlaps the math of tile t; one barrier per tile).  A 4-slot ring with counted vmcnt, asm fragment
-//     reads and a raw barrier for the launches that do not fill the chip (the 768-query attentions of the memory build, one block per CU) was measured:
-//     11.5 -> 11.6 us, build 23.45 -> 23.77 ms (profiles/r4_attn_ring_ab.txt) - a lone wave per SIMD is bound by its own MFMA -> softmax -> MFMA
-//     dependency chain (~1 900 cycles per key tile), not by the tile's round trip.
+//   * K/V tiles are double buffered (DMA of tile t+1 overlaps the math of tile t; one barrier per tile).
 //   * masked / out-of-range keys get the finite sentinel -1e30 (no inf-inf NaNs; a later real key rescales the
 //     sentinel contributions to exactly 0).
 #include "common.h"

@@ -337,9 +337,11 @@ def auto_nsplit(B, H, Nq, Nk):
     # long memories (the build's 768 queries x 12 heads against >= 6 144 keys): enough splits that 128-query blocks fill the chip - pst_attn_fwd
     # takes its 128-query variant when blocks x splits >= 256, and every K / V fragment read then feeds two MFMAs (measured, tools/attn_split_bench.py:
     # 11 520 keys 54.1 -> 48.3 us, 24 576 keys 103.4 -> 82.7 us; below 6 144 keys the 64-query blocks with 3 splits stay ahead)
+    # round 4 (XCD-contiguous block order, tools/nsplit_bench.py -> profiles/r4_nsplit_bench.txt): two blocks per CU, not three - 7 splits of the build's 72
+    # blocks beat 9 - 10 from 5 376 keys on (11 520 keys: 46.1 -> 45.6 us, 9 216: 41.6 -> 39.3, 5 376: 31.0 with 3 splits of 64-query blocks -> 29.6)
     blocks128 = ((Nq + 127) // 128) * H * B
-    if Nk >= 6144:
-        ns = min(768 // blocks128, Nk // 1024, 12)
+    if Nk >= 5376:
+        ns = min(512 // blocks128, Nk // 768, 12) if Nk <= 12288 else min(768 // blocks128, Nk // 1024, 12)        # (beyond 16 keyframes: the round-3 rule, not re-swept)
         if blocks128 * ns >= 256:
             return ns
     return max(1, min(512 // blocks, Nk // 512, 32))

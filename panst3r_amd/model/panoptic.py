@@ -18,6 +18,7 @@ MI355X-first data layout: every feature map is pixel/token-major ([view, pixel, 
     a full-resolution einsum + resize; the never-consumed aux_outputs are not produced.
 """
 import math
+import os
 import torch
 import torch.nn as nn
 
@@ -27,6 +28,19 @@ from .common import (HipModule, qscale, Packed, Layout, adt, empty, vit_block, p
 from .params import BlockP, MlpP, CrossAttnP, MHAP
 
 VIEW_CHUNK = 16     # views per upscaler pass (bounds the [rows, 22528] / [P, 384] workspaces)
+BALANCED_CHUNKS = os.environ.get('PST_BALANCED_CHUNKS', '1') != '0'      # A/B switch (0: full passes + a remainder, as before round 4)
+
+
+def view_chunks(V):
+    """(first view, views) of the upscaler passes over V same-shape views: as few passes as VIEW_CHUNK allows, of BALANCED sizes - the scene's 34 views that
+    are not keyframes go as 12 + 11 + 11, not 16 + 16 + 2 (a 2-view pass runs the same launches at an eighth of the rows: tile quantisation and launch
+    floors).  Every per-view result is independent of the pass it is computed in."""
+    n = (V + VIEW_CHUNK - 1) // VIEW_CHUNK
+    v0 = 0
+    for i in range(n):
+        c = (V // n + (1 if i < V % n else 0)) if BALANCED_CHUNKS else min(VIEW_CHUNK, V - v0)
+        yield v0, c
+        v0 += c
 
 
 # =========================================================================================== InputMixer
@@ -102,8 +116,7 @@ class PixelShuffleUpscaler(HipModule):
         pk = self.packed(dev)
         T = h * w
         d1, d2, d3 = self.fp_dim[1], self.fp_dim[2], self.fp_dim[3]
-        for v0 in range(0, V, VIEW_CHUNK):
-            n = min(VIEW_CHUNK, V - v0)
+        for v0, n in view_chunks(V):
             a = cat[v0 * T:(v0 + n) * T]
             hid = empty(n * T, pk['fc1'].n, adt(), dev)
             hip.gemm(a, pk['fc1'].w, hid, bias=pk['fc1'].b, act='gelu')
@@ -213,8 +226,7 @@ class LoftUpUpscaler(HipModule):
         H2, W2 = imgs.shape[2] // 2, imgs.shape[3] // 2
         P = H2 * W2
         out = empty(V * P, C, adt(), dev)
-        for v0 in range(0, V, VIEW_CHUNK):
-            n = min(VIEW_CHUNK, V - v0)
+        for v0, n in view_chunks(V):
             # Fourier features + GroupNorm(1) in two recomputing passes straight to bf16: no [n, P, 203] fp32 feature buffer
             # (pst_loftup_guidance + pst_groupnorm_apply did the same through a 639 MB round trip: 1076 -> 254 us per 16 views)
             st0 = hip.stats_buffer(n, 1, dev)
@@ -261,8 +273,7 @@ class LoftUpUpscaler(HipModule):
         hip.gemm(lr, pk['lr_proj'].w, kv, bias=pk['lr_proj'].b, grp=lay.grp)
         kvn = empty(lay.rows, C, torch.float32, dev)
         hip.layernorm(kv, pk['lr_norm'][0], pk['lr_norm'][1], kvn, pk['lr_norm'][2])
-        for v0 in range(0, V, VIEW_CHUNK):
-            n = min(VIEW_CHUNK, V - v0)
+        for v0, n in view_chunks(V):
             # ---- 2 x cross-only blocks: 49k queries per view attend to the view's T low-res tokens (hd 96).
             # The residual stream of these two blocks is kept in bf16: they are HBM-bound over P x C elements per view
             # (fp32 would double the read-modify-write traffic of both residual GEMMs and of every LayerNorm).

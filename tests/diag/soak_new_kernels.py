@@ -49,6 +49,33 @@ for (M, N, K) in [(38800, 4096, 1024), (38400, 768, 768), (26112, 2048, 1024), (
             hip.gemm(a, w, y, bias=b, res=y, xcopy=x, stats_out=s, kernel=kern)
             return y, x, s
         check('persistent residual+fold producer %s' % ((M, N, K),), lambda: rr(y1, x1, s1, 256), lambda: rr(y2, x2, s2, 128))
+# round 4: the fold consumer's partials travel by LDS-DMA into operand buffer 1 and are reduced by the wave that requested them (no barrier); tables of the next tile
+# are committed inside the epilogue; two problems per launch.  Multi-tile workgroups (> 256 tiles), fold + GELU / RoPE / transposed, pairs.
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools'))
+from gemm_cases import case
+for (M, N, K, kind) in [(38800, 4096, 1024, 'fc1'), (26112, 2048, 1024, 'qk'), (38800, 2048, 1024, 'q'), (38800, 1024, 1024, 'vt'), (38400, 3072, 768, 'fc1'), (38400, 1536, 768, 'qk'),
+                        (9000, 1024, 128, 'q'), (5008, 768, 768, 'vt')]:
+    a, w, o, kw = case(M, N, K, kind)
+    o2 = torch.zeros_like(o)
+    small = M * N < 6e7
+    check('persistent fold consumer %-4s %s' % (kind, (M, N, K)), lambda: (hip.gemm(a, w, o, kernel=256, **kw),), (lambda: (hip.gemm(a, w, o2, kernel=128, **kw),)) if small else None)
+for kind in ('fc1', 'q', 'vt', 'res'):
+    N, K = (1024, 4096) if kind == 'res' else ((4096, 1024) if kind == 'fc1' else (1024, 1024))
+    A, B = case(26112, N, K, kind), case(38800, N, K, kind)
+    def pair():
+        hip.gemm_pair((A[0], A[1], A[2], A[3]), (B[0], B[1], B[2], B[3]))
+        outs = [A[2], B[2]]
+        for c in (A, B):
+            outs += [c[3][k_] for k_ in ('xcopy', 'stats_out') if k_ in c[3]]
+        return outs
+    if kind == 'res':
+        r0, r1 = A[2].clone(), B[2].clone()
+        def pair_res():
+            A[2].copy_(r0); B[2].copy_(r1)
+            return pair()
+        check('two problems per launch %-4s' % kind, pair_res)
+    else:
+        check('two problems per launch %-4s' % kind, pair)
 for M in (786432, 98304, 32 * 1237):
     a, w, b = rn(M, 384).to(dt).to(dev), rn(384, 384, scale=384 ** -0.5).to(dt).to(dev), rn(384).to(dev)
     r0 = rn(M, 384).to(dt).to(dev)

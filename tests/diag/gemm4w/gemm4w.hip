@@ -3,7 +3,8 @@
 // anybody ports nine epilogue modes to it.  Plain C = A W^T with a 16-bit row-major store, M, N multiples of 256, K a multiple of 64.
 //   LDS: two buffers of [A 256 rows | W 256 rows] x 128 B (XOR-swizzled 16-byte chunks, filled by LDS-DMA, 16 instructions per wave and K tile).
 //   Per K tile and wave: 2 kk halves x (8 A + 8 W fragment reads, 64 MFMAs); the reads of half kk + 1 are issued before the MFMAs of half kk.
-//   VARIANT 0: one barrier per K tile (DMA of tile t + 2 issued at the tile boundary).  VARIANT 1: two barriers, DMA issued in the middle of the tile.
+//   VARIANT bit 0: 0 = one barrier per K tile (DMA of tile t + 2 issued at the tile boundary), 1 = two barriers, DMA issued in the middle of the tile.
+//   Timing ablations (results are garbage): bit 1 = no MFMAs, bit 2 = no LDS-DMA inside the K loop, bit 3 = no fragment reads.
 #include "../../../panst3r_amd/csrc/common.h"
 
 namespace pst {
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
   }
   const int nk = K / 64;
   auto stage = [&](int kt) {
-    if (kt >= nk) return;
+    if (kt >= nk || ((VARIANT & 4) && kt >= 2)) return;
     char* dst = smem + (kt & 1) * X_BUF + wave * 1024;
     const int k0 = kt * 64;
 #pragma unroll
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[2][8], wf[2][8];
   auto read_half = [&](uint32_t buf, auto kk, auto set) {
+    if constexpr ((VARIANT & 8) != 0) return;
     static_for<0, 8>([&](auto j) { ds_read128<j * 2048>(wf[set][j], buf + (w_off ^ (uint32_t)(kk << 6))); });
     static_for<0, 8>([&](auto i) { ds_read128<i * 2048>(af[set][i], buf + (a_off ^ (uint32_t)(kk << 6))); });
   };
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
     static_for<0, 8>([&](auto i) { lds_tie(af[set][i]); lds_tie(wf[set][i]); });
   };
   auto mma = [&](auto set) {
+    if constexpr ((VARIANT & 2) != 0) return;
     __builtin_amdgcn_s_setprio(1);
     static_for<0, 8>([&](auto i) {
       static_for<0, 8>([&](auto j) { acc[i][j] = H16<F16>::mfma(wf[set][j], af[set][i], acc[i][j]); });
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
     mma(c0);
     __builtin_amdgcn_sched_barrier(0);
     settle(c1);                                     // every read of this buffer by this wave has returned
-    if constexpr (VARIANT == 1) {
+    if constexpr ((VARIANT & 1) == 1) {
       __builtin_amdgcn_s_barrier();                 // ... by every wave: the buffer may be refilled
       stage(kt + 2);
       __builtin_amdgcn_sched_barrier(0);
@@ -132,7 +135,11 @@ extern "C" int gemm4w(const void* A, const void* W, void* C, int M, int N, int K
   const int lds = 2 * X_BUF;
 #define GO(F, V) do { (void)hipFuncSetAttribute((const void*)gemm4w_kernel<F, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
   hipLaunchKernelGGL((gemm4w_kernel<F, V>), dim3(tm * tn), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, tm, tn); } while (0)
-  if (f16) { if (variant) GO(true, 1); else GO(true, 0); } else { if (variant) GO(false, 1); else GO(false, 0); }
+  if (!f16) return -2;
+  switch (variant) {
+    case 0: GO(true, 0); break; case 1: GO(true, 1); break; case 3: GO(true, 3); break; case 5: GO(true, 5); break; case 9: GO(true, 9); break;
+    case 7: GO(true, 7); break; case 11: GO(true, 11); break; case 13: GO(true, 13); break; default: return -3;
+  }
 #undef GO
   return (int)hipGetLastError();
 }

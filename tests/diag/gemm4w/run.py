@@ -53,3 +53,11 @@ for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (38400, 4096, 1024), (
     fl = 2.0 * M * N * K
     print('%-22s rel err %.1e %.1e %.1e  bit-identical to the product kernel %s | one barrier %7.1f us %5.0f TF | two barriers %7.1f us %5.0f TF | product 8-wave %7.1f us %5.0f TF' %
           ((M, N, K), err[0], err[1], err[2], same, t[0], fl / t[0] / 1e6, t[1], fl / t[1] / 1e6, t[2], fl / t[2] / 1e6), flush=True)
+
+# timing ablations of the two-barrier loop (garbage results): what each of the three streams costs alone and in pairs
+M = N = K = 4096
+a = torch.randn(M, K, device=dev).half(); w = (torch.randn(N, K, device=dev) * K ** -0.5).half(); o = torch.empty(M, N, dtype=torch.float16, device=dev)
+names = {1: 'full loop', 3: 'no MFMA', 5: 'no DMA in the loop', 9: 'no fragment reads', 7: 'no MFMA, no DMA (reads alone)', 11: 'no MFMA, no reads (DMA alone)', 13: 'no DMA, no reads (MFMA alone)'}
+fns = [(lambda v=v: L.gemm4w(C.c_void_p(a.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(o.data_ptr()), M, N, K, 1, v, st())) for v in names]
+for v, t in zip(names, compare(fns)):
+    print('4096^3 ablation %-34s %7.1f us  (%4.0f cycles per K tile at 2.4 GHz)' % (names[v], t, t * 2400 / 64), flush=True)

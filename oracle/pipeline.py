@@ -83,12 +83,65 @@ class PanSt3R(nn.Module):
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None):
-        """panst3r.py:286-296 for one scene: all n views are memory views and all are rendered."""
-        n = imgs.shape[1]
-        pms, panout = self.forward_inference_multi_ar(list(imgs[0]), true_shape[0], classes, num_keyframes=n, max_bs=max_bs)
-        panout = dict(panout)
-        panout['pred_masks'] = torch.stack([m[0] for m in panout['pred_masks']])[None]
-        return panout, torch.stack([p[0] for p in pms])[None]
+        """panst3r.py:286-296: imgs [B,n,3,H,W], B independent scenes; all n views of a scene are memory views and all are rendered.  `max_bs` chunks
+        the backbone calls only (:288-290, per-view work): the panoptic decoder is called WITHOUT it (:294), so its batched_map makes ONE chunk of all
+        B * n views (panoptic_decoder.py:56-62) and LoftUp's MinMaxScaler pools over all of them - per orientation, because the upscaler wrapper runs
+        once on the landscape and once on the portrait views of the chunk (utils.py:36-56).  Views stored transposed (true_shape = (W, H) of the tensor,
+        the DUSt3R convention) are computed in their true orientation and handed back in the storage layout."""
+        B, n = imgs.shape[:2]
+        Ht, Wt = imgs.shape[-2:]
+        scenes = []
+        for b in range(B):
+            views, shapes, stored = [], [], []
+            for i in range(n):
+                th, tw = (int(v) for v in true_shape[b, i].tolist())
+                back = (th, tw) != (Ht, Wt)
+                assert not back or (th, tw) == (Wt, Ht)
+                views.append(imgs[b, i].transpose(-1, -2) if back else imgs[b, i])
+                shapes.append([th, tw])
+                stored.append(back)
+            x_enc, pos = encoder_multi_ar(self.must3r_encoder, views, torch.tensor(shapes))
+            mem = build_memory(self.must3r_decoder, x_enc, pos, shapes, mem_batches_for(n))
+            pms, cats = [], []
+            for i in range(n):
+                _, pm, out = self.must3r_decoder.forward_list([x_enc[i][None]], [pos[i][None]], [shapes[i]], mem, render=True)
+                xd = self.dino_encoder(views[i][None], torch.tensor([shapes[i]]))
+                pms.append(pm[0])
+                cats.append(torch.cat([x_enc[i][None], out[0], xd], dim=-1)[0])
+            scenes.append(dict(views=views, shapes=shapes, stored=stored, pos=pos, pms=pms, cats=cats))
+        pd = self.panoptic_decoder
+        flat = [(b, i) for b in range(B) for i in range(n)]
+        by_shape = {}
+        for b, i in flat:
+            by_shape.setdefault(tuple(scenes[b]['shapes'][i]), []).append((b, i))
+        feats = {}
+        for sh, members in by_shape.items():                         # ONE chunk per orientation over all scenes of the batch
+            ts = torch.tensor([[list(sh)] * len(members)])
+            fpn, mf = pd.features(torch.stack([scenes[b]['cats'][i] for b, i in members])[None], torch.stack([scenes[b]['views'][i] for b, i in members])[None],
+                                  torch.stack([scenes[b]['pos'][i] for b, i in members])[None], ts, max_bs=None)
+            for j, m in enumerate(members):
+                feats[m] = (fpn[:, j:j + 1], mf[:, j:j + 1], torch.tensor([[list(sh)]]))
+        cls_emb = pd.text_encoder(classes)
+        mt = pd.mask_transformer
+        logits, masks, queries, pointmaps = [], [], [], []
+        for b in range(B):
+            f = [feats[(b, i)] for i in range(n)]
+            out = mt([[x[0] for x in f]], [x[1] for x in f], [x[2] for x in f], cls_emb, multi_ar=True)
+            mk = []
+            for i in range(n):
+                m, pm = out['pred_masks'][i][0, 0], scenes[b]['pms'][i][0]
+                if scenes[b]['stored'][i]:
+                    pm = pm.transpose(0, 1)
+                    if tuple(m.shape[-2:]) != (Ht // 2, Wt // 2):
+                        m = m.transpose(-1, -2)
+                mk.append(m)
+                scenes[b]['pms'][i] = pm
+            logits.append(out['pred_logits'])
+            queries.append(out['out_queries'])
+            masks.append(torch.stack(mk))
+            pointmaps.append(torch.stack(scenes[b]['pms']))
+        panout = {'pred_logits': torch.cat(logits), 'pred_masks': torch.stack(masks), 'out_queries': torch.cat(queries, dim=1)}
+        return panout, torch.stack(pointmaps)
 
 
 def build(variant='v1', **over):

@@ -312,7 +312,7 @@ class MUSt3R(HipModule):
         out = empty(lay.rows, D, torch.float32, dev)
         hip.layernorm(hs[-1], pk['norm'][0], pk['norm'][1], out, pk['norm'][2])
         fb = None
-        if self.feedback_type and not getattr(self, '_test_skip_feedback', False):      # (_test_skip_feedback: tests/test_hip_negative.py's deliberately wrong bank)
+        if self.feedback_type:
             fbn = empty(lay.rows, D, adt(), dev)
             hip.layernorm(out, pk['fb_norm'][0], pk['fb_norm'][1], fbn, pk['fb_norm'][2])
             hh = empty(lay.rows, pk['fb1'].n, adt(), dev)
@@ -344,14 +344,15 @@ class MUSt3R(HipModule):
             hip.gemm(y[0], pk['mem_vw'][0], tmp[0], bias=pk['mem_vb'][0], trans_out=True,
                      batch=(L, rows * D, pk['mem_vw'].stride(0), tmp.stride(0), D))
             bank.Vt_all[:, :, bank.n:bank.n + rows].copy_(tmp[:, :, :rows])
-        if bank.f32 is not None:
-            self._append_f32(bank, hs, hs_all, fb, lay, rows)
+        n0 = bank.n
         bank.n += n * T
         bank.labels += list(range(bank.nimgs, bank.nimgs + n))
         bank.nimgs += n
+        if bank.f32 is not None:                          # after the counters: the twin copies them
+            self._append_f32(bank, hs, hs_all, fb, lay, rows, n0)
         return out
 
-    def _append_f32(self, bank, hs, hs_all, fb, lay, rows):
+    def _append_f32(self, bank, hs, hs_all, fb, lay, rows, n0):
         """the fp32 twin of the append: norm_y(h_l + feedback) and projk / projv in float32 (fp32 weights, fp32-input MFMA) from the SAME streams the
         16-bit build produced - what the reference's fp32 render of the other views reads out of the autocast-built memory (panst3r.py:268)."""
         from .common import precision
@@ -365,14 +366,13 @@ class MUSt3R(HipModule):
                 for l, bw in enumerate(pk['blocks']):
                     c = bw.cross
                     hip.layernorm(hs[l], c['norm_y'][0], c['norm_y'][1], y[l], c['norm_y'][2], rows=rows, grp=lay.grp, add=fb)
-            hip.gemm(y[0], pk['mem_kw'][0], b32.K_all[0, bank.n: bank.n + rows], bias=pk['mem_kb'][0],
+            hip.gemm(y[0], pk['mem_kw'][0], b32.K_all[0, n0: n0 + rows], bias=pk['mem_kb'][0],
                      batch=(L, rows * D, pk['mem_kw'].stride(0), b32.K_all.stride(0), D))
             tmp = torch.empty(L, D, (rows + 7) // 8 * 8 + 8, dtype=torch.float32, device=dev)
             hip.gemm(y[0], pk['mem_vw'][0], tmp[0], bias=pk['mem_vb'][0], trans_out=True,
                      batch=(L, rows * D, pk['mem_vw'].stride(0), tmp.stride(0), D))
-            b32.Vt_all[:, :, bank.n:bank.n + rows].copy_(tmp[:, :, :rows])
-        b32.n = bank.n + rows
-        b32.labels, b32.nimgs = bank.labels, bank.nimgs
+            b32.Vt_all[:, :, n0:n0 + rows].copy_(tmp[:, :, :rows])
+        b32.n, b32.labels, b32.nimgs = bank.n, list(bank.labels), bank.nimgs
 
     # ------------------------------------------------------------------ reference-signature wrapper
     def forward(self, x, pos, true_shape, mem=None, render=False, return_feats=False):

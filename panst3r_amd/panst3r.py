@@ -241,7 +241,7 @@ class PanSt3R(nn.Module):
     @torch.no_grad()
     def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=None,
                                    outdevice=None, amp=False, sim_matrix=None, keyframes=None, check_finite=True, cache_graphs=False,
-                                   panoptic_precision=None):
+                                   panoptic_precision=None, _mm_tables=None):
         """imgs: list[V] of [3,H,W] in [-1,1]; true_shape [V,2]; returns (pointmaps list[V] of [1,H,W,7],
         {'pred_logits' [1,Q,Ncls], 'pred_masks' list[V] of [1,Q,H/2,W/2], 'out_queries' [Q,1,768]}).
         Keyframes: linspace over the views (panst3r.py:183-186) by default.  `use_retrieval=True` (panst3r.py:179-180) takes the
@@ -268,7 +268,7 @@ class PanSt3R(nn.Module):
         shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
         H, W = shapes[0]
         fmt = amp_dtype(amp)                    # tells (once) that amp=False is the slow fp32 mode
-        runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs, panoptic_precision)
+        runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs, panoptic_precision, _mm_tables)
         res, scene = runner.run(outdevice)
         if check_finite and fmt == torch.float16:
             # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: ONE fused flag over everything the
@@ -292,7 +292,7 @@ class PanSt3R(nn.Module):
             runner.release()                    # a one-off scene keeps no intermediates (stacked inputs, features, mask features) alive
         return pms, panout
 
-    def _runner_for(self, imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs=1, panoptic_precision=None):
+    def _runner_for(self, imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs=1, panoptic_precision=None, mm_tables=None):
         """The SceneRunner of a call.  Default: a fresh eager runner, dropped after the call (what the reference's per-call execution
         costs in memory).  cache_graphs=True: runners are kept per scene SIGNATURE - everything a captured graph depends on: shapes,
         keyframe schedule, class list, device, format, and the version of every weight and class embedding (module generations bumped
@@ -304,7 +304,9 @@ class PanSt3R(nn.Module):
         H, W = shapes[0]
         if not cache_graphs:
             return SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
-                               keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pan_amp_of(amp, panoptic_precision))
+                               keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pan_amp_of(amp, panoptic_precision), mm_override=mm_tables)
+        if mm_tables is not None:
+            raise NotImplementedError('caller-pooled MinMaxScaler tables are per call: not combined with cache_graphs')
         from .model.common import HipModule
         te = self.panoptic_decoder.text_encoder
         gens = tuple(m.generation for m in self.modules() if isinstance(m, HipModule))
@@ -356,19 +358,15 @@ class PanSt3R(nn.Module):
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False):
         """Same-shape batch variant (panst3r.py:286-296): imgs [B,n,3,H,W] -> (panout, pointmaps [B,n,H,W,7]); B scenes, each with its own
         memory and queries; every view is a memory view (mem batches [2,1,...]) and every view is rendered.  `amp` as forward_inference_multi_ar (the reference
-        runs this entry point under the caller's autocast)."""
+        runs this entry point under the caller's autocast).  `max_bs` only chunks the backbone work in the reference (:288-290) - nothing here depends on it:
+        the panoptic decoder is called WITHOUT it (:294), so LoftUp's MinMaxScaler always pools over all B * n views of the call (per orientation)."""
         B, n = imgs.shape[:2]
         Ht, Wt = int(imgs.shape[-2]), int(imgs.shape[-1])
-        if B > 1 and self.panoptic_decoder.minmax_scaled() and (max_bs is None or n % int(max_bs)):
-            # the reference flattens (B, n) before it chunks by max_bs (panoptic_decoder.py:56-62): LoftUp's MinMaxScaler would pool min / max ACROSS the
-            # scenes of the batch.  The scenes run one after another here, so only chunkings that stay inside a scene are reproduced.
-            raise NotImplementedError('PanSt3R.forward with B > 1 and the LoftUp upscaler: max_bs=%r makes MinMaxScaler chunks span scenes of the batch '
-                                      '(reference semantics); pass max_bs dividing n=%d (1 = per view, the demo\'s convention) or one scene per call' % (max_bs, n))
-        outs = []
-        for b in range(B):                      # the scenes of a batch are independent (own memory, own queries)
-            # DUSt3R storage convention (utils.py:8-61 transpose_to_landscape): a same-shape batch may hold PORTRAIT views stored transposed, marked
-            # by true_shape = (W_tensor, H_tensor).  They are computed in their true orientation ("predict in the correct aspect-ratio") and their
-            # results transposed back into the storage layout, as the reference's wrapper does for every head output.
+        # views in their TRUE orientation.  DUSt3R storage convention (utils.py:8-61 transpose_to_landscape): a same-shape batch may hold PORTRAIT views stored
+        # transposed, marked by true_shape = (W_tensor, H_tensor).  They are computed in their true orientation ("predict in the correct aspect-ratio") and
+        # their results transposed back into the storage layout, as the reference's wrapper does for every head output.
+        scenes = []
+        for b in range(B):
             views, stored = [], []
             for i in range(n):
                 th, tw = (int(v) for v in true_shape[b, i].tolist())
@@ -379,8 +377,29 @@ class PanSt3R(nn.Module):
                     stored.append(i)
                 else:
                     raise ValueError('view %d: true_shape %s matches neither the tensor shape (%d, %d) nor its transpose' % (i, (th, tw), Ht, Wt))
+            scenes.append((views, stored))
+        # LoftUp's MinMaxScaler scope: the reference's forward hands the panoptic decoder ALL B * n views at once and does NOT pass max_bs on
+        # (panst3r.py:294), so batched_map makes one chunk of them (panoptic_decoder.py:56-62) and the scaler pools min / max over the whole batch -
+        # per orientation, because transpose_to_landscape runs the upscaler once on the landscape and once on the portrait views (utils.py:36-56).
+        # The scenes execute one after another here, so the pooled tables are taken up front and handed to every scene.
+        mm_tables = [None] * B
+        if self.panoptic_decoder.minmax_scaled():
+            flat = [(b, i, v) for b, (views, _) in enumerate(scenes) for i, v in enumerate(views)]
+            by_shape = {}
+            for j, (_, _, v) in enumerate(flat):
+                by_shape.setdefault(tuple(v.shape[-2:]), []).append(j)
+            stacks = [torch.stack([flat[j][2] for j in idx]).float().contiguous() for idx in by_shape.values()]
+            scope = torch.tensor([g for g, idx in enumerate(by_shape.values()) for _ in idx], dtype=torch.int32).to(imgs.device)
+            pooled = self.panoptic_decoder.minmax_tables(stacks, scope)
+            mm_tables = [dict() for _ in range(B)]
+            for idx, tab in zip(by_shape.values(), pooled):
+                for r, j in enumerate(idx):
+                    mm_tables[flat[j][0]][flat[j][1]] = tab[r]
+        outs = []
+        for b in range(B):                      # the scenes of a batch are independent (own memory, own queries)
+            views, stored = scenes[b]
             ts = torch.tensor([list(v.shape[-2:]) for v in views])
-            pms, panout = self.forward_inference_multi_ar(views, ts, classes, num_keyframes=n, outdevice=outdevice, amp=amp, max_bs=max_bs)
+            pms, panout = self.forward_inference_multi_ar(views, ts, classes, num_keyframes=n, outdevice=outdevice, amp=amp, max_bs=1, _mm_tables=mm_tables[b])
             masks = list(panout['pred_masks'])
             for i in stored:
                 pms[i] = pms[i].transpose(1, 2)

@@ -95,6 +95,21 @@ def gather_keyframe_rows(local_rows, K, T, rank, world, group):
     return out
 
 
+def gather_view_rows(local_rows, owner, rank, world, group):
+    """local_rows [n_local, ...] (this rank's views in local order = ascending position in `order`) -> the rows of ALL views by position in `order`"""
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local_rows
+    shape = local_rows.shape[1:]
+    flat = local_rows.reshape(local_rows.shape[0], -1)
+    counts = [sum(1 for o in owner if o == r) for r in range(world)]
+    blocks = _all_gather_rows(flat, counts, world, group)
+    out = torch.empty(len(owner), flat.shape[1], dtype=flat.dtype, device=flat.device)
+    for r, blk in enumerate(blocks):
+        pos = [i for i, o in enumerate(owner) if o == r]
+        out[torch.tensor(pos, dtype=torch.long, device=out.device)] = blk
+    return out.reshape(len(owner), *shape)
+
+
 def broadcast_tensors(tensors, src, world, group):
     """broadcast a list of equally-shaped-on-every-rank tensors from `src` (byte views: every backend moves uint8)."""
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
@@ -116,7 +131,7 @@ DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a calla
 
 class _Group:
     """The views of one image shape owned by this rank (keyframes first)."""
-    __slots__ = ('H', 'W', 'h', 'w', 'T', 'idx', 'k', 'imgs', 'cat', 'pointmaps', 'fpn', 'mf', 'guid', 'mm', 'enc')
+    __slots__ = ('H', 'W', 'h', 'w', 'T', 'idx', 'k', 'imgs', 'cat', 'pointmaps', 'fpn', 'mf', 'guid', 'mm', 'enc', 'pos')
 
 
 class SceneRunner:
@@ -133,7 +148,7 @@ class SceneRunner:
     (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
     def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None,
-                 amp=None, plan='replicated', minmax_bs=1, pan_amp=None):
+                 amp=None, plan='replicated', minmax_bs=1, pan_amp=None, mm_override=None):
         self.b, self.V, self.classes = backend, V, classes
         # reference AMP placement (panst3r.py:174-175,204-245,268): `amp` names the format of the encoder, the memory build and the keyframes' render +
         # DINOv2; `pan_amp` (None = the same format) that of the panoptic decoder AND of the render + DINOv2 of the views that are not keyframes.
@@ -143,10 +158,12 @@ class SceneRunner:
         # LoftUp's MinMaxScaler scope (loftup.py:14-19 pools min / max over the chunk of views it is handed; the reference chunks by max_bs):
         # 1 = per view (the demo's max_bs=1, tools/demo_panst3r.py:201 - the default here and what bench.py times); k = same-shape keyframes /
         # same-shape other views in chunks of k, None = all of them together (the reference with max_bs=None: stack_views + batched_map,
-        # panst3r.py:212-216,244,257-270).  Pooling over views of OTHER ranks would need a collective the path does not have.
+        # panst3r.py:212-216,244,257-270).  A scope may span ranks: every rank takes the per-view (min, max) table of ITS views in stage 1, the
+        # tables travel with the first all-gather (6 floats per view) and every rank pools the whole table over the same scope ids (exact:
+        # min / max do not depend on the order).  `mm_override`: {view id: fp32 [3, 2] (min, max)} = tables pooled by the caller over a
+        # scope the scene does not see (PanSt3R.forward pools over ALL scenes of a batch, panst3r.py:294 / panoptic_decoder.py:56-62).
         self.minmax_bs = minmax_bs
-        if minmax_bs != 1 and world > 1 and getattr(backend, 'minmax_scaled', lambda: False)():
-            raise NotImplementedError('a MinMaxScaler scope wider than one view (max_bs != 1) is not sharded: use max_bs=1 or one rank')
+        self.mm_override = mm_override
         self.amp = amp                # False | 'bf16' | 'fp16' (reference utils.py:206-215): 16-bit format of this runner, fixed for its lifetime
         self._refs = None             # packed weights / tables the captured graphs point into (kept alive with the runner)
         self.rank, self.world, self.group = rank, world, group
@@ -198,18 +215,28 @@ class SceneRunner:
         for g in self.groups:
             for r, j in enumerate(g.idx):
                 self.where[j] = (g, r)
-        self.mm_scope = None                  # per group: scope id of every row (views with equal ids share one min-max scale), or None = per view
-        if minmax_bs != 1 and getattr(backend, 'minmax_scaled', lambda: False)():
-            ids, nxt = [], 0
-            for g in self.groups:             # rows of a group: its keyframes (schedule order) first, then its other views (ascending)
-                row = []
-                for lo, hi in ((0, g.k), (g.k, len(g.idx))):
-                    bs = max(hi - lo, 1) if minmax_bs is None else int(minmax_bs)
-                    row += [nxt + i // bs for i in range(hi - lo)]
-                    nxt = (row[-1] + 1) if row else nxt
-                ids.append(row)
-            if any(len(set(r)) < len(r) for r in ids):
-                self.mm_scope = backend.scope_ids(ids, self.groups[0].imgs.device)
+        for g in self.groups:                 # position in `order` of every row of the group
+            g.pos = [self.mine[j] for j in g.idx]
+        # scope id of every view, by position in `order` (identical on every rank): views with equal ids share one min-max scale.  The reference
+        # stacks same-shape keyframes and same-shape other views separately (stack_views, panst3r.py:212-216,257-261), in chunks of max_bs.
+        self.mm_scope = self.mm_all = self.mm_send = None
+        self.owner = owner
+        if getattr(backend, 'minmax_scaled', lambda: False)():
+            if mm_override is not None:
+                self.mm_all = backend.table_of([mm_override[self.order[i]] for i in range(V)], self.groups[0].imgs.device)
+            elif minmax_bs != 1:
+                ids, nxt = [0] * V, 0
+                for lo, hi in ((0, K), (K, V)):
+                    by_shape = {}
+                    for i in range(lo, hi):
+                        by_shape.setdefault(self.shapes[self.order[i]], []).append(i)
+                    for members in by_shape.values():
+                        bs = len(members) if minmax_bs is None else int(minmax_bs)
+                        for c, i in enumerate(members):
+                            ids[i] = nxt + c // bs
+                        nxt = ids[members[-1]] + 1
+                if len(set(ids)) < V:
+                    self.mm_scope = backend.scope_ids(ids, self.groups[0].imgs.device)
         self.use_graphs = use_graphs
         self.serial = not (OVERLAP_DEFAULT if overlap is None else overlap)      # True: the two branches of stage 2 run back-to-back
         self.graphs = None
@@ -240,6 +267,10 @@ class SceneRunner:
                 b.encode_enc(g.imgs[:g.k], g.cat[:g.k * g.T], None if g.enc is None else g.enc[:g.k * g.T])
             rows.append(b.enc_rows(g.cat if g.enc is None else g.enc, g.k * g.T))
         self.enc_send = self._kf_rows(rows)
+        if self.mm_scope is not None:          # per-view (min, max) of this rank's views, in local order (6 floats per view; pooled behind gather 1)
+            with b.precision(self.pan_amp):
+                tabs = [b.minmax_local(g.imgs) for g in self.groups]
+            self.mm_send = tabs[0] if len(self.groups) == 1 else b.rows_in_order(tabs, [g.idx for g in self.groups], self.n_local)
 
     def _encode_rest(self):
         """Everything the build does not depend on: encoder of the non-keyframe views + DINOv2 of every view."""
@@ -260,10 +291,12 @@ class SceneRunner:
                     with b.precision(self.pan_amp):
                         b.encode_dino(g.imgs[g.k:], g.cat[g.k * g.T:])
         with b.precision(self.pan_amp):
-            mms = b.minmax_tables([g.imgs for g in self.groups], self.mm_scope) if self.mm_scope is not None else [None] * len(self.groups)
-            for g, mm in zip(self.groups, mms):     # image-only part of the upscaler (LoftUp guidance convs, SURVEY 8(e) phase A): memory-independent,
-                g.mm = mm                         # so it belongs to this branch (with overlap=True it fills the tail of the memory build)
-                g.guid = b.guidance(g.imgs, g.h, g.w, mm)
+            pooled = self.mm_all
+            if self.mm_scope is not None:           # the whole scene's per-view table pooled over the scope ids (every rank: same table, same ids)
+                pooled = b.minmax_pool(self.mm_all, self.mm_scope)
+            for g in self.groups:                   # image-only part of the upscaler (LoftUp guidance convs, SURVEY 8(e) phase A): memory-independent,
+                g.mm = None if pooled is None else b.table_rows(pooled, g.pos)         # so it belongs to this branch (with overlap=True it fills the
+                g.guid = b.guidance(g.imgs, g.h, g.w, g.mm)                            # tail of the memory build)
 
     def gather1(self):
         kf = gather_keyframe_rows(self.enc_send, self.K, self.kf_T, rank=self.rank, world=self.world, group=self.group)
@@ -271,6 +304,12 @@ class SceneRunner:
             self.enc_kf = kf
         else:
             self.enc_kf.copy_(kf)
+        if self.mm_scope is not None:
+            tab = gather_view_rows(self.mm_send, self.owner, self.rank, self.world, self.group)
+            if self.mm_all is None or self.mm_all is tab:
+                self.mm_all = tab
+            else:
+                self.mm_all.copy_(tab)
 
     def stage2(self):
         """replicated plan: everything between the two all-gathers as ONE stage (one captured graph)."""
@@ -397,6 +436,7 @@ class SceneRunner:
         for g in self.groups:
             g.imgs = g.cat = g.pointmaps = g.fpn = g.mf = g.guid = g.mm = g.enc = None
         self.enc_kf = self.both_kf = self.enc_send = self.both_send = self.out = self.graphs = self._refs = self.bank = None
+        self.mm_all = self.mm_send = None
 
     def set_images(self, images):
         """Load a new scene of the SAME shapes / schedule into the static input buffers (the captured graphs read them in place).
@@ -562,11 +602,36 @@ class HipBackend:
         return self.m.panoptic_decoder.minmax_scaled()
 
     def scope_ids(self, ids, device):
-        """per-group scope-id lists -> one static int32 device tensor (made once, outside any graph capture)"""
-        return torch.tensor([i for row in ids for i in row], dtype=torch.int32).to(device)
+        """scope id per view (by position in the scene's order) -> a static int32 device tensor (made once, outside any graph capture)"""
+        return torch.tensor(list(ids), dtype=torch.int32).to(device)
 
-    def minmax_tables(self, img_stacks, scope):
-        return self.m.panoptic_decoder.minmax_tables(img_stacks, scope)
+    def table_of(self, rows, device):
+        return torch.stack([r.float().reshape(3, 2) for r in rows]).to(device).contiguous()
+
+    def minmax_local(self, imgs):
+        """per (view, channel) (min, max) of the x0.5 guidance image: fp32 [n, 3, 2]"""
+        from . import hip
+        return hip.loftup_minmax(imgs, torch.empty(imgs.shape[0], 3, 2, dtype=torch.float32, device=imgs.device))
+
+    def rows_in_order(self, tabs, idxs, n):
+        out = torch.empty(n, *tabs[0].shape[1:], dtype=tabs[0].dtype, device=tabs[0].device)
+        for t, idx in zip(tabs, idxs):
+            out[self._index(idx, t.device)] = t
+        return out
+
+    def _index(self, idx, device):
+        cache = self.__dict__.setdefault('_idx', {})          # static index tensors: made once (a host->device copy cannot be captured)
+        key = (tuple(idx), str(device))
+        if key not in cache:
+            cache[key] = torch.tensor(list(idx), dtype=torch.long).to(device)
+        return cache[key]
+
+    def minmax_pool(self, table, scope):
+        from . import hip
+        return hip.minmax_merge(table.contiguous(), scope, torch.empty_like(table))
+
+    def table_rows(self, table, pos):
+        return table.index_select(0, self._index(pos, table.device)).contiguous()
 
     def guidance(self, imgs, h, w, mm=None):
         return self.m.panoptic_decoder.guidance_tokens(imgs, h, w, mm=mm)

@@ -9,6 +9,17 @@ import torch
 import torch.nn.functional as F
 
 
+class _FixedScaler(torch.nn.Module):
+    """oracle/panoptic.py MinMaxScaler with given per-channel bounds (a scope wider than the batch at hand)"""
+
+    def __init__(self, lo, hi):
+        super().__init__()
+        self.lo, self.hi = lo.reshape(1, -1, 1, 1), hi.reshape(1, -1, 1, 1)
+
+    def forward(self, x):
+        return (x - self.lo) / (self.hi - self.lo).clamp_min(1e-4) - 0.5
+
+
 class OracleBackend:
     def precision(self, amp):
         import contextlib
@@ -83,25 +94,57 @@ class OracleBackend:
         return type(self.m.panoptic_decoder.upscaler).__name__ == 'LoftUpUpscaler'
 
     def scope_ids(self, ids, device):
-        return ids             # per-group lists of scope ids; features() chunks by them
+        return torch.tensor(list(ids), dtype=torch.int32)
 
-    def minmax_tables(self, img_stacks, scope):
-        return scope           # the oracle's MinMaxScaler pools over the chunk it is handed: hand it the chunks
+    def table_of(self, rows, device):
+        return torch.stack([r.float().reshape(3, 2) for r in rows])
+
+    def minmax_local(self, imgs):
+        """per (view, channel) (min, max) of the image LoftUp's MinMaxScaler sees (oracle/panoptic.py: x0.5 bilinear first; loftup.py:14-19,154-156)"""
+        from oracle.panoptic import half_bilinear
+        x = half_bilinear(imgs.float())
+        return torch.stack([x.amin(dim=(2, 3)), x.amax(dim=(2, 3))], dim=-1)
+
+    def rows_in_order(self, tabs, idxs, n):
+        out = torch.empty(n, *tabs[0].shape[1:])
+        for t, idx in zip(tabs, idxs):
+            out[torch.tensor(list(idx))] = t
+        return out
+
+    def minmax_pool(self, table, scope):
+        out = torch.empty_like(table)
+        for s in set(scope.tolist()):
+            m = scope == s
+            out[m, :, 0] = table[m, :, 0].amin(0)
+            out[m, :, 1] = table[m, :, 1].amax(0)
+        return out
+
+    def table_rows(self, table, pos):
+        return table[torch.tensor(list(pos))]
 
     def guidance(self, imgs, h, w, mm=None):
         return None            # the oracle computes the guidance branch inside features()
 
     def features(self, cat, imgs, n, h, w, guidance=None, mm=None):
+        """mm: None = every view scaled on its own (the demo's max_bs=1); else [n, 3, 2] (min, max) per view, pooled by the runner over the view's scope:
+        the oracle's MinMaxScaler (which pools over the batch it is handed) is swapped for one with those fixed bounds - same arithmetic"""
         T, p = h * w, self.patch_size
         pos1 = self._pos(h, w)[None]
-        chunks = [[i] for i in range(n)] if mm is None else [[i for i in range(n) if mm[i] == s] for s in sorted(set(mm))]
+        up = self.m.panoptic_decoder.upscaler
         fpns, mfs = [None] * n, [None] * n
-        for ch in chunks:           # one MinMaxScaler scope per chunk (mm is None: per view, the demo's max_bs=1)
-            ts = torch.tensor([[[h * p, w * p]] * len(ch)])
-            c = torch.stack([cat[i * T:(i + 1) * T] for i in ch])[None]
-            fpn, mf = self.m.panoptic_decoder.features(c, torch.stack([imgs[i] for i in ch])[None], pos1.expand(1, len(ch), -1, -1), ts, max_bs=None)
-            for j, i in enumerate(ch):
-                fpns[i], mfs[i] = fpn[0, j], mf[0, j]
+        for i in range(n):
+            ts = torch.tensor([[[h * p, w * p]]])
+            c = cat[i * T:(i + 1) * T][None, None]
+            saved = None
+            if mm is not None:
+                saved = up.fourier_feat[0]
+                up.fourier_feat[0] = _FixedScaler(mm[i, :, 0], mm[i, :, 1])
+            try:
+                fpn, mf = self.m.panoptic_decoder.features(c, imgs[i][None, None], pos1, ts, max_bs=None)
+            finally:
+                if saved is not None:
+                    up.fourier_feat[0] = saved
+            fpns[i], mfs[i] = fpn[0, 0], mf[0, 0]
         fpn, mf = torch.stack(fpns), torch.stack(mfs)
         return fpn.flatten(2).transpose(1, 2).reshape(n * T, -1).contiguous(), mf          # tokens, [n,C,Hm,Wm]
 

@@ -31,13 +31,26 @@ ENC_CHUNK = 64        # views per encoder / DINOv2 / render pass (M = views*T ro
 
 
 def pan_amp_of(amp, panoptic_precision):
-    """`panoptic_precision` -> the `amp` value of the panoptic decoder (+ the other views' render): None / 'amp' = the scene's format, 'reference' = fp32
-    (the reference runs those parts outside torch.autocast, panst3r.py:236-245,268)"""
-    if panoptic_precision in (None, 'amp'):
-        return None
-    if panoptic_precision != 'reference':
-        raise ValueError("panoptic_precision must be None, 'amp' or 'reference' (got %r)" % (panoptic_precision,))
-    return False
+    """`panoptic_precision` -> (pan_amp, pan_scope) of a SceneRunner: the `amp` value of the second format (None = none, everything in `amp`) and how far
+    it reaches ('decoder': the panoptic decoder only; 'reference': also the render + DINOv2 of the views that are not keyframes).
+      None / 'auto'  the default.  amp='bf16': the panoptic decoder on F16 operands - the reference runs it in fp32, OUTSIDE its autocast (panst3r.py:236-245),
+                     so bf16 there is this build's choice, and every GEMM / attention operand of that stage sits behind a LayerNorm / GroupNorm / softmax
+                     (bounded by construction), which is where f16's three extra mantissa bits cost nothing and its range is not at risk (guarded by
+                     check_finite like amp='fp16').  Measured on configs[2] (v2, 16 = 16, profiles/r5_bf16_probe.txt): mask logits 2.1e-2 / 99.41 % of signs
+                     (worst view 98.9 %) with bf16 operands -> 4.9e-3 / 99.87 % (worst view 99.76 %), the level of the reference's own placement (4.6e-3).
+                     amp='fp16' / False: nothing to add (one format).
+      'amp'          everything in the format `amp` names, the panoptic decoder included (pure bf16: outside SURVEY 8(d)'s mask tolerances on configs[2])
+      'reference'    the reference's own placement under --amp: fp32 panoptic decoder AND fp32 render + DINOv2 of the views that are not keyframes
+      'fp16' / 'bf16' / 'fp32'   that format for the panoptic decoder only"""
+    if panoptic_precision in (None, 'auto'):
+        return ('fp16', 'decoder') if amp_dtype(amp, quiet=True) == torch.bfloat16 else (None, 'decoder')
+    if panoptic_precision == 'amp':
+        return None, 'decoder'
+    if panoptic_precision == 'reference':
+        return False, 'reference'
+    if panoptic_precision in ('fp16', 'bf16', 'fp32'):
+        return (False if panoptic_precision == 'fp32' else panoptic_precision), 'decoder'
+    raise ValueError("panoptic_precision must be None, 'auto', 'amp', 'reference', 'fp16', 'bf16' or 'fp32' (got %r)" % (panoptic_precision,))
 
 
 class PanSt3R(nn.Module):
@@ -251,8 +264,9 @@ class PanSt3R(nn.Module):
         `max_bs` (reference default None; the demo passes 1): the reference stacks same-shape views in chunks of max_bs and LoftUp's MinMaxScaler
         pools min / max over each chunk (loftup.py:14-19, panst3r.py:212-216,257-261) - None scales all same-shape keyframes
         together and all same-shape other views together, 1 scales every view on its own.  Everything else is chunk-invariant and batched here.
-        `panoptic_precision` (not in the reference): None = everything in the format `amp` names (the fast default: InputMixer, upscaler, query decoder and
-        mask head on 16-bit operands as well - SURVEY 8(d) sanctions it against the stated tolerances).  'reference' = the reference's own placement
+        `panoptic_precision` (not in the reference; see pan_amp_of): None = the fast default - everything on 16-bit operands, InputMixer, upscaler, query decoder
+        and mask head included (SURVEY 8(d) sanctions it against the stated tolerances); with amp='bf16' that stage takes F16 operands (the reference computes it
+        in fp32; bounded operands, +3 mantissa bits at the same speed), 'amp' forces the scene's format there too.  'reference' = the reference's own placement
         under --amp (panst3r.py:174-175,204-234 autocast the encoder, the memory build and the keyframes' render + DINOv2 only; the WHOLE panoptic
         decoder :236-245 and the render + DINOv2 + heads of the views that are not keyframes :268 run outside autocast): those parts run on the fp32
         kernels here too (measured 4.7x the scene time at 50 views / 16 keyframes; the encoder tokens of every view stay 16-bit-computed, as in the reference).
@@ -270,7 +284,8 @@ class PanSt3R(nn.Module):
         fmt = amp_dtype(amp)                    # tells (once) that amp=False is the slow fp32 mode
         runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs, panoptic_precision, _mm_tables)
         res, scene = runner.run(outdevice)
-        if check_finite and fmt == torch.float16:
+        pan_fmt = fmt if runner.pan_amp is None else amp_dtype(runner.pan_amp, quiet=True)
+        if check_finite and torch.float16 in (fmt, pan_fmt):
             # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: ONE fused flag over everything the
             # call returns (queries, class logits, pointmaps, mask logits), one host sync; raises, as the reference's "--amp fp16 might be
             # unstable" would show up.  (amp=False is fp32 and amp='bf16' has the fp32 range: neither can overflow this way.)
@@ -284,6 +299,9 @@ class PanSt3R(nn.Module):
             if not bool(ok):
                 if not cache_graphs:
                     runner.release()
+                if fmt != torch.float16:
+                    raise FloatingPointError("non-finite outputs: an activation of the panoptic decoder left the f16 range (amp='bf16' runs that stage on f16 "
+                                             "operands); run with panoptic_precision='amp' (bf16 there too) or 'reference' (fp32 there)")
                 raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16' (or amp=False)")
         panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
                   'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
@@ -303,8 +321,9 @@ class PanSt3R(nn.Module):
         V = len(imgs)
         H, W = shapes[0]
         if not cache_graphs:
+            pa, ps = pan_amp_of(amp, panoptic_precision)
             return SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
-                               keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pan_amp_of(amp, panoptic_precision), mm_override=mm_tables)
+                               keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pa, pan_scope=ps, mm_override=mm_tables)
         if mm_tables is not None:
             raise NotImplementedError('caller-pooled MinMaxScaler tables are per call: not combined with cache_graphs')
         from .model.common import HipModule
@@ -318,8 +337,9 @@ class PanSt3R(nn.Module):
         if ent is None:
             while len(self._runners) >= max(1, self.max_cached_runners):
                 self._runners.pop(next(iter(self._runners)))
+            pa, ps = pan_amp_of(amp, panoptic_precision)
             runner = SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
-                                 keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pan_amp_of(amp, panoptic_precision))
+                                 keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pa, pan_scope=ps)
             ent = self._runners[key] = [0, runner]
         else:
             ent[1].set_images(imgs)
@@ -351,8 +371,9 @@ class PanSt3R(nn.Module):
         import torch.distributed as dist
         from .scene import SceneRunner, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        pa, ps = pan_amp_of(amp, panoptic_precision)
         return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes, amp=amp,
-                           plan=plan, minmax_bs=max_bs, pan_amp=pan_amp_of(amp, panoptic_precision))
+                           plan=plan, minmax_bs=max_bs, pan_amp=pa, pan_scope=ps)
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False):

@@ -148,13 +148,20 @@ class SceneRunner:
     (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
     def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None,
-                 amp=None, plan='replicated', minmax_bs=1, pan_amp=None, mm_override=None):
+                 amp=None, plan='replicated', minmax_bs=1, pan_amp=None, mm_override=None, pan_scope='reference'):
         self.b, self.V, self.classes = backend, V, classes
         # reference AMP placement (panst3r.py:174-175,204-245,268): `amp` names the format of the encoder, the memory build and the keyframes' render +
         # DINOv2; `pan_amp` (None = the same format) that of the panoptic decoder AND of the render + DINOv2 of the views that are not keyframes.
         # With two formats in play (`mixed`) the feature concat is kept in the panoptic format and the encoder tokens additionally in the scene's.
+        # `pan_scope` says how far the second format reaches: 'reference' = as just described (the reference's autocast boundary); 'decoder' = the panoptic
+        # decoder ONLY (InputMixer, upscaler, query decoder, mask head) - every view's encoder, DINOv2 and render stay in the scene's format.  That is the
+        # default placement of amp='bf16' (PanSt3R.forward_inference_multi_ar: bf16 where the reference autocasts, f16 - 3 more mantissa bits at the same MFMA
+        # rate - where it computes in fp32 and every operand sits behind a normalisation).
         self.pan_amp = amp if pan_amp is None else pan_amp
         self.mixed = pan_amp is not None and not backend.same_format(amp, pan_amp)
+        if pan_scope not in ('reference', 'decoder'):
+            raise ValueError("pan_scope must be 'reference' or 'decoder' (got %r)" % (pan_scope,))
+        self.ref_split = self.mixed and pan_scope == 'reference'        # the other views' render + DINOv2 run in the panoptic format too
         # LoftUp's MinMaxScaler scope (loftup.py:14-19 pools min / max over the chunk of views it is handed; the reference chunks by max_bs):
         # 1 = per view (the demo's max_bs=1, tools/demo_panst3r.py:201 - the default here and what bench.py times); k = same-shape keyframes /
         # same-shape other views in chunks of k, None = all of them together (the reference with max_bs=None: stack_views + batched_map,
@@ -276,13 +283,13 @@ class SceneRunner:
         """Everything the build does not depend on: encoder of the non-keyframe views + DINOv2 of every view."""
         b = self.b
         for g in self.groups:
-            if not self.mixed and len(g.idx) > g.k and hasattr(b, 'encode_rest_paired'):
+            if not self.ref_split and len(g.idx) > g.k and hasattr(b, 'encode_rest_paired'):
                 # the encoder of the views that are not keyframes and DINOv2 of all views, layer by layer in lock-step (shared launches)
-                b.encode_rest_paired(g.imgs[g.k:], g.cat[g.k * g.T:], g.imgs, g.cat)
+                b.encode_rest_paired(g.imgs[g.k:], g.cat[g.k * g.T:], g.imgs, g.cat, None if g.enc is None else g.enc[g.k * g.T:])
                 continue
             if len(g.idx) > g.k:
                 b.encode_enc(g.imgs[g.k:], g.cat[g.k * g.T:], None if g.enc is None else g.enc[g.k * g.T:])
-            if not self.mixed:
+            if not self.ref_split:
                 b.encode_dino(g.imgs, g.cat)
             else:               # reference placement: DINOv2 of the keyframes under autocast (panst3r.py:229-230), of the other views outside it (:150 via :268)
                 if g.k:
@@ -326,16 +333,16 @@ class SceneRunner:
         dev = self.groups[0].imgs.device
         if self.split:
             if self.builder:
-                self.bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.mixed)
+                self.bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.ref_split)
             else:
                 self._encode_rest()
-                self.bank = b.bank_alloc(self.K, self.kf_grids, dev, self.mixed)
+                self.bank = b.bank_alloc(self.K, self.kf_grids, dev, self.ref_split)
             return
         # (measured +5 % frames/s at 50 views, but unsafe on this platform - see OVERLAP_DEFAULT - hence only when asked for)
         side = b.side_stream(dev) if not self.serial else None
         if side is None:
             self._encode_rest()
-            bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.mixed)
+            bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.ref_split)
         else:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
@@ -344,9 +351,9 @@ class SceneRunner:
             if DIAG_CONCURRENT is not None:        # diagnostics only (tests/diag/dino_taps.py): some other workload beside the side branch
                 DIAG_CONCURRENT()
                 main.wait_stream(side)
-                bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.mixed)
+                bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.ref_split)
             else:
-                bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.mixed)
+                bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.ref_split)
                 main.wait_stream(side)
         self.bank = bank
 
@@ -365,6 +372,8 @@ class SceneRunner:
             n = len(g.idx)
             if not self.mixed:
                 g.pointmaps = b.render(g.cat, n, g.h, g.w, bank)
+            elif not self.ref_split:      # second format for the panoptic decoder only: every view rendered in the scene's format from its copy of the encoder tokens
+                g.pointmaps = b.render(g.cat, n, g.h, g.w, bank, g.enc)
             else:               # reference placement: keyframes rendered in the scene's format (panst3r.py:221-227), the other views in the panoptic one (:268)
                 kT = g.k * g.T
                 pms = [b.render(g.cat[:kT], g.k, g.h, g.w, bank, g.enc[:kT])] if g.k else []
@@ -566,8 +575,11 @@ class HipBackend:
     def bank_f32(self, bank):
         return bank.f32
 
-    def encode_rest_paired(self, imgs_enc, cat_enc, imgs_dino, cat_dino):
+    def encode_rest_paired(self, imgs_enc, cat_enc, imgs_dino, cat_dino, enc_rows=None):
         self.m.encode_views_paired(imgs_enc, cat_enc, imgs_dino, cat_dino)
+        if enc_rows is not None:
+            from . import hip
+            hip.add_cast(cat_enc[:, :self.De], enc_rows)
 
     def encode_dino(self, imgs, cat_rows):
         self.m.encode_views(imgs, cat_rows, enc=False)

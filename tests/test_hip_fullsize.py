@@ -64,7 +64,7 @@ def heads_only_parity(built, V, K, ref, amp='fp16'):
     with torch.no_grad():
         runner.run()
         mt = model.panoptic_decoder.mask_transformer
-        with precision(amp):
+        with precision(runner.pan_amp):          # the format the scene runs its panoptic decoder in (f16 operands under amp='bf16' as well)
             cls = model.panoptic_decoder.text_encoder.normalized_bf16(names, dev)
             hs = mt.head_state(pan_o['out_queries'].reshape(-1, mt.hidden_dim).float().to(dev).contiguous(), cls)
             out = []
@@ -78,12 +78,11 @@ def heads_only_parity(built, V, K, ref, amp='fp16'):
 # ASSERTED bounds at full size, per format: ~3x the error measured on MI355X (profiles/r4_parity_margins.json), never looser than the five tolerances
 # SURVEY 8(d) states (bench.TOLERANCE).  `dm_*`: the run with the query decoder's discrete decisions matched to the oracle's (what the arithmetic does),
 # asserted for EVERY view; `free_*`: the free-running scene, mask criteria pooled over the scene's pixels; `bits`: attention-mask decisions equal.
-# bf16 is asserted at ITS level: 8 mantissa bits do not reach the stated mask tolerances on the v2 configurations at full size (16 / 16: 2.3e-2 pooled,
-# 3.5e-2 on the worst view, 99.3 % signs) - said in the bench line ("configs_named_bf16") and in DESIGN.md section 2, not hidden in a relaxed assert;
-# amp='bf16' with panoptic_precision='reference' (the reference's own placement: fp32 panoptic decoder) is the configuration that meets them.
+# amp='bf16' (bf16 where the reference autocasts, f16 operands in the panoptic decoder - panst3r.pan_amp_of) is asserted AT the stated tolerances since round 5
+# (rounds 3-4 had relaxed bounds for the all-bf16 panoptic decoder: 16 / 16 at 2.3e-2 pooled, 3.5e-2 / 98.9 % on the worst view).
 FULL_BOUNDS = {
     'fp16': dict(pm=3e-3, dm_mask=9e-3, dm_sign=0.997, dm_q=2.5e-3, dm_logits=1.5e-3, free_mask=1e-2, free_sign=0.997, free_logits=5e-3, free_q=1e-2, bits=0.99),
-    'bf16': dict(pm=2e-2, dm_mask=5e-2, dm_sign=0.98, dm_q=2e-2, dm_logits=1e-2, free_mask=4e-2, free_sign=0.99, free_logits=2e-2, free_q=2e-2, bits=0.975),
+    'bf16': dict(pm=2e-2, dm_mask=3e-2, dm_sign=0.995, dm_q=2e-2, dm_logits=1e-2, free_mask=3e-2, free_sign=0.995, free_logits=2e-2, free_q=2e-2, bits=0.975),
 }
 
 
@@ -334,7 +333,9 @@ def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, k
     runners = []
     for r in range(world):
         mine = {order_owner[1][i]: imgs[order_owner[1][i]] for i in range(V) if order_owner[2][i] == r}
-        runners.append(S.SceneRunner(S.HipBackend(model), mine, V, H, W, K, names, rank=r, world=world, keyframes=keyframes, amp=amp, plan=plan))
+        from panst3r_amd.panst3r import pan_amp_of
+        pa, ps = pan_amp_of(amp, None)          # the product's default placement of the format (scene_runner does the same)
+        runners.append(S.SceneRunner(S.HipBackend(model), mine, V, H, W, K, names, rank=r, world=world, keyframes=keyframes, amp=amp, plan=plan, pan_amp=pa, pan_scope=ps))
     sends = []
     monkeypatch.setattr(S, '_all_gather_rows', lambda t, counts, w, g: [s[:c] for s, c in zip(sends, counts)])
     from panst3r_amd.model.common import precision

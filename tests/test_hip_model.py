@@ -25,8 +25,15 @@ def pair(request):
     o = tiny.build(tiny.OracleNS, variant)
     h = tiny.build(tiny.hip_ns(), variant).to(DEV)
     h.amp = amp
+    h.pan_amp = 'fp16'        # the format a scene of this mode runs its panoptic decoder in (panst3r.pan_amp_of: f16 operands under amp='bf16' as well)
     with precision(amp):
         yield variant, o, h
+
+
+def pan(h):
+    """format context of MODULE-level panoptic-decoder calls: the format the mode's scenes run that stage in"""
+    from panst3r_amd.model.common import precision
+    return precision(h.pan_amp)
 
 
 # Asserted bounds, PER FORMAT: ~3x the error measured on MI355X with these weights and inputs (profiles/r4_parity_margins.json is the record of every
@@ -40,8 +47,10 @@ BOUNDS = {
     # measured worst over the suite (gpurun r4b): tok 9.6e-4, pm 9.4e-4, q 5.5e-3 (typically 0.7-1.5e-3; a flipped attention-mask decision of the query
     # decoder moves single queries by several %), logits 1.6e-3, mask 4.0e-3, mask_view 8.2e-3, sign 99.93 %, sign_view 99.91 %
     'fp16': dict(tok=3e-3, pm=3e-3, q=1.2e-2, logits=6e-3, mask=1e-2, mask_view=1.8e-2, sign=0.998, sign_view=0.997),
-    # measured worst: tok 8.0e-3, pm 7.5e-3, q 2.2e-2 (decoder-level call, pooled MinMaxScaler), logits 1.6e-2, mask 1.6e-2, mask_view 3.7e-2, sign 99.5 %, sign_view 99.2 %
-    'bf16': dict(tok=2e-2, pm=2e-2, q=3e-2, logits=3e-2, mask=3e-2, mask_view=4.5e-2, sign=0.993, sign_view=0.99),
+    # amp='bf16' = bf16 operands where the reference autocasts (encoder, DINOv2, memory build, render) and f16 operands in the panoptic decoder (the reference:
+    # fp32 there; panst3r.pan_amp_of).  Round 5: every bound is AT the SURVEY 8(d) statement (rounds 3-4 had relaxed q / mask_view / sign for the all-bf16
+    # panoptic decoder).  Pure bf16 (panoptic_precision='amp') is measured, not asserted at these: test_pure_bf16_is_an_opt_in.
+    'bf16': dict(tok=2e-2, pm=2e-2, q=2e-2, logits=3e-2, mask=3e-2, mask_view=3e-2, sign=0.995, sign_view=0.995),
 }
 
 
@@ -121,7 +130,7 @@ def test_panoptic_decoder(pair):
     imgs = torch.stack(tiny.images(n, H, W))[None]
     pos = grid_pos(4, 6)[None].expand(1, n, -1, -1).contiguous()
     ts = torch.tensor([[[H, W]] * n])
-    with torch.no_grad():
+    with torch.no_grad(), pan(h):
         ro = o.panoptic_decoder(feats, imgs, pos, ts, tiny.NAMES, max_bs=1)
         rh = h.panoptic_decoder(tuple(f.to(DEV) for f in feats), imgs.to(DEV), pos.to(DEV), ts, tiny.NAMES, max_bs=1)
         # per-module: features (mixer + upscaler) in the reference layouts
@@ -136,7 +145,7 @@ def test_panoptic_decoder(pair):
     chk(h, 'mask', rel_l2(mk_h, mk_o), '')
     chk(h, 'sign', float(((mk_h > 0) == (mk_o > 0)).float().mean()))
     # heads-only path with the oracle's queries
-    with torch.no_grad():
+    with torch.no_grad(), pan(h):
         r2o = o.panoptic_decoder(feats, imgs, pos, ts, tiny.NAMES, max_bs=1, memory_queries=ro['out_queries'])
         r2h = h.panoptic_decoder(tuple(f.to(DEV) for f in feats), imgs.to(DEV), pos.to(DEV), ts, tiny.NAMES, max_bs=1,
                                  memory_queries=ro['out_queries'].to(DEV))
@@ -294,7 +303,7 @@ def test_minmax_scope_follows_max_bs(pair, max_bs):
     im = torch.stack(tiny.images(n, H, W))[None]
     pos = grid_pos(4, 6)[None].expand(1, n, -1, -1).contiguous()
     t5 = torch.tensor([[[H, W]] * n])
-    with torch.no_grad():
+    with torch.no_grad(), pan(h):
         ro = o.panoptic_decoder(feats, im, pos, t5, tiny.NAMES, max_bs=max_bs)
         rh = h.panoptic_decoder(tuple(f.to(DEV) for f in feats), im.to(DEV), pos.to(DEV), t5, tiny.NAMES, max_bs=max_bs)
     chk(h, 'mask', rel_l2(rh['pred_masks'].cpu(), ro['pred_masks']), '')
@@ -312,7 +321,7 @@ def test_reference_amp_placement(pair):
     ts = torch.tensor([[H, W]] * V)
     dimgs = [i.to(DEV) for i in imgs]
     pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K)
-    pm_a, pan_a = h.forward_inference_multi_ar(dimgs, ts, tiny.NAMES, num_keyframes=K, amp=h.amp)
+    pm_a, pan_a = h.forward_inference_multi_ar(dimgs, ts, tiny.NAMES, num_keyframes=K, amp=h.amp, panoptic_precision='amp')       # the scene's format everywhere
     pm_r, pan_r = h.forward_inference_multi_ar(dimgs, ts, tiny.NAMES, num_keyframes=K, amp=h.amp, panoptic_precision='reference')
     for a, b in zip(pm_r, pm_o):
         chk(h, 'pm', rel_l2(a.cpu(), b), 'reference placement')
@@ -334,6 +343,31 @@ def test_reference_amp_placement(pair):
     assert torch.equal(scene['out_queries'], pan_r['out_queries'])
     for i in range(V):
         assert torch.equal(res[i][0], pm_r[i]) and torch.equal(res[i][1], pan_r['pred_masks'][i]), i
+
+
+def test_pure_bf16_is_an_opt_in(pair):
+    """amp='bf16' runs the panoptic decoder on f16 operands by default (panst3r.pan_amp_of); panoptic_precision='amp' forces bf16 there too.  The backbone
+    is the same in both (identical pointmaps); against the fp32 oracle the default's mask logits are closer, and the pure mode's level is RECORDED
+    (gpurun_out/parity_margins.jsonl, kind 'pure_bf16_*'), not asserted at the stated tolerances it does not reach at full size."""
+    variant, o, h = pair
+    if h.amp != 'bf16':
+        pytest.skip('one format')
+    V, K, H, W = 5, 3, 64, 96
+    imgs = tiny.images(V, H, W)
+    ts = torch.tensor([[H, W]] * V)
+    dimgs = [i.to(DEV) for i in imgs]
+    pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K, max_bs=1)
+    pm_d, pan_d = h.forward_inference_multi_ar(dimgs, ts, tiny.NAMES, num_keyframes=K, amp='bf16', max_bs=1)
+    pm_p, pan_p = h.forward_inference_multi_ar(dimgs, ts, tiny.NAMES, num_keyframes=K, amp='bf16', max_bs=1, panoptic_precision='amp')
+    for a, b in zip(pm_d, pm_p):
+        assert torch.equal(a, b)
+    e_d = max(rel_l2(a.cpu(), b) for a, b in zip(pan_d['pred_masks'], pan_o['pred_masks']))
+    e_p = max(rel_l2(a.cpu(), b) for a, b in zip(pan_p['pred_masks'], pan_o['pred_masks']))
+    _record('pure_bf16', dict(variant=variant, default_mask_view=e_d, pure_mask_view=e_p,
+                              default_q=rel_l2(pan_d['out_queries'].cpu(), pan_o['out_queries']), pure_q=rel_l2(pan_p['out_queries'].cpu(), pan_o['out_queries'])))
+    chk(h, 'mask_view', e_d, 'default placement')
+    assert e_d < e_p, (e_d, e_p)
+    assert e_p < 0.1                                          # sanity only: pure bf16 is an opt-in outside SURVEY 8(d)'s mask tolerances
 
 
 @pytest.mark.parametrize('K', [2, 5])
@@ -364,7 +398,7 @@ def test_panoptic_decoder_portrait(pair):
     imgs = torch.stack([tiny.synth_image(i, H, W, 3) for i in range(n)])[None]
     pos = grid_pos(6, 4)[None].expand(1, n, -1, -1).contiguous()
     ts = torch.tensor([[[H, W]] * n])
-    with torch.no_grad():
+    with torch.no_grad(), pan(h):
         ro = o.panoptic_decoder(feats, imgs, pos, ts, tiny.NAMES, max_bs=1)
         rh = h.panoptic_decoder(tuple(f.to(DEV) for f in feats), imgs.to(DEV), pos.to(DEV), ts, tiny.NAMES, max_bs=1)
     assert rh['pred_masks'].shape == ro['pred_masks'].shape

@@ -145,8 +145,34 @@ def report(name, o, ref):
     print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in rec.items()}), flush=True)
 
 
+def run_product(amp, panoptic_precision=None):
+    """the product's own placement (PanSt3R.scene_runner -> panst3r.pan_amp_of), no overrides"""
+    REC.clear()
+    r = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=False, amp=amp, panoptic_precision=panoptic_precision)
+    mg = type(r.b).masks_group
+
+    def rec(self, head, mf):
+        REC['E'], REC['F'] = head.embed.float(), mf.float()
+        return mg(self, head, mf)
+    type(r.b).masks_group = rec
+    try:
+        res, scene = r.run()
+    finally:
+        type(r.b).masks_group = mg
+    torch.cuda.synchronize()
+    out = dict(pm=[res[i][0] for i in range(V)], mk=[res[i][1] for i in range(V)], q=scene['out_queries'].clone(), lg=scene['pred_logits'].clone(),
+               E=REC['E'].clone(), F=REC['F'].clone())
+    r.release()
+    return out
+
+
 with torch.no_grad():
     ref = run(False)
+    report("product: amp='bf16' (default placement)", run_product('bf16'), ref)
+    report("product: amp='bf16', panoptic_precision='amp' (pure)", run_product('bf16', 'amp'), ref)
+    report("product: amp='fp16'", run_product('fp16'), ref)
+    if len(sys.argv) > 3 and sys.argv[3] == 'quick':
+        sys.exit(0)
     report('fp32 again (determinism of the reference)', run(False), ref)
     report('f16 everywhere', run('fp16'), ref)
     report('bf16 everywhere', run('bf16'), ref)

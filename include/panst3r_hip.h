@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 17
+#define PST_ABI_VERSION 18
 
 /* element type codes: every `*_type` / `dtype16` argument below (and the former `*_fp32` flags: 0 and 1 keep their meaning) */
 #define PST_BF16 0   /* bfloat16, raw uint16 */
@@ -198,6 +198,24 @@ int pst_layernorm_add_batch(const void* x, int64_t ldx, int in_fp32, const float
  * the bf16 MFMA path.  Used for the 200-query mask-embedding MLP (mask_transformer.py:230), whose result is one factor of the
  * ill-conditioned query x pixel product. */
 int pst_split3(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, int dtype16, void* stream);
+
+/* ---------------------------------------------------------------- fp32-grade contractions at three 16-bit MFMAs per product (ABI 18)
+ * The reference's default is fp32 (amp=False, tools/demo_panst3r.py:88), and under --amp it still runs the whole panoptic decoder and the render of the
+ * views that are not keyframes in fp32 (src/panst3r/panst3r.py:236-245,268).  With x = x_hi + x_lo (x_hi = rn16(x), x_lo = rn16(x - x_hi): 22 mantissa bits in
+ * f16) a product is x_hi y_hi + x_hi y_lo + x_lo y_hi to 2^-22, so a GEMM on fp32 operands is ONE 16-bit pst_gemm over a 3 x longer K and attention
+ * takes (hi, lo) planes - the 16-bit matrix rate / 3 instead of the fp32-input MFMA's 1 / 16.
+ *   split_operand  x fp32 [rows, K] -> 16-bit [rows, 3 Kpad]: three blocks of Kpad columns (zero beyond K), side 0 (a GEMM's A operand) [hi | hi | lo],
+ *                  side 1 (its W operand, nn.Linear layout) [hi | lo | hi]; with an implicit 3x3 conv the pixel rows of the NHWC image are split with
+ *                  Kpad = conv_c (conv_c' = 3 conv_c) and the weights per tap.  pst_split3 is side 0 with Kpad = K.
+ *   split2         x fp32 [rows, K] -> planes hi, lo 16-bit [rows, ldo], or with transpose != 0 the planes of x^T ([K, ldo], ldo >= rows): the V^T operand
+ *   transpose_f32  y[c][r] = x[r][c]
+ *   attn_x3        pst_attn_fwd on split operands: p->Q / K / Vt are the hi planes (format p->dtype16), Q_lo / K_lo / Vt_lo the lo planes with the SAME
+ *                  strides, p->O is fp32 (strides in floats).  Softmax in fp32; P is split in registers; mask / split-K / prescaled as pst_attn_fwd. */
+int pst_split_operand(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, int Kpad, int side, int dtype16, void* stream);
+int pst_split2(const float* x, int64_t ldx, void* hi, void* lo, int64_t ldo, int rows, int K, int transpose, int dtype16, void* stream);
+int pst_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, void* stream);
+int pst_attn_x3(const pst_attn_params* p, const void* Q_lo, const void* K_lo, const void* Vt_lo, void* stream);
+const char* pst_attn_x3_variant(const pst_attn_params* p);
 
 /* ---------------------------------------------------------------- RoPE-2D (in place on bf16 q and k)
  * Replaces cuRoPE2D / RoPE2D 'RoPE100' (README.md:67-71, input_mixer.py:16): per head the first hd/2 channels

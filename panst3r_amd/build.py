@@ -29,7 +29,7 @@ def _hipcc():
 # attention.hip: keep MFMA results in VGPRs.  By default the register allocator puts the S / O accumulators in AGPRs
 # and the online softmax then pays 160 v_accvgpr_read/write per 64-key tile (more VALU time than the 34 v_exp) at
 # 125 + 35 registers; in VGPR form the same kernel needs 124 registers, no copies, occupancy 4 instead of 3.
-PER_FILE_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
+PER_FILE_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'attn_x3.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def source_hash():

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PST_LIB') or os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')      # PST_LIB: A/B builds of the same ABI (measurement)
-ABI_VERSION = 17
+ABI_VERSION = 18
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -40,7 +40,7 @@ class AttnParams(C.Structure):
 
 
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_gemm_pair', 'pst_gemm_pair_variant', 'pst_tune', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_pair', 'pst_attn_pair_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
-           'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_rope2d',
+           'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_split_operand', 'pst_split2', 'pst_transpose_f32', 'pst_attn_x3', 'pst_attn_x3_variant', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_loftup_minmax', 'pst_minmax_merge', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize', 'pst_pointmap_activate', 'pst_focal_weiszfeld', 'pst_rigid_moments',
@@ -61,6 +61,7 @@ def lib():
     L.pst_gemm_pair_variant.restype = C.c_char_p
     L.pst_attn_variant.restype = C.c_char_p
     L.pst_attn_pair_variant.restype = C.c_char_p
+    L.pst_attn_x3_variant.restype = C.c_char_p
     L.pst_attn_workspace_bytes.restype = C.c_int64
     L.pst_qubo_workspace_floats.restype = C.c_int64
     L.pst_qubo_workspace_floats.argtypes = [C.c_int, C.c_int64]
@@ -269,8 +270,124 @@ def _gemm_params(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None
     return p, 2.0 * Mv * N * K * (batch[0] if batch else 1), tag
 
 
+# ----------------------------------------------------------------------------------------------------------- fp32 operands on 3 x 16-bit MFMA
+# fp32 mode (the reference's amp=False, and the stages it runs outside its autocast): X3 = True evaluates every contraction on fp32 operands as three
+# 16-bit MFMAs on split operands (x = hi + lo in X3_FMT: 22 mantissa bits in f16, the lo x lo term dropped; include/panst3r_hip.h "fp32-grade
+# contractions") - one 16-bit GEMM over a 3 x longer K, attention on (hi, lo) planes; ~1e-6 against float64 at a third of the 16-bit matrix rate.
+# X3 = False: the fp32-input-MFMA kernels (gemm_f32.hip / attn_f32.hip: exact fp32 products, 1 / 16 of the 16-bit rate).  Switched by
+# model.common.precision (amp=False / 'fp32' -> X3; 'fp32_exact' -> the exact kernels).
+X3 = True
+X3_FMT = torch.float16
+
+
+def split_operand(x, side, kpad=None, out=None, fmt=None):
+    """fp32 x [rows, K] -> 16-bit [rows, 3 kpad] = [hi | hi | lo] (side 0: a GEMM's A operand) or [hi | lo | hi] (side 1: its W operand); zero beyond K"""
+    _dev(x, torch.float32)
+    rows, K = x.shape
+    kpad = (K + 63) // 64 * 64 if kpad is None else kpad
+    if out is None:
+        out = torch.empty(rows, 3 * kpad, dtype=fmt or X3_FMT, device=x.device)
+    _check(lib().pst_split_operand(_ptr(x), i64(_rowmajor(x)), _ptr(out), i64(_rowmajor(out)), rows, K, kpad, int(side), _tc(out), _stream()), 'pst_split_operand')
+    return out
+
+
+def split2(x, transpose=False, hi=None, lo=None, fmt=None):
+    """fp32 x [rows, K] -> (hi, lo) 16-bit planes of x (or of x^T: [K, rows rounded up to 8])"""
+    _dev(x, torch.float32)
+    rows, K = x.shape
+    if hi is None:
+        shape = (K, (rows + 7) // 8 * 8) if transpose else (rows, K)
+        hi, lo = torch.empty(shape, dtype=fmt or X3_FMT, device=x.device), torch.empty(shape, dtype=fmt or X3_FMT, device=x.device)
+    _check(lib().pst_split2(_ptr(x), i64(_rowmajor(x)), _ptr(hi), _ptr(lo), i64(_rowmajor(hi)), rows, K, int(transpose), _tc(hi), _stream()), 'pst_split2')
+    return hi, lo
+
+
+def transpose_f32(x, out):
+    """out[c, r] = x[r, c] (fp32; out row-major with leading dimension >= rows)"""
+    _dev(x, torch.float32); _dev(out, torch.float32)
+    rows, cols = x.shape
+    _check(lib().pst_transpose_f32(_ptr(x), i64(_rowmajor(x)), _ptr(out), i64(_rowmajor(out)), rows, cols, _stream()), 'pst_transpose_f32')
+    return out
+
+
+def _x3_wanted(a, w):
+    return a.dtype == torch.float32 and (w.dtype in H16 or (w.dtype == torch.float32 and X3))
+
+
+def _x3_prepare(a, w, out, kw):
+    """One fp32-operand GEMM as a 16-bit GEMM over the 3 x longer K: returns (a3, w3, out', kw', finish).  `w` is a pre-split weight (16-bit [N, 3 Kpad],
+    model.common.Packed) or an fp32 matrix split here; `finish()` runs what follows the launch (the transpose of a trans_out result: the 16-bit kernels
+    store transposed results in 16 bit only)."""
+    kw = dict(kw)
+    if out.dtype != torch.float32:
+        raise RuntimeError('fp32-operand GEMM: the output must be fp32')
+    conv, batch = kw.get('conv'), kw.get('batch')
+    c64 = lambda n: (n + 63) // 64 * 64
+    if w.dtype == torch.float32:                 # an fp32 W operand (activations on the W side: mask features, class embeddings; tests): split here
+        N = w.shape[0]
+        if conv is not None:                     # per tap (the K index of the implicit conv is tap-major)
+            cc = conv[0]
+            w = split_operand(w.reshape(N * 9, cc), 1, kpad=c64(cc)).reshape(N, 27 * c64(cc))
+        elif batch is not None:
+            count, a_bs, w_bs, c_bs, bias_bs = batch
+            if w_bs != N * _rowmajor(w):
+                raise RuntimeError('fp32-operand GEMM: batched W problems must be stacked row blocks')
+            w = split_operand(w.as_strided((count * N, w.shape[1]), (_rowmajor(w), 1)), 1)
+            kw['batch'] = batch = (count, a_bs, N * w.shape[1], c_bs, bias_bs)
+            w = w[:N]
+        else:
+            w = split_operand(w, 1)
+    fmt = w.dtype
+    if conv is not None:
+        cc, ch, cw = conv
+        a3 = split_operand(a.reshape(-1, cc), 0, kpad=c64(cc), fmt=fmt)
+        assert w.shape[1] == 27 * c64(cc), (tuple(w.shape), cc)
+        kw['conv'] = (3 * c64(cc), ch, cw)
+    else:
+        kpad = w.shape[1] // 3
+        if w.shape[1] != 3 * kpad or kpad % 64 or a.shape[1] > kpad:
+            raise RuntimeError('fp32-operand GEMM: a 16-bit W next to an fp32 A must be a split-packed weight [N, 3 Kpad] with Kpad >= K (A %s, W %s)'
+                               % (tuple(a.shape), tuple(w.shape)))
+        rows = a.shape[0] if kw.get('M') is None else kw['M']
+        src = a[:rows]
+        if batch is not None:
+            count, a_bs, w_bs, c_bs, bias_bs = batch
+            lda = _rowmajor(a)
+            if a_bs != rows * lda:
+                raise RuntimeError('fp32-operand GEMM: batched A problems must be stacked row blocks')
+            src = a.as_strided((count * rows, a.shape[1]), (lda, 1))
+            kw['batch'] = batch = (count, rows * 3 * kpad, w_bs, c_bs, bias_bs)
+            kw['M'] = rows                       # rows of ONE problem (a3 stacks all of them)
+        a3 = split_operand(src, 0, kpad=kpad, fmt=fmt)
+    finish = None
+    if kw.get('trans_out'):
+        # C^T in fp32: row-major result into scratch, then one transpose per problem into the caller's (strided) buffer
+        kw['trans_out'] = False
+        cnt = batch[0] if batch else 1
+        M, N = a3.shape[0] // cnt, w.shape[0]
+        tmp = torch.empty(cnt, M, N, dtype=torch.float32, device=a.device)
+        dst, c_bs = out, (batch[3] if batch else 0)
+        if batch:
+            kw['batch'] = kw['batch'][:3] + (M * N, kw['batch'][4])
+        ld_out = _rowmajor(dst)
+
+        def finish():
+            for i in range(cnt):
+                o = dst if i == 0 else dst.as_strided((N, M), (ld_out, 1), dst.storage_offset() + i * c_bs)
+                transpose_f32(tmp[i], o)
+        out = tmp[0]
+    return a3, w, out, kw, finish
+
+
 def gemm(a, w, out, **kw):
-    """out = epi(a @ w.T): see _gemm_params for the arguments"""
+    """out = epi(a @ w.T): see _gemm_params for the arguments.  fp32 `a` with a pre-split 16-bit `w` (or, under X3, an fp32 `w`): the 3 x 16-bit
+    evaluation (_x3_prepare)."""
+    if _x3_wanted(a, w):
+        a3, w3, o3, kw3, finish = _x3_prepare(a, w, out, kw)
+        gemm(a3, w3, o3, **kw3)
+        if finish is not None:
+            finish()
+        return out
     p, flops, tag = _gemm_params(a, w, out, **kw)
     if TIMER is not None:
         name = lib().pst_gemm_variant(C.byref(p))          # the C side names the kernel it dispatches to (no re-derived rule here)
@@ -288,6 +405,23 @@ def gemm_pair(first, second):
     (`first` row-major, `second` trans_out: the q|k and V^T projections of the memory build) or two big problems of the same persistent-kernel class
     whose tile lists fill the chip better side by side (the same layer of two independent ViTs), else two launches; same bits either way."""
     (a1, w1, o1, k1), (a2, w2, o2, k2) = first, second
+    if _x3_wanted(a1, w1) or _x3_wanted(a2, w2):
+        fin = []
+        if _x3_wanted(a1, w1):
+            a1, w1, o1x, k1, f = _x3_prepare(a1, w1, o1, k1)
+            fin.append(f)
+        else:
+            o1x = o1
+        if _x3_wanted(a2, w2):
+            a2, w2, o2x, k2, f = _x3_prepare(a2, w2, o2, k2)
+            fin.append(f)
+        else:
+            o2x = o2
+        gemm_pair((a1, w1, o1x, k1), (a2, w2, o2x, k2))
+        for f in fin:
+            if f is not None:
+                f()
+        return o1, o2
     p1, f1, t1 = _gemm_params(a1, w1, o1, **k1)
     p2, f2, t2 = _gemm_params(a2, w2, o2, **k2)
     if TIMER is not None:
@@ -383,6 +517,8 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
               mask_strides=(0, 0), nsplit=None, ws=None, prescaled=False):
     """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row).
     prescaled: q was produced with scale * LOG2E folded in (see `qscale`): softmax in the exp2 domain without a per-score multiply."""
+    if q.dtype == torch.float32 and X3:
+        return _attention_x3(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale, mask, mask_strides, nsplit, ws, prescaled)
     p, ws, flops, tag = _attn_params(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale, mask, mask_strides, nsplit, ws, prescaled)
     if TIMER is not None:
         name = lib().pst_attn_variant(C.byref(p))
@@ -395,10 +531,84 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
     return out
 
 
+def _span(B, H, N, strides, width):
+    """[min, max) element offsets (relative to the operand's pointer) an attention operand with (batch, head, row) strides touches"""
+    bs, hs, rs = strides
+    offs = [b * bs + h * hs + r * rs for b in (0, B - 1) for h in (0, H - 1) for r in (0, N - 1)]
+    return min(offs), max(offs) + width
+
+
+def _attention_x3(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale, mask, mask_strides, nsplit, ws, prescaled):
+    """attention on fp32 operands as 3 x 16-bit MFMA (pst_attn_x3): the memory spans the call touches are split into (hi, lo) planes once - operands
+    that share a buffer (q | k of one projection, both halves of a pair) share the pass - and the kernel reads the planes with the caller's strides."""
+    for t in (q, k, vt, out):
+        _dev(t, torch.float32)
+    spans = []
+    for t, (lo_, hi_) in ((q, _span(B, H, Nq, q_strides, hd)), (k, _span(B, H, Nk, k_strides, hd)), (vt, _span(B, H, hd, v_strides, (Nk + 7) // 8 * 8))):         # (the kernel reads V^T in 8-key chunks: the last one may reach into the row's pad)
+        # (whole 16-byte groups: a key count that is not a multiple of 4 - DINOv2's 769 - ends inside the pad columns every V^T buffer carries)
+        spans.append([t.data_ptr() + 4 * lo_, t.data_ptr() + 4 * ((hi_ + 3) // 4 * 4)])
+    merged = []
+    for a0, a1 in sorted(spans):
+        if merged and a0 <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], a1)
+        else:
+            merged.append([a0, a1])
+    planes = []
+    for a0, a1 in merged:
+        n = (a1 - a0) // 4
+        assert a0 % 16 == 0 and n % 4 == 0, 'attention operands must be 16-byte aligned with strides that are multiples of 8'
+        hi = torch.empty(n, dtype=X3_FMT, device=q.device)
+        lo = torch.empty(n, dtype=X3_FMT, device=q.device)
+        _check(lib().pst_split2(vp(a0), i64(n), _ptr(hi), _ptr(lo), i64(n), 1, n, 0, _TC[X3_FMT], _stream()), 'pst_split2')
+        planes.append((a0, a1, hi, lo))
+
+    def plane_ptrs(t):
+        addr = t.data_ptr()
+        for a0, a1, hi, lo in planes:
+            if a0 <= addr < a1:                   # (an operand's own span always contains its pointer: offset 0 is one of the offsets it touches)
+                off = (addr - a0) // 2            # fp32 byte offset -> 16-bit byte offset
+                return hi.data_ptr() + off, lo.data_ptr() + off
+        raise AssertionError('attention operand outside the planes')
+    p = AttnParams()
+    p.dtype16 = _TC[X3_FMT]
+    (qh, ql), (kh, kl), (vh, vl) = plane_ptrs(q), plane_ptrs(k), plane_ptrs(vt)
+    p.Q, (p.q_bs, p.q_hs, p.q_rs) = vp(qh), q_strides
+    p.K, (p.k_bs, p.k_hs, p.k_rs) = vp(kh), k_strides
+    p.Vt, (p.v_bs, p.v_hs, p.v_ds) = vp(vh), v_strides
+    p.O, (p.o_bs, p.o_hs, p.o_rs) = _ptr(out), o_strides
+    if mask is not None:
+        _dev(mask, torch.uint8)
+        p.mask, (p.m_bs, p.m_rs) = _ptr(mask), mask_strides
+    p.B, p.H, p.Nq, p.Nk, p.hd = B, H, Nq, Nk, hd
+    p.scale = float(hd ** -0.5 if scale is None else scale)
+    p.prescaled = 1 if prescaled else 0
+    p.zeros = _ptr(zeros_page(q.device))
+    ns = auto_nsplit(B, H, Nq, Nk) if nsplit is None else nsplit
+    if ns > 1:
+        n = ns * B * H * Nq * (hd + 2)
+        if ws is None:
+            ws = torch.empty(n, dtype=torch.float32, device=q.device)
+        assert ws.dtype == torch.float32 and ws.numel() >= n
+        p.nsplit, p.ws, p.ws_bytes = ns, _ptr(ws), ws.numel() * 4
+    ev = None
+    if TIMER is not None:
+        name = lib().pst_attn_x3_variant(C.byref(p))
+        ev = TIMER.bracket(name.decode() if name else 'attn_x3?', 3 * 4.0 * B * H * Nq * Nk * hd, (B, H, Nq, Nk, hd))
+        ev[0].record()
+    _check(lib().pst_attn_x3(C.byref(p), vp(ql), vp(kl), vp(vl), _stream()), 'pst_attn_x3')
+    if ev is not None:
+        ev[1].record()
+    return out
+
+
 def attention_pair(first, second):
     """Two independent attention calls, each (args tuple, kwargs dict) of hip.attention, through pst_attn_pair: ONE launch over both block lists when both
     take the same 128-query kernel variant (the self-attentions of two ViT towers in lock-step), else two launches; same bits either way."""
     (a1, k1), (a2, k2) = first, second
+    if a1[0].dtype == torch.float32 and X3:
+        attention(*a1, **k1)
+        attention(*a2, **k2)
+        return
     p1, w1, f1, t1 = _attn_params(*a1, **k1)
     p2, w2, f2, t2 = _attn_params(*a2, **k2)
     if TIMER is not None:

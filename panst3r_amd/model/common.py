@@ -18,13 +18,17 @@ class _Precision:
     tools/demo_panst3r.py:88, utils.py:206-215) on the MFMA kernels, or float32 (amp=False, the reference's default: fp32 end to end) on
     the fp32-input-MFMA GEMM / attention kernels - the precision path, ~8x slower.  Accumulation, residual streams, softmax and normalisation
     statistics are fp32 in all three.  Process-wide, switched by the `precision(...)` context (a SceneRunner enters it around every
-    stage, so graphs are captured - and weights packed - in the runner's format)."""
+    stage, so graphs are captured - and weights packed - in the runner's format).
+    `x3` (meaningful with dtype float32): the fp32 mode's contractions run as THREE 16-bit MFMAs on split operands (hip.X3: weights packed as
+    [W_hi | W_lo | W_hi] f16, activations split per call; ~1e-6 against float64 at a third of the 16-bit matrix rate) - the default of amp=False;
+    amp='fp32_exact' selects the fp32-input-MFMA kernels instead (exact fp32 products, 1 / 16 of the 16-bit rate)."""
     dtype = torch.float16
+    x3 = True
 
 
 PREC = _Precision()
 AMP_DTYPES = {'bf16': torch.bfloat16, 'fp16': torch.float16, torch.bfloat16: torch.bfloat16, torch.float16: torch.float16,
-              'fp32': torch.float32, torch.float32: torch.float32}
+              'fp32': torch.float32, torch.float32: torch.float32, 'fp32_exact': torch.float32}
 
 
 def adt():
@@ -44,13 +48,14 @@ def warn_once(key, msg):
 
 def amp_dtype(amp, quiet=False):
     """`amp` argument of the reference API (False | 'bf16' | 'fp16', utils.py:206-215) -> storage / operand dtype of the HIP path.
-    amp=False is the reference's fp32 mode (tools/demo_panst3r.py:88 default): float32 activations and weights, the fp32-input-MFMA GEMM
-    (csrc/gemm_f32.hip) and attention (csrc/attn_f32.hip) kernels - the reference's arithmetic, at fp32 speed (1/16 of the 16-bit MFMA rate: ~8x the time of
-    a 16-bit scene), said once per process.  ('fp32' is accepted as a synonym of False.)"""
-    if amp is None or amp is False or amp == 'fp32' or amp is torch.float32:
+    amp=False is the reference's fp32 mode (tools/demo_panst3r.py:88 default): float32 activations; every GEMM / attention contraction as three f16 MFMAs
+    on split operands (x = hi + lo: 22 mantissa bits, ~1e-6 against float64; csrc/split.hip, attn_x3.hip) - a third of the 16-bit matrix rate, said once
+    per process.  ('fp32' is a synonym of False; 'fp32_exact' = the fp32-input-MFMA kernels csrc/gemm_f32.hip / attn_f32.hip: exact fp32 products at 1 / 16
+    of the 16-bit rate.)"""
+    if amp is None or amp is False or amp in ('fp32', 'fp32_exact') or amp is torch.float32:
         if not quiet:
-            warn_once('amp_false', "panst3r_amd: amp=False is the fp32 mode (float32 operands on the fp32-input MFMA): exact to ~1e-5 but "
-                                   "~8x slower than amp='fp16' / 'bf16' - pass one of those for the fast path")
+            warn_once('amp_false', "panst3r_amd: amp=False is the fp32 mode (float32 activations, contractions as 3 x f16 MFMA on split operands: ~1e-6): "
+                                   "~3x slower than amp='fp16' / 'bf16' - pass one of those for the fast path")
         return torch.float32
     if amp not in AMP_DTYPES:
         raise ValueError("amp must be False, 'bf16' or 'fp16' (got %r)" % (amp,))
@@ -61,13 +66,20 @@ class precision:
     def __init__(self, dtype):
         # internal plumbing (runners, tests): the API entry points do the telling.  None = keep the format in effect (default: f16)
         self.dtype = PREC.dtype if dtype is None else amp_dtype(dtype, quiet=True)
+        self.x3 = PREC.x3 if dtype is None else (not (isinstance(dtype, str) and dtype == 'fp32_exact'))
 
     def __enter__(self):
-        self.prev, PREC.dtype = PREC.dtype, self.dtype
+        self.prev, PREC.dtype = (PREC.dtype, PREC.x3, hip.X3), self.dtype
+        PREC.x3 = hip.X3 = self.x3
         return self
 
     def __exit__(self, *a):
-        PREC.dtype = self.prev
+        PREC.dtype, PREC.x3, hip.X3 = self.prev
+
+
+def x3():
+    """fp32 mode with its contractions on 3 x 16-bit MFMA (split operands) in effect"""
+    return PREC.dtype == torch.float32 and PREC.x3
 
 
 def ceil_to(x, m):
@@ -75,10 +87,12 @@ def ceil_to(x, m):
 
 
 class Packed:
-    """weight [N, Kpad] in the format in effect (K zero-padded to a multiple of 64) + fp32 bias."""
+    """weight [N, Kpad] in the format in effect (K zero-padded to a multiple of 64) + fp32 bias.  fp32 mode with split operands (x3()): the weight is
+    packed as f16 [N, 3 Kpad] = [W_hi | W_lo | W_hi] (hip.split_operand side 1 at pack time; `taps` > 1: per tap of an implicit conv, whose K index is
+    tap-major) and `k` stays the logical Kpad - hip.gemm splits the fp32 activations to match."""
     __slots__ = ('w', 'b', 'n', 'k', 'cs', 'eps', 'ln')
 
-    def __init__(self, weight, bias=None, device=None, row_perm=None):
+    def __init__(self, weight, bias=None, device=None, row_perm=None, taps=1):
         w = weight.detach().reshape(weight.shape[0], -1).float()
         b = None if bias is None else bias.detach().float()
         if row_perm is not None:
@@ -86,10 +100,22 @@ class Packed:
             b = None if b is None else b[row_perm]
         n, k = w.shape
         kp = ceil_to(k, 64)
-        wp = torch.zeros(n, kp, dtype=adt(), device=device)
-        wp[:, :k] = w.to(device=device, dtype=adt())
-        if adt() == F16 and not bool(torch.isfinite(wp).all()):
-            raise OverflowError('a weight exceeds the f16 range (max |w| = %.3g): use amp=\'bf16\' for this checkpoint' % float(w.abs().max()))
+        if x3():
+            assert k % taps == 0 and (taps == 1 or (k // taps) % 64 == 0)
+            kt = kp // taps if taps > 1 else kp
+            wf = torch.zeros(n, taps, kt, dtype=torch.float32, device=device)
+            wf[:, :, :k // taps] = w.to(device).reshape(n, taps, k // taps)
+            hi = wf.to(hip.X3_FMT)
+            if not bool(torch.isfinite(hi).all()):
+                raise OverflowError('a weight exceeds the f16 range (max |w| = %.3g): the split-operand fp32 mode packs weights as f16 pairs; use '
+                                    "amp='fp32_exact'" % float(w.abs().max()))
+            lo = (wf - hi.float()).to(hip.X3_FMT)
+            wp = torch.cat([hi, lo, hi], dim=2).reshape(n, 3 * kp).contiguous()
+        else:
+            wp = torch.zeros(n, kp, dtype=adt(), device=device)
+            wp[:, :k] = w.to(device=device, dtype=adt())
+            if adt() == F16 and not bool(torch.isfinite(wp).all()):
+                raise OverflowError('a weight exceeds the f16 range (max |w| = %.3g): use amp=\'bf16\' for this checkpoint' % float(w.abs().max()))
         self.w, self.n, self.k = wp, n, kp
         self.b = None if b is None else b.to(device).contiguous()
 
@@ -156,7 +182,7 @@ class HipModule(nn.Module):
         raise NotImplementedError
 
     def packed(self, device):
-        key = (str(device), adt())
+        key = (str(device), adt(), x3())
         pk = self._packs.get(key)
         if pk is None:
             if device.type != 'cuda':

@@ -188,7 +188,7 @@ class LoftUpUpscaler(HipModule):
             wt = conv.weight.detach().float().permute(0, 2, 3, 1)
             out = torch.zeros(wt.shape[0], 3, 3, cpad)
             out[..., :wt.shape[-1]] = wt
-            return Packed(out.reshape(wt.shape[0], -1), conv.bias, device)
+            return Packed(out.reshape(wt.shape[0], -1), conv.bias, device, taps=9)
         c0 = ceil_to(self.start_dim, 64)
         fc = self.first_conv
         blocks = []

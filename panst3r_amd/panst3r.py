@@ -332,7 +332,7 @@ class PanSt3R(nn.Module):
         pver = sum(p._version for p in self.parameters())
         cver = tuple((c, te.class_embeddings[c].data_ptr(), te.class_embeddings[c]._version) if c in te.class_embeddings else (c,) for c in classes)
         key = (tuple(shapes), num_keyframes, None if keyframes is None else tuple(int(k) for k in keyframes), str(dev),
-               amp_dtype(amp, quiet=True), gens, pver, cver, getattr(te, '_cls_gen', 0), max_bs, panoptic_precision)
+               amp_dtype(amp, quiet=True), str(amp), gens, pver, cver, getattr(te, '_cls_gen', 0), max_bs, panoptic_precision)
         ent = self._runners.get(key)
         if ent is None:
             while len(self._runners) >= max(1, self.max_cached_runners):

@@ -1,10 +1,13 @@
 """The fp32 mode (reference `amp=False`, tools/demo_panst3r.py:88: torch.float32 end to end) of the HIP path.
 
-Operands and activations are float32; the GEMMs (csrc/gemm_f32.hip) and attention (csrc/attn_f32.hip) run on the fp32-input MFMA, and the
-streaming kernels read / write float32 rows (type code PST_F32).  Against a float64 evaluation of the same fp32 inputs only the summation
-order differs, so the bounds here are two to three orders of magnitude tighter than the 16-bit ones: ops rel-L2 <= 1e-5, tiny-model
-tokens / pointmaps / queries / mask logits rel-L2 <= 1e-4 (measured 1e-6 .. 2e-6) with >= 99.99 % sign agreement against the fp32 CPU
-oracle, v1 and v2.
+Operands and activations are float32 and the streaming kernels read / write float32 rows (type code PST_F32).  The contractions run on one of TWO kernel
+families, and every test of this file runs on both (the `kernels` fixture):
+  x3     (amp=False, the default since round 5) three f16 MFMAs per product on split operands x = hi + lo (csrc/split.hip, csrc/attn_x3.hip, the 16-bit
+         GEMM kernels over a 3 x longer K): 22 mantissa bits, the lo x lo term dropped
+  exact  (amp='fp32_exact') the fp32-input MFMA (csrc/gemm_f32.hip, csrc/attn_f32.hip): exact fp32 products
+Against a float64 evaluation of the same fp32 inputs the bounds are two to three orders of magnitude tighter than the 16-bit ones: ops rel-L2 <= 1e-5,
+tiny-model tokens / pointmaps / queries / mask logits rel-L2 <= 1e-4 (measured 1e-6 .. 2e-6 on the exact kernels) with >= 99.99 % sign agreement against the
+fp32 CPU oracle, v1 and v2.
 """
 import numpy as np
 import pytest
@@ -17,6 +20,15 @@ import tiny
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 F32 = torch.float32
+
+
+@pytest.fixture(scope='module', autouse=True, params=['x3', 'exact'])
+def kernels(request):
+    """which fp32 kernel family hip.gemm / hip.attention use for float32 operands in this pass over the file"""
+    from panst3r_amd import hip
+    prev, hip.X3 = hip.X3, request.param == 'x3'
+    yield request.param
+    hip.X3 = prev
 
 
 def rn(seed, *shape, scale=1.0):
@@ -46,8 +58,10 @@ def test_gemm_f32(M, N, K, act):
     assert rel64(out, ref) < 1e-5
 
 
-def test_gemm_f32_identity_and_variant_name():
+def test_gemm_f32_identity_and_variant_name(kernels):
     from panst3r_amd import hip
+    if kernels != 'exact':
+        pytest.skip('names the fp32-input-MFMA kernel')
     K = 128
     w = torch.arange(256 * K, dtype=F32).reshape(256, K) % 251 - 125
     out = torch.zeros(K, 256, dtype=F32, device=DEV)
@@ -131,15 +145,17 @@ def test_gemm_f32_strided_batch():
     assert rel64(outT[:, :, :M], (torch.einsum('bmk,bnk->bmn', a.double(), w.double()) + b.double()[:, None]).transpose(1, 2)) < 1e-5
 
 
-def test_gemm_f32_rejects_16bit_only_features():
+def test_gemm_f32_rejects_16bit_only_features(kernels):
     from panst3r_amd import hip
+    if kernels != 'exact':
+        pytest.skip('argument checks of the fp32-input-MFMA kernel')
     a, w = d(rn(22, 64, 64)), d(rn(23, 64, 64))
     with pytest.raises(RuntimeError, match='C must be fp32'):
         hip.gemm(a, w, torch.zeros(64, 64, dtype=torch.float16, device=DEV))
     pos = torch.zeros(64, 2, dtype=torch.int32, device=DEV)
     with pytest.raises(RuntimeError, match='fused RoPE'):
         hip.gemm(a, w, torch.zeros(64, 64, dtype=F32, device=DEV), rope=(pos, hip.rope_table(4, 64, 100.0, DEV)))
-    with pytest.raises(RuntimeError, match='share one'):
+    with pytest.raises(RuntimeError, match='split-packed'):          # fp32 A + 16-bit W = a pre-split weight [N, 3 Kpad] (the split-operand path) or nothing
         hip.gemm(a, w.half(), torch.zeros(64, 64, dtype=F32, device=DEV))
     with pytest.raises(RuntimeError, match='K %'):
         hip.gemm(d(rn(24, 64, 24)), d(rn(25, 64, 24)), torch.zeros(64, 64, dtype=F32, device=DEV))
@@ -196,7 +212,7 @@ def test_attention_f32(B, H, Nq, Nk, hd, masked, pre):
     assert rel64(got, ref) < 1e-5
 
 
-def test_attention_f32_fully_masked_rows_are_zero_and_spike():
+def test_attention_f32_fully_masked_rows_are_zero_and_spike(kernels):
     from panst3r_amd import hip
     H, Nq, Nk, hd = 2, 40, 300, 64
     q, k, v = rn(33, 1, H, Nq, hd), rn(34, 1, H, Nk, hd), rn(35, 1, H, Nk, hd)
@@ -218,8 +234,14 @@ def test_attention_f32_fully_masked_rows_are_zero_and_spike():
     assert torch.isfinite(got).all() and float(got[:, 3].abs().max()) == 0.0
     keep = [i for i in range(Nq) if i != 3]
     assert rel64(got[:, keep], ref[0][:, keep]) < 1e-5
-    with pytest.raises(RuntimeError, match='no split-K'):
-        hip.attention(qd, kd, vt, od, 1, H, Nq, Nk, hd, (0, hd, D), (0, hd, D), (0, hd * vt.stride(0), vt.stride(0)), (0, hd, D), nsplit=3)
+    if kernels == 'exact':
+        with pytest.raises(RuntimeError, match='no split-K'):
+            hip.attention(qd, kd, vt, od, 1, H, Nq, Nk, hd, (0, hd, D), (0, hd, D), (0, hd * vt.stride(0), vt.stride(0)), (0, hd, D), nsplit=3)
+    else:                                                         # the split-operand kernel splits the key range like the 16-bit one
+        od.fill_(float('nan'))
+        hip.attention(qd, kd, vt, od, 1, H, Nq, Nk, hd, (0, hd, D), (0, hd, D), (0, hd * vt.stride(0), vt.stride(0)), (0, hd, D), mask=md, mask_strides=(0, Nk), nsplit=3)
+        got = od.cpu().reshape(Nq, H, hd).permute(1, 0, 2)
+        assert float(got[:, 3].abs().max()) == 0.0 and rel64(got[:, keep], ref[0][:, keep]) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------------------- streaming kernels, fp32 rows
@@ -338,11 +360,12 @@ def test_loftup_guidance_and_groupnorm_f32():
 
 # ---------------------------------------------------------------------------------------------------------------- the model in fp32
 @pytest.fixture(scope='module', params=['v1', 'v2'])
-def pair(request):
+def pair(request, kernels):
     from panst3r_amd.model.common import precision
     o = tiny.build(tiny.OracleNS, request.param)
     h = tiny.build(tiny.hip_ns(), request.param).to(DEV)
-    with precision(False):
+    h.amp = False if kernels == 'x3' else 'fp32_exact'           # the `amp` value of scene-level calls in this pass
+    with precision(h.amp):
         yield request.param, o, h
 
 
@@ -438,7 +461,7 @@ def test_scene_fp32(pair, shapes, K):
     imgs = [tiny.images(i + 1, a, b)[i] for i, (a, b) in enumerate(shapes)]
     ts = torch.tensor(shapes)
     pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K)
-    pm_h, pan_h = h.forward_inference_multi_ar([d(i) for i in imgs], ts, tiny.NAMES, num_keyframes=K, amp=False)
+    pm_h, pan_h = h.forward_inference_multi_ar([d(i) for i in imgs], ts, tiny.NAMES, num_keyframes=K, amp=h.amp)
     assert pm_h[0].dtype == F32 and pan_h['pred_masks'][0].dtype == F32
     for i, (a, b) in enumerate(zip(pm_h, pm_o)):
         assert a.shape == b.shape and rel_l2(a.cpu(), b) < 1e-4, i
@@ -457,7 +480,7 @@ def test_scene_fp32_graph_replay_is_bit_identical(pair):
     variant, o, h = pair
     H, W, V, K = 64, 96, 4, 2
     imgs = {i: d(im) for i, im in enumerate(tiny.images(V, H, W))}
-    runner = h.scene_runner(imgs, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=False)
+    runner = h.scene_runner(imgs, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=h.amp)
     r1, s1 = runner.run()
     r2, s2 = runner.run()
     assert torch.equal(s1['out_queries'], s2['out_queries'])
@@ -473,13 +496,13 @@ def test_scene_fp32_odd_token_grids_and_graph_replay(pair, H, W, V, K):
     imgs = tiny.images(V, H, W)
     ts = torch.tensor([[H, W]] * V)
     pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K)
-    pm_h, pan_h = h.forward_inference_multi_ar([d(i) for i in imgs], ts, tiny.NAMES, num_keyframes=K, amp=False)
+    pm_h, pan_h = h.forward_inference_multi_ar([d(i) for i in imgs], ts, tiny.NAMES, num_keyframes=K, amp=h.amp)
     for a, b in zip(pm_h, pm_o):
         assert rel_l2(a.cpu(), b) < 1e-4
     assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 1e-4
     for a, b in zip(pan_h['pred_masks'], pan_o['pred_masks']):
         assert rel_l2(a.cpu(), b) < mask_tol(variant)
-    runner = h.scene_runner({i: d(im) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=False, max_bs=None)
+    runner = h.scene_runner({i: d(im) for i, im in enumerate(imgs)}, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp=h.amp, max_bs=None)
     runner.run()
     res, scene = runner.run()
     assert torch.equal(scene['out_queries'], pan_h['out_queries'])
@@ -495,7 +518,7 @@ def test_forward_fp32_224_padded_layout(pair):
     imgs = tiny.images(2, H, W)
     ts = torch.tensor([[H, W]] * 2)
     pm_o, pan_o = o.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=2)
-    pan_h, pm_h = h.forward(d(torch.stack(imgs)[None]), ts[None], tiny.NAMES)
+    pan_h, pm_h = h.forward(d(torch.stack(imgs)[None]), ts[None], tiny.NAMES, amp=h.amp)
     assert pm_h.dtype == F32 and pm_h.shape == (1, 2, H, W, 7)
     for i in range(2):
         assert rel_l2(pm_h[0, i].cpu(), pm_o[i][0]) < 1e-4

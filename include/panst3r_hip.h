@@ -34,6 +34,8 @@ extern "C" {
 #define PST_BF16 0   /* bfloat16, raw uint16 */
 #define PST_F32  1   /* float */
 #define PST_F16  2   /* IEEE half, raw uint16 (amp="fp16": tools/demo_panst3r.py:88, src/panst3r/utils.py:206-215) */
+#define PST_X3H  4   /* OUTPUT type of pst_layernorm*, pst_groupnorm_apply and pst_attn_x3 only (ABI 18): the result as the split A operand of a 3 x f16 GEMM - f16 rows of three blocks
+                        [hi | hi | lo], each ld / 3 columns wide (the producer writes what pst_split_operand(side 0) would make of its fp32 result: no fp32 round trip) */
 
 int pst_abi_version(void);
 const char* pst_last_error(void);
@@ -91,6 +93,11 @@ typedef struct pst_gemm_params {
   void* xcopy; int64_t ldxc;
   float* stats_out; int32_t stats_ld;
   const float* ln_stats; int32_t ln_groups; const float* ln_colsum; float ln_eps;
+  /* ---- (ABI 18) split store: x3_block > 0 with out_fp32 = 1 stores the fp32 result as the f16 split A operand of the NEXT 3 x f16 GEMM instead (PST_X3H):
+     C = f16 [M, 3 x3_block], ldc in f16 elements, row m = [hi | hi | lo] with hi = rn16(v), lo = rn16(v - hi), blocks of x3_block >= N columns
+     (x3_block % 4 == 0; the caller zero-fills columns N .. x3_block if any).  Plain row-major store (no ps / trans_out / xcopy / stats_out); dtype16 = PST_F16.
+     The MLP's hidden activation GELU(fc1) goes to fc2 this way: no fp32 round trip and no split pass. */
+  int32_t x3_block;
 } pst_gemm_params;
 
 int pst_gemm(const pst_gemm_params* p, void* stream);
@@ -210,11 +217,13 @@ int pst_split3(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, in
  *   split2         x fp32 [rows, K] -> planes hi, lo 16-bit [rows, ldo], or with transpose != 0 the planes of x^T ([K, ldo], ldo >= rows): the V^T operand
  *   transpose_f32  y[c][r] = x[r][c]
  *   attn_x3        pst_attn_fwd on split operands: p->Q / K / Vt are the hi planes (format p->dtype16), Q_lo / K_lo / Vt_lo the lo planes with the SAME
- *                  strides, p->O is fp32 (strides in floats).  Softmax in fp32; P is split in registers; mask / split-K / prescaled as pst_attn_fwd. */
+ *                  strides, p->O is fp32 (out_type PST_F32, strides in floats) or, with out_type PST_X3H, f16 rows [hi | hi | lo] with blocks of out_block
+ *                  columns (strides in f16 elements; the A operand of the output projection).  Softmax in fp32; P is split in registers; mask / split-K /
+ *                  prescaled as pst_attn_fwd. */
 int pst_split_operand(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, int Kpad, int side, int dtype16, void* stream);
 int pst_split2(const float* x, int64_t ldx, void* hi, void* lo, int64_t ldo, int rows, int K, int transpose, int dtype16, void* stream);
 int pst_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, void* stream);
-int pst_attn_x3(const pst_attn_params* p, const void* Q_lo, const void* K_lo, const void* Vt_lo, void* stream);
+int pst_attn_x3(const pst_attn_params* p, const void* Q_lo, const void* K_lo, const void* Vt_lo, int out_type, int64_t out_block, void* stream);
 const char* pst_attn_x3_variant(const pst_attn_params* p);
 
 /* ---------------------------------------------------------------- RoPE-2D (in place on bf16 q and k)

@@ -40,9 +40,21 @@ __device__ __forceinline__ float x3_max_rows(float v) {
   return m;
 }
 
-struct x3_lo {            // the lo planes (same strides as the hi planes in pst_attn_params)
+struct x3_lo {            // the lo planes (same strides as the hi planes in pst_attn_params) + the output form
   const void* Q; const void* K; const void* Vt;
+  int out_split;          // 0: O fp32; else O = f16 rows [hi | hi | lo] with blocks of out_split columns (PST_X3H)
 };
+
+// 4 consecutive results of one output row -> fp32, or the split form
+__device__ __forceinline__ void x3_store4(const pst_attn_params& p, const x3_lo& lo, int64_t off, float a, float b, float c, float d) {
+  if (!lo.out_split) { *(float4*)((float*)p.O + off) = make_float4(a, b, c, d); return; }
+  const uint32_t h0 = pack2h(a, b), h1 = pack2h(c, d);
+  const uint32_t l0 = pack2h(a - H16<true>::lo(h0), b - H16<true>::hi(h0)), l1 = pack2h(c - H16<true>::lo(h1), d - H16<true>::hi(h1));
+  uint16_t* dst = (uint16_t*)p.O + off;
+  *(uint2*)dst = make_uint2(h0, h1);
+  *(uint2*)(dst + lo.out_split) = make_uint2(h0, h1);
+  *(uint2*)(dst + 2 * lo.out_split) = make_uint2(l0, l1);
+}
 
 template <int HD, int QF, bool F16, bool PRE>
 __global__ __launch_bounds__(256) void attn_x3_kernel(const pst_attn_params p, const x3_lo lo, const int xcd) {
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_x3_kernel(const pst_attn_params p, c
   const bf16_t* Kl = (const bf16_t*)lo.K + ko;
   const bf16_t* Vh = (const bf16_t*)p.Vt + vo;
   const bf16_t* Vl = (const bf16_t*)lo.Vt + vo;
-  float* Op = (float*)p.O + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs;
+  const int64_t oo = (int64_t)b * p.o_bs + (int64_t)h * p.o_hs;
   const uint8_t* Mp = p.mask ? p.mask + (int64_t)b * p.m_bs : nullptr;
 
   const int q_wave0 = qb * (64 * QF) + wave * (16 * QF);
@@ -326,14 +338,14 @@ __global__ __launch_bounds__(256) void attn_x3_kernel(const pst_attn_params p, c
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     const int q = q_wave0 + a * 16 + l16;
     if (q < p.Nq) {
-      float* dst = Op + (int64_t)q * p.o_rs + 4 * g;
+      const int64_t dst = oo + (int64_t)q * p.o_rs + 4 * g;
 #pragma unroll
-      for (int hf = 0; hf < NHF; ++hf) *(float4*)(dst + hf * 16) = make_float4(o[hf][a][0] * inv, o[hf][a][1] * inv, o[hf][a][2] * inv, o[hf][a][3] * inv);
+      for (int hf = 0; hf < NHF; ++hf) x3_store4(p, lo, dst + hf * 16, o[hf][a][0] * inv, o[hf][a][1] * inv, o[hf][a][2] * inv, o[hf][a][3] * inv);
     }
   }
 }
 
-__global__ void attn_x3_combine_kernel(const pst_attn_params p, int hd) {
+__global__ void attn_x3_combine_kernel(const pst_attn_params p, const x3_lo lo, int hd) {
   const int64_t rows = (int64_t)p.B * p.H * p.Nq;
   const int per_row = hd / 4;
   const int64_t total = rows * per_row;
@@ -356,8 +368,7 @@ __global__ void attn_x3_combine_kernel(const pst_attn_params p, int hd) {
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     const int q = (int)(row % p.Nq);
     const int bh = (int)(row / p.Nq), h = bh % p.H, b = bh / p.H;
-    float* dst = (float*)p.O + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)q * p.o_rs + d;
-    *(float4*)dst = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    x3_store4(p, lo, (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)q * p.o_rs + d, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
   }
 }
 
@@ -375,7 +386,7 @@ static int launch_x3(const pst_attn_params& p, const x3_lo& lo, hipStream_t s) {
     const int64_t total = (int64_t)p.B * p.H * p.Nq * (HD / 4);
     int64_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(attn_x3_combine_kernel, dim3((unsigned)g), dim3(256), 0, s, p, HD);
+    hipLaunchKernelGGL(attn_x3_combine_kernel, dim3((unsigned)g), dim3(256), 0, s, p, lo, HD);
   }
   return check_launch("attn_x3");
 }
@@ -384,13 +395,15 @@ static int launch_x3(const pst_attn_params& p, const x3_lo& lo, hipStream_t s) {
 
 using namespace pst;
 
-static int x3_validate(const pst_attn_params* pp, const void* Qlo, const void* Klo, const void* Vlo) {
+static int x3_validate(const pst_attn_params* pp, const void* Qlo, const void* Klo, const void* Vlo, int out_type, int64_t out_block) {
   if (!pp) { set_error("attn_x3: null params"); return PST_EINVAL; }
   const pst_attn_params& p = *pp;
   if (p.dtype16 != DT_BF16 && p.dtype16 != DT_F16) { set_error("attn_x3: dtype16 (format of the operand planes) must be PST_BF16 or PST_F16"); return PST_EINVAL; }
   if (p.prescaled != 0 && p.prescaled != 1) { set_error("attn_x3: prescaled must be 0 or 1"); return PST_EINVAL; }
   if (!p.prescaled && !(p.scale > 0.f)) { set_error("attn_x3: scale must be positive"); return PST_EINVAL; }
   if (p.hd != 64 && p.hd != 96) { set_error("attn_x3: head dim %d unsupported (64 or 96)", p.hd); return PST_EINVAL; }
+  if (out_type != DT_F32 && out_type != DT_X3H) { set_error("attn_x3: out_type must be PST_F32 or PST_X3H"); return PST_EINVAL; }
+  if (out_type == DT_X3H && (p.dtype16 != DT_F16 || out_block < (int64_t)p.H * p.hd || out_block % 4 || out_block >= (1ll << 30))) { set_error("attn_x3: a split output needs f16 planes and out_block >= H * hd, %% 4 == 0"); return PST_EINVAL; }
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) { set_error("attn_x3: bad shape"); return PST_EINVAL; }
   if (!p.Q || !p.K || !p.Vt || !p.O || !p.zeros || !Qlo || !Klo || !Vlo) { set_error("attn_x3: null operand"); return PST_EINVAL; }
   if ((p.q_rs | p.q_hs | p.q_bs | p.k_rs | p.k_hs | p.k_bs | p.v_ds | p.v_hs | p.v_bs) % 8) { set_error("attn_x3: Q/K/Vt strides must be multiples of 8 elements"); return PST_EINVAL; }
@@ -408,21 +421,23 @@ static int x3_validate(const pst_attn_params* pp, const void* Qlo, const void* K
 
 static bool x3_big(const pst_attn_params& p) { return (long)((p.Nq + 127) / 128) * p.H * p.B * (p.nsplit > 1 ? p.nsplit : 1) >= 256; }
 
-extern "C" int pst_attn_x3(const pst_attn_params* pp, const void* Q_lo, const void* K_lo, const void* Vt_lo, void* stream) {
-  if (int rc = x3_validate(pp, Q_lo, K_lo, Vt_lo)) return rc;
+extern "C" int pst_attn_x3(const pst_attn_params* pp, const void* Q_lo, const void* K_lo, const void* Vt_lo, int out_type, int64_t out_block, void* stream) {
+  if (int rc = x3_validate(pp, Q_lo, K_lo, Vt_lo, out_type, out_block)) return rc;
   const pst_attn_params& p = *pp;
-  const x3_lo lo{Q_lo, K_lo, Vt_lo};
+  const x3_lo lo{Q_lo, K_lo, Vt_lo, out_type == DT_X3H ? (int)out_block : 0};
   hipStream_t s = (hipStream_t)stream;
   const bool h = p.dtype16 == DT_F16, pre = p.prescaled != 0;
 #define PST_X3(HD, QF) (h ? (pre ? launch_x3<HD, QF, true, true>(p, lo, s) : launch_x3<HD, QF, true, false>(p, lo, s)) \
                           : (pre ? launch_x3<HD, QF, false, true>(p, lo, s) : launch_x3<HD, QF, false, false>(p, lo, s)))
   if (p.hd == 64) return x3_big(p) ? PST_X3(64, 2) : PST_X3(64, 1);
-  return PST_X3(96, 1);            // head dim 96: one query fragment per wave (the two planes of a 96-wide tile pair fill 112 KB of LDS: one block per CU either way)
+  // head dim 96: the two planes of a 96-wide tile pair fill 112 KB of LDS - one block (4 waves) per CU whatever the block size, so the 128-query block
+  // (every K / V fragment read feeds two query fragments) is what keeps the matrix pipe fed
+  return x3_big(p) ? PST_X3(96, 2) : PST_X3(96, 1);
 #undef PST_X3
 }
 
 extern "C" const char* pst_attn_x3_variant(const pst_attn_params* pp) {
   if (!pp || (pp->hd != 64 && pp->hd != 96)) return nullptr;
   if (pp->hd == 64) return x3_big(*pp) ? "attn_x3_kernel<64,2>" : "attn_x3_kernel<64,1>";
-  return "attn_x3_kernel<96,1>";
+  return x3_big(*pp) ? "attn_x3_kernel<96,2>" : "attn_x3_kernel<96,1>";
 }

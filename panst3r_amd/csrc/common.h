@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
 // Every 16-bit tensor on the path is either bfloat16 (8-bit mantissa, fp32 range; amp='bf16') or IEEE half (11-bit mantissa,
 // |x| <= 65504; amp='fp16', tools/demo_panst3r.py:88, src/panst3r/utils.py:206-215).  Both feed v_mfma_f32_16x16x32_{bf16,f16} at
 // the same rate with fp32 accumulation.  Element type codes of the C ABI: 0 = bf16, 1 = fp32, 2 = f16.
-enum { DT_BF16 = 0, DT_F32 = 1, DT_F16 = 2 };
+enum { DT_BF16 = 0, DT_F32 = 1, DT_F16 = 2, DT_X3H = 4 };      // DT_X3H: OUTPUT type only - f16 split rows [hi | hi | lo] (panst3r_hip.h PST_X3H)
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 

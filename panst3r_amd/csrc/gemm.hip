@@ -46,6 +46,16 @@ __device__ __forceinline__ int perm_row(int row) {
   return sub * (16 * F) + g * (4 * F) + 4 * f + r;
 }
 
+// 4 consecutive fp32 results of output row `orow`, columns n .. n + 3: the fp32 store, or (pst_gemm_params.x3_block) the split A-operand form
+__device__ __forceinline__ void store_c4(const pst_gemm_params& p, int64_t orow, int n, const float4& f) {
+  if (p.x3_block == 0) { *(float4*)((float*)p.C + orow * p.ldc + n) = f; return; }
+  const uint32_t h0 = pack2h(f.x, f.y), h1 = pack2h(f.z, f.w);
+  uint16_t* d = (uint16_t*)p.C + orow * p.ldc + n;
+  *(uint2*)d = make_uint2(h0, h1);
+  *(uint2*)(d + p.x3_block) = make_uint2(h0, h1);
+  *(uint2*)(d + 2 * p.x3_block) = make_uint2(pack2h(f.x - H16<true>::lo(h0), f.y - H16<true>::hi(h0)), pack2h(f.z - H16<true>::lo(h1), f.w - H16<true>::hi(h1)));
+}
+
 // Whole-row write-back of the LDS-staged C tile: thread -> (row, 16-B chunk); consecutive lanes = consecutive bytes of one
 // output row.  F32: fp32 output (residual values were prefetched into resv by the caller), else bf16 output.
 template <int BM, int BN, bool F32, bool F16>
@@ -124,7 +134,8 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
 #pragma unroll
         for (int q = 0; q < 4; ++q) { ln_acc(H16<F16>::lo(w32[q]), ssum, ssq); ln_acc(H16<F16>::hi(w32[q]), ssum, ssq); }
       }
-      *(uint4*)((char*)p.C + ((int64_t)orow[it] * p.ldc + n) * (F32 ? 4 : 2)) = val;
+      if (F32) store_c4(p, orow[it], n, *(const float4*)&val);
+      else *(uint4*)((char*)p.C + ((int64_t)orow[it] * p.ldc + n) * 2) = val;
       if (F32) {
         const float4 f = *(const float4*)&val;
         if (p.xcopy) *(uint2*)((bf16_t*)p.xcopy + (int64_t)orow[it] * p.ldxc + n) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
@@ -170,7 +181,7 @@ __device__ __forceinline__ void row_phase(const pst_gemm_params& p, const char* 
         f.x += H16<F16>::lo(q.x); f.y += H16<F16>::hi(q.x);
         f.z += H16<F16>::lo(q.y); f.w += H16<F16>::hi(q.y);
       }
-      *(float4*)((float*)p.C + off) = f;
+      if (p.x3_block) store_c4(p, orow, n, f); else *(float4*)((float*)p.C + off) = f;
       // LayerNorm fold (plain row-major stores only, N % 64 == 0: a 16-lane group = one 64-column group, wholly inside or outside)
       if (p.xcopy) *(uint2*)((bf16_t*)p.xcopy + (int64_t)orow * p.ldxc + n) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
       if (p.stats_out) { float ss, sq; ln_acc4(f, ss, sq); ln_fold_stats<16>(p, ss, sq, c, orow, n); }
@@ -587,6 +598,10 @@ static int gemm_validate(const pst_gemm_params* pp) {
   }
   if (p.ln_stats && (!p.ln_colsum || p.ln_groups <= 0 || p.conv_c || p.batch > 1 || !(p.ln_eps > 0.f))) {
     set_error("gemm: LayerNorm-fold consumer needs ln_colsum, ln_groups > 0, ln_eps > 0 (no conv / batch mode)"); return PST_EINVAL;
+  }
+  if (p.x3_block && (!p.out_fp32 || p.dtype16 != DT_F16 || p.x3_block < p.N || p.x3_block % 4 || p.ldc < 3 * (int64_t)p.x3_block || p.ldc % 4 || p.ps_p || p.trans_out || p.xcopy ||
+                     p.stats_out || p.batch > 1 || ((uintptr_t)p.C & 7))) {
+    set_error("gemm: the split store (x3_block) needs out_fp32, f16 operands, x3_block >= N, ldc >= 3 x3_block, a plain row-major store"); return PST_EINVAL;
   }
   if (p.batch > 1 && (p.gamma || p.res || p.conv_c || p.rope_hd || p.ps_p || p.grp_in || p.kernel == 256 || p.batch > 65535 ||
                       (p.a_bs | p.w_bs | p.c_bs) % 8 || p.bias_bs % 4)) {

@@ -292,7 +292,13 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const pst_gemm_params p
           f.x += H16<F16>::lo(q.x); f.y += H16<F16>::hi(q.x);
           f.z += H16<F16>::lo(q.y); f.w += H16<F16>::hi(q.y);
         }
-        *(float4*)((float*)p.C + off) = f;
+        if (p.x3_block) {              // split store (pst_gemm_params.x3_block): the fp32 result as the f16 A-operand rows [hi | hi | lo] of the next GEMM
+          const uint32_t h0 = pack2h(f.x, f.y), h1 = pack2h(f.z, f.w);
+          uint16_t* d = (uint16_t*)p.C + off;
+          *(uint2*)d = make_uint2(h0, h1);
+          *(uint2*)(d + p.x3_block) = make_uint2(h0, h1);
+          *(uint2*)(d + 2 * p.x3_block) = make_uint2(pack2h(f.x - H16<true>::lo(h0), f.y - H16<true>::hi(h0)), pack2h(f.z - H16<true>::lo(h1), f.w - H16<true>::hi(h1)));
+        } else *(float4*)((float*)p.C + off) = f;
         // LayerNorm fold, producer side: a row is one wave here (64 chunks of 4 columns), a 64-column group = 16 lanes
         if (p.xcopy) *(uint2*)((bf16_t*)p.xcopy + (int64_t)orow * p.ldxc + n) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
         if (p.stats_out) { float ss, sq; ln_acc4(f, ss, sq); ln_fold_stats<16>(p, ss, sq, c, orow, n); }
@@ -1047,7 +1053,7 @@ int launch_gemm256(const pst_gemm_params& p, hipStream_t s) {
 // the persistent kernel's two classes: 1 = plain 16-bit row-major output (bias / activation / LayerScale / LayerNorm-fold consumer),
 // 2 = fp32 residual stream (C = res + ..., optional 16-bit copy + fold statistics); 0 = not eligible
 int gemm256_persistent_class(const pst_gemm_params& p) {
-  if (p.ps_p || p.grp_in || p.res_mod || p.N % 64 || p.conv_c || p.batch > 1) return 0;
+  if (p.ps_p || p.grp_in || p.res_mod || p.N % 64 || p.conv_c || p.batch > 1 || p.x3_block) return 0;
   // fold consumers: the partials travel as 16-byte pairs of groups into 128-byte LDS rows (tables_commit): an even number of groups, at most 16 (D <= 1024)
   if (p.ln_stats && ((p.ln_groups & 1) || p.ln_groups < 2 || p.ln_groups > 16 || ((uintptr_t)p.ln_stats & 15))) return 0;
   if (p.trans_out)        // class 3: transposed 16-bit store (bias / activation / fold consumer)

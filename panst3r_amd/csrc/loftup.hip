@@ -270,7 +270,8 @@ __global__ void gn_stats_kernel(const void* x, int64_t ldx, float* part, int P, 
 template <int VEC>
 __global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
                                 void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, int tc) {
-  const int64_t cols = ldy / VEC;
+  const int blk = tc == DT_X3H ? (int)(ldy / 3) : 0;            // split output (PST_X3H): rows [hi | hi | lo], blocks of ldy / 3 columns (zero beyond C)
+  const int64_t cols = (blk ? blk : ldy) / VEC;
   const int64_t total = (int64_t)nimg * P * cols;
   const float inv_n = 1.0f / ((float)P * (C / G));
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -297,7 +298,13 @@ __global__ void gn_apply_kernel(const void* x, int64_t ldx, int x_fp32, const fl
         if (relu) o[k] = fmaxf(o[k], 0.f);
       }
     }
-    if (VEC == 4 && tc == DT_F32) *(float4*)((float*)y + row * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    if (VEC == 4 && blk) {
+      const uint32_t h0 = pack2h(o[0], o[1]), h1 = pack2h(o[2], o[3]);
+      uint16_t* d = (uint16_t*)y + row * ldy + c;
+      *(uint2*)d = make_uint2(h0, h1);
+      *(uint2*)(d + blk) = make_uint2(h0, h1);
+      *(uint2*)(d + 2 * blk) = make_uint2(pack2h(o[0] - H16<true>::lo(h0), o[1] - H16<true>::hi(h0)), pack2h(o[2] - H16<true>::lo(h1), o[3] - H16<true>::hi(h1)));
+    } else if (VEC == 4 && tc == DT_F32) *(float4*)((float*)y + row * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
     else if (VEC == 4) *(uint2*)((bf16_t*)y + row * ldy + c) = make_uint2(pack2(o[0], o[1], tc), pack2(o[2], o[3], tc));
     else store1(y, row * ldy + c, tc, o[0]);
   }
@@ -413,7 +420,8 @@ extern "C" int pst_groupnorm_stats(const void* x, int64_t ldx, int x_fp32, float
 
 extern "C" int pst_groupnorm_apply(const void* x, int64_t ldx, int x_fp32, const float* stats, const float* gamma, const float* beta,
                                    void* y, int64_t ldy, int nimg, int P, int C, int G, float eps, int relu, int dtype16, void* stream) {
-  if ((dtype16 != DT_BF16 && dtype16 != DT_F16 && dtype16 != DT_F32) || !x || !stats || !gamma || !beta || !y || nimg <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G || ldy < C) { set_error("groupnorm_apply: bad argument"); return PST_EINVAL; }
+  if ((dtype16 != DT_BF16 && dtype16 != DT_F16 && dtype16 != DT_F32 && dtype16 != DT_X3H) || !x || !stats || !gamma || !beta || !y || nimg <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G || ldy < C) { set_error("groupnorm_apply: bad argument"); return PST_EINVAL; }
+  if (dtype16 == DT_X3H && (ldy % 12 || ldy / 3 < C || C % 4 || (C / G) % 4 || ldx % 4 || ((uintptr_t)y & 7))) { set_error("groupnorm_apply: a split (PST_X3H) output needs ldy = 3 x block >= 3 C, C %% 4 == 0"); return PST_EINVAL; }
   if (x_fp32 == dtype16 && dtype16 != DT_F32 && C % 8 == 0 && (C / G) % 8 == 0 && ldx == C && ldy == C && C / 8 <= 256 && !(((uintptr_t)x | (uintptr_t)y) & 15)) {
     const int c8n = C / 8, rpb = 256 / c8n, rows_per_block = 16 * rpb;
     hipLaunchKernelGGL(gn_apply8_kernel, dim3((P + rows_per_block - 1) / rows_per_block, nimg), dim3(c8n * rpb), 0, (hipStream_t)stream, (const bf16_t*)x, stats, gamma, beta,

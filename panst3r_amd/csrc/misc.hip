@@ -61,6 +61,17 @@ __device__ __forceinline__ void store4(void* base, int64_t idx, int tc, const fl
   else *(uint2*)((bf16_t*)base + idx) = make_uint2(pack2(v[0], v[1], tc), pack2(v[2], v[3], tc));
 }
 
+// 4 consecutive fp32 results -> the f16 split A-operand row [hi | hi | lo] (PST_X3H; `blk` = columns per block)
+__device__ __forceinline__ void store4_x3(uint16_t* dst, int blk, const float (&v)[4]) {
+  uint16_t hi[4], lo[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { hi[k] = f2h(v[k]); lo[k] = f2h(v[k] - h2f(hi[k])); }
+  const uint2 h2 = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+  *(uint2*)dst = h2;
+  *(uint2*)(dst + blk) = h2;
+  *(uint2*)(dst + 2 * blk) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+}
+
 // ------------------------------------------------------------------ LayerNorm: one wave per row, row in registers
 // RPW rows per wave: the loads of all of a wave's rows are issued before the first reduction, so a wave keeps RPW x (row bytes) in flight instead
 // of one short row (LoftUp's final norms: 786 432 rows of 384 16-bit values = 768 B per row: 2.8 TB/s with one row per wave; the arithmetic of a row is
@@ -125,7 +136,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int64_t l
         const float4 bt = *(const float4*)(beta + c);
         float o[4] = {(v[j][it][0] - mean) * rstd * gm.x + bt.x, (v[j][it][1] - mean) * rstd * gm.y + bt.y,
                       (v[j][it][2] - mean) * rstd * gm.z + bt.z, (v[j][it][3] - mean) * rstd * gm.w + bt.w};
-        store4(y, (int64_t)row * ldy + c, out_fp32, o);
+        if (out_fp32 == DT_X3H) store4_x3((uint16_t*)y + (int64_t)row * ldy + c, (int)(ldy / 3), o);
+        else store4(y, (int64_t)row * ldy + c, out_fp32, o);
       }
     }
   }
@@ -438,7 +450,8 @@ static int launch_layernorm(const void* x, int64_t ldx, int in_fp32, const float
                             void* stream, int nbatch = 1, int64_t x_bs = 0, int64_t y_bs = 0, int64_t w_bs = 0) {
   if (nbatch < 1 || nbatch > 65535 || (nbatch > 1 && ((x_bs | y_bs | w_bs) % 4))) { set_error("layernorm: bad batch (n=%d)", nbatch); return PST_EINVAL; }
   if (!x || !y || !gamma || !beta || rows <= 0) { set_error("layernorm: null/empty argument"); return PST_EINVAL; }
-  if ((in_fp32 != DT_BF16 && in_fp32 != DT_F32 && in_fp32 != DT_F16) || (out_fp32 != DT_BF16 && out_fp32 != DT_F32 && out_fp32 != DT_F16)) { set_error("layernorm: bad element type code"); return PST_EINVAL; }
+  if ((in_fp32 != DT_BF16 && in_fp32 != DT_F32 && in_fp32 != DT_F16) || (out_fp32 != DT_BF16 && out_fp32 != DT_F32 && out_fp32 != DT_F16 && out_fp32 != DT_X3H)) { set_error("layernorm: bad element type code"); return PST_EINVAL; }
+  if (out_fp32 == DT_X3H && (ldy % 12 || ldy / 3 < D || ((uintptr_t)y & 7))) { set_error("layernorm: a split (PST_X3H) output needs ldy = 3 x block, block >= D, block %% 4 == 0"); return PST_EINVAL; }
   if (D <= 0 || D % 4 || D > 4096 || ldx % 4 || ldy % 4 || (add && ld_add % 4)) { set_error("layernorm: need D%%4==0, D<=4096, ld%%4==0 (D=%d)", D); return PST_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   if (D == 384 && in_fp32 == out_fp32 && in_fp32 != DT_F32 && !add && grp_in <= 0 && nbatch == 1 && ldx % 8 == 0 && ldy % 8 == 0 && !(((uintptr_t)x | (uintptr_t)y) & 15) &&

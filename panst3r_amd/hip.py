@@ -26,7 +26,7 @@ class GemmParams(C.Structure):
                 ('ps_p', i32), ('ps_c', i32), ('ps_h', i32), ('ps_w', i32),
                 ('conv_c', i32), ('conv_h', i32), ('conv_w', i32), ('zeros', vp), ('rope_pos', vp), ('rope_cs', vp), ('rope_hd', i32), ('rope_npos', i32), ('res_bf16', i32), ('kernel', i32),
                 ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('c_bs', i64), ('bias_bs', i64), ('dtype16', i32),
-                ('xcopy', vp), ('ldxc', i64), ('stats_out', vp), ('stats_ld', i32), ('ln_stats', vp), ('ln_groups', i32), ('ln_colsum', vp), ('ln_eps', f32)]
+                ('xcopy', vp), ('ldxc', i64), ('stats_out', vp), ('stats_ld', i32), ('ln_stats', vp), ('ln_groups', i32), ('ln_colsum', vp), ('ln_eps', f32), ('x3_block', i32)]
 
 
 class AttnParams(C.Structure):
@@ -208,7 +208,7 @@ ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 
 
 def _gemm_params(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None, trans_out=False, grp=None, ps=None, conv=None,
-                 M=None, kernel=0, rope=None, batch=None, xcopy=None, stats_out=None, ln=None):
+                 M=None, kernel=0, rope=None, batch=None, xcopy=None, stats_out=None, ln=None, x3_block=None):
     """pst_gemm_params of one hip.gemm call + (flops, shape tag) for the kernel timer.
     out = epi(a @ w.T).  a [M,K] 16-bit (row-major view), w [N,K] 16-bit, out 16-bit / fp32 2-D view (or raw buffer for ps).
     a, w, out (and res) all fp32: the amp=False mode's fp32-input-MFMA GEMM (same epilogues; no fused RoPE, no LayerNorm fold).
@@ -248,6 +248,9 @@ def _gemm_params(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None
         p.batch, p.a_bs, p.w_bs, p.c_bs, p.bias_bs = batch
     p.act = ACT[act]
     p.out_fp32 = int(out.dtype == torch.float32)
+    if x3_block:                    # split store: the fp32 result as the f16 A-operand rows [hi | hi | lo] of the next 3 x f16 GEMM (pst_gemm_params.x3_block)
+        assert out.dtype == X3_FMT and out.shape[1] >= 3 * x3_block
+        p.out_fp32, p.x3_block = 1, int(x3_block)
     p.trans_out = int(trans_out)
     p.kernel = kernel
     if rope is not None:            # (pos int32 [rows,2], table fp32 [npos,16,2]): RoPE-2D fused into the store, hd 64
@@ -278,6 +281,7 @@ def _gemm_params(a, w, out, bias=None, gamma=None, res=None, res_mod=0, act=None
 # model.common.precision (amp=False / 'fp32' -> X3; 'fp32_exact' -> the exact kernels).
 X3 = True
 X3_FMT = torch.float16
+X3H = 4            # PST_X3H: output type code of layernorm / attention - f16 rows [hi | hi | lo] (the split A operand of the next GEMM)
 
 
 def split_operand(x, side, kpad=None, out=None, fmt=None):
@@ -314,13 +318,33 @@ def _x3_wanted(a, w):
     return a.dtype == torch.float32 and (w.dtype in H16 or (w.dtype == torch.float32 and X3))
 
 
+def _trans_f32(M, N, out, kw):
+    """C^T in fp32 from a 16-bit GEMM (whose kernels store transposed results in 16 bit only): the row-major result goes to scratch and one transpose per
+    problem moves it into the caller's (strided) buffer.  Returns (scratch output, kwargs without trans_out, finish())."""
+    kw = dict(kw)
+    kw['trans_out'] = False
+    batch = kw.get('batch')
+    cnt = batch[0] if batch else 1
+    tmp = torch.empty(cnt, M, N, dtype=torch.float32, device=out.device)
+    dst, c_bs = out, (batch[3] if batch else 0)
+    if batch:
+        kw['batch'] = batch[:3] + (M * N, batch[4])
+    ld_out = _rowmajor(dst)
+
+    def finish():
+        for i in range(cnt):
+            o = dst if i == 0 else dst.as_strided((N, M), (ld_out, 1), dst.storage_offset() + i * c_bs)
+            transpose_f32(tmp[i], o)
+    return tmp[0], kw, finish
+
+
 def _x3_prepare(a, w, out, kw):
     """One fp32-operand GEMM as a 16-bit GEMM over the 3 x longer K: returns (a3, w3, out', kw', finish).  `w` is a pre-split weight (16-bit [N, 3 Kpad],
     model.common.Packed) or an fp32 matrix split here; `finish()` runs what follows the launch (the transpose of a trans_out result: the 16-bit kernels
     store transposed results in 16 bit only)."""
     kw = dict(kw)
-    if out.dtype != torch.float32:
-        raise RuntimeError('fp32-operand GEMM: the output must be fp32')
+    if out.dtype != torch.float32 and not kw.get('x3_block'):
+        raise RuntimeError('fp32-operand GEMM: the output must be fp32 (or the split form, x3_block=)')
     conv, batch = kw.get('conv'), kw.get('batch')
     c64 = lambda n: (n + 63) // 64 * 64
     if w.dtype == torch.float32:                 # an fp32 W operand (activations on the W side: mask features, class embeddings; tests): split here
@@ -361,21 +385,7 @@ def _x3_prepare(a, w, out, kw):
         a3 = split_operand(src, 0, kpad=kpad, fmt=fmt)
     finish = None
     if kw.get('trans_out'):
-        # C^T in fp32: row-major result into scratch, then one transpose per problem into the caller's (strided) buffer
-        kw['trans_out'] = False
-        cnt = batch[0] if batch else 1
-        M, N = a3.shape[0] // cnt, w.shape[0]
-        tmp = torch.empty(cnt, M, N, dtype=torch.float32, device=a.device)
-        dst, c_bs = out, (batch[3] if batch else 0)
-        if batch:
-            kw['batch'] = kw['batch'][:3] + (M * N, kw['batch'][4])
-        ld_out = _rowmajor(dst)
-
-        def finish():
-            for i in range(cnt):
-                o = dst if i == 0 else dst.as_strided((N, M), (ld_out, 1), dst.storage_offset() + i * c_bs)
-                transpose_f32(tmp[i], o)
-        out = tmp[0]
+        out, kw, finish = _trans_f32(a3.shape[0] // (batch[0] if batch else 1), w.shape[0], out, kw)
     return a3, w, out, kw, finish
 
 
@@ -387,6 +397,11 @@ def gemm(a, w, out, **kw):
         gemm(a3, w3, o3, **kw3)
         if finish is not None:
             finish()
+        return out
+    if kw.get('trans_out') and out.dtype == torch.float32 and a.dtype in H16:       # split operands prepared by the producer (LayerNorm PST_X3H), fp32 C^T wanted
+        o3, kw3, finish = _trans_f32(a.shape[0] if kw.get('M') is None else kw['M'], w.shape[0], out, kw)
+        gemm(a, w, o3, **kw3)
+        finish()
         return out
     p, flops, tag = _gemm_params(a, w, out, **kw)
     if TIMER is not None:
@@ -405,6 +420,11 @@ def gemm_pair(first, second):
     (`first` row-major, `second` trans_out: the q|k and V^T projections of the memory build) or two big problems of the same persistent-kernel class
     whose tile lists fill the chip better side by side (the same layer of two independent ViTs), else two launches; same bits either way."""
     (a1, w1, o1, k1), (a2, w2, o2, k2) = first, second
+    t32 = lambda a, o, k: k.get('trans_out') and o.dtype == torch.float32 and a.dtype in H16
+    if t32(a1, o1, k1) or t32(a2, o2, k2):           # fp32 C^T from split operands: no fused form, two launches
+        gemm(a1, w1, o1, **k1)
+        gemm(a2, w2, o2, **k2)
+        return o1, o2
     if _x3_wanted(a1, w1) or _x3_wanted(a2, w2):
         fin = []
         if _x3_wanted(a1, w1):
@@ -517,7 +537,7 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
               mask_strides=(0, 0), nsplit=None, ws=None, prescaled=False):
     """Strided flash attention; *_strides = (batch, head, row) in elements (v: batch, head, head-dim row).
     prescaled: q was produced with scale * LOG2E folded in (see `qscale`): softmax in the exp2 domain without a per-score multiply."""
-    if q.dtype == torch.float32 and X3:
+    if (isinstance(q, Planes) or q.dtype == torch.float32) and X3:
         return _attention_x3(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale, mask, mask_strides, nsplit, ws, prescaled)
     p, ws, flops, tag = _attn_params(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale, mask, mask_strides, nsplit, ws, prescaled)
     if TIMER is not None:
@@ -541,10 +561,15 @@ def _span(B, H, N, strides, width):
 def _attention_x3(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, o_strides, scale, mask, mask_strides, nsplit, ws, prescaled):
     """attention on fp32 operands as 3 x 16-bit MFMA (pst_attn_x3): the memory spans the call touches are split into (hi, lo) planes once - operands
     that share a buffer (q | k of one projection, both halves of a pair) share the pass - and the kernel reads the planes with the caller's strides."""
-    for t in (q, k, vt, out):
-        _dev(t, torch.float32)
+    _dev(out, torch.float32, X3_FMT)            # fp32, or (16-bit `out` [rows, 3 x block]) the split A operand of the output projection: PST_X3H
+    out_type, out_block = (1, 0) if out.dtype == torch.float32 else (X3H, out.shape[-1] // 3)
+    dev = out.device
     spans = []
-    for t, (lo_, hi_) in ((q, _span(B, H, Nq, q_strides, hd)), (k, _span(B, H, Nk, k_strides, hd)), (vt, _span(B, H, hd, v_strides, (Nk + 7) // 8 * 8))):         # (the kernel reads V^T in 8-key chunks: the last one may reach into the row's pad)
+    for t, (lo_, hi_) in ((q, _span(B, H, Nq, q_strides, hd)), (k, _span(B, H, Nk, k_strides, hd)),
+                          (vt, _span(B, H, hd, v_strides, (Nk + 7) // 8 * 8))):         # (the kernel reads V^T in 8-key chunks: the last one may reach into the row's pad)
+        if isinstance(t, Planes):               # prepared by the caller
+            continue
+        _dev(t, torch.float32)
         # (whole 16-byte groups: a key count that is not a multiple of 4 - DINOv2's 769 - ends inside the pad columns every V^T buffer carries)
         spans.append([t.data_ptr() + 4 * lo_, t.data_ptr() + 4 * ((hi_ + 3) // 4 * 4)])
     merged = []
@@ -557,12 +582,14 @@ def _attention_x3(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strid
     for a0, a1 in merged:
         n = (a1 - a0) // 4
         assert a0 % 16 == 0 and n % 4 == 0, 'attention operands must be 16-byte aligned with strides that are multiples of 8'
-        hi = torch.empty(n, dtype=X3_FMT, device=q.device)
-        lo = torch.empty(n, dtype=X3_FMT, device=q.device)
+        hi = torch.empty(n, dtype=X3_FMT, device=dev)
+        lo = torch.empty(n, dtype=X3_FMT, device=dev)
         _check(lib().pst_split2(vp(a0), i64(n), _ptr(hi), _ptr(lo), i64(n), 1, n, 0, _TC[X3_FMT], _stream()), 'pst_split2')
         planes.append((a0, a1, hi, lo))
 
     def plane_ptrs(t):
+        if isinstance(t, Planes):
+            return t.hi.data_ptr(), t.lo.data_ptr()
         addr = t.data_ptr()
         for a0, a1, hi, lo in planes:
             if a0 <= addr < a1:                   # (an operand's own span always contains its pointer: offset 0 is one of the offsets it touches)
@@ -582,12 +609,12 @@ def _attention_x3(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strid
     p.B, p.H, p.Nq, p.Nk, p.hd = B, H, Nq, Nk, hd
     p.scale = float(hd ** -0.5 if scale is None else scale)
     p.prescaled = 1 if prescaled else 0
-    p.zeros = _ptr(zeros_page(q.device))
+    p.zeros = _ptr(zeros_page(dev))
     ns = auto_nsplit(B, H, Nq, Nk) if nsplit is None else nsplit
     if ns > 1:
         n = ns * B * H * Nq * (hd + 2)
         if ws is None:
-            ws = torch.empty(n, dtype=torch.float32, device=q.device)
+            ws = torch.empty(n, dtype=torch.float32, device=dev)
         assert ws.dtype == torch.float32 and ws.numel() >= n
         p.nsplit, p.ws, p.ws_bytes = ns, _ptr(ws), ws.numel() * 4
     ev = None
@@ -595,7 +622,7 @@ def _attention_x3(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strid
         name = lib().pst_attn_x3_variant(C.byref(p))
         ev = TIMER.bracket(name.decode() if name else 'attn_x3?', 3 * 4.0 * B * H * Nq * Nk * hd, (B, H, Nq, Nk, hd))
         ev[0].record()
-    _check(lib().pst_attn_x3(C.byref(p), vp(ql), vp(kl), vp(vl), _stream()), 'pst_attn_x3')
+    _check(lib().pst_attn_x3(C.byref(p), vp(ql), vp(kl), vp(vl), out_type, i64(out_block), _stream()), 'pst_attn_x3')
     if ev is not None:
         ev[1].record()
     return out
@@ -632,8 +659,9 @@ def attn_workspace_floats(B, H, Nq, Nk, hd, nsplit=None):
 
 
 # ----------------------------------------------------------------------------------------------------------- the rest
-def layernorm_batch(x_all, gamma_all, beta_all, out_all, eps, rows=None, grp=None, add=None):
-    """out_all[i] = LN(x_all[i] [+ add]) * gamma_all[i] + beta_all[i] for i < n in ONE launch; x_all [n, R, D], out_all [n, rows, D]."""
+def layernorm_batch(x_all, gamma_all, beta_all, out_all, eps, rows=None, grp=None, add=None, split=False):
+    """out_all[i] = LN(x_all[i] [+ add]) * gamma_all[i] + beta_all[i] for i < n in ONE launch; x_all [n, R, D], out_all [n, rows, D]
+    (split=True: out_all f16 [n, rows, 3 D] = the split A operand rows [hi | hi | lo], PST_X3H)."""
     _dev(x_all, torch.float32, *H16); _dev(out_all, torch.float32, *H16)
     n, D = x_all.shape[0], gamma_all.shape[1]
     assert x_all.dim() == 3 and out_all.dim() == 3 and x_all.stride(2) == 1 and out_all.stride(2) == 1 and gamma_all.is_contiguous() and beta_all.is_contiguous()
@@ -641,19 +669,25 @@ def layernorm_batch(x_all, gamma_all, beta_all, out_all, eps, rows=None, grp=Non
     g = grp or (0, 0, 0)
     _check(lib().pst_layernorm_add_batch(_ptr(x_all), i64(x_all.stride(1)), _tc(x_all),
                                          _ptr(_dev(add, torch.float32)) if add is not None else vp(0), i64(_rowmajor(add)) if add is not None else i64(0),
-                                         _ptr(out_all), i64(out_all.stride(1)), _tc(out_all),
+                                         _ptr(out_all), i64(out_all.stride(1)), X3H if split else _tc(out_all),
                                          _ptr(_dev(gamma_all, torch.float32)), _ptr(_dev(beta_all, torch.float32)), rows, D, f32(eps),
                                          g[0], g[1], g[2], n, i64(x_all.stride(0)), i64(out_all.stride(0)), i64(D), _stream()), 'pst_layernorm_add_batch')
     return out_all
 
 
-@hbm_timed('layernorm', lambda x, gamma, beta, out, eps, rows=None, grp=None, add=None: (out.shape[0] if rows is None else rows) * gamma.numel() * (_esz(x) + _esz(out) + (4 if add is not None else 0)))
-def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None):
-    """out = LN(x [+ add]); `add`: optional fp32 rows indexed like x (fused residual-style addend)."""
+@hbm_timed('layernorm', lambda x, gamma, beta, out, eps, rows=None, grp=None, add=None, split=False: (out.shape[0] if rows is None else rows) * gamma.numel() * (_esz(x) + (6 if split else _esz(out)) + (4 if add is not None else 0)))
+def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None, split=False):
+    """out = LN(x [+ add]); `add`: optional fp32 rows indexed like x (fused residual-style addend).  split=True: `out` f16 [rows, 3 x block] receives the
+    result as the split A operand of a 3 x f16 GEMM (rows [hi | hi | lo], PST_X3H) - what split_operand(side 0) would make of the fp32 result."""
     _dev(x, torch.float32, *H16); _dev(out, torch.float32, *H16)
     D = gamma.numel()
     rows = out.shape[0] if rows is None else rows
     g = grp or (0, 0, 0)
+    if split:
+        assert add is None and out.dtype == X3_FMT
+        _check(lib().pst_layernorm(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(out), i64(_rowmajor(out)), X3H, _ptr(_dev(gamma, torch.float32)),
+                                   _ptr(_dev(beta, torch.float32)), rows, D, f32(eps), g[0], g[1], g[2], _stream()), 'pst_layernorm')
+        return out
     if add is not None:
         _check(lib().pst_layernorm_add(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(_dev(add, torch.float32)),
                                        i64(_rowmajor(add)), _ptr(out), i64(_rowmajor(out)), _tc(out),
@@ -839,12 +873,22 @@ def groupnorm_stats(x, stats, nimg, P, Cc, G):
            'pst_groupnorm_stats')
 
 
-@hbm_timed('groupnorm_apply', lambda x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu: nimg * P * (Cc * _esz(x) + out.shape[1] * 2))
-def groupnorm_apply(x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu):
+@hbm_timed('groupnorm_apply', lambda x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu, split=False: nimg * P * (Cc * _esz(x) + out.shape[1] * 2))
+def groupnorm_apply(x, stats, gamma, beta, out, nimg, P, Cc, G, eps, relu, split=False):
+    """split=True: `out` f16 [rows, 3 x block] receives the split A operand rows [hi | hi | lo] (PST_X3H) of the conv that follows"""
     _dev(x); _dev(out, *FMT)
     _check(lib().pst_groupnorm_apply(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(stats), _ptr(gamma), _ptr(beta),
-                                     _ptr(out), i64(_rowmajor(out)), nimg, P, Cc, G, f32(eps), int(relu), _tc(out), _stream()), 'pst_groupnorm_apply')
+                                     _ptr(out), i64(_rowmajor(out)), nimg, P, Cc, G, f32(eps), int(relu), X3H if split else _tc(out), _stream()), 'pst_groupnorm_apply')
     return out
+
+
+class Planes:
+    """(hi, lo) 16-bit planes of an fp32 attention operand prepared by the caller (split2): same shape and strides for both"""
+    __slots__ = ('hi', 'lo')
+
+    def __init__(self, hi, lo):
+        assert hi.dtype == lo.dtype and hi.shape == lo.shape and hi.stride() == lo.stride()
+        self.hi, self.lo = hi, lo
 
 
 def loftup_lr_pe(biases, out, col0, nimg, h, w):

@@ -241,6 +241,27 @@ def empty(rows, cols, dtype, device):
     return torch.empty(rows, cols, dtype=dtype, device=device)
 
 
+def mlp_hidden(s, fc1, rows, device):
+    """h = GELU(fc1(LN(stream s))) as the A operand of fc2: [rows, n] in the format in effect - or, in the split-operand fp32 mode, f16 [rows, 3 n] written by
+    the GEMM's split store (rows [hi | hi | lo], pst_gemm_params.x3_block: no fp32 round trip of the widest activation of a block, no split pass).
+    Returns the (a, w, out, kwargs) call for hip.gemm / hip.gemm_pair."""
+    a, ln = s.operand(fc1)
+    if x3():
+        h = torch.empty(rows, 3 * fc1.n, dtype=hip.X3_FMT, device=device)
+        return (a, fc1.w, h, dict(bias=fc1.b, act='gelu', ln=ln, x3_block=fc1.n))
+    h = torch.empty(rows, fc1.n, dtype=adt(), device=device)
+    return (a, fc1.w, h, dict(bias=fc1.b, act='gelu', ln=ln))
+
+
+def attn_out(rows, D, device):
+    """output buffer of an attention call whose result feeds an output-projection GEMM: [rows, D] in the format in effect - or, in the split-operand
+    fp32 mode, f16 [rows, 3 D]: the kernel writes the split A operand rows [hi | hi | lo] itself (PST_X3H; no fp32 round trip, no split pass).
+    Strides of the call: row = the buffer's leading dimension, head = head dim."""
+    if x3():
+        return torch.empty(rows, 3 * D, dtype=hip.X3_FMT, device=device)
+    return torch.empty(rows, D, dtype=adt(), device=device)
+
+
 def self_attention_parts(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None):
     """The self-attention of LN(stream s) with the folded weights w_qk / w_v as (q|k projection call, V^T projection call, finish): the two calls are
     (a, w, out, kwargs) tuples for hip.gemm / hip.gemm_pair, finish() runs what follows them (stand-alone RoPE where it is not fused, flash attention)
@@ -258,21 +279,27 @@ def self_attention_parts(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None)
     assert xv is xn, 'self_attention: w_qk and w_v must share one LayerNorm (row slices of one qkv pack)'
     fused_rope = rope is not None and hd == 64 and adt() != torch.float32   # RoPE-2D applied in the GEMM's store phase
     qk_call = (xn, w_qk.w, qk, dict(bias=w_qk.b, gamma=qs, ln=lq, **({'rope': (pos, rope)} if fused_rope else {})))
-    vt_call = (xv, w_v.w, vt, dict(bias=w_v.b, trans_out=True, ln=lv))
+    if x3():        # V row-major in fp32; the (hi, lo) planes of V^T come out of ONE transposing split pass (no fp32 V^T, no second pass inside hip.attention)
+        v32 = empty(lay.rows, D, torch.float32, dev)
+        vt_call = (xv, w_v.w, v32, dict(bias=w_v.b, ln=lv))
+    else:
+        vt_call = (xv, w_v.w, vt, dict(bias=w_v.b, trans_out=True, ln=lv))
 
     def finish(launch=True):
         """launch=False: everything but the attention launch; returns (output buffer, hip.attention args, kwargs) for hip.attention_pair"""
         if rope is not None and not fused_rope:
             hip.rope2d_(qk, pos, rope, 2 * H, hd)
-        o = empty(lay.rows, D, adt(), dev)
+        o = attn_out(lay.rows, D, dev)
+        ldo = o.stride(0)
         if lay.Tp != lay.N:
-            o.view(lay.V, lay.Tp, D)[:, lay.N:].zero_()      # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
-        ldq, ldv = qk.stride(0), vt.stride(0)
-        st = dict(q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq), v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D), prescaled=True)
+            o.view(lay.V, lay.Tp, ldo)[:, lay.N:].zero_()    # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
+        vts = hip.Planes(*hip.split2(v32, transpose=True)) if x3() else vt
+        ldq, ldv = qk.stride(0), (vts.hi if x3() else vt).stride(0)
+        st = dict(q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq), v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * ldo, hd, ldo), prescaled=True)
         # (tried in round 4: DINOv2's 769 queries as two launches - 768 patch queries in full 128-row blocks + the CLS queries of all (view, head) pairs in
         # one-row blocks - to save every 7th block's walk over 13 key tiles: 4.58 + 0.97 ms against 5.05 ms for the one launch, i.e. slower; the one-row
         # launch is a 40 us latency chain of its own)
-        args = (qk, qk[:, D:], vt, o, lay.V, H, lay.N, lay.N, hd)
+        args = (qk, qk[:, D:], vts, o, lay.V, H, lay.N, lay.N, hd)
         if not launch:
             return o, args, st
         hip.attention(*args, **st)
@@ -350,6 +377,8 @@ class Stream:
         self.x, self.fold, self.dirty, self.eps = x, fold_in_epilogue(), True, None
         if x.dtype != torch.float32 and self.fold:
             self.xb = x                               # a 16-bit stream is its own raw operand
+        elif x3():
+            self.xb = empty(rows, 3 * D, hip.X3_FMT, x.device)       # LN(x) as the split A operand [hi | hi | lo] of the 3 x f16 GEMMs (written by the LayerNorm kernel)
         else:
             self.xb = empty(rows, D, adt(), x.device) if xb is None else xb
         self.st = None
@@ -368,7 +397,7 @@ class Stream:
             return self.xb, (self.st, pk.cs, pk.eps)
         g, bt, lid = pk.ln
         if self.dirty or self.eps != lid:             # one pass per version of x and per LayerNorm (qk / v share norm1's)
-            hip.layernorm(self.x, g, bt, self.xb, pk.eps)
+            hip.layernorm(self.x, g, bt, self.xb, pk.eps, split=self.xb.dtype != self.x.dtype and x3())
             self.dirty, self.eps = False, lid
         return self.xb, None
 
@@ -392,9 +421,8 @@ def vit_block(s, bw, lay, H, hd, pos=None, rope=None):
     dev = s.x.device
     o = self_attention(s, lay, H, hd, bw.qk, bw.v, pos, rope)
     s.residual(o, bw.proj, gamma=bw.ls1)
-    h = empty(lay.rows, bw.fc1.n, adt(), dev)
-    a, ln = s.operand(bw.fc1)
-    hip.gemm(a, bw.fc1.w, h, bias=bw.fc1.b, act='gelu', ln=ln)
+    a, w, h, kw = mlp_hidden(s, bw.fc1, lay.rows, dev)
+    hip.gemm(a, w, h, **kw)
     s.residual(h, bw.fc2, gamma=bw.ls2)
     return s
 
@@ -411,11 +439,9 @@ def vit_block_pair(a, b):
     (oa, aa, ka), (ob, ab, kb) = fa(launch=False), fb(launch=False)
     hip.attention_pair((aa, ka), (ab, kb))              # one grid over both towers' query blocks (pst_attn_pair)
     hip.gemm_pair(sa.residual_call(oa, wa.proj, gamma=wa.ls1), sb.residual_call(ob, wb.proj, gamma=wb.ls1))
-    ha, hb = empty(la.rows, wa.fc1.n, adt(), sa.x.device), empty(lb.rows, wb.fc1.n, adt(), sb.x.device)
-    xa, lna = sa.operand(wa.fc1)
-    xb, lnb = sb.operand(wb.fc1)
-    hip.gemm_pair((xa, wa.fc1.w, ha, dict(bias=wa.fc1.b, act='gelu', ln=lna)), (xb, wb.fc1.w, hb, dict(bias=wb.fc1.b, act='gelu', ln=lnb)))
-    hip.gemm_pair(sa.residual_call(ha, wa.fc2, gamma=wa.ls2), sb.residual_call(hb, wb.fc2, gamma=wb.ls2))
+    ca, cb = mlp_hidden(sa, wa.fc1, la.rows, sa.x.device), mlp_hidden(sb, wb.fc1, lb.rows, sb.x.device)
+    hip.gemm_pair(ca, cb)
+    hip.gemm_pair(sa.residual_call(ca[2], wa.fc2, gamma=wa.ls2), sb.residual_call(cb[2], wb.fc2, gamma=wb.ls2))
 
 
 class ParamLinear(nn.Linear):

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .common import (HipModule, qscale, Packed, Layout, adt, BlockW, empty, pack_norm, pack_croco_block, self_attention, f32,
+from .common import (HipModule, qscale, Packed, Layout, adt, BlockW, empty, attn_out, mlp_hidden, x3, pack_norm, pack_croco_block, self_attention, f32,
                      ParamLinear, grid_pos, grow_table, Stream, fold_ln, ln_of, fold_in_epilogue)
 from .params import BlockP, CrossAttnP, MlpP, AttnP
 
@@ -153,9 +153,8 @@ class MUSt3R(HipModule):
         return q
 
     def _mlp(self, s, bw):
-        h = empty(s.x.shape[0], bw.fc1.n, adt(), s.x.device)
-        a, ln = s.operand(bw.fc1)
-        hip.gemm(a, bw.fc1.w, h, bias=bw.fc1.b, act='gelu', ln=ln)
+        a, w, h, kw = mlp_hidden(s, bw.fc1, s.x.shape[0], s.x.device)
+        hip.gemm(a, w, h, **kw)
         s.residual(h, bw.fc2)
 
     def _head(self, pk, feat, V, h, w):
@@ -181,10 +180,10 @@ class MUSt3R(HipModule):
             o = self_attention(s, lay, H, hd, bw.qk, bw.v, pos, rope)
             s.residual(o, bw.proj)
             q = self._cross_q(s, bw)
-            o = empty(lay.rows, D, adt(), dev)
+            o = attn_out(lay.rows, D, dev)
             ldv = bank.Vt[l].stride(0)
             hip.attention(q, bank.K[l], bank.Vt[l], o, 1, H, lay.rows, bank.n, hd,
-                          q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D), prescaled=True)
+                          q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, o.stride(0)), prescaled=True)
             s.residual(o, bw.cross['proj'])
             self._mlp(s, bw)
         if feat_out is None:
@@ -229,7 +228,8 @@ class MUSt3R(HipModule):
             o = self_attention(s_in, lay, H, hd, bw.qk, bw.v, pos, rope, vt=vt_self)
             s.residual(o, bw.proj, res=s_in.x)
             c = bw.cross
-            o = empty(lay.rows, D, adt(), dev)
+            o = attn_out(lay.rows, D, dev)
+            ldo = o.stride(0)
             if n == 2:
                 # each image attends to the other image's layer input (norm_y folded into projk / projv, on the fly)
                 kk = empty(lay.rows, D, adt(), dev)
@@ -241,14 +241,14 @@ class MUSt3R(HipModule):
                 ldv = vt.stride(0)
                 hip.attention(q, kk[lay.Tp:], vt[:, lay.Tp:], o, 2, H, T, T, hd,
                               q_strides=(lay.Tp * D, hd, D), k_strides=(-lay.Tp * D, hd, D),
-                              v_strides=(-lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * D, hd, D), prescaled=True)
+                              v_strides=(-lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * ldo, hd, ldo), prescaled=True)
                 if lay.Tp != T:
-                    o.view(2, lay.Tp, D)[:, T:] = 0
+                    o.view(2, lay.Tp, ldo)[:, T:] = 0
             else:
                 q = self._cross_q(s, bw)
                 ldv = bank.Vt[l].stride(0)
                 hip.attention(q, bank.K[l], bank.Vt[l], o, 1, H, lay.rows, bank.n, hd,
-                              q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D), prescaled=True)
+                              q_strides=(0, hd, D), k_strides=(0, hd, D), v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, ldo), prescaled=True)
             s.residual(o, c['proj'])
             self._mlp(s, bw)
             hs.append(s.x)
@@ -294,10 +294,10 @@ class MUSt3R(HipModule):
                 s.residual(o, bw.proj, res=s_in.x)
                 q = self._cross_q(s, bw)
                 kk, vt = kvs[1 - i]
-                o = torch.zeros(lay.rows, D, dtype=adt(), device=dev)
+                o = attn_out(lay.rows, D, dev).zero_()
                 ldv = vt.stride(0)
                 hip.attention(q, kk, vt, o, 1, H, lay.T, Ts[1 - i], hd, q_strides=(0, hd, D), k_strides=(0, hd, D),
-                              v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, D), prescaled=True)
+                              v_strides=(0, hd * ldv, ldv), o_strides=(0, hd, o.stride(0)), prescaled=True)
                 s.residual(o, c['proj'])
                 self._mlp(s, bw)
                 S[i].append(s)

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .common import (HipModule, qscale, Packed, Layout, adt, empty, vit_block, pack_croco_block, pack_norm, f32, ParamLinear,
+from .common import (HipModule, qscale, Packed, Layout, adt, empty, attn_out, mlp_hidden, x3, vit_block, pack_croco_block, pack_norm, f32, ParamLinear,
                      grid_pos, ceil_to, grow_table, Stream, fold_ln, ln_of)
 from .params import BlockP, MlpP, CrossAttnP, MHAP
 
@@ -240,8 +240,14 @@ class LoftUpUpscaler(HipModule):
             st = hip.stats_buffer(n, 8, dev)
             hip.groupnorm_stats(c1, st, n, P, C, 8)
             g1 = out[v0 * P:(v0 + n) * P]
-            hip.groupnorm_apply(c1, st, pk['gn1'][0], pk['gn1'][1], g1, n, P, C, 8, pk['gn1'][2], True)
-            hip.gemm(g1, pk['conv2'].w, c1, bias=pk['conv2'].b, conv=(C, H2, W2))
+            if x3():     # the first GroupNorm's result only feeds conv2: written as that GEMM's split A operand (rows [hi | hi | lo]: no fp32 round trip)
+                g1s = torch.empty(n * P, 3 * C, dtype=hip.X3_FMT, device=dev)
+                hip.groupnorm_apply(c1, st, pk['gn1'][0], pk['gn1'][1], g1s, n, P, C, 8, pk['gn1'][2], True, split=True)
+                hip.gemm(g1s, pk['conv2'].w, c1, bias=pk['conv2'].b, conv=(3 * C, H2, W2))
+                del g1s
+            else:
+                hip.groupnorm_apply(c1, st, pk['gn1'][0], pk['gn1'][1], g1, n, P, C, 8, pk['gn1'][2], True)
+                hip.gemm(g1, pk['conv2'].w, c1, bias=pk['conv2'].b, conv=(C, H2, W2))
             hip.groupnorm_stats(c1, st, n, P, C, 8)
             hip.groupnorm_apply(c1, st, pk['gn2'][0], pk['gn2'][1], g1, n, P, C, 8, pk['gn2'][2], True)
             del g0, c1
@@ -278,7 +284,8 @@ class LoftUpUpscaler(HipModule):
             # The residual stream of these two blocks is kept in bf16: they are HBM-bound over P x C elements per view
             # (fp32 would double the read-modify-write traffic of both residual GEMMs and of every LayerNorm).
             x = guidance[v0 * P:(v0 + n) * P]
-            q, o = empty(n * P, C, adt(), dev), empty(n * P, C, adt(), dev)
+            q, o = empty(n * P, C, adt(), dev), attn_out(n * P, C, dev)
+            ldo = o.stride(0)
             # LayerNorm fold on the 16-bit stream: norm2 / norm3 live in projq / fc1; in f16 their row statistics come out of the epilogues
             # of the two residual GEMMs (no stand-alone pass over the [n*P, C] tensor: 4 of the 16 passes per chunk gone)
             s = Stream(x).refresh()
@@ -294,11 +301,17 @@ class LoftUpUpscaler(HipModule):
                 hip.gemm(a, bw['q'].w, q, bias=bw['q'].b, gamma=qscale(C, C, hd, dev), ln=ln)
                 ldv = vt.stride(0)
                 hip.attention(q, kk, vt, o, n, Hh, P, T, hd, q_strides=(P * C, hd, C), k_strides=(lay.Tp * C, hd, C),
-                              v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(P * C, hd, C), prescaled=True)
+                              v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(P * ldo, hd, ldo), prescaled=True)
                 s.residual(o, bw['proj'])
-                a, ln = s.operand(bw['fc1'])
-                hip.gemm(a, bw['fc1'].w, q, bias=bw['fc1'].b, act='gelu', ln=ln)
-                s.residual(q, bw['fc2'])
+                if x3():            # (the split-operand fp32 mode: the hidden activation leaves fc1 as fc2's split A operand)
+                    a, w_, hmid, kw = mlp_hidden(s, bw['fc1'], n * P, dev)
+                    hip.gemm(a, w_, hmid, **kw)
+                    s.residual(hmid, bw['fc2'])
+                    del hmid
+                else:
+                    a, ln = s.operand(bw['fc1'])
+                    hip.gemm(a, bw['fc1'].w, q, bias=bw['fc1'].b, act='gelu', ln=ln)
+                    s.residual(q, bw['fc2'])
             hip.layernorm(x, pk['norm'][0], pk['norm'][1], mask_out[v0:v0 + n].view(n * P, C), pk['norm'][2])
             del x, q, o, s
         return fpn_out, mask_out

@@ -107,3 +107,18 @@ def test_attention_x3_shared_buffers_negative_strides_and_split_k():
         assert rel64(o2.cpu().reshape(Nq, H, hd).permute(1, 0, 2), ref2) < 3e-6
     finally:
         hip.X3 = prev
+
+
+@pytest.mark.parametrize('M,N,K,kernel', [(300, 384, 1152, 0), (1000, 4096, 192, 0), (512, 512, 1024, 256), (4096, 384, 1152, 0), (130, 68, 64, 0)])
+def test_gemm_split_store_is_split_operand_of_the_fp32_result(M, N, K, kernel):
+    """pst_gemm_params.x3_block: the GEMM that produces an MLP's hidden activation stores it as the f16 split A operand of the next GEMM - bit for bit what
+    pst_split_operand makes of the same kernel's fp32 output (every tile program: 64 / 128 / 256 tiles, interior and ragged tiles)"""
+    from panst3r_amd import hip
+    a, w, b = rn(11, M, K).to(DEV).half(), rn(12, N, K, scale=K ** -0.5).to(DEV).half(), rn(13, N, scale=0.1).to(DEV)
+    o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    hip.gemm(a, w, o32, bias=b, act='gelu', kernel=kernel)
+    blk = (N + 63) // 64 * 64
+    ref = hip.split_operand(o32, 0, kpad=blk)
+    got = torch.zeros(M, 3 * blk, dtype=torch.float16, device=DEV)
+    hip.gemm(a, w, got, bias=b, act='gelu', kernel=kernel, x3_block=blk)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))

@@ -60,23 +60,28 @@ class Dust3rEncoder(HipModule):
         D, Hh = self.embed_dim, self.num_heads
         return [(st['s'], bw, st['lay'], Hh, D // Hh, st['pos'], st['rope']) for bw in st['pk']['blocks']]
 
-    def finish_tokens(self, st, out=None):
+    def finish_tokens(self, st, out=None, copy=None):
+        """final norm -> out[:, :D]; `copy`: a second buffer (another format) that receives the SAME fp32 result rounded once to its own format - the
+        decoder's copy of the encoder tokens when the feature concat is kept in the panoptic decoder's format (one more launch of a 40 us kernel
+        instead of a rounding of a rounding)"""
         pk, lay, D = st['pk'], st['lay'], self.embed_dim
         if out is None:
             out = empty(st['V'] * lay.T, D, adt(), st['dev'])
-        hip.layernorm(st['x'], pk['norm'][0], pk['norm'][1], out[:, :D] if out.shape[1] != D else out, pk['norm'][2],
-                      rows=st['V'] * lay.T, grp=lay.grp)
+        for dst in (out, copy):
+            if dst is not None:
+                hip.layernorm(st['x'], pk['norm'][0], pk['norm'][1], dst[:, :D] if dst.shape[1] != D else dst, pk['norm'][2],
+                              rows=st['V'] * lay.T, grp=lay.grp)
         return out, grid_pos(st['V'], st['gh'], st['gw'], lay.T, 0, st['dev'])
 
     @torch.no_grad()
-    def encode_tokens(self, img, out=None, patches=None):
+    def encode_tokens(self, img, out=None, patches=None, copy=None):
         """img fp32 [V,3,H,W] (one shape) -> 16-bit tokens [V*T, out_ld] written into `out[:, :D]` (or a new buffer),
         plus int32 positions [V*T, 2].  `patches`: the 16x16 patch rows when the caller already produced them (hip.patch_rows makes the
         rows of both ViTs in one launch)."""
         st = self.begin_tokens(img, patches)
         for args in self.blocks(st):
             vit_block(*args)
-        return self.finish_tokens(st, out)
+        return self.finish_tokens(st, out, copy)
 
     def forward(self, img, true_shape=None):
         V = img.shape[0]

@@ -191,8 +191,8 @@ class MUSt3R(HipModule):
         hip.layernorm(x, pk['norm'][0], pk['norm'][1], feat_out, pk['norm'][2], rows=V * lay.T, grp=lay.grp)
         head_in = feat_out
         if pointmaps and feat_out.dtype != adt():       # reference AMP placement: the feature concat is kept in another format than this render's
-            head_in = empty(V * lay.T, D, adt(), dev)    # (the norm's fp32 result rounded once: what the kernel stores when it writes 16 bit itself)
-            hip.add_cast(feat_out, head_in)
+            head_in = empty(V * lay.T, D, adt(), dev)    # (the norm's fp32 result rounded ONCE to this render's format: the norm kernel writes it itself)
+            hip.layernorm(x, pk['norm'][0], pk['norm'][1], head_in, pk['norm'][2], rows=V * lay.T, grp=lay.grp)
         pm = self._head(pk, head_in, V, h, w) if pointmaps else None
         return pm, feat_out
 

@@ -158,7 +158,7 @@ class PanSt3R(nn.Module):
         return (pms, mks) if multi_ar else (pms[0], mks[0])
 
     @torch.no_grad()
-    def encode_views_paired(self, imgs_enc, cat_enc, imgs_dino, cat_dino):
+    def encode_views_paired(self, imgs_enc, cat_enc, imgs_dino, cat_dino, enc_copy=None):
         """CroCo encoder of `imgs_enc` and DINOv2 of `imgs_dino` (two independent ViT-L towers, panst3r.py:174-175 and :229-230) layer by layer in
         LOCK-STEP: the GEMMs of layer l of both towers go through hip.gemm_pair and share one persistent launch where the two tile lists fill the chip
         better side by side (model/common.py vit_block_pair).  Results are bit-identical to encode_views(enc only) + encode_views(dino only).
@@ -167,7 +167,7 @@ class PanSt3R(nn.Module):
         Ve, Vd = imgs_enc.shape[0], imgs_dino.shape[0]
         if Ve == 0 or Vd == 0 or Ve > ENC_CHUNK or Vd > ENC_CHUNK or tuple(imgs_enc.shape[1:]) != tuple(imgs_dino.shape[1:]):
             if Ve:
-                self.encode_views(imgs_enc, cat_enc, dino=False)
+                self.encode_views(imgs_enc, cat_enc, dino=False, enc_copy=enc_copy)
             if Vd:
                 self.encode_views(imgs_dino, cat_dino, enc=False)
             return
@@ -182,7 +182,7 @@ class PanSt3R(nn.Module):
             vit_block_pair(be[l], bd[l])
         for args in be[n:] + bd[n:]:
             vit_block(*args)
-        self.must3r_encoder.finish_tokens(se, cat_enc)
+        self.must3r_encoder.finish_tokens(se, cat_enc, enc_copy)
         self.dino_encoder.finish_tokens(sd, cat_dino, col0=De + Dd)
 
     # ------------------------------------------------------------------ scene stages (token level)
@@ -190,8 +190,9 @@ class PanSt3R(nn.Module):
         return self.must3r_encoder.embed_dim + self.must3r_decoder.embed_dim + self.dino_encoder.embed_dim
 
     @torch.no_grad()
-    def encode_views(self, imgs, cat, enc=True, dino=True):
-        """imgs fp32 [V,3,H,W]; writes encoder tokens to cat[:, :De] and DINOv2 tokens to cat[:, De+Dd:]."""
+    def encode_views(self, imgs, cat, enc=True, dino=True, enc_copy=None):
+        """imgs fp32 [V,3,H,W]; writes encoder tokens to cat[:, :De] and DINOv2 tokens to cat[:, De+Dd:].  enc_copy: the encoder tokens once more, in the
+        format in effect, when `cat` is kept in another one (rows [V*T, >= De])."""
         V, _, H, W = imgs.shape
         p = self.must3r_encoder.patch_size
         T = (H // p) * (W // p)
@@ -207,7 +208,7 @@ class PanSt3R(nn.Module):
                 pdn = torch.empty(n * T, self.dino_encoder.patch_width(im.device), dtype=adt(), device=im.device)
                 hip.patch_rows(im, enc=pe, dino=pdn, p_enc=p, p_dino=self.dino_encoder.patch_size, dino_transposed=tr)
             if enc:
-                self.must3r_encoder.encode_tokens(im, out=cat[sl], patches=pe)
+                self.must3r_encoder.encode_tokens(im, out=cat[sl], patches=pe, copy=None if enc_copy is None else enc_copy[sl])
             if dino:
                 self.dino_encoder.encode_tokens(im, cat[sl], col0=De + Dd, patches=pdn, transposed=tr)
 

@@ -567,19 +567,13 @@ class HipBackend:
     def encode_enc(self, imgs, cat_rows, enc_rows=None):
         """enc_rows: additionally the tokens in the format in effect when `cat_rows` is kept in another one (the final LayerNorm's fp32 result rounded once,
         exactly what the LayerNorm kernel stores when it writes that format itself)"""
-        self.m.encode_views(imgs, cat_rows, dino=False)
-        if enc_rows is not None:
-            from . import hip
-            hip.add_cast(cat_rows[:, :self.De], enc_rows)
+        self.m.encode_views(imgs, cat_rows, dino=False, enc_copy=enc_rows)
 
     def bank_f32(self, bank):
         return bank.f32
 
     def encode_rest_paired(self, imgs_enc, cat_enc, imgs_dino, cat_dino, enc_rows=None):
-        self.m.encode_views_paired(imgs_enc, cat_enc, imgs_dino, cat_dino)
-        if enc_rows is not None:
-            from . import hip
-            hip.add_cast(cat_enc[:, :self.De], enc_rows)
+        self.m.encode_views_paired(imgs_enc, cat_enc, imgs_dino, cat_dino, enc_rows)
 
     def encode_dino(self, imgs, cat_rows):
         self.m.encode_views(imgs, cat_rows, enc=False)

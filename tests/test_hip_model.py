@@ -550,7 +550,9 @@ def test_rccl_collectives_at_world_1(pair):
 def test_forward_batch_and_dust3r_storage_convention(pair):
     """PanSt3R.forward (panst3r.py:286-296) on a batch of B = 2 scenes whose second scene holds a PORTRAIT view in the DUSt3R storage convention
     (stored transposed in the landscape-shaped tensor, true_shape = its real (H, W); utils.py:8-61): each scene == the same views run natively
-    through forward_inference_multi_ar, with the stored view's pointmaps / masks transposed into the storage layout."""
+    through forward_inference_multi_ar, with the stored view's pointmaps / masks transposed into the storage layout.  LoftUp's MinMaxScaler pools over ALL
+    views of the batch, per orientation, whatever max_bs says (the reference does not pass max_bs on, panst3r.py:294): the per-scene runs get the pooled tables;
+    the whole batch is also compared with the oracle's forward (which follows the reference, tests/test_oracle_forward.py)."""
     variant, o, h = pair
     H, W, n = 64, 96, 3
     a = tiny.images(n, H, W)                                             # scene 0: three landscape views
@@ -558,11 +560,21 @@ def test_forward_batch_and_dust3r_storage_convention(pair):
     stored = [b[0], b[1].transpose(-1, -2).contiguous(), b[2]]
     imgs = torch.stack([torch.stack(a), torch.stack(stored)]).to(DEV)
     ts = torch.tensor([[[H, W]] * n, [[H, W], [W, H], [H, W]]])
-    pan, pm = h.forward(imgs, ts, tiny.NAMES, amp=h.amp, max_bs=1)          # (max_bs=None would pool LoftUp's MinMaxScaler over the batch: refused for B > 1)
+    pan, pm = h.forward(imgs, ts, tiny.NAMES, amp=h.amp, max_bs=1)
     assert pm.shape == (2, n, H, W, 7) and pan['pred_masks'].shape == (2, n, 24, H // 2, W // 2) and pan['out_queries'].shape[1] == 2
+    pan_o, pm_o = o.forward(imgs.cpu(), ts, tiny.NAMES)
+    chk(h, 'pm', rel_l2(pm.cpu(), pm_o), 'forward B = 2')
+    chk(h, 'mask', rel_l2(pan['pred_masks'].cpu(), pan_o['pred_masks']), 'forward B = 2')
+    chk(h, 'q', rel_l2(pan['out_queries'].cpu(), pan_o['out_queries']), 'forward B = 2')
+    tabs = [None, None]
+    if h.panoptic_decoder.minmax_scaled():       # the batch-wide tables of the two orientations, as forward() pools them
+        land = [v.to(DEV) for v in a + [b[0], b[2]]]
+        tl = h.panoptic_decoder.minmax_tables([torch.stack(land).float().contiguous()], torch.zeros(len(land), dtype=torch.int32, device=DEV))[0]
+        tp = h.panoptic_decoder.minmax_tables([b[1][None].to(DEV).float().contiguous()], torch.zeros(1, dtype=torch.int32, device=DEV))[0]
+        tabs = [{i: tl[i] for i in range(n)}, {0: tl[n], 1: tp[0], 2: tl[n + 1]}]
     for s, views in enumerate((a, b)):
         t2 = torch.tensor([list(v.shape[-2:]) for v in views])
-        pm_n, pan_n = h.forward_inference_multi_ar([v.to(DEV) for v in views], t2, tiny.NAMES, num_keyframes=n, amp=h.amp, max_bs=1)
+        pm_n, pan_n = h.forward_inference_multi_ar([v.to(DEV) for v in views], t2, tiny.NAMES, num_keyframes=n, amp=h.amp, max_bs=1, _mm_tables=tabs[s])
         assert torch.equal(pan['out_queries'][:, s], pan_n['out_queries'][:, 0])
         for i in range(n):
             back = views[i].shape[-2] != H

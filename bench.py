@@ -155,6 +155,7 @@ def full_size_parity(model, dev, ref, imgs, ts, names, amp='fp16', K=2, panoptic
 
 
 REAL_STDOUT = 1
+OVERLAP_PICK = {}        # --overlap auto: per measured mode, what the warm-up timing chose
 
 
 def cpu_c1(threads):
@@ -260,8 +261,11 @@ def main():
     ap.add_argument('--no-depth-parity', action='store_true', help='skip the K = 16 parity scene (16 views = 16 keyframes = BASELINE configs[2]; ~1.5 min of host time)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--parity-c4', action='store_true', help='also compare the TIMED configuration itself (v2, 50 views / 16 keyframes, full size) with the oracle on the host: several minutes')
-    ap.add_argument('--overlap', action='store_true', help='MEASUREMENT ONLY: run the memory build beside the independent encoder/DINOv2 work on a second stream '
-                    '(+8 %% frames/s; was not reproducible until one kernel was fixed, mechanism not understood: DESIGN.md section 4); default: back to back')
+    ap.add_argument('--overlap', default='auto', choices=['auto', 'off', 'masked', 'plain'],
+                    help="stage 2 of the scene: 'off' = the memory build and the bulk encoder / DINOv2 work back to back on one stream; 'masked' = the build on "
+                         "a CU-masked stream beside the first tower layers on the other CUs (disjoint CU sets: panst3r_amd/scene.py); 'auto' (default) = both "
+                         "are captured and timed during warm-up, the faster one runs the timed steps (same bits either way); 'plain' = MEASUREMENT ONLY, two "
+                         "ordinary streams (loses writes on this platform: tests/diag/cu_mask_two_queue.py)")
     ap.add_argument('--no-overlap', action='store_true', help=argparse.SUPPRESS)       # former switch; serial is the default now
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying HIP graphs')
     ap.add_argument('--plan', default='auto', choices=['auto', 'replicated', 'broadcast'],
@@ -327,8 +331,14 @@ def main():
 
     def measure(amp, steps, warmup, instrument, panoptic_precision=None):
         """W untimed warm-up steps (the first also captures the three HIP graphs), then EXACTLY `steps` timed steps between two fences."""
-        runner = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager, overlap=args.overlap and not args.no_overlap, amp=amp, plan=args.plan,
-                                    panoptic_precision=panoptic_precision)
+        mk = lambda ov: model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager, overlap=ov, amp=amp, plan=args.plan,
+                                           panoptic_precision=panoptic_precision)
+        if args.overlap == 'auto' and not args.eager and world == 1:
+            from panst3r_amd.scene import pick_overlap
+            runner, picked = pick_overlap(mk)
+            OVERLAP_PICK.setdefault(str(amp) + '/' + str(panoptic_precision), {k: (round(v, 2) if isinstance(v, float) else v) for k, v in picked.items()})
+        else:
+            runner = mk({'auto': False, 'off': False, 'masked': 'masked', 'plain': True}[args.overlap])
         for _ in range(max(warmup, 1)):
             runner.run(copy=False)
         timer = None
@@ -386,8 +396,11 @@ def main():
                        'operands': "%s MFMA operands, fp32 accumulate / residual streams / softmax / statistics (reference --amp %s, tools/demo_panst3r.py:88)"
                                    % ('f16' if args.amp == 'fp16' else 'bf16', args.amp),
                        'launch': 'eager' if args.eager else 'HIP-graph replay (3 graphs per scene; last timed step eager + HIP-event instrumented)',
-                       'overlap': 'memory build || non-keyframe encoder + DINOv2 (2 streams; opt-in, DESIGN.md section 4)' if (args.overlap and not args.no_overlap)
-                                  else 'off (one stream; the two-stream variant is opt-in, DESIGN.md section 4)',
+                       'overlap_auto': OVERLAP_PICK.get(str(args.amp) + '/None'),
+                       'overlap': {'auto': 'auto: the serial and the CU-masked two-queue stage 2 are both captured and timed during warm-up, the faster runs '
+                                           '(overlap_auto; bit-identical results: tests/test_hip_fullsize.py::test_full_size_masked_overlap_equals_serial)',
+                                   'off': 'off (one stream)', 'plain': 'memory build || non-keyframe encoder + DINOv2 on two ordinary streams (measurement only)',
+                                   'masked': 'memory build on a CU-masked stream || first layers of the two ViT-L towers on the other CUs (panst3r_amd/scene.py)'}[args.overlap],
                        'median_ms_per_graph_step': None if median_ms is None else round(median_ms, 3),
                        'median_frames_per_s': None if median_ms is None else round(V / (median_ms * 1e-3), 2),
                        'scene_algorithmic_tflop': round(scene_flops / 1e12, 2),

@@ -123,6 +123,7 @@ const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_param
 #define PST_TUNE_DEEP_RING 8    /* LDS slabs of the 64x64-tile GEMM when a launch has at most one tile per CU: 4 (the ring of every other launch), 6 or 8 */
 #define PST_TUNE_PAIR_ATTN 7    /* 1 (default): pst_attn_pair may put two attention problems into one launch, 0: never */
 #define PST_TUNE_ATTN_XCD 9     /* 1 (default): attention blocks in XCD-contiguous order (the query blocks of one head share its K / V tiles through ONE L2), 0: plain order */
+#define PST_TUNE_CUS 10        /* CUs the launches enqueued from now on may assume (grid of the persistent kernels): set around work enqueued on a CU-masked stream (hipExtStreamCreateWithCUMask); 0 (default) = all CUs of the device */
 #define PST_TUNE_PAIR_DELAY 6   /* start delay of the second problem of a shared launch in % of a tile period (default 0 = none; measured slower): de-phases its epilogues from the first's */
 #define PST_TUNE_PAIR_RES 5     /* 1 (default): ... including fp32 residual-stream problems at K >= 1024 that would run on the 128x128 kernel on their own */
 int pst_tune(int knob, int value);

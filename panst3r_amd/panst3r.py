@@ -163,27 +163,47 @@ class PanSt3R(nn.Module):
         LOCK-STEP: the GEMMs of layer l of both towers go through hip.gemm_pair and share one persistent launch where the two tile lists fill the chip
         better side by side (model/common.py vit_block_pair).  Results are bit-identical to encode_views(enc only) + encode_views(dino only).
         Falls back to the two sequential passes when a tower needs more than one chunk of views."""
-        from .model.common import vit_block, vit_block_pair
         Ve, Vd = imgs_enc.shape[0], imgs_dino.shape[0]
-        if Ve == 0 or Vd == 0 or Ve > ENC_CHUNK or Vd > ENC_CHUNK or tuple(imgs_enc.shape[1:]) != tuple(imgs_dino.shape[1:]):
+        if not self.paired_ok(imgs_enc, imgs_dino):
             if Ve:
                 self.encode_views(imgs_enc, cat_enc, dino=False, enc_copy=enc_copy)
             if Vd:
                 self.encode_views(imgs_dino, cat_dino, enc=False)
             return
+        st = self.paired_begin(imgs_enc, imgs_dino)
+        self.paired_layers(st, 0, st['n'])
+        self.paired_finish(st, cat_enc, cat_dino, enc_copy)
+
+    def paired_ok(self, imgs_enc, imgs_dino):
+        """the two towers can run in lock-step (one chunk of views each, same image shape)"""
+        Ve, Vd = imgs_enc.shape[0], imgs_dino.shape[0]
+        return not (Ve == 0 or Vd == 0 or Ve > ENC_CHUNK or Vd > ENC_CHUNK or tuple(imgs_enc.shape[1:]) != tuple(imgs_dino.shape[1:]))
+
+    # the lock-step pass in three parts, so that a scene runner can put the first layers beside the memory build and the rest behind it (scene.py, masked overlap)
+    @torch.no_grad()
+    def paired_begin(self, imgs_enc, imgs_dino):
         H, W = imgs_dino.shape[-2:]
-        De, Dd = self.must3r_encoder.embed_dim, self.must3r_decoder.embed_dim
         tr = bool(H > W and self.dino_encoder.landscape_only)
         se = self.must3r_encoder.begin_tokens(imgs_enc.contiguous())
         sd = self.dino_encoder.begin_tokens(imgs_dino.contiguous(), transposed=tr)
         be, bd = self.must3r_encoder.blocks(se), self.dino_encoder.blocks(sd)
-        n = min(len(be), len(bd))
-        for l in range(n):
-            vit_block_pair(be[l], bd[l])
-        for args in be[n:] + bd[n:]:
-            vit_block(*args)
-        self.must3r_encoder.finish_tokens(se, cat_enc, enc_copy)
-        self.dino_encoder.finish_tokens(sd, cat_dino, col0=De + Dd)
+        return dict(se=se, sd=sd, be=be, bd=bd, n=max(len(be), len(bd)))
+
+    @torch.no_grad()
+    def paired_layers(self, st, lo, hi):
+        from .model.common import vit_block, vit_block_pair
+        be, bd = st['be'], st['bd']
+        for l in range(lo, hi):
+            if l < len(be) and l < len(bd):
+                vit_block_pair(be[l], bd[l])
+            else:
+                vit_block(*(be[l] if l < len(be) else bd[l]))
+
+    @torch.no_grad()
+    def paired_finish(self, st, cat_enc, cat_dino, enc_copy=None):
+        De, Dd = self.must3r_encoder.embed_dim, self.must3r_decoder.embed_dim
+        self.must3r_encoder.finish_tokens(st['se'], cat_enc, enc_copy)
+        self.dino_encoder.finish_tokens(st['sd'], cat_dino, col0=De + Dd)
 
     # ------------------------------------------------------------------ scene stages (token level)
     def _cat_width(self):

@@ -126,7 +126,47 @@ def broadcast_tensors(tensors, src, world, group):
 # tests/diag/dino_taps.py); the mechanism is not understood, so results must not depend on it.
 # One stream is reproducible in every trial.  `overlap=True` (bench.py --overlap) re-enables the two streams.
 OVERLAP_DEFAULT = False
+# Round 5: the effect needs waves of BOTH queues on the SAME CU.  With the two queues on disjoint CU sets (hipExtStreamCreateWithCUMask) the stand-alone
+# reproducer deviates 0 of 25 times on three boxes where plain (and full-mask) stream pairs deviate 25 of 25 (tests/diag/cu_mask_two_queue.py,
+# profiles/r5_cu_mask_two_queue_box{1,2,3}.txt), a captured graph runs on the CUs of the stream it is launched on and two graphs on two masked streams run
+# side by side (tests/diag/cu_mask_graph.py).  `overlap='masked'`: the sequential memory build on MASK_BUILD_CUS CUs beside the first MASK_LAYERS layers of
+# the two ViT-L towers on the rest; everything behind the join on all CUs again.  The kernels are told their CU budget (pst_tune PST_TUNE_CUS: grids of the
+# persistent kernels); which kernel variant runs never changes a bit, so the masked scene equals the serial one bit for bit (tests/test_hip_fullsize.py).
+# Measured (tools/overlap_bench.py, profiles/r5_overlap_bench.txt; 50 views / 16 keyframes): 128 CUs (16 per XCD = 4 per shader engine) for the build and 10 of
+# the 24 tower layers beside it: 150.4 ms against 158.1 serial (+5 %); the build alone on a masked stream: 33 ms on 128 CUs, but 50 - 88 ms on 48 ... 112 and
+# 144 ... 192 CUs (tools/masked_build_bench.py) - CU sets that are not a power of two per shader engine run its short kernels several times slower - so the
+# split is fixed at half the chip and `pick_overlap` below keeps the masked form only where it is measured faster on the box at hand.
+MASK_BUILD_CUS = int(__import__('os').environ.get('PST_MASK_BUILD_CUS', '128'))
+MASK_LAYERS = int(__import__('os').environ.get('PST_MASK_LAYERS', '10'))
 DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a callable run on the main stream beside the side branch
+
+
+def pick_overlap(make_runner, steps=3):
+    """overlap='auto': build the serial and the masked runner of a scene (make_runner(overlap) -> SceneRunner with captured graphs), time `steps` replays of
+    each and keep the faster one; the other is released.  Returns (runner, {'chosen', 'serial_ms', 'masked_ms'}).  Both produce the same bits."""
+    import time
+    res = {}
+    runners = {}
+    for mode in (False, 'masked'):
+        r = make_runner(mode)
+        if mode == 'masked' and not r.masked:          # the scene cannot take the masked form (plan, shapes): serial
+            r.release()
+            continue
+        r.run(copy=False)
+        r.run(copy=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.run(copy=False)
+        torch.cuda.synchronize()
+        res['masked_ms' if mode else 'serial_ms'] = 1e3 * (time.perf_counter() - t0) / steps
+        runners[mode] = r
+    best = 'masked' if ('masked_ms' in res and res['masked_ms'] < 0.99 * res['serial_ms']) else False
+    for mode, r in runners.items():
+        if mode != best:
+            r.release()
+    res['chosen'] = 'masked' if best else 'serial'
+    return runners[best], res
 
 
 class _Group:
@@ -245,11 +285,15 @@ class SceneRunner:
                 if len(set(ids)) < V:
                     self.mm_scope = backend.scope_ids(ids, self.groups[0].imgs.device)
         self.use_graphs = use_graphs
-        self.serial = not (OVERLAP_DEFAULT if overlap is None else overlap)      # True: the two branches of stage 2 run back-to-back
+        ov = OVERLAP_DEFAULT if overlap is None else overlap
+        # 'masked': the build and the first tower layers on disjoint CU sets (above); needs the lock-step tower pass for every shape group and a rank that builds
+        self.masked = ov == 'masked' and not self.split and self.builder and not self.ref_split and hasattr(backend, 'masked_streams') and \
+            all(backend.rest_pairable(g.imgs[g.k:], g.imgs) for g in self.groups)
+        self.serial = self.masked or not ov      # True: no plain two-stream stage 2 (the two branches back-to-back, or the masked form)
         self.graphs = None
         self.coll_events = None       # bench.py: [] -> every eager collective is bracketed by HIP events (collective_ms)
         self.enc_kf = self.both_kf = None
-        self.out = self.bank = None
+        self.out = self.bank = self._rest = None
 
     def _kf_rows(self, per_group_rows):
         """concatenate this rank's keyframe rows (one [k_g*T_g, C] tensor per group) in deal order."""
@@ -297,6 +341,10 @@ class SceneRunner:
                 if len(g.idx) > g.k:
                     with b.precision(self.pan_amp):
                         b.encode_dino(g.imgs[g.k:], g.cat[g.k * g.T:])
+        self._guidance()
+
+    def _guidance(self):
+        b = self.b
         with b.precision(self.pan_amp):
             pooled = self.mm_all
             if self.mm_scope is not None:           # the whole scene's per-view table pooled over the scope ids (every rank: same table, same ids)
@@ -413,7 +461,48 @@ class SceneRunner:
         bank broadcast"""
         if self.split:
             return [(self.stage1, self.gather1), (self.stage2a, self.bank_exchange), (self.stage2b, self.gather2), (self.stage3, None)]
+        if self.masked:       # a PAIR of stages = two branches on two CU-masked streams, joined before the next segment
+            return [(self.stage1, self.gather1), ((self.stage2_build, self.stage2_head), None), (self.stage2_tail, self.gather2), (self.stage3, None)]
         return [(self.stage1, self.gather1), (self.stage2, self.gather2), (self.stage3, None)]
+
+    # ---- masked overlap: stage 2 as  [build || first tower layers]  ->  [remaining layers, guidance, render, upscale]
+    def stage2_build(self):
+        self.bank = self.b.build_memory(self.enc_kf, self.K, self.kf_grids, False)
+
+    def stage2_head(self):
+        b = self.b
+        self._rest = [b.rest_begin(g.imgs[g.k:], g.imgs) for g in self.groups]
+        for st in self._rest:
+            b.rest_layers(st, 0, min(MASK_LAYERS, st['n']))
+
+    def stage2_tail(self):
+        b = self.b
+        for g, st in zip(self.groups, self._rest):
+            b.rest_layers(st, min(MASK_LAYERS, st['n']), st['n'])
+            b.rest_finish(st, g.cat[g.k * g.T:], g.cat, None if g.enc is None else g.enc[g.k * g.T:])
+        self._rest = None
+        self._guidance()
+        self.stage2b()
+
+    def _par(self, pair, graphs=None):
+        """run the two branches of a masked pair: eagerly, or (graphs = the two captured graphs) by replaying one graph per masked stream"""
+        b = self.b
+        cur = torch.cuda.current_stream()
+        sa, sb, ca, cb = b.masked_streams(self.groups[0].imgs.device, MASK_BUILD_CUS)
+        sa.wait_stream(cur)
+        sb.wait_stream(cur)
+        for i, (stage, s, cus) in enumerate(((pair[0], sa, ca), (pair[1], sb, cb))):
+            with torch.cuda.stream(s):
+                if graphs is not None:
+                    graphs[i].replay()
+                else:
+                    b.cu_budget(cus)
+                    try:
+                        stage()
+                    finally:
+                        b.cu_budget(0)
+        cur.wait_stream(sa)
+        cur.wait_stream(sb)
 
     def _collective(self, coll):
         """run one eager collective; with `coll_events` set (bench.py) it is bracketed by HIP events on the launch stream"""
@@ -435,7 +524,10 @@ class SceneRunner:
 
     def _eager(self):
         for stage, coll in self._segments():
-            stage()
+            if isinstance(stage, tuple):
+                self._par(stage)
+            else:
+                stage()
             if coll is not None:
                 self._collective(coll)
 
@@ -445,7 +537,7 @@ class SceneRunner:
         for g in self.groups:
             g.imgs = g.cat = g.pointmaps = g.fpn = g.mf = g.guid = g.mm = g.enc = None
         self.enc_kf = self.both_kf = self.enc_send = self.both_send = self.out = self.graphs = self._refs = self.bank = None
-        self.mm_all = self.mm_send = None
+        self.mm_all = self.mm_send = self._rest = None
 
     def set_images(self, images):
         """Load a new scene of the SAME shapes / schedule into the static input buffers (the captured graphs read them in place).
@@ -464,6 +556,23 @@ class SceneRunner:
         pool = torch.cuda.graph_pool_handle()
         self.graphs = []
         for stage, gather in self._segments():
+            if isinstance(stage, tuple):
+                # two branches that REPLAY CONCURRENTLY: each captured on its own masked stream with the CU budget of that stream, each with a memory pool
+                # of its own (graphs that share a pool must not run at the same time: their temporaries alias)
+                sa, sb, ca, cb = self.b.masked_streams(self.groups[0].imgs.device, MASK_BUILD_CUS)
+                pair = []
+                for st, s_, cus in ((stage[0], sa, ca), (stage[1], sb, cb)):
+                    g = torch.cuda.CUDAGraph()
+                    self.b.cu_budget(cus)
+                    try:
+                        with torch.cuda.graph(g, stream=s_, capture_error_mode='thread_local'):
+                            st()
+                    finally:
+                        self.b.cu_budget(0)
+                    pair.append(g)
+                self.graphs.append(tuple(pair))
+                self._par(stage, pair)
+                continue
             g = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of torch.distributed may query events while we capture
             with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
@@ -482,18 +591,23 @@ class SceneRunner:
         graph-pool buffers, valid only until the next run() (bench.py, which consumes nothing, uses that)."""
         if serial is not None:
             assert eager or not self.use_graphs or self.graphs is None, 'overlap mode is fixed once the graphs are captured'
-            prev, self.serial = self.serial, serial
+            prev, self.serial = (self.serial, self.masked), serial
+            if serial:
+                self.masked = False          # one stream, all CUs (bench.py's instrumented step: event durations not inflated by a co-runner)
             try:
                 return self.run(outdevice, eager, copy=copy)
             finally:
-                self.serial = prev
+                self.serial, self.masked = prev
         with self.b.precision(self.amp):
             if self.use_graphs and not eager:
                 if self.graphs is None:
                     self._capture()
                 else:
-                    for g, (_, coll) in zip(self.graphs, self._segments()):
-                        g.replay()
+                    for g, (stage, coll) in zip(self.graphs, self._segments()):
+                        if isinstance(g, tuple):
+                            self._par(stage, g)
+                        else:
+                            g.replay()
                         if coll is not None:
                             self._collective(coll)
             else:
@@ -582,6 +696,49 @@ class HipBackend:
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(device=device)
         return self._side
+
+    _MASKED = {}
+
+    def masked_streams(self, device, build_cus):
+        """(stream A, stream B, CUs of A, CUs of B): two HIP streams whose queues may only use DISJOINT CU sets - A the first `build_cus` mask bits, B the
+        rest (hipExtStreamCreateWithCUMask; the driver deals consecutive mask bits round-robin over the 8 XCDs, so both sets span all of them).
+        One pair per (device, split), for the life of the process."""
+        key = (str(device), int(build_cus))
+        if key not in HipBackend._MASKED:
+            import ctypes
+            rt = ctypes.CDLL('libamdhip64.so')
+            ncu = torch.cuda.get_device_properties(device).multi_processor_count
+            build_cus = max(8, min(int(build_cus), ncu - 8))
+            words = (ncu + 31) // 32
+
+            def mk(lo, hi):
+                mask = (ctypes.c_uint32 * words)()
+                for i in range(lo, hi):
+                    mask[i // 32] |= 1 << (i % 32)
+                h = ctypes.c_void_p()
+                rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+                if rc != 0:
+                    raise RuntimeError('hipExtStreamCreateWithCUMask failed (%d)' % rc)
+                return torch.cuda.ExternalStream(h.value, device=device)
+            with torch.cuda.device(device):
+                HipBackend._MASKED[key] = (mk(0, build_cus), mk(build_cus, ncu), build_cus, ncu - build_cus)
+        return HipBackend._MASKED[key]
+
+    def cu_budget(self, cus):
+        from . import hip
+        hip.tune(hip.TUNE_CUS, int(cus))
+
+    def rest_pairable(self, imgs_enc, imgs_dino):
+        return self.m.paired_ok(imgs_enc, imgs_dino)
+
+    def rest_begin(self, imgs_enc, imgs_dino):
+        return self.m.paired_begin(imgs_enc, imgs_dino)
+
+    def rest_layers(self, st, lo, hi):
+        self.m.paired_layers(st, lo, hi)
+
+    def rest_finish(self, st, cat_enc, cat_dino, enc_rows=None):
+        self.m.paired_finish(st, cat_enc, cat_dino, enc_rows)
 
     def enc_rows(self, cat, rows):
         return cat[:rows, :self.De].contiguous()

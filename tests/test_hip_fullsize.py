@@ -307,6 +307,30 @@ def test_full_dim_mask_transformer_vs_reference_golden(tag):
     assert rel(got_h, ref_h) <= 3e-2 and float(((got_h > 0) == (ref_h > 0)).float().mean()) >= 0.995
 
 
+def test_full_size_masked_overlap_equals_serial(full):
+    """overlap='masked' (panst3r_amd/scene.py): the memory build on a CU-masked stream beside the first layers of the two ViT-L towers on the other CUs -
+    two captured graphs replayed on two streams whose queues share NO compute unit (two ordinary streams lose writes on this platform,
+    tests/diag/cu_mask_two_queue.py; 13 / 4 is the shape at which the unmasked form deviated in most replays).  Every replay, and the eager launch, must
+    equal the serial scene BIT FOR BIT: the kernels' CU budget changes grids, never results."""
+    from panst3r_amd.synthetic import synth_image
+    model, _, names, _ = full
+    dev = torch.device('cuda:0')
+    V, K, H, W = 13, 4, 384, 512
+    imgs = {i: synth_image(i, H, W).to(dev) for i in range(V)}
+    ser = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=True, amp='fp16', overlap=False)
+    r0, s0 = ser.run()
+    ref = {k: (a.clone(), b.clone()) for k, (a, b) in r0.items()}
+    q = s0['out_queries'].clone()
+    ser.release()
+    runner = model.scene_runner(imgs, V, H, W, names, num_keyframes=K, use_graphs=True, amp='fp16', overlap='masked')
+    assert runner.masked and runner.serial
+    runs = [runner.run()] + [runner.run() for _ in range(8)] + [runner.run(eager=True)]
+    for res, sc in runs:
+        assert torch.equal(sc['out_queries'], q)
+        for i in range(V):
+            assert torch.equal(res[i][0], ref[i][0]) and torch.equal(res[i][1], ref[i][1]), i
+
+
 def test_full_size_graph_replay_equals_eager(full):
     """Size-independent property at the real shapes: a 13-view / 4-keyframe 384x512 scene (padded 769-token DINOv2 layout, 256x256- and
     128x128-tile GEMM dispatch, split-K attention in the memory build) gives the same bits every time its three captured HIP graphs are

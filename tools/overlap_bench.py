@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""The masked two-queue stage 2 (panst3r_amd/scene.py overlap='masked') on the bench scene: frames/s against the serial runner for a sweep of
+(CUs of the build stream, tower layers beside the build), and a SOAK - every replay's outputs compared bit for bit with the serial scene.
+    python tools/overlap_bench.py [soak replays] [cus:layers ...]      e.g.  python tools/overlap_bench.py 30 72:8 96:10"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from panst3r_amd.panst3r import CONFIG_V2, build_from_config                  # noqa: E402
+from panst3r_amd.synthetic import fill_module_, synth_image, synth_class_embeddings   # noqa: E402
+import panst3r_amd.scene as S                                                 # noqa: E402
+
+V, K, H, W = int(os.environ.get('PST_V', 50)), int(os.environ.get('PST_K', 16)), 384, 512
+SOAK = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+combos = [tuple(int(x) for x in a.split(':')) for a in sys.argv[2:]] or [(72, 8)]
+dev = torch.device('cuda:0')
+model = build_from_config(CONFIG_V2).eval()
+fill_module_(model, seed=1)
+names, emb = synth_class_embeddings(100)
+model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(names, emb)}
+model.to(dev)
+images = {i: synth_image(i, H, W).to(dev) for i in range(V)}
+
+
+def timed(runner, n=8):
+    runner.run(copy=False); runner.run(copy=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        runner.run(copy=False)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+ser = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=True, amp='fp16', overlap=False)
+ref, sref = ser.run()
+ref = {k: (a.clone(), b.clone()) for k, (a, b) in ref.items()}
+qref = sref['out_queries'].clone()
+dt = timed(ser)
+print('serial                         %8.2f ms per scene  %7.2f frames/s' % (1e3 * dt, V / dt), flush=True)
+for cus, layers in combos:
+    S.MASK_BUILD_CUS, S.MASK_LAYERS = cus, layers
+    r = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=True, amp='fp16', overlap='masked')
+    assert r.masked
+    res, sc = r.run()
+    bad = 0
+    for rep in range(SOAK):
+        res, sc = r.run(copy=False)
+        torch.cuda.synchronize()
+        ok = torch.equal(sc['out_queries'], qref) and all(torch.equal(res[i][0], ref[i][0]) and torch.equal(res[i][1], ref[i][1]) for i in range(V))
+        bad += not ok
+    dt = timed(r)
+    print('masked build on %3d CUs, %2d layers beside it  %8.2f ms per scene  %7.2f frames/s   soak: %d of %d replays deviate from the serial scene'
+          % (cus, layers, 1e3 * dt, V / dt, bad, SOAK), flush=True)
+    r.release()
+    del r
+    torch.cuda.empty_cache()

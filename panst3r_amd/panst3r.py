@@ -243,18 +243,33 @@ class PanSt3R(nn.Module):
         for T in Ts:
             offs.append(offs[-1] + T)
         bank = self.must3r_decoder.new_bank(enc_kf.device, offs[-1], f32=f32_bank)        # f32_bank: fp32 twin for the reference's AMP placement
-        De = self.must3r_encoder.embed_dim
-        start = 0
-        for nb in self.get_must3r_mem_batches(K):
-            rows = enc_kf[offs[start]:offs[start + nb], :De]
-            if nb == 1 or grids[start] == grids[start + 1]:
-                self.must3r_decoder.update_tokens(rows, nb, grids[start][0], grids[start][1], bank)
-            else:
-                assert nb == 2
-                self.must3r_decoder.update_pair_tokens([enc_kf[offs[start]:offs[start + 1], :De], enc_kf[offs[start + 1]:offs[start + 2], :De]],
-                                                       grids[start:start + 2], bank)
-            start += nb
+        for u in range(len(self.get_must3r_mem_batches(K))):
+            self.build_memory_step(bank, enc_kf, K, grids, u)
         return bank
+
+    def memory_update_spans(self, K, grids):
+        """[(first keyframe, keyframes, first token, tokens)] of the memory updates [2,1,1,...] of a K-keyframe build"""
+        Ts = [a * b for a, b in grids]
+        out, start, tok = [], 0, 0
+        for nb in self.get_must3r_mem_batches(K):
+            n = sum(Ts[start:start + nb])
+            out.append((start, nb, tok, n))
+            start, tok = start + nb, tok + n
+        return out
+
+    @torch.no_grad()
+    def build_memory_step(self, bank, enc_kf, K, grids, u):
+        """memory update `u` of the sequential build (one call of the reference's decoder with render=False, engine/must3r.py:28-69): appends its keyframes'
+        entries to `bank`.  Split out so that a scene runner can hand each update's entries to the other ranks while the next update computes."""
+        start, nb, tok, n = self.memory_update_spans(K, grids)[u]
+        De = self.must3r_encoder.embed_dim
+        rows = enc_kf[tok:tok + n, :De]
+        if nb == 1 or grids[start] == grids[start + 1]:
+            self.must3r_decoder.update_tokens(rows, nb, grids[start][0], grids[start][1], bank)
+        else:
+            assert nb == 2
+            n0 = grids[start][0] * grids[start][1]
+            self.must3r_decoder.update_pair_tokens([enc_kf[tok:tok + n0, :De], enc_kf[tok + n0:tok + n, :De]], grids[start:start + 2], bank)
 
     @torch.no_grad()
     def render_views(self, cat, V, h, w, bank, enc=None):
@@ -304,9 +319,11 @@ class PanSt3R(nn.Module):
         H, W = shapes[0]
         fmt = amp_dtype(amp)                    # tells (once) that amp=False is the slow fp32 mode
         runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs, panoptic_precision, _mm_tables)
-        res, scene = runner.run(outdevice)
         pan_fmt = fmt if runner.pan_amp is None else amp_dtype(runner.pan_amp, quiet=True)
-        if check_finite and torch.float16 in (fmt, pan_fmt):
+        checked = check_finite and torch.float16 in (fmt, pan_fmt)
+        # (with a finite check AND an output device, the check runs on the GPU first - on the runner's own buffers, no clones - and the copy follows)
+        res, scene = runner.run(None if checked else outdevice, copy=not (checked and outdevice is not None))
+        if checked:
             # f16 stores overflow to inf (|x| > 65504) and the inf reaches the outputs as inf / NaN: ONE fused flag over everything the
             # call returns (queries, class logits, pointmaps, mask logits), one host sync; raises, as the reference's "--amp fp16 might be
             # unstable" would show up.  (amp=False is fp32 and amp='bf16' has the fp32 range: neither can overflow this way.)
@@ -324,6 +341,9 @@ class PanSt3R(nn.Module):
                     raise FloatingPointError("non-finite outputs: an activation of the panoptic decoder left the f16 range (amp='bf16' runs that stage on f16 "
                                              "operands); run with panoptic_precision='amp' (bf16 there too) or 'reference' (fp32 there)")
                 raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16' (or amp=False)")
+            if outdevice is not None:
+                res = {i: (res[i][0].to(outdevice), res[i][1].to(outdevice)) for i in range(V)}
+                scene = {'pred_logits': scene['pred_logits'], 'out_queries': scene['out_queries'].clone()}
         panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
                   'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
         pms = [res[i][0] for i in range(V)]

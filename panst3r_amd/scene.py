@@ -188,7 +188,7 @@ class SceneRunner:
     (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
     def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None,
-                 amp=None, plan='replicated', minmax_bs=1, pan_amp=None, mm_override=None, pan_scope='reference'):
+                 amp=None, plan='replicated', minmax_bs=1, pan_amp=None, mm_override=None, pan_scope='reference', stream_bank=True):
         self.b, self.V, self.classes = backend, V, classes
         # reference AMP placement (panst3r.py:174-175,204-245,268): `amp` names the format of the encoder, the memory build and the keyframes' render +
         # DINOv2; `pan_amp` (None = the same format) that of the panoptic decoder AND of the render + DINOv2 of the views that are not keyframes.
@@ -232,6 +232,10 @@ class SceneRunner:
         self.builder = plan == 'replicated' or rank == 0        # this rank runs the sequential memory build
         # the broadcast plan's split stage 2 also runs on a 1-rank process group (PST_FORCE_DIST=1: the collectives execute on RCCL at world = 1)
         self.split = plan == 'broadcast' and (world > 1 or (dist.is_available() and dist.is_initialized()))
+        # broadcast plan: the bank travels PER MEMORY UPDATE (the entries of update u go out while update u + 1 computes: K - 1 async broadcasts of 13.5 MiB x
+        # keyframes each instead of one of 27 MiB x K after the whole build - off the critical path); stream_bank=False: one broadcast at the end
+        self.stream_bank = bool(stream_bank) and self.split and hasattr(backend, 'bank_update_payload')
+        self._works, self._staged = [], []
         self.mine = [i for i in range(V) if owner[i] == rank]       # positions in `order`; keyframe positions first
         self.n_local = len(self.mine)
         self.k_local = sum(1 for i in self.mine if i < K)
@@ -384,7 +388,8 @@ class SceneRunner:
                 self.bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.ref_split)
             else:
                 self._encode_rest()
-                self.bank = b.bank_alloc(self.K, self.kf_grids, dev, self.ref_split)
+                if not self.stream_bank:          # (streamed: allocated when the receives were posted, before this stage)
+                    self.bank = b.bank_alloc(self.K, self.kf_grids, dev, self.ref_split)
             return
         # (measured +5 % frames/s at 50 views, but unsafe on this platform - see OVERLAP_DEFAULT - hence only when asked for)
         side = b.side_stream(dev) if not self.serial else None
@@ -404,6 +409,55 @@ class SceneRunner:
                 bank = b.build_memory(self.enc_kf, self.K, self.kf_grids, self.ref_split)
                 main.wait_stream(side)
         self.bank = bank
+
+    # ---- broadcast plan with a streamed bank: per-update stages / collectives (callables are cached: _segments is called more than once)
+    def _cached(self, key, make):
+        c = self.__dict__.setdefault('_seg_cache', {})
+        if key not in c:
+            c[key] = make()
+        return c[key]
+
+    def _build_step(self, u):
+        def step():
+            b = self.b
+            if u == 0:
+                self.bank = b.bank_new(self.K, self.kf_grids, self.groups[0].imgs.device, self.ref_split)
+            b.build_step(self.bank, self.enc_kf, self.K, self.kf_grids, u)
+        step.__name__ = 'build_step_%d' % u
+        return self._cached(('step', u), lambda: step)
+
+    def _bank_send(self, u):
+        def send():
+            if u == 0:
+                self._works, self._staged = [], []
+            payload = self.b.bank_update_payload(self.bank, self.K, self.kf_grids, u)        # contiguous staging copies of the update's entries
+            self._staged.append(payload)                                                    # (alive until the transfer is done)
+            for t in payload:
+                self._works.append(dist.broadcast(t.view(torch.uint8) if t.is_contiguous() else t, 0, group=self.group, async_op=True))
+            if u == len(self.b.update_spans(self.K, self.kf_grids)) - 1:
+                for w in self._works:
+                    w.wait()
+                self._works, self._staged = [], []
+                self.bank = self.b.bank_final(self.bank)
+        send.__name__ = 'bank_send_%d' % u
+        return self._cached(('send', u), lambda: send)
+
+    def _bank_post_recvs(self):
+        b = self.b
+        self.bank = b.bank_alloc(self.K, self.kf_grids, self.groups[0].imgs.device, self.ref_split)
+        self._works, self._staged = [], []
+        for u in range(len(b.update_spans(self.K, self.kf_grids))):
+            payload = b.bank_update_buffers(self.bank, self.K, self.kf_grids, u)
+            self._staged.append(payload)
+            for t in payload:
+                self._works.append(dist.broadcast(t.view(torch.uint8) if t.is_contiguous() else t, 0, group=self.group, async_op=True))
+
+    def _bank_finish(self):
+        for w in self._works:
+            w.wait()
+        for u, payload in enumerate(self._staged):
+            self.b.bank_update_store(self.bank, self.K, self.kf_grids, u, payload)
+        self._works, self._staged = [], []
 
     def bank_exchange(self):
         """plan='broadcast': the projected K / V^T caches of all layers go from rank 0 to everybody (RCCL broadcast over xGMI; 27 MiB x K)."""
@@ -459,6 +513,13 @@ class SceneRunner:
     def _segments(self):
         """[(stage, collective run eagerly behind it | None)]: the replicated plan has three stages, the broadcast plan splits stage 2 around the
         bank broadcast"""
+        if self.split and self.stream_bank:
+            U = len(self.b.update_spans(self.K, self.kf_grids))
+            if self.builder:
+                mid = [(self._build_step(u), self._bank_send(u)) for u in range(U)]
+            else:         # the receives are posted BEFORE this rank's own stage 2a work (they complete behind it, on the transport's stream)
+                mid = [(None, self._bank_post_recvs), (self.stage2a, self._bank_finish)]
+            return [(self.stage1, self.gather1)] + mid + [(self.stage2b, self.gather2), (self.stage3, None)]
         if self.split:
             return [(self.stage1, self.gather1), (self.stage2a, self.bank_exchange), (self.stage2b, self.gather2), (self.stage3, None)]
         if self.masked:       # a PAIR of stages = two branches on two CU-masked streams, joined before the next segment
@@ -526,7 +587,7 @@ class SceneRunner:
         for stage, coll in self._segments():
             if isinstance(stage, tuple):
                 self._par(stage)
-            else:
+            elif stage is not None:
                 stage()
             if coll is not None:
                 self._collective(coll)
@@ -573,6 +634,10 @@ class SceneRunner:
                 self.graphs.append(tuple(pair))
                 self._par(stage, pair)
                 continue
+            if stage is None:                  # a collective-only segment (posting the bank receives)
+                self.graphs.append(None)
+                gather()
+                continue
             g = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of torch.distributed may query events while we capture
             with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
@@ -606,7 +671,7 @@ class SceneRunner:
                     for g, (stage, coll) in zip(self.graphs, self._segments()):
                         if isinstance(g, tuple):
                             self._par(stage, g)
-                        else:
+                        elif g is not None:
                             g.replay()
                         if coll is not None:
                             self._collective(coll)
@@ -632,7 +697,7 @@ class SceneRunner:
 
 @torch.no_grad()
 def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None, keyframes=None, amp=None, plan='replicated',
-              minmax_bs=1):
+              minmax_bs=1, stream_bank=True):
     """Run one scene eagerly.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
     Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
     {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W);
@@ -642,7 +707,7 @@ def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=No
     _, order, owner = assign_views(V, Kc, world, keyframes, plan)
     images = {order[i]: get_image(order[i]) for i in range(V) if owner[i] == rank}
     return SceneRunner(backend, images, V, H, W, K, classes, rank, world, group, use_graphs=False, shapes=shapes, keyframes=keyframes, amp=amp, plan=plan,
-                       minmax_bs=minmax_bs).run(outdevice)
+                       minmax_bs=minmax_bs, stream_bank=stream_bank).run(outdevice)
 
 
 class HipBackend:
@@ -748,6 +813,35 @@ class HipBackend:
 
     def bank_payload(self, bank):
         return [bank.K_all, bank.Vt_all] + ([bank.f32.K_all, bank.f32.Vt_all] if bank.f32 is not None else [])
+
+    # ---- the bank per memory update (broadcast plan, streamed)
+    def update_spans(self, K, grids):
+        return self.m.memory_update_spans(K, grids)
+
+    def bank_new(self, K, grids, device, f32_bank=False):
+        return self.m.must3r_decoder.new_bank(device, sum(a * c for a, c in grids), f32=f32_bank)
+
+    def build_step(self, bank, enc_kf, K, grids, u):
+        self.m.build_memory_step(bank, enc_kf, K, grids, u)
+
+    def bank_final(self, bank):
+        return bank
+
+    def _bank_views(self, bank, K, grids, u):
+        _, _, tok, n = self.update_spans(K, grids)[u]
+        banks = [bank] + ([bank.f32] if bank.f32 is not None else [])
+        return [v for bk in banks for v in (bk.K_all[:, tok:tok + n], bk.Vt_all[:, :, tok:tok + n])]
+
+    def bank_update_payload(self, bank, K, grids, u):
+        """the entries update `u` appended, as contiguous copies (K rows [L, n, D] and V^T columns [L, D, n] per bank): what goes on the wire"""
+        return [v.contiguous() for v in self._bank_views(bank, K, grids, u)]
+
+    def bank_update_buffers(self, bank, K, grids, u):
+        return [torch.empty(v.shape, dtype=v.dtype, device=v.device) for v in self._bank_views(bank, K, grids, u)]
+
+    def bank_update_store(self, bank, K, grids, u, payload):
+        for dst, src in zip(self._bank_views(bank, K, grids, u), payload):
+            dst.copy_(src)
 
     def bank_alloc(self, K, grids, device, f32_bank=False):
         """an empty memory bank of the shape build_memory leaves behind (plan='broadcast': filled by the broadcast from rank 0)"""

@@ -75,6 +75,48 @@ class OracleBackend:
     def bank_payload(self, bank):
         return list(bank[0]) + [bank[1]]
 
+    # ---- the bank per memory update (broadcast plan, streamed): the oracle's memory is a tuple (per-layer values [1, n, D], labels [1, n], nimgs, ...)
+    def update_spans(self, K, grids):
+        from oracle.must3r import mem_batches_for
+        Ts = [a * c for a, c in grids]
+        out, start, tok = [], 0, 0
+        for nb in mem_batches_for(K):
+            n = sum(Ts[start:start + nb])
+            out.append((start, nb, tok, n))
+            start, tok = start + nb, tok + n
+        return out
+
+    def bank_new(self, K, grids, device, f32_bank=False):
+        return [None]                      # a box holding the oracle's memory tuple (grows with every update)
+
+    def build_step(self, bank, enc_kf, K, grids, u):
+        start, nb, tok, n = self.update_spans(K, grids)[u]
+        p = self.patch_size
+        xs, poss, shapes, o = [], [], [], tok
+        for h, w in grids[start:start + nb]:
+            xs.append(enc_kf[o:o + h * w][None])
+            poss.append(self._pos(h, w))
+            shapes.append([h * p, w * p])
+            o += h * w
+        bank[0], _, _ = self.m.must3r_decoder.forward_list(xs, poss, shapes, bank[0], render=False)
+
+    def bank_final(self, bank):
+        return bank[0]                     # unbox: the memory tuple every other stage takes
+
+    def bank_update_payload(self, bank, K, grids, u):
+        _, _, tok, n = self.update_spans(K, grids)[u]
+        mem = bank[0]
+        return [v[:, tok:tok + n].contiguous() for v in mem[0]] + [mem[1][:, tok:tok + n].contiguous()]
+
+    def bank_update_buffers(self, bank, K, grids, u):
+        _, _, tok, n = self.update_spans(K, grids)[u]
+        return [torch.zeros(1, n, self.Dd) for _ in range(self.m.must3r_decoder.depth)] + [torch.zeros(1, n, dtype=torch.long)]
+
+    def bank_update_store(self, bank, K, grids, u, payload):
+        _, _, tok, n = self.update_spans(K, grids)[u]
+        for dst, src in zip(list(bank[0]) + [bank[1]], payload):
+            dst[:, tok:tok + n] = src
+
     def bank_alloc(self, K, grids, device, f32_bank=False):
         n = sum(a * c for a, c in grids)
         vals = [torch.zeros(1, n, self.Dd) for _ in range(self.m.must3r_decoder.depth)]

@@ -364,7 +364,8 @@ def run_sharded_on_one_gpu(model, imgs, V, H, W, K, names, world, monkeypatch, k
         mine = {order_owner[1][i]: imgs[order_owner[1][i]] for i in range(V) if order_owner[2][i] == r}
         from panst3r_amd.panst3r import pan_amp_of
         pa, ps = pan_amp_of(amp, None)          # the product's default placement of the format (scene_runner does the same)
-        runners.append(S.SceneRunner(S.HipBackend(model), mine, V, H, W, K, names, rank=r, world=world, keyframes=keyframes, amp=amp, plan=plan, pan_amp=pa, pan_scope=ps))
+        runners.append(S.SceneRunner(S.HipBackend(model), mine, V, H, W, K, names, rank=r, world=world, keyframes=keyframes, amp=amp, plan=plan, pan_amp=pa, pan_scope=ps,
+                                     stream_bank=False))          # (the collectives are replaced by device copies below: the bank in one piece)
     sends = []
     monkeypatch.setattr(S, '_all_gather_rows', lambda t, counts, w, g: [s[:c] for s, c in zip(sends, counts)])
     from panst3r_amd.model.common import precision

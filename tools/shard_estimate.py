@@ -45,7 +45,7 @@ def main():
             continue
         _, order, owner = S.assign_views(V, K, world, plan=plan)
         runners = [S.SceneRunner(S.HipBackend(model), {order[i]: imgs[order[i]] for i in range(V) if owner[i] == r}, V, H, W, K, names,
-                                 rank=r, world=world, plan=plan) for r in range(world)]
+                                 rank=r, world=world, plan=plan, stream_bank=False) for r in range(world)]
         split = plan == 'broadcast'
         for rn in runners:
             rn.split = split

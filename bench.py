@@ -397,6 +397,7 @@ def main():
                                    % ('f16' if args.amp == 'fp16' else 'bf16', args.amp),
                        'launch': 'eager' if args.eager else 'HIP-graph replay (3 graphs per scene; last timed step eager + HIP-event instrumented)',
                        'overlap_auto': OVERLAP_PICK.get(str(args.amp) + '/None'),
+                       'overlap_streams': {k[1]: v for k, v in __import__('panst3r_amd.scene', fromlist=['HipBackend']).HipBackend._MASKED_LOG.items()} or None,
                        'overlap': {'auto': 'auto: the serial and the CU-masked two-queue stage 2 are both captured and timed during warm-up, the faster runs '
                                            '(overlap_auto; bit-identical results: tests/test_hip_fullsize.py::test_full_size_masked_overlap_equals_serial)',
                                    'off': 'off (one stream)', 'plain': 'memory build || non-keyframe encoder + DINOv2 on two ordinary streams (measurement only)',

@@ -132,12 +132,12 @@ OVERLAP_DEFAULT = False
 # side by side (tests/diag/cu_mask_graph.py).  `overlap='masked'`: the sequential memory build on MASK_BUILD_CUS CUs beside the first MASK_LAYERS layers of
 # the two ViT-L towers on the rest; everything behind the join on all CUs again.  The kernels are told their CU budget (pst_tune PST_TUNE_CUS: grids of the
 # persistent kernels); which kernel variant runs never changes a bit, so the masked scene equals the serial one bit for bit (tests/test_hip_fullsize.py).
-# Measured (tools/overlap_bench.py, profiles/r5_overlap_bench.txt; 50 views / 16 keyframes): 128 CUs (16 per XCD = 4 per shader engine) for the build and 10 of
-# the 24 tower layers beside it: 150.4 ms against 158.1 serial (+5 %); the build alone on a masked stream: 33 ms on 128 CUs, but 50 - 88 ms on 48 ... 112 and
-# 144 ... 192 CUs (tools/masked_build_bench.py) - CU sets that are not a power of two per shader engine run its short kernels several times slower - so the
-# split is fixed at half the chip and `pick_overlap` below keeps the masked form only where it is measured faster on the box at hand.
-MASK_BUILD_CUS = int(__import__('os').environ.get('PST_MASK_BUILD_CUS', '128'))
-MASK_LAYERS = int(__import__('os').environ.get('PST_MASK_LAYERS', '10'))
+# Measured (tools/overlap_bench.py, profiles/r5_overlap_bench.txt; 50 views / 16 keyframes, healthy streams): the optimum is flat between 96 and 128 CUs for the
+# build with 10 - 12 of the 24 tower layers beside it: 148.5 - 151.4 ms against 158.3 - 160.5 serial (+5 ... 7 %); 64 or 160 CUs for the build: no gain.  Some masked
+# queues come up in a slow state on this platform (every kernel 3 - 6 x slower; HipBackend.masked_streams calibrates and re-creates them), so `pick_overlap`
+# below still keeps the masked form only where it is measured faster on the box at hand.
+MASK_BUILD_CUS = int(__import__('os').environ.get('PST_MASK_BUILD_CUS', '112'))
+MASK_LAYERS = int(__import__('os').environ.get('PST_MASK_LAYERS', '11'))
 DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a callable run on the main stream beside the side branch
 
 
@@ -292,7 +292,7 @@ class SceneRunner:
         ov = OVERLAP_DEFAULT if overlap is None else overlap
         # 'masked': the build and the first tower layers on disjoint CU sets (above); needs the lock-step tower pass for every shape group and a rank that builds
         self.masked = ov == 'masked' and not self.split and self.builder and not self.ref_split and hasattr(backend, 'masked_streams') and \
-            all(backend.rest_pairable(g.imgs[g.k:], g.imgs) for g in self.groups)
+            all(backend.rest_pairable(g.imgs[g.k:], g.imgs) for g in self.groups) and backend.masked_streams(self.groups[0].imgs.device, MASK_BUILD_CUS) is not None
         self.serial = self.masked or not ov      # True: no plain two-stream stage 2 (the two branches back-to-back, or the masked form)
         self.graphs = None
         self.coll_events = None       # bench.py: [] -> every eager collective is bracketed by HIP events (collective_ms)
@@ -763,11 +763,12 @@ class HipBackend:
         return self._side
 
     _MASKED = {}
+    _MASKED_LOG = {}       # per (device, split): the calibration timings of the streams that were tried
 
     def masked_streams(self, device, build_cus):
         """(stream A, stream B, CUs of A, CUs of B): two HIP streams whose queues may only use DISJOINT CU sets - A the first `build_cus` mask bits, B the
         rest (hipExtStreamCreateWithCUMask; the driver deals consecutive mask bits round-robin over the 8 XCDs, so both sets span all of them).
-        One pair per (device, split), for the life of the process."""
+        One pair per (device, split), for the life of the process; None when no healthy pair could be made (the caller runs serially)."""
         key = (str(device), int(build_cus))
         if key not in HipBackend._MASKED:
             import ctypes
@@ -784,9 +785,58 @@ class HipBackend:
                 rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
                 if rc != 0:
                     raise RuntimeError('hipExtStreamCreateWithCUMask failed (%d)' % rc)
-                return torch.cuda.ExternalStream(h.value, device=device)
+                return h
+
+            # Some masked queues come up SLOW on this platform: every kernel on them takes 3 - 6 x as long (profiles/r5_masked_kernel_probe.txt: a 768^3 GEMM 6.1 us
+            # on the default stream, 7.7 / 8.8 us on the 192- / 96-CU streams, 34 / 31 us on the 128- / 64-CU streams created between them; which ones
+            # alternates with the creation order, not with the mask).  Each stream is therefore calibrated when it is made - a captured chain of small GEMMs
+            # against the same chain on the default stream - and re-created (up to 6 times) until it runs at the speed its CU share allows.
+            a_ = torch.randn(768, 768, device=device).half()
+            c_ = torch.empty(768, 768, device=device, dtype=torch.float16)
+
+            def chain_us(stream):
+                def chain():
+                    for _ in range(64):
+                        torch.mm(a_, a_, out=c_)
+                chain()
+                torch.cuda.synchronize(device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    chain()
+                import time
+                best = 1e9
+                for _ in range(3):
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    if stream is None:
+                        g.replay()
+                    else:
+                        with torch.cuda.stream(stream):
+                            g.replay()
+                    torch.cuda.synchronize(device)
+                    best = min(best, (time.perf_counter() - t0) * 1e6 / 64)
+                return best
+
+            def good(lo, hi, ref_us):
+                share = (hi - lo) / float(ncu)
+                limit = ref_us * max(2.0, 1.2 / share)             # a 144-tile GEMM on a quarter of the chip may take ~4 x; a slow queue takes that on HALF of it
+                tried = []
+                for _ in range(6):
+                    h = mk(lo, hi)
+                    s_ = torch.cuda.ExternalStream(h.value, device=device)
+                    us = chain_us(s_)
+                    tried.append(round(us, 1))
+                    if us <= limit:
+                        return s_, tried
+                    del s_
+                    rt.hipStreamDestroy(h)
+                return None, tried
             with torch.cuda.device(device):
-                HipBackend._MASKED[key] = (mk(0, build_cus), mk(build_cus, ncu), build_cus, ncu - build_cus)
+                ref_us = chain_us(None)
+                sa, ta = good(0, build_cus, ref_us)
+                sb, tb = good(build_cus, ncu, ref_us) if sa is not None else (None, [])
+                HipBackend._MASKED[key] = (sa, sb, build_cus, ncu - build_cus) if sb is not None else None
+                HipBackend._MASKED_LOG[key] = dict(default_stream_us=round(ref_us, 1), build_stream_tries_us=ta, bulk_stream_tries_us=tb)
         return HipBackend._MASKED[key]
 
     def cu_budget(self, cus):

@@ -45,6 +45,7 @@ print('serial                         %8.2f ms per scene  %7.2f frames/s' % (1e3
 for cus, layers in combos:
     S.MASK_BUILD_CUS, S.MASK_LAYERS = cus, layers
     r = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=True, amp='fp16', overlap='masked')
+    print('   stream calibration:', S.HipBackend._MASKED_LOG, flush=True)
     assert r.masked
     res, sc = r.run()
     bad = 0

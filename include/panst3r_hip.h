@@ -224,6 +224,10 @@ int pst_split3(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, in
 int pst_split_operand(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int K, int Kpad, int side, int dtype16, void* stream);
 int pst_split2(const float* x, int64_t ldx, void* hi, void* lo, int64_t ldo, int rows, int K, int transpose, int dtype16, void* stream);
 int pst_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, void* stream);
+/* rope2d_split: pst_rope2d on fp32 rows x [rows, nheads*hd] (leading dimension ld) written as the (hi, lo) planes of the rotated values ([rows, ldo] each): the
+ * rotation in front of pst_attn_x3 without an fp32 write-back and a second pass (same arithmetic as pst_rope2d followed by pst_split2) */
+int pst_rope2d_split(const float* x, int64_t ld, const int32_t* pos, const float* cs, void* hi, void* lo, int64_t ldo, int rows, int nheads, int hd, int dtype16,
+                     void* stream);
 int pst_attn_x3(const pst_attn_params* p, const void* Q_lo, const void* K_lo, const void* Vt_lo, int out_type, int64_t out_block, void* stream);
 const char* pst_attn_x3_variant(const pst_attn_params* p);
 

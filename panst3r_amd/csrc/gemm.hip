@@ -501,7 +501,6 @@ __device__ __forceinline__ void gemm_tile(const pst_gemm_params& p_in, const int
 }
 
 static int g_cu_budget = 0;           // PST_TUNE_CUS: CUs the launches enqueued now may assume (a CU-masked stream); 0 = the device's
-namespace pst { int cu_budget() { return g_cu_budget; } }
 static int num_cus() {
   if (g_cu_budget > 0) return g_cu_budget;
   static int cus = 0;
@@ -723,7 +722,7 @@ extern "C" int pst_tune(int knob, int value) {
   if (knob == PST_TUNE_ATTN_XCD) return pst::attn_xcd_order(value);
   if (knob == PST_TUNE_DEEP_RING) { const int prev = g_deep_ring; if (value == 4 || value == 6 || value == 8) g_deep_ring = value; return prev; }
   if (knob == PST_TUNE_PAIR) { const int prev = g_pair; g_pair = value != 0; return prev; }
-  if (knob == PST_TUNE_CUS) { const int prev = g_cu_budget; if (value >= 0 && value <= 1024) g_cu_budget = value; return prev; }
+  if (knob == PST_TUNE_CUS) { const int prev = pst::g_cu_budget; if (value >= 0 && value <= 1024) pst::g_cu_budget = value; return prev; }
   return -1;
 }
 

@@ -102,6 +102,40 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* x, int64_t 
   }
 }
 
+// RoPE-2D on fp32 q | k rows, written as (hi, lo) planes: the stand-alone rotation of the fp32 mode (misc.hip rope2d_kernel: same pairs, same rope_pair arithmetic)
+// fused with the split pass in front of attn_x3 - x is read once, nothing is written back in fp32.
+__global__ void rope2d_split_kernel(const float* x, int64_t ld, const int32_t* pos, const float* cs, uint16_t* hi, uint16_t* lo, int64_t ldo, int rows, int nheads,
+                                    int hd, int tc) {
+  const int nf = hd / 4;
+  const int per_row = nheads * 2 * (nf / 4);
+  const int64_t total = (int64_t)rows * per_row;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / per_row);
+    int r = (int)(i - (int64_t)row * per_row);
+    const int fq = (r % (nf / 4)) * 4; r /= (nf / 4);
+    const int half = r & 1, head = r >> 1;
+    const int pp = pos[2 * row + half];
+    const int col = head * hd + half * (hd / 2) + fq;
+    const float4 a4 = *(const float4*)(x + (int64_t)row * ld + col), b4 = *(const float4*)(x + (int64_t)row * ld + col + nf);
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float* t = cs + ((int64_t)pp * nf + fq) * 2;
+    float oa[4], ob[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = t[2 * k], sn = t[2 * k + 1];
+      oa[k] = rope_pair(a[k], b[k], c, sn, false);
+      ob[k] = rope_pair(b[k], a[k], c, sn, true);
+    }
+    uint2 h2, l2;
+    split4(oa, tc, h2, l2);
+    *(uint2*)(hi + (int64_t)row * ldo + col) = h2;
+    *(uint2*)(lo + (int64_t)row * ldo + col) = l2;
+    split4(ob, tc, h2, l2);
+    *(uint2*)(hi + (int64_t)row * ldo + col + nf) = h2;
+    *(uint2*)(lo + (int64_t)row * ldo + col + nf) = l2;
+  }
+}
+
 }  // namespace pst
 
 using namespace pst;
@@ -134,4 +168,15 @@ extern "C" int pst_transpose_f32(const float* x, int64_t ldx, float* y, int64_t 
   const int vec = (ldy % 4 == 0 && !((uintptr_t)y & 15)) ? 1 : 0;         // 16-byte stores along the transposed rows where they are aligned
   hipLaunchKernelGGL(transpose_kernel<false>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, (void*)y, (void*)nullptr, ldy, rows, cols, 0, vec);
   return check_launch("transpose_f32");
+}
+
+extern "C" int pst_rope2d_split(const float* x, int64_t ld, const int32_t* pos, const float* cs, void* hi, void* lo, int64_t ldo, int rows, int nheads, int hd, int dtype16,
+                                void* stream) {
+  if (bad16(dtype16) || !x || !pos || !cs || !hi || !lo || rows <= 0 || nheads <= 0 || hd % 16 || ld % 4 || ldo % 4 || ldo < (int64_t)nheads * hd ||
+      ((uintptr_t)x & 15) || (((uintptr_t)hi | (uintptr_t)lo) & 7)) {
+    set_error("rope2d_split: bad argument (hd=%d)", hd); return PST_EINVAL;
+  }
+  const int64_t total = (int64_t)rows * nheads * 2 * (hd / 16);
+  hipLaunchKernelGGL(rope2d_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ld, pos, cs, (uint16_t*)hi, (uint16_t*)lo, ldo, rows, nheads, hd, dtype16);
+  return check_launch("rope2d_split");
 }

@@ -40,7 +40,7 @@ class AttnParams(C.Structure):
 
 
 EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 'pst_gemm_pair', 'pst_gemm_pair_variant', 'pst_tune', 'pst_mask_head', 'pst_mask_head_supported', 'pst_attn_fwd', 'pst_attn_variant', 'pst_attn_pair', 'pst_attn_pair_variant', 'pst_attn_workspace_bytes', 'pst_layernorm', 'pst_layernorm_add',
-           'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_split_operand', 'pst_split2', 'pst_transpose_f32', 'pst_attn_x3', 'pst_attn_x3_variant', 'pst_rope2d',
+           'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_split_operand', 'pst_split2', 'pst_transpose_f32', 'pst_rope2d_split', 'pst_attn_x3', 'pst_attn_x3_variant', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_loftup_minmax', 'pst_minmax_merge', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
            'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize', 'pst_pointmap_activate', 'pst_focal_weiszfeld', 'pst_rigid_moments',
@@ -304,6 +304,18 @@ def split2(x, transpose=False, hi=None, lo=None, fmt=None):
         hi, lo = torch.empty(shape, dtype=fmt or X3_FMT, device=x.device), torch.empty(shape, dtype=fmt or X3_FMT, device=x.device)
     _check(lib().pst_split2(_ptr(x), i64(_rowmajor(x)), _ptr(hi), _ptr(lo), i64(_rowmajor(hi)), rows, K, int(transpose), _tc(hi), _stream()), 'pst_split2')
     return hi, lo
+
+
+def rope2d_split(x, pos, table, nheads, hd, fmt=None):
+    """RoPE-2D of the first nheads*hd columns of the fp32 rows x -> Planes(hi, lo) [rows, nheads*hd] of the rotated values (the q | k operand of attention on
+    split operands; x is not modified): rope2d_ + split2 in one pass"""
+    _dev(x, torch.float32); _dev(pos, torch.int32); _dev(table, torch.float32)
+    rows, cols = x.shape[0], nheads * hd
+    hi = torch.empty(rows, cols, dtype=fmt or X3_FMT, device=x.device)
+    lo = torch.empty(rows, cols, dtype=fmt or X3_FMT, device=x.device)
+    _check(lib().pst_rope2d_split(_ptr(x), i64(_rowmajor(x)), _ptr(pos), _ptr(table), _ptr(hi), _ptr(lo), i64(cols), rows, nheads, hd, _tc(hi), _stream()),
+           'pst_rope2d_split')
+    return Planes(hi, lo)
 
 
 def transpose_f32(x, out):
@@ -632,7 +644,7 @@ def attention_pair(first, second):
     """Two independent attention calls, each (args tuple, kwargs dict) of hip.attention, through pst_attn_pair: ONE launch over both block lists when both
     take the same 128-query kernel variant (the self-attentions of two ViT towers in lock-step), else two launches; same bits either way."""
     (a1, k1), (a2, k2) = first, second
-    if a1[0].dtype == torch.float32 and X3:
+    if (isinstance(a1[0], Planes) or a1[0].dtype == torch.float32) and X3:
         attention(*a1, **k1)
         attention(*a2, **k2)
         return

@@ -279,27 +279,41 @@ def self_attention_parts(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None)
     assert xv is xn, 'self_attention: w_qk and w_v must share one LayerNorm (row slices of one qkv pack)'
     fused_rope = rope is not None and hd == 64 and adt() != torch.float32   # RoPE-2D applied in the GEMM's store phase
     qk_call = (xn, w_qk.w, qk, dict(bias=w_qk.b, gamma=qs, ln=lq, **({'rope': (pos, rope)} if fused_rope else {})))
+    qk3 = None
     if x3():        # V row-major in fp32; the (hi, lo) planes of V^T come out of ONE transposing split pass (no fp32 V^T, no second pass inside hip.attention)
         v32 = empty(lay.rows, D, torch.float32, dev)
         vt_call = (xv, w_v.w, v32, dict(bias=w_v.b, ln=lv))
+        if rope is None and xn.dtype != torch.float32:
+            # no rotation between the projection and the attention (DINOv2): q | k leave the GEMM through its split store - rows [hi | hi | lo], whose first
+            # and last blocks ARE the two planes the attention kernel reads (row stride 6 D) - no fp32 q | k, no split pass
+            qk3 = torch.empty(lay.rows, 6 * D, dtype=hip.X3_FMT, device=dev)
+            qk_call = (xn, w_qk.w, qk3, dict(bias=w_qk.b, gamma=qs, ln=lq, x3_block=2 * D))
     else:
         vt_call = (xv, w_v.w, vt, dict(bias=w_v.b, trans_out=True, ln=lv))
 
     def finish(launch=True):
         """launch=False: everything but the attention launch; returns (output buffer, hip.attention args, kwargs) for hip.attention_pair"""
-        if rope is not None and not fused_rope:
-            hip.rope2d_(qk, pos, rope, 2 * H, hd)
+        q_op, k_op = qk, qk[:, D:]
+        if qk3 is not None:
+            q_op = hip.Planes(qk3[:, :2 * D], qk3[:, 4 * D:])
+            k_op = hip.Planes(qk3[:, D:2 * D], qk3[:, 5 * D:])
+        elif rope is not None and not fused_rope:
+            if x3():                                  # the rotation and the split into planes in one pass over the fp32 q | k
+                q_op = hip.rope2d_split(qk, pos, rope, 2 * H, hd)
+                k_op = hip.Planes(q_op.hi[:, D:], q_op.lo[:, D:])
+            else:
+                hip.rope2d_(qk, pos, rope, 2 * H, hd)
         o = attn_out(lay.rows, D, dev)
         ldo = o.stride(0)
         if lay.Tp != lay.N:
             o.view(lay.V, lay.Tp, ldo)[:, lay.N:].zero_()    # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
         vts = hip.Planes(*hip.split2(v32, transpose=True)) if x3() else vt
-        ldq, ldv = qk.stride(0), (vts.hi if x3() else vt).stride(0)
+        ldq, ldv = (q_op.hi if isinstance(q_op, hip.Planes) else qk).stride(0), (vts.hi if x3() else vt).stride(0)
         st = dict(q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq), v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * ldo, hd, ldo), prescaled=True)
         # (tried in round 4: DINOv2's 769 queries as two launches - 768 patch queries in full 128-row blocks + the CLS queries of all (view, head) pairs in
         # one-row blocks - to save every 7th block's walk over 13 key tiles: 4.58 + 0.97 ms against 5.05 ms for the one launch, i.e. slower; the one-row
         # launch is a 40 us latency chain of its own)
-        args = (qk, qk[:, D:], vts, o, lay.V, H, lay.N, lay.N, hd)
+        args = (q_op, k_op, vts, o, lay.V, H, lay.N, lay.N, hd)
         if not launch:
             return o, args, st
         hip.attention(*args, **st)

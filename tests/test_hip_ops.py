@@ -1009,6 +1009,53 @@ def test_gemm_pair_two_problems_one_persistent_launch(kind, Ma, Mb):
                 assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('Ve,Vd', [(1, 50), (4, 20), (10, 16), (20, 20), (34, 50), (48, 50)])
+@pytest.mark.parametrize('K', [1024, 4096])
+def test_gemm_pair_residual_class_does_not_depend_on_the_pairing(Ve, Vd, K):
+    """ADVICE r4: whether two residual-stream GEMMs share a persistent launch is decided from the row counts of BOTH towers (pair_split_256p's time model;
+    PST_TUNE_PAIR_RES moves K = 1024 problems that run on 128 x 128 tiles alone to the 256 x 256 persistent kernel when paired) - i.e. by the scene's
+    composition (Ve encoder views, Vd DINOv2 views).  A view's result must not: for a sweep of compositions the paired call (knobs at their defaults),
+    the paired call with PAIR_RES off, and two single launches give the SAME bits - output, 16-bit copy and fold statistics."""
+    from panst3r_amd import hip
+    N = 1024
+    Ma, Mb = Ve * 768, Vd * 776
+
+    def problem(seed, M, side):
+        a = bf(rn(seed, M, K)).to(dev())
+        w = bf(rn(seed + 1, N, K, scale=K ** -0.5)).to(dev())
+        b = rn(seed + 2, N).to(dev())
+        res = rn(seed + 4, M, N).to(dev())
+        kw = dict(bias=b, res=res)
+        if side == 1:
+            kw['gamma'] = (1 + 0.1 * rn(seed + 3, N)).to(dev())
+        return a, w, kw, M
+
+    probs = [problem(3000, Ma, 0), problem(3100, Mb, 1)]
+
+    def run(mode):
+        outs, calls = [], []
+        for a, w, kw, M in probs:
+            o = dict(out=torch.full((M, N), float('nan'), device=dev()), xcopy=torch.zeros(M, N, dtype=d16(), device=dev()), stats=torch.zeros(M, N // 64, 2, device=dev()))
+            calls.append((a, w, o['out'], dict(kw, xcopy=o['xcopy'], stats_out=o['stats'])))
+            outs.append([o['out'], o['xcopy'], o['stats']])
+        prev = hip.tune(hip.TUNE_PAIR_RES, 0 if mode == 'pair_res_off' else 1)
+        try:
+            if mode == 'single':
+                for c in calls:
+                    hip.gemm(c[0], c[1], c[2], **c[3])
+            else:
+                hip.gemm_pair(calls[0], calls[1])
+        finally:
+            hip.tune(hip.TUNE_PAIR_RES, prev)
+        return outs
+    ref = run('single')
+    for mode in ('pair', 'pair_res_off'):
+        got = run(mode)
+        for r, g in zip(ref, got):
+            for x, y in zip(r, g):
+                assert torch.equal(x, y), (mode, Ve, Vd, K)
+
+
 def test_loftup_minmax_and_merge():
     """the MinMaxScaler statistics for scopes wider than one view (loftup.py:14-19 pools min / max over the batch it is handed): per-view table of
     the 2x2-mean image, pooled over scope ids - exact (min / max are order-independent), and the guidance kernel scaled with the pooled table

@@ -122,3 +122,22 @@ def test_gemm_split_store_is_split_operand_of_the_fp32_result(M, N, K, kernel):
     got = torch.zeros(M, 3 * blk, dtype=torch.float16, device=DEV)
     hip.gemm(a, w, got, bias=b, act='gelu', kernel=kernel, x3_block=blk)
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize('hd,H', [(64, 12), (96, 4)])
+def test_rope2d_split_is_rope_then_split(hd, H):
+    """pst_rope2d_split: the stand-alone RoPE-2D of the fp32 mode fused with the split into attention planes - bit for bit pst_rope2d (in place, fp32) followed
+    by pst_split2, and the input is left untouched"""
+    from panst3r_amd import hip
+    rows, D = 200, 2 * H * hd
+    x = rn(21, rows, D + 8)[:, :D].to(DEV)
+    keep = x.clone()
+    g = np.random.Generator(np.random.PCG64(3))
+    pos = torch.from_numpy(g.integers(0, 32, size=(rows, 2)).astype(np.int32)).to(DEV)
+    table = hip.rope_table(32, hd, 100.0, DEV)
+    pl = hip.rope2d_split(x, pos, table, 2 * H, hd)
+    assert torch.equal(x, keep)
+    y = x.clone().contiguous()
+    hip.rope2d_(y, pos, table, 2 * H, hd)
+    hi, lo = hip.split2(y)
+    assert torch.equal(pl.hi, hi) and torch.equal(pl.lo, lo)

@@ -262,6 +262,7 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--parity-c4', action='store_true', help='also compare the TIMED configuration itself (v2, 50 views / 16 keyframes, full size) with the oracle on the host: several minutes')
     ap.add_argument('--parity-c5', action='store_true', help='also compare BASELINE configs[4] (v2, 200 views / 32 keyframes, fp16, full size) with the oracle on the host: ~15 min, ~12 GB of host memory')
+    ap.add_argument('--c5-views', type=int, default=200, help='views of the --parity-c5 scene (32 keyframes stay: the memory size class of configs[4]; the host oracle costs ~4 s / view)')
     ap.add_argument('--overlap', default='auto', choices=['auto', 'off', 'masked', 'plain'],
                     help="stage 2 of the scene: 'off' = the memory build and the bulk encoder / DINOv2 work back to back on one stream; 'masked' = the build on "
                          "a CU-masked stream beside the first tower layers on the other CUs (disjoint CU sets: panst3r_amd/scene.py); 'auto' (default) = both "
@@ -572,8 +573,8 @@ def main():
                 out['parity']['C4'] = full_size_parity(model, dev, refc, imgsc, tsc, names, args.amp, K=K)
                 del refc
             if args.parity_c5:
-                rec5, ref5, imgs5, ts5 = cpu_baseline(args.variant, H, W, state, names, emb, threads, V=200, K=32)
-                samples['C5_measured'] = {'config': 'C5: %s, 200 views / 32 keyframes, %dx%d, fp32 torch on %d host threads' % (args.variant, H, W, threads), 'frames_per_s': rec5['value']}
+                rec5, ref5, imgs5, ts5 = cpu_baseline(args.variant, H, W, state, names, emb, threads, V=args.c5_views, K=32)
+                samples['C5_measured'] = {'config': 'C5: %s, %d views / 32 keyframes, %dx%d, fp32 torch on %d host threads' % (args.variant, args.c5_views, H, W, threads), 'frames_per_s': rec5['value']}
                 out['parity']['C5'] = full_size_parity(model, dev, ref5, imgs5, ts5, names, 'fp16', K=32)
                 del ref5
             if not out['parity']['within_tolerance']:

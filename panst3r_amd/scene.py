@@ -18,6 +18,8 @@ results (the bank is built once, by the same kernels, and copied bit for bit).
 `run_scene` is written against a small stage backend so that the same orchestration is exercised on the GPU
 (HipBackend: the HIP kernels) and in the world_size-2 gloo tests on CPU (tests/ provide an oracle-driven backend).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -841,6 +843,8 @@ class HipBackend:
 
     def cu_budget(self, cus):
         from . import hip
+        if os.environ.get('PST_NO_CU_BUDGET') == '1':        # A/B measurements only (tools/overlap_bench.py): grids sized for the whole device
+            cus = 0
         hip.tune(hip.TUNE_CUS, int(cus))
 
     def rest_pairable(self, imgs_enc, imgs_dino):

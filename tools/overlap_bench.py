@@ -54,6 +54,16 @@ for cus, layers in combos:
         torch.cuda.synchronize()
         ok = torch.equal(sc['out_queries'], qref) and all(torch.equal(res[i][0], ref[i][0]) and torch.equal(res[i][1], ref[i][1]) for i in range(V))
         bad += not ok
+        if not ok:               # what deviates, and how: lost tile writes leave contiguous blocks, a summation-order change touches everything a little
+            dq = (sc['out_queries'] != qref)
+            print('      replay %d: out_queries %d of %d elements differ (max |d| %.3g)' % (rep, int(dq.sum()), dq.numel(), float((sc['out_queries'].float() - qref.float()).abs().max())), flush=True)
+            for i in range(V):
+                for j, nm in ((0, 'pointmap'), (1, 'masks')):
+                    d = res[i][j] != ref[i][j]
+                    if bool(d.any()):
+                        idx = d.flatten().nonzero().flatten()
+                        print('         view %2d %-8s %9d of %9d differ, flat index %d .. %d, max |d| %.3g' % (
+                            i, nm, idx.numel(), d.numel(), int(idx[0]), int(idx[-1]), float((res[i][j].float() - ref[i][j].float()).abs().max())), flush=True)
     dt = timed(r)
     print('masked build on %3d CUs, %2d layers beside it  %8.2f ms per scene  %7.2f frames/s   soak: %d of %d replays deviate from the serial scene'
           % (cus, layers, 1e3 * dt, V / dt, bad, SOAK), flush=True)

@@ -132,14 +132,17 @@ OVERLAP_DEFAULT = False
 # reproducer deviates 0 of 25 times on three boxes where plain (and full-mask) stream pairs deviate 25 of 25 (tests/diag/cu_mask_two_queue.py,
 # profiles/r5_cu_mask_two_queue_box{1,2,3}.txt), a captured graph runs on the CUs of the stream it is launched on and two graphs on two masked streams run
 # side by side (tests/diag/cu_mask_graph.py).  `overlap='masked'`: the sequential memory build on MASK_BUILD_CUS CUs beside the first MASK_LAYERS layers of
-# the two ViT-L towers on the rest; everything behind the join on all CUs again.  The kernels are told their CU budget (pst_tune PST_TUNE_CUS: grids of the
-# persistent kernels); which kernel variant runs never changes a bit, so the masked scene equals the serial one bit for bit (tests/test_hip_fullsize.py).
+# the two ViT-L towers on the rest; everything behind the join on all CUs again.  The kernels keep the grids they have on the whole device (a masked queue maps a persistent
+# kernel's 256 workgroups onto its CUs, two per CU); which kernel variant runs never changes a bit, so the masked scene equals the serial one bit for bit
+# (tests/test_hip_fullsize.py).  Telling the kernels the CU count of their stream (pst_tune PST_TUNE_CUS -> grids of 112 / 144 workgroups; PST_CU_BUDGET=1 here)
+# was measured and is OFF: the masked scene got slower (171 vs 154 ms, serial 160) and 2 of 36 replays deviated from the serial scene in the masks of the last
+# view that is not a keyframe - 0 of 130+ without it (profiles/r5_overlap_soak_budget.txt, r5_overlap_soak_nobudget.txt).  Not understood; not used.
 # Measured (tools/overlap_bench.py, profiles/r5_overlap_bench.txt; 50 views / 16 keyframes, healthy streams): the optimum is flat between 96 and 128 CUs for the
 # build with 10 - 12 of the 24 tower layers beside it: 148.5 - 151.4 ms against 158.3 - 160.5 serial (+5 ... 7 %); 64 or 160 CUs for the build: no gain.  Some masked
 # queues come up in a slow state on this platform (every kernel 3 - 6 x slower; HipBackend.masked_streams calibrates and re-creates them), so `pick_overlap`
 # below still keeps the masked form only where it is measured faster on the box at hand.
-MASK_BUILD_CUS = int(__import__('os').environ.get('PST_MASK_BUILD_CUS', '112'))
-MASK_LAYERS = int(__import__('os').environ.get('PST_MASK_LAYERS', '11'))
+MASK_BUILD_CUS = int(os.environ.get('PST_MASK_BUILD_CUS', '112'))
+MASK_LAYERS = int(os.environ.get('PST_MASK_LAYERS', '11'))
 DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a callable run on the main stream beside the side branch
 
 
@@ -843,7 +846,7 @@ class HipBackend:
 
     def cu_budget(self, cus):
         from . import hip
-        if os.environ.get('PST_NO_CU_BUDGET') == '1':        # A/B measurements only (tools/overlap_bench.py): grids sized for the whole device
+        if os.environ.get('PST_CU_BUDGET') != '1':           # measurement switch (tools/overlap_bench.py); off: see the note at MASK_BUILD_CUS
             cus = 0
         hip.tune(hip.TUNE_CUS, int(cus))
 

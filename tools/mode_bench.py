@@ -23,7 +23,9 @@ model.to(dev)
 images = {i: synth_image(i, H, W).to(dev) for i in range(V)}
 MODES = {'fp16': ('fp16', None), 'bf16': ('bf16', None), 'fp32': (False, None), 'fp32_exact': ('fp32_exact', None), 'fp16+reference': ('fp16', 'reference'),
          'bf16+reference': ('bf16', 'reference')}
-for mode in (sys.argv[1:] or ['fp16', 'fp32', 'fp16+reference']):
+SHAPES = '--shapes' in sys.argv           # also: one eager scene with every MFMA launch bracketed by HIP events, summed per (kernel, shape tag)
+argv = [a for a in sys.argv[1:] if a != '--shapes']
+for mode in (argv or ['fp16', 'fp32', 'fp16+reference']):
     exact = mode.endswith('_exact') and '+' in mode
     amp, pp = MODES[mode[:-6] if exact else mode]
     if exact:                                     # the fp32 segments of the reference placement on the fp32-input-MFMA kernels (round-4 behaviour)
@@ -41,6 +43,19 @@ for mode in (sys.argv[1:] or ['fp16', 'fp32', 'fp16+reference']):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     print('%-22s %8.2f ms per scene  %7.2f frames/s' % (mode, 1e3 * dt, V / dt), flush=True)
+    if SHAPES:
+        eager = model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=False, amp=amp, panoptic_precision=pp)
+        eager.run(copy=False)
+        hip.TIMER = timer = hip.KernelTimer()
+        eager.run(copy=False)
+        hip.TIMER = None
+        rows = sorted(timer.by_tag().items(), key=lambda kv: -kv[1]['ms'])
+        tot = sum(d['ms'] for _, d in rows)
+        print('   instrumented launches: %.1f ms in %d (kernel, shape) rows' % (tot, len(rows)))
+        for (name, tag), d in rows[:40]:
+            print('   %-22s %-70s x%-4d %8.2f ms %7.1f TF' % (name, tag, d['launches'], d['ms'], d['flops'] / max(d['ms'], 1e-9) * 1e-9), flush=True)
+        eager.release()
+        del eager
     if exact:
         P.pan_amp_of = orig
     runner.release()

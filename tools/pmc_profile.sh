@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $ROOT/bench.py --no-cpu-baseline --steps 10 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || true
 for P in a b c; do
   case $P in a) C="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES";; b) C="FETCH_SIZE";; c) C="WRITE_SIZE";; esac
-  timeout -k 5 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$P -o $P -- python $ROOT/bench.py --no-cpu-baseline --steps 1 --eager --no-kernel-timing > /dev/null 2> $OUT/$P.err || true
+  timeout -k 5 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$P -o $P -- python $ROOT/bench.py --no-cpu-baseline --steps 1 --eager --no-kernel-timing --overlap off > /dev/null 2> $OUT/$P.err || true
   # flatten: pmc_summary.py expects the csv files directly under the pass directory
   find $OUT/$P -name '*counter_collection.csv' -exec cp {} $OUT/$P/ \; ; find $OUT/$P -name '*kernel_trace.csv' -exec cp {} $OUT/$P/ \;
 done

@@ -305,7 +305,8 @@ class MaskTransformer(nn.Module):
     def __init__(self, in_dim, hidden_dim, ff_dim, mask_dim, num_queries, num_heads, dec_layers, lang_dim=768,
                  num_feature_levels=1, landscape_only=False, **kw):
         super().__init__()
-        assert num_feature_levels == 1 and not kw.get('two_stage', False)
+        assert num_feature_levels == 1
+        self.two_stage = bool(kw.get('two_stage', False))
         in_dim = [in_dim] if isinstance(in_dim, int) else list(in_dim)
         assert in_dim[0] == hidden_dim, 'released configs: fpn_dim == hidden_dim, input_proj is empty (mask_transformer.py:72-77)'
         self.pe_layer = PositionEmbeddingSine(hidden_dim // 2, normalize=True)
@@ -315,8 +316,9 @@ class MaskTransformer(nn.Module):
         self.ffn_layers = nn.ModuleList(FFNLayer(hidden_dim, ff_dim) for _ in range(dec_layers))
         self.decoder_norm = nn.LayerNorm(hidden_dim)
         self.num_queries = num_queries
-        self.query_feat = nn.Embedding(num_queries, hidden_dim)
-        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        if not self.two_stage:                                      # learnt queries (mask_transformer.py:61-65); two-stage: selected from the keyframe tokens
+            self.query_feat = nn.Embedding(num_queries, hidden_dim)
+            self.query_embed = nn.Embedding(num_queries, hidden_dim)
         self.level_embed = nn.Embedding(1, hidden_dim)
         self.input_proj = nn.ModuleList([nn.Sequential()])
         self.lang_embed = nn.Linear(hidden_dim, lang_dim)
@@ -344,8 +346,11 @@ class MaskTransformer(nn.Module):
             src.append(s + self.level_embed.weight[0][None, None])
         src, pos = torch.cat(src, 0), torch.cat(pos, 0)
         bs = src.shape[1]
-        qpos = self.query_embed.weight[:, None].repeat(1, bs, 1)
-        out = self.query_feat.weight[:, None].repeat(1, bs, 1)
+        if self.two_stage:                                          # :143-148
+            out, qpos = self.query_selection(src, pos, cls_embeddings)
+        else:
+            qpos = self.query_embed.weight[:, None].repeat(1, bs, 1)
+            out = self.query_feat.weight[:, None].repeat(1, bs, 1)
         cls, masks, amask = self.forward_prediction_heads(out, mask_feats, cls_embeddings, sizes, max_bs, outdevice, multi_ar)
         all_cls, all_masks = [cls], [masks]
         for i in range(self.num_layers):
@@ -361,12 +366,21 @@ class MaskTransformer(nn.Module):
                 'aux_outputs': [{'pred_logits': a, 'pred_masks': b} for a, b in zip(all_cls[:-1], all_masks[:-1])],
                 'out_queries': out.detach()}
 
-    def class_and_embed(self, output):
+    def query_selection(self, feats, pos, cls_embeddings):
+        """two_stage (mask_transformer.py:85-104): the num_queries tokens whose best class logit is largest become the initial queries, their
+        positional encodings the query positions.  feats, pos [NK, B, C] -> ([Q, B, C], [Q, B, C]), in descending order of that logit."""
+        lang, _ = self.class_and_embed(feats, embed=False)                                        # [B, NK, L], unit norm (:91-96)
+        logit = self.cls_logit_scale.exp() * lang @ cls_embeddings[None].transpose(1, 2)          # :97
+        idx = torch.topk(logit.max(-1)[0], self.num_queries, dim=1)[1]                            # [B, Q] (:99-100)
+        idx = idx.T[:, :, None].expand(-1, -1, feats.shape[-1])
+        return torch.gather(feats, 0, idx), torch.gather(pos, 0, idx)                             # :101-103
+
+    def class_and_embed(self, output, embed=True):
         """decoder_norm -> (unit-norm language embedding, mask embedding); mask_transformer.py:222-230."""
         d = self.decoder_norm(output).transpose(0, 1)
         lang = self.lang_embed(d)
         lang = lang / (lang.norm(dim=-1, keepdim=True) + 1e-7)
-        return lang, self.mask_embed(d)
+        return lang, (self.mask_embed(d) if embed else None)
 
     def forward_prediction_heads(self, output, mask_feats, cls_embeddings, attn_mask_target_size=None, max_bs=None,
                                  outdevice=None, multi_ar=False):
@@ -407,15 +421,21 @@ class PanopticDecoder(nn.Module):
                  num_queries=200, num_heads=8, dec_layers=6, text_encoder='siglip', fixed_vocab=True, label_mode='sigmoid',
                  two_stage=False, landscape_only=True, deep_supervision=True):
         super().__init__()
-        assert upscaler is not None and label_mode == 'sigmoid' and not two_stage
+        assert upscaler is not None and label_mode in ('sigmoid', 'softmax')
         self.input_mixer = input_mixer
         self.upscaler = upscaler
         self.landscape_only = landscape_only
         self.text_encoder = TextEncoder(text_encoder, out_dim=hidden_dim)
         self.label_mode = label_mode
+        if label_mode == 'softmax':                                 # one more class row, "no object", learnt and NOT normalised (panoptic_decoder.py:30-31,66-67)
+            self.nocls_token = nn.Parameter(torch.randn(self.text_encoder.embed_dim))
         self.mask_transformer = MaskTransformer(list(fpn_dim), hidden_dim, ff_dim, mask_dim, num_queries, num_heads, dec_layers,
                                                 lang_dim=self.text_encoder.embed_dim, num_feature_levels=len(fpn_dim),
-                                                landscape_only=landscape_only)
+                                                landscape_only=landscape_only, two_stage=two_stage)
+
+    def class_matrix(self, classes):
+        e = self.text_encoder(classes)
+        return torch.cat([e, self.nocls_token[None]], dim=0) if self.label_mode == 'softmax' else e
 
     def features(self, cat_feats, imgs, pos, true_shape, max_bs=None):
         """mixer + upscaler over a [B,n,...] stack in chunks of max_bs (panoptic_decoder.py:50-62)."""
@@ -437,7 +457,7 @@ class PanopticDecoder(nn.Module):
         else:
             f, mask_f = self.features(torch.cat(in_feats, dim=-1), in_imgs, pos, true_shape, max_bs)
             fpn = [f]
-        cls_emb = self.text_encoder(classes)
+        cls_emb = self.class_matrix(classes)
         if memory_queries is None:
             return self.mask_transformer(fpn, mask_f, true_shape, cls_emb, max_bs=max_bs, outdevice=outdevice, multi_ar=multi_ar)
         cls, masks, _ = self.mask_transformer.forward_prediction_heads(memory_queries, mask_f, cls_emb, multi_ar=multi_ar)

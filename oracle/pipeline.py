@@ -70,7 +70,7 @@ class PanSt3R(nn.Module):
                                           torch.stack([pos[i] for i in ch])[None], ts, max_bs=None)
                     for j, i in enumerate(ch):
                         feats[i] = (fpn[:, j:j + 1], mf[:, j:j + 1], torch.tensor([[list(sh)]]))
-        cls_emb = pd.text_encoder(classes)
+        cls_emb = pd.class_matrix(classes)
         mt = pd.mask_transformer
         out = mt([[f[0] for f in feats[:K]]], [f[1] for f in feats[:K]], [f[2] for f in feats[:K]], cls_emb, multi_ar=True)  # :244
         masks = [m[:, 0] for m in out['pred_masks']]
@@ -121,7 +121,7 @@ class PanSt3R(nn.Module):
                                   torch.stack([scenes[b]['pos'][i] for b, i in members])[None], ts, max_bs=None)
             for j, m in enumerate(members):
                 feats[m] = (fpn[:, j:j + 1], mf[:, j:j + 1], torch.tensor([[list(sh)]]))
-        cls_emb = pd.text_encoder(classes)
+        cls_emb = pd.class_matrix(classes)
         mt = pd.mask_transformer
         logits, masks, queries, pointmaps = [], [], [], []
         for b in range(B):

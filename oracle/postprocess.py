@@ -9,15 +9,19 @@ queries (:77), per-query area test mask_area / original_area >= overlap_threshol
 Pinned by tests/golden/postprocess_v2*.npz, generated from the reference's own function (tests/golden/make_golden.py G6).
 The selection of a query in one round does not depend on the other queries' selection in that round (the argmax is
 taken once per round, before the loop), so the per-query Python loop of the reference is restated as vector ops.
-Only 'sigmoid' label mode is restated (the released configs, configs/base.yaml:24).
+Both label modes are restated: 'sigmoid' (the released configs, configs/base.yaml:24) and 'softmax' (:48-51,59-60: the last class column is
+"no object"; pinned by tests/golden/postprocess_v2_softmax.npz).
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 
-def query_scores(mask_cls, cls_threshold=0.1, temperature=None):
-    """postprocess.py:40-47: scores, labels, keep of one scene's class logits [Q, Ncls]."""
+def query_scores(mask_cls, cls_threshold=0.1, temperature=None, label_mode='sigmoid'):
+    """postprocess.py:40-51: scores, labels, keep of one scene's class logits [Q, Ncls] (softmax mode: column Ncls-1 = "no object")."""
+    if label_mode == 'softmax':                                                                   # :48-51 (the temperature is not read in this mode)
+        scores, labels = F.softmax(mask_cls, dim=-1).max(-1)
+        return scores, labels, labels.ne(mask_cls.shape[-1] - 1) & (scores > cls_threshold)
     probs = mask_cls.sigmoid()
     scores, labels = probs.max(-1)
     keep = scores > cls_threshold
@@ -31,7 +35,7 @@ def panoptic_inference_v2(mask_cls, mask_pred, true_shape, label_mode='sigmoid',
                           mask_threshold=0.25, overlap_threshold=0.5, niters=2, void_confidence=0.1, device=None, multi_ar=True):
     """mask_cls [1,Q,Ncls]; mask_pred list[V] of [1,Q,h,w] logits; true_shape [V,2].
     Returns [{'pan': list[V] int32 [H,W], 'segments_info': [...], 'conf': list[V] fp32 [H,W]}]."""
-    assert label_mode == 'sigmoid' and multi_ar and mask_cls.shape[0] == 1
+    assert label_mode in ('sigmoid', 'softmax') and multi_ar and mask_cls.shape[0] == 1
     shapes = [tuple(int(v) for v in s) for s in true_shape]
     V = len(mask_pred)
     Hm, Wm = max(s[0] for s in shapes), max(s[1] for s in shapes)
@@ -40,7 +44,7 @@ def panoptic_inference_v2(mask_cls, mask_pred, true_shape, label_mode='sigmoid',
     for i, m in enumerate(mask_pred):
         up = F.interpolate(m.float().sigmoid(), size=list(shapes[i]), mode='bilinear', align_corners=False)   # :20-21
         probs[:, i, :shapes[i][0], :shapes[i][1]] = up[0]
-    scores, labels, keep = query_scores(mask_cls[0].float(), cls_threshold, temperature)
+    scores, labels, keep = query_scores(mask_cls[0].float(), cls_threshold, temperature, label_mode)
     cur_idx = torch.nonzero(keep)[:, 0]
     cur_scores, cur_classes, cur_masks = scores[cur_idx], labels[cur_idx], probs[cur_idx]         # :54-58
     cur_prob = cur_scores.view(-1, 1, 1, 1) * cur_masks                                           # :64

@@ -398,6 +398,65 @@ def golden_retrieval():
     save('keyframes_retrieval', **out)
 
 
+def golden_variants(R):
+    """G9: the two constructor variants the released configs leave off - `two_stage=True` (mask_transformer.py:85-104,143-148: queries selected from
+    the keyframe tokens) and `label_mode='softmax'` (panoptic_decoder.py:30-31,66-67: a learnt "no object" class row; postprocess.py:48-51,59-60)."""
+    from panst3r_amd.synthetic import fill_module_
+    MT = R['mask_transformer']
+    m = MT.MaskTransformer([64], 64, 128, 32, 16, 4, 2, lang_dim=48, num_feature_levels=1, two_stage=True, landscape_only=True).eval()
+    fill_module_(m, seed=17)
+    assert not hasattr(m, 'query_feat')
+    fpn = rnd(120, 1, 2, 64, 4, 6)
+    mf = rnd(121, 1, 2, 32, 32, 48)
+    ts = torch.tensor([[[64, 96], [64, 96]]])
+    cls = torch.nn.functional.normalize(rnd(122, 5, 48), dim=-1)
+    src = fpn.permute(0, 2, 1, 3, 4).flatten(-3).permute(2, 0, 1) + m.level_embed.weight[0][None, None]
+    pos = m.get_pe_with_transpose(fpn[:, 0], ts[:, 0]).repeat(2, 1, 1)
+    q0, qpos = m.query_selection([src], [pos], cls)
+    out = m([fpn], mf, ts, cls)
+    save('mask_transformer_two_stage_tiny', fpn=npy(fpn), mf=npy(mf), ts=npy(ts), cls=npy(cls), selected=npy(q0), selected_pos=npy(qpos),
+         pred_logits=npy(out['pred_logits']), pred_masks=npy(out['pred_masks']), out_queries=npy(out['out_queries']))
+
+    PD = R['panoptic_decoder'].PanopticDecoder
+    PS = R['pixel_shuffle'].PixelShuffleUpscaler
+    names = ['c%d' % i for i in range(5)]
+    cemb = rnd(130, 5, 768)
+    dec = PD(input_mixer=None, upscaler=PS(input_dim=40, fp_dim=[64, 32, 16, 8]), fpn_dim=[64], hidden_dim=64, mask_dim=8, ff_dim=128, num_queries=16,
+             num_heads=4, dec_layers=2, label_mode='softmax', two_stage=True).eval()
+    fill_module_(dec, seed=18)
+    dec.text_encoder.class_embeddings = {n: e for n, e in zip(names, cemb)}
+    f = (rnd(140, 1, 2, 24, 16), rnd(141, 1, 2, 24, 8), rnd(142, 1, 2, 24, 16))
+    imgs = rnd(143, 1, 2, 3, 64, 96).clamp(-1, 1)
+    ys, xs = torch.meshgrid(torch.arange(4), torch.arange(6), indexing='ij')
+    pos = torch.stack([ys, xs], -1).reshape(1, 1, -1, 2).expand(1, 2, -1, -1).contiguous()
+    o = dec(f, imgs, pos, ts, names, max_bs=1)
+    o3 = dec(f, imgs, pos, ts, names, max_bs=1, memory_queries=o['out_queries'])
+    assert o['pred_logits'].shape[-1] == 6
+    save('panoptic_decoder_softmax_two_stage_tiny', cemb=npy(cemb), f0=npy(f[0]), f1=npy(f[1]), f2=npy(f[2]), imgs=npy(imgs), pos=npy(pos), ts=npy(ts),
+         pred_logits=npy(o['pred_logits']), pred_masks=npy(o['pred_masks']), out_queries=npy(o['out_queries']), heads_logits=npy(o3['pred_logits']))
+
+    PP = R['postprocess']
+    seed, Q, ncls = 160, 16, 6                                 # 5 classes + "no object"
+    g = np.random.Generator(np.random.PCG64(seed))
+    logits = rnd(seed, 1, Q, ncls) * 2
+    logits[0, 3, -1] += 6.0                                    # queries 3 and 7: "no object" wins -> dropped whatever their score
+    logits[0, 7, -1] += 6.0
+    masks = []
+    for i, (h, w) in enumerate([(16, 24), (12, 24), (24, 16)]):
+        mm = rnd(seed + 1 + i, 1, Q, h, w) * 1.5 - 3.0
+        for q in range(Q):
+            y0, x0 = int(g.integers(0, h - 2)), int(g.integers(0, w - 2))
+            y1, x1 = int(g.integers(y0 + 2, h + 1)), int(g.integers(x0 + 2, w + 1))
+            mm[0, q, y0:y1, x0:x1] += 6.0
+        masks.append(mm)
+    size = np.array([[32, 48], [24, 48], [48, 32]])
+    for tag, fn, kw in (('v2', PP.panoptic_inference_v2, dict(cls_threshold=0.3)), ('v1', PP.panoptic_inference_v1, dict(cls_threshold=0.3))):
+        res = fn(logits.clone(), [x.clone() for x in masks], size, label_mode='softmax', device='cpu', multi_ar=True, **kw)[0]
+        info = np.array([[d['id'], d['query_id'], d['category_id']] for d in res['segments_info']], dtype=np.int64).reshape(-1, 3)
+        save('postprocess_%s_softmax' % tag, logits=npy(logits), masks=npy(masks), size=size, info=info,
+             pan=[np.asarray(p) for p in npy(res['pan'])], conf=[np.asarray(c) for c in npy(res['conf'])])
+
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'g2':
     golden_g2()
     sys.exit(0)
@@ -408,6 +467,9 @@ if __name__ == '__main__':
     elif len(sys.argv) > 1 and sys.argv[1] == 'qubo':             # G6b only
         with torch.no_grad():
             golden_qubo(import_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == 'variants':         # G9 only
+        with torch.no_grad():
+            golden_variants(import_reference())
     elif len(sys.argv) > 1 and sys.argv[1] == 'postprocess':      # regenerate G6 only
         with torch.no_grad():
             golden_postprocess(import_reference())

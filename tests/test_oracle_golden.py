@@ -268,3 +268,56 @@ def test_postprocess_qubo(golden, tag):
         assert torch.equal(a, b)
     for a, b in zip(res['conf'], g.lst('conf')):
         assert float((a - b).abs().max()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- G9: two_stage / label_mode='softmax'
+@torch.no_grad()
+def test_mask_transformer_two_stage(golden):
+    """two_stage=True (mask_transformer.py:85-104,143-148): the queries are the 16 keyframe tokens with the largest best-class logit, in that order;
+    the module has no learnt query tables.  Golden from the reference's own class (make_golden.py G9)."""
+    g = golden('mask_transformer_two_stage_tiny')
+    m = OP.MaskTransformer([64], 64, 128, 32, 16, 4, 2, lang_dim=48, num_feature_levels=1, landscape_only=True, two_stage=True).eval()
+    fill_module_(m, seed=17)
+    assert not any(k.startswith('query_') for k in m.state_dict())
+    fpn, ts = g.t('fpn'), g.t('ts')
+    src = fpn.permute(0, 2, 1, 3, 4).flatten(-3).permute(2, 0, 1) + m.level_embed.weight[0][None, None]
+    q0, qpos = m.query_selection(src, m._pos(fpn[:, 0], ts[:, 0]).repeat(2, 1, 1), g.t('cls'))
+    assert torch.equal(q0, g.t('selected')) and torch.equal(qpos, g.t('selected_pos'))
+    out = m([fpn], g.t('mf'), ts, g.t('cls'))
+    close(out['pred_logits'], g.t('pred_logits'))
+    close(out['pred_masks'], g.t('pred_masks'))
+    close(out['out_queries'], g.t('out_queries'))
+
+
+@torch.no_grad()
+def test_panoptic_decoder_softmax_two_stage(golden):
+    """label_mode='softmax' (panoptic_decoder.py:30-31,66-67): one more class column from the learnt, un-normalised `nocls_token`; with two_stage=True."""
+    g = golden('panoptic_decoder_softmax_two_stage_tiny')
+    d = OP.PanopticDecoder(input_mixer=None, upscaler=OP.PixelShuffleUpscaler(input_dim=40, fp_dim=[64, 32, 16, 8]), fpn_dim=[64], hidden_dim=64,
+                           mask_dim=8, ff_dim=128, num_queries=16, num_heads=4, dec_layers=2, label_mode='softmax', two_stage=True).eval()
+    fill_module_(d, seed=18)
+    assert 'nocls_token' in d.state_dict()
+    names = ['c%d' % i for i in range(5)]
+    d.text_encoder.class_embeddings = {n: e for n, e in zip(names, g.t('cemb'))}
+    f = (g.t('f0'), g.t('f1'), g.t('f2'))
+    o = d(f, g.t('imgs'), g.t('pos'), g.t('ts'), names, max_bs=1)
+    assert o['pred_logits'].shape[-1] == 6
+    close(o['pred_logits'], g.t('pred_logits'))
+    close(o['pred_masks'], g.t('pred_masks'))
+    close(o['out_queries'], g.t('out_queries'))
+    o3 = d(f, g.t('imgs'), g.t('pos'), g.t('ts'), names, max_bs=1, memory_queries=g.t('out_queries'))
+    close(o3['pred_logits'], g.t('heads_logits'))
+
+
+@pytest.mark.parametrize('ver', ['v2', 'v1'])
+def test_postprocess_softmax(golden, ver):
+    """label_mode='softmax' (engine/postprocess.py:48-51): softmax scores, the last column is "no object" (queries 3 and 7 of the golden)."""
+    import oracle.postprocess as OPP
+    g = golden('postprocess_%s_softmax' % ver)
+    res = getattr(OPP, 'panoptic_inference_' + ver)(g.t('logits'), g.lst('masks'), g.z['size'], label_mode='softmax', cls_threshold=0.3)[0]
+    info = [[d['id'], d['query_id'], d['category_id']] for d in res['segments_info']]
+    assert info == g.z['info'].tolist() and not {3, 7} & {i[1] for i in info}
+    for a, b in zip(res['pan'], g.lst('pan')):
+        assert torch.equal(a, b)
+    for a, b in zip(res['conf'], g.lst('conf')):
+        assert float((a - b).abs().max()) < 1e-6

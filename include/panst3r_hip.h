@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PST_ABI_VERSION 18
+#define PST_ABI_VERSION 19
 
 /* element type codes: every `*_type` / `dtype16` argument below (and the former `*_fp32` flags: 0 and 1 keep their meaning) */
 #define PST_BF16 0   /* bfloat16, raw uint16 */
@@ -337,6 +337,9 @@ int pst_loftup_lr_pe(const float* biases, void* out, int64_t ld, int col0, int n
  *   pp_finalize pan = seg_id[best_q] if best_m >= mask_threshold else 0; conf = best_m or void_confidence (:105-106) */
 int pst_pp_scores(const float* logits, int Q, int Ncls, float cls_threshold, float temperature, float* scores,
                   int* labels, int* keep, void* stream);
+/* (ABI 19) label_mode='softmax' (engine/postprocess.py:48-51): scores = softmax(logits).max, labels = its column, keep = label != Ncls - 1 (the
+ * "no object" column of panoptic_decoder.py:66-67) && score > cls_threshold; the temperature is not read in this mode */
+int pst_pp_scores_softmax(const float* logits, int Q, int Ncls, float cls_threshold, float* scores, int* labels, int* keep, void* stream);
 int pst_pp_sigmoid(const float* logits, const int* keep, float* probs, int Q, int P, void* stream);
 int pst_pp_argmax(const float* probs, const float* scores, const int* keep, int Q, int Hm, int Wm, int H, int W,
                   float mask_threshold, int* best_q, float* best_m, int* cnt_orig, int* cnt_mask, void* stream);

@@ -46,6 +46,34 @@ __global__ __launch_bounds__(64) void pp_scores_kernel(const float* logits, int 
   }
 }
 
+// label_mode='softmax' (:48-51): score = max softmax, label = its column, keep = label is not the last ("no object") column and score > threshold
+__global__ __launch_bounds__(64) void pp_scores_softmax_kernel(const float* logits, int Ncls, float cls_thr, float* scores, int* labels, int* keep) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const float* row = logits + (int64_t)q * Ncls;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < Ncls; c += 64) {
+    const float v = row[c];
+    if (v > best) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  float sum = 0.f;
+  for (int c = lane; c < Ncls; c += 64) sum += expf(row[c] - best);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if (lane == 0) {
+    const float score = 1.0f / sum;
+    scores[q] = score;
+    labels[q] = bi;
+    keep[q] = (bi != Ncls - 1 && score > cls_thr) ? 1 : 0;
+  }
+}
+
 // ------------------------------------------------------------------ sigmoid of the surviving queries of one view (:20)
 __global__ __launch_bounds__(256) void pp_sigmoid_kernel(const float* logits, const int* keep, float* probs, int P) {
   const int q = blockIdx.y;
@@ -302,6 +330,12 @@ extern "C" int pst_pp_scores(const float* logits, int Q, int Ncls, float cls_thr
   if (!logits || !scores || !labels || !keep || Q <= 0 || Ncls <= 0) { set_error("pp_scores: bad argument"); return PST_EINVAL; }
   hipLaunchKernelGGL(pp_scores_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, logits, Ncls, cls_threshold, temperature, scores, labels, keep);
   return check_launch("pp_scores");
+}
+
+extern "C" int pst_pp_scores_softmax(const float* logits, int Q, int Ncls, float cls_threshold, float* scores, int* labels, int* keep, void* stream) {
+  if (!logits || !scores || !labels || !keep || Q <= 0 || Ncls <= 1) { set_error("pp_scores_softmax: bad argument"); return PST_EINVAL; }
+  hipLaunchKernelGGL(pp_scores_softmax_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, logits, Ncls, cls_threshold, scores, labels, keep);
+  return check_launch("pp_scores_softmax");
 }
 
 extern "C" int pst_pp_sigmoid(const float* logits, const int* keep, float* probs, int Q, int P, void* stream) {

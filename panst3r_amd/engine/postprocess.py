@@ -22,8 +22,8 @@ def panoptic_inference_v2(mask_cls, mask_pred, true_shape, label_mode='sigmoid',
     [V,Q,h,w] / [1,V,Q,h,w] tensor; true_shape [V,2] (H, W) per view, or one (H, W) for a same-shape stack.
     Returns [{'pan': int32 maps, 'segments_info': [{'id','query_id','category_id'}], 'conf': fp32 maps}] with per-view
     lists for multi_ar=True (postprocess.py:121-123) and stacked [V,H,W] tensors otherwise; maps stay on the device."""
-    if label_mode != 'sigmoid':
-        raise NotImplementedError("released configs use label_mode='sigmoid' (configs/base.yaml:24)")
+    if label_mode not in ('sigmoid', 'softmax'):
+        raise ValueError("label_mode must be 'sigmoid' or 'softmax' (engine/postprocess.py:40-51), got %r" % (label_mode,))
     if isinstance(mask_pred, torch.Tensor):
         mp = mask_pred[0] if mask_pred.dim() == 5 else mask_pred
         views = [mp[i] for i in range(mp.shape[0])]
@@ -46,7 +46,10 @@ def panoptic_inference_v2(mask_cls, mask_pred, true_shape, label_mode='sigmoid',
     scores = torch.empty(Q, dtype=torch.float32, device=device)
     labels, keep = torch.empty(Q, **i32), torch.empty(Q, **i32)
     cnt_orig, cnt_mask, seg_id = torch.zeros(Q, **i32), torch.zeros(Q, **i32), torch.zeros(Q, **i32)
-    hip.pp_scores(logits, cls_threshold, temperature, scores, labels, keep)
+    if label_mode == 'softmax':         # the last class column is "no object" (:48-51); the reference does not read the temperature in this mode
+        hip.pp_scores_softmax(logits, cls_threshold, scores, labels, keep)
+    else:
+        hip.pp_scores(logits, cls_threshold, temperature, scores, labels, keep)
     fused = [hip.pp_fused_fits(Q, m.shape[-2], m.shape[-1], shapes[i][0], shapes[i][1]) for i, m in enumerate(views)]
     probs = None
     if not all(fused):     # strong down-sampling: the tile footprint does not fit in LDS -> probability scratch, reused per view
@@ -145,8 +148,9 @@ def panoptic_inference_qubo(mask_cls, mask_pred, true_shape, label_mode='sigmoid
     reference.  Result structure as the reference's (:206-217): 'pan' / 'conf' per view for multi_ar, stacked otherwise; `query_id` is the
     index among the SELECTED queries, exactly as the reference reports it (:202)."""
     import numpy as np
-    if label_mode != 'sigmoid':
-        raise NotImplementedError("released configs use label_mode='sigmoid' (configs/base.yaml:24)")
+    if label_mode != 'sigmoid':         # the reference itself cannot run this combination: :166-167 reads `cur_mask_cls` before any assignment (NameError)
+        raise NotImplementedError("panoptic_inference_qubo with label_mode='softmax' fails in the reference too (engine/postprocess.py:166-167); "
+                                  "use panoptic_inference_v2 / v1 for softmax-label models")
     device = torch.device(device)
     if device.type != 'cuda':
         raise RuntimeError('panst3r_amd.postprocess runs on the GPU only (got device=%s); there is no CPU fallback' % device)

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PST_LIB') or os.path.join(_HERE, 'lib', 'libpanst3r_hip.so')      # PST_LIB: A/B builds of the same ABI (measurement)
-ABI_VERSION = 18
+ABI_VERSION = 19
 STATS_BLOCKS = 128        # PST_STATS_BLOCKS
 _lib = None
 
@@ -43,7 +43,7 @@ EXPORTS = ['pst_abi_version', 'pst_last_error', 'pst_gemm', 'pst_gemm_variant', 
            'pst_layernorm_add_batch', 'pst_rowstats', 'pst_split3', 'pst_split_operand', 'pst_split2', 'pst_transpose_f32', 'pst_rope2d_split', 'pst_attn_x3', 'pst_attn_x3_variant', 'pst_rope2d',
            'pst_patchify', 'pst_dino_preprocess', 'pst_image_prepare', 'pst_patch_rows', 'pst_add_cast', 'pst_l2norm_rows', 'pst_mean4', 'pst_resize_bilinear',
            'pst_attn_mask_from_logits', 'pst_loftup_guidance_gn', 'pst_loftup_minmax', 'pst_minmax_merge', 'pst_groupnorm_stats', 'pst_groupnorm_apply',
-           'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize', 'pst_pointmap_activate', 'pst_focal_weiszfeld', 'pst_rigid_moments',
+           'pst_loftup_lr_pe', 'pst_pp_scores', 'pst_pp_scores_softmax', 'pst_pp_sigmoid', 'pst_pp_argmax', 'pst_pp_argmax_logits', 'pst_pp_select', 'pst_pp_finalize', 'pst_pointmap_activate', 'pst_focal_weiszfeld', 'pst_rigid_moments',
            'pst_qubo_upsample', 'pst_qubo_workspace_floats', 'pst_qubo_overlap', 'pst_qubo_argmax']
 
 
@@ -915,6 +915,12 @@ def pp_scores(logits, cls_threshold, temperature, scores, labels, keep):
     Q, Ncls = logits.shape
     _check(lib().pst_pp_scores(_ptr(logits), Q, Ncls, C.c_float(cls_threshold), C.c_float(temperature or 0.0), _ptr(scores), _ptr(labels),
                                _ptr(keep), _stream()), 'pst_pp_scores')
+
+
+def pp_scores_softmax(logits, cls_threshold, scores, labels, keep):
+    _dev(logits, torch.float32); _dev(scores, torch.float32); _dev(labels, torch.int32); _dev(keep, torch.int32)
+    Q, Ncls = logits.shape
+    _check(lib().pst_pp_scores_softmax(_ptr(logits), Q, Ncls, C.c_float(cls_threshold), _ptr(scores), _ptr(labels), _ptr(keep), _stream()), 'pst_pp_scores_softmax')
 
 
 def pp_sigmoid(logits, keep, probs, Q, P):

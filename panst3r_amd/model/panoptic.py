@@ -380,7 +380,8 @@ class MaskTransformer(HipModule):
                  num_feature_levels=1, landscape_only=False, **kw):
         super().__init__()
         in_dim = [in_dim] if isinstance(in_dim, int) else list(in_dim)
-        assert num_feature_levels == 1 and in_dim[0] == hidden_dim and not kw.get('two_stage', False)
+        assert num_feature_levels == 1 and in_dim[0] == hidden_dim
+        self.two_stage = bool(kw.get('two_stage', False))
         if mask_dim % 64 or (hidden_dim // num_heads) not in (64, 96):
             raise NotImplementedError('HIP MaskTransformer: mask_dim %% 64 == 0 and head dim 64/96 (got %d, %d)'
                                       % (mask_dim, hidden_dim // num_heads))
@@ -390,8 +391,9 @@ class MaskTransformer(HipModule):
         self.cross_attn_layers = nn.ModuleList(_CrossLayerP(hidden_dim) for _ in range(dec_layers))
         self.ffn_layers = nn.ModuleList(_FFNP(hidden_dim, ff_dim) for _ in range(dec_layers))
         self.decoder_norm = nn.LayerNorm(hidden_dim)
-        self.query_feat = nn.Embedding(num_queries, hidden_dim)
-        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        if not self.two_stage:             # learnt queries (mask_transformer.py:61-65); two_stage selects them from the keyframe tokens (:85-104)
+            self.query_feat = nn.Embedding(num_queries, hidden_dim)
+            self.query_embed = nn.Embedding(num_queries, hidden_dim)
         self.level_embed = nn.Embedding(1, hidden_dim)
         self.input_proj = nn.ModuleList([nn.Sequential()])
         self.lang_embed = ParamLinear(hidden_dim, lang_dim)
@@ -411,8 +413,8 @@ class MaskTransformer(HipModule):
             layers.append(dict(ca=mha(ca.multihead_attn), ca_norm=pack_norm(ca.norm, device), sa=mha(sa.self_attn),
                                sa_norm=pack_norm(sa.norm, device), l1=Packed(ff.linear1.weight, ff.linear1.bias, device),
                                l2=Packed(ff.linear2.weight, ff.linear2.bias, device), ff_norm=pack_norm(ff.norm, device)))
-        return dict(layers=layers, dn=pack_norm(self.decoder_norm, device), qf=f32(self.query_feat.weight, device),
-                    qe=f32(self.query_embed.weight, device), lvl=f32(self.level_embed.weight, device),
+        return dict(layers=layers, dn=pack_norm(self.decoder_norm, device), qf=None if self.two_stage else f32(self.query_feat.weight, device),
+                    qe=None if self.two_stage else f32(self.query_embed.weight, device), lvl=f32(self.level_embed.weight, device),
                     lang=Packed(self.lang_embed.weight, self.lang_embed.bias, device),
                     me=[Packed(l.weight, l.bias, device) for l in self.mask_embed.layers],
                     # the same MLP for split-precision evaluation: weights [W_hi | W_lo | W_hi] bf16, fp32 bias
@@ -469,6 +471,23 @@ class MaskTransformer(HipModule):
         gam = gams[cls_bf16.shape[0]]
         hip.gemm(ln, cls_bf16, logits, gamma=gam)
         return logits
+
+    def _select_queries(self, pk, fpn, grids, portrait, cls_bf16):
+        """two_stage (mask_transformer.py:85-104): decoder_norm -> lang_embed -> unit norm -> class logits of EVERY keyframe token; the num_queries tokens
+        with the largest best-class logit, in descending order, are the initial queries (their fp32 `fpn + level_embed` rows) and their sine encodings
+        the query positions.  The logits run through the same kernels as the class head; the top-k and the two row gathers are ATen ops."""
+        dev = fpn.device
+        NK, d = fpn.shape
+        if NK < self.num_queries:
+            raise ValueError('two_stage: %d keyframe tokens cannot supply %d queries (torch.topk fails the same way in the reference)' % (NK, self.num_queries))
+        src32 = empty(NK, d, torch.float32, dev)
+        hip.add_cast(fpn, src32, b=pk['lvl'], b_mod=1)
+        pos32 = torch.cat([self._pe(pk, h, w, pt, dev) for (h, w), pt in zip(grids, portrait)])
+        dn = empty(NK, d, adt(), dev)
+        hip.layernorm(src32, pk['dn'][0], pk['dn'][1], dn, pk['dn'][2])
+        best = self._class_logits(pk, dn, cls_bf16).max(-1)[0]
+        idx = torch.topk(best, self.num_queries)[1]
+        return src32.index_select(0, idx), pos32.index_select(0, idx), idx
 
     @torch.no_grad()
     def head_state(self, out_queries, cls_bf16):
@@ -560,8 +579,10 @@ class MaskTransformer(HipModule):
             for (h, w), pt in zip(grids, portrait):
                 hip.add_cast(src[o0:o0 + h * w], srcpos[o0:o0 + h * w], b=self._pe(pk, h, w, pt, dev))
                 o0 += h * w
-        out = pk['qf'].clone()
-        qpos = pk['qe']
+        if self.two_stage:
+            out, qpos, _ = self._select_queries(pk, fpn, grids, portrait, cls_bf16)
+        else:
+            out, qpos = pk['qf'].clone(), pk['qe']
         NKm = ceil_to(NK, 4)                   # mask rows are 4-byte aligned and the logit GEMM wants N % 4 == 0: odd token grids (21 x 21 at 336 x 336)
         mask = torch.zeros(Q, NKm, dtype=torch.uint8, device=dev)
         logits_attn = empty(Q, NKm, torch.float32, dev)[:, :NK]
@@ -689,14 +710,31 @@ class PanopticDecoder(HipModule):
                  landscape_only=True, deep_supervision=True):
         super().__init__()
         assert upscaler is not None, 'Upscaler module must be provided'
-        if label_mode != 'sigmoid' or two_stage:
-            raise NotImplementedError('released configs use label_mode=sigmoid, two_stage=False')
+        if label_mode not in ('sigmoid', 'softmax'):
+            raise ValueError("label_mode must be 'sigmoid' or 'softmax' (panoptic_decoder.py:20,30), got %r" % (label_mode,))
         self.input_mixer, self.upscaler = input_mixer, upscaler
         self.text_encoder = TextEncoder(text_encoder, out_dim=hidden_dim, fixed_vocab=fixed_vocab)
         self.label_mode, self.landscape_only = label_mode, landscape_only
+        if label_mode == 'softmax':        # a learnt "no object" class row behind the vocabulary, NOT normalised (panoptic_decoder.py:30-31,66-67)
+            self.nocls_token = nn.Parameter(torch.randn(self.text_encoder.embed_dim))
         self.mask_transformer = MaskTransformer(list(fpn_dim), hidden_dim, ff_dim, mask_dim, num_queries, num_heads, dec_layers,
                                                 lang_dim=self.text_encoder.embed_dim, num_feature_levels=len(fpn_dim),
-                                                landscape_only=landscape_only)
+                                                landscape_only=landscape_only, two_stage=two_stage)
+
+    def class_rows(self, classes, device):
+        """the W operand of the class-logit GEMM: unit-norm class embeddings [Ncls, 768 padded to 64] in the operand format, plus - label_mode='softmax' -
+        the raw `nocls_token` as row Ncls (panoptic_decoder.py:65-67).  Cached per vocabulary / token version; entries are never replaced (captured graphs)."""
+        rows = self.text_encoder.normalized_bf16(classes, device)
+        if self.label_mode != 'softmax':
+            return rows
+        cache = self.__dict__.setdefault('_rows_cache', {})
+        key = (rows.data_ptr(), rows.shape, rows.dtype, self.nocls_token.data_ptr(), self.nocls_token._version)
+        if key not in cache:
+            out = torch.zeros(rows.shape[0] + 1, rows.shape[1], dtype=rows.dtype, device=device)
+            out[:-1].copy_(rows)
+            out[-1, :self.nocls_token.numel()].copy_(self.nocls_token.detach().to(device))
+            cache[key] = (out, rows)               # `rows` kept alive: its address is part of the key
+        return cache[key][0]
 
     def _pack(self, device):
         return {}
@@ -816,7 +854,7 @@ class PanopticDecoder(HipModule):
         dev = feats[0][0].device
         p = self.upscaler.patch_size
         mt = self.mask_transformer
-        cls = self.text_encoder.normalized_bf16(classes, dev)
+        cls = self.class_rows(classes, dev)
         fpns, fms, mfs, grids, portraits = [], [], [], [], []
         for si in range(len(imgs)):
             n, T = feats[0][si].shape[1:3]

@@ -964,7 +964,7 @@ class HipBackend:
 
     def decode(self, fpn_kf, fm_kf, K, grids, classes, portrait):
         pd = self.m.panoptic_decoder
-        cls = pd.text_encoder.normalized_bf16(classes, fpn_kf.device)
+        cls = pd.class_rows(classes, fpn_kf.device)
         return pd.mask_transformer.decode_tokens(fpn_kf, fm_kf, list(grids), cls, list(portrait))
 
     def masks(self, head, mf, j):

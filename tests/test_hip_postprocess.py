@@ -62,6 +62,38 @@ def test_postprocess_v1_golden(golden, tag):
     _compare(res, ref, frac=0.0)
 
 
+@pytest.mark.parametrize('ver', ['v2', 'v1'])
+def test_postprocess_softmax_golden(golden, ver):
+    """label_mode='softmax' (engine/postprocess.py:48-51; pst_pp_scores_softmax): softmax scores, the last class column is "no object" - against the golden
+    generated from the reference's own function (make_golden.py G9); the QUBO variant refuses the mode as the reference fails in it (:166-167)."""
+    import panst3r_amd.engine as E
+    g = golden('postprocess_%s_softmax' % ver)
+    res = getattr(E, 'panoptic_inference_' + ver)(g.t('logits').to(DEV), [m.to(DEV) for m in g.lst('masks')], g.z['size'], label_mode='softmax',
+                                                  cls_threshold=0.3, multi_ar=True)[0]
+    ref = {'segments_info': [{'id': int(a), 'query_id': int(b), 'category_id': int(c)} for a, b, c in g.z['info'].tolist()],
+           'pan': g.lst('pan'), 'conf': g.lst('conf')}
+    _compare(res, ref, frac=0.0)
+    with pytest.raises(NotImplementedError, match='166'):
+        E.panoptic_inference_qubo(g.t('logits').to(DEV), [m.to(DEV) for m in g.lst('masks')], g.z['size'], label_mode='softmax', multi_ar=True)
+    with pytest.raises(ValueError):
+        E.panoptic_inference_v2(g.t('logits').to(DEV), [m.to(DEV) for m in g.lst('masks')], g.z['size'], label_mode='argmax', multi_ar=True)
+
+
+@pytest.mark.parametrize('Q,ncls', [(200, 101), (7, 2), (64, 65)])
+def test_pp_scores_softmax_kernel(Q, ncls):
+    from panst3r_amd import hip
+    from oracle.postprocess import query_scores
+    g = torch.Generator().manual_seed(Q)
+    logits = torch.randn(Q, ncls, generator=g) * 3
+    logits[::3, -1] += 5.0
+    s, l, k = query_scores(logits, 0.2, None, 'softmax')
+    sc, lb, kp = torch.empty(Q, device=DEV), torch.empty(Q, dtype=torch.int32, device=DEV), torch.empty(Q, dtype=torch.int32, device=DEV)
+    hip.pp_scores_softmax(logits.to(DEV), 0.2, sc, lb, kp)
+    assert torch.equal(lb.cpu().long(), l) and float((sc.cpu() - s).abs().max()) < 1e-6
+    near = (s - 0.2).abs() < 1e-6
+    assert torch.equal(kp.cpu().bool()[~near], k[~near])
+
+
 @pytest.mark.parametrize('kw', [{}, dict(niters=1), dict(niters=3, overlap_threshold=0.3), dict(cls_threshold=2.0),
                                 dict(mask_threshold=0.4, void_confidence=0.0)])
 def test_postprocess_vs_oracle(kw):

@@ -9,18 +9,19 @@ CAT = 128 + 128 + 128
 NAMES = ['c%d' % i for i in range(8)]
 
 
-def build(ns, variant, seed=21, sharp=1.0):
-    """ns: module namespace providing the reference class names (oracle.* or panst3r_amd.model)."""
+def build(ns, variant, seed=21, sharp=1.0, **pan_kw):
+    """ns: module namespace providing the reference class names (oracle.* or panst3r_amd.model); pan_kw: extra PanopticDecoder ctor arguments
+    (label_mode='softmax', two_stage=True: the variants the released configs leave off)."""
     enc = ns.Dust3rEncoder(**ENC)
     dec = ns.MUSt3R(**DEC)
     dino = ns.DinoV2Encoder(**DINO)
     if variant == 'v1':
         pan = ns.PanopticDecoder(input_mixer=None, upscaler=ns.PixelShuffleUpscaler(input_dim=CAT, fp_dim=[192, 128, 64, 64]),
-                                 fpn_dim=[192], hidden_dim=192, mask_dim=64, ff_dim=256, num_queries=24, num_heads=2, dec_layers=2)
+                                 fpn_dim=[192], hidden_dim=192, mask_dim=64, ff_dim=256, num_queries=24, num_heads=2, dec_layers=2, **pan_kw)
     else:
         pan = ns.PanopticDecoder(input_mixer=ns.InputMixer([96, 96], 16, CAT, 128, num_heads=2, num_layers=1, ff_dim_mult=2),
                                  upscaler=ns.LoftUpUpscaler(input_dim=128, dim=192, num_heads=2), fpn_dim=[128], hidden_dim=128,
-                                 mask_dim=192, ff_dim=256, num_queries=24, num_heads=2, dec_layers=2)
+                                 mask_dim=192, ff_dim=256, num_queries=24, num_heads=2, dec_layers=2, **pan_kw)
     model = ns.PanSt3R(enc, dec, dino, pan).eval()
     fill_module_(model, seed=seed, sharp=sharp)
     g = torch.Generator().manual_seed(5)

@@ -464,13 +464,24 @@ class MaskTransformer(HipModule):
         hip.gemm(dn, pk['lang'].w, lang, bias=pk['lang'].b)
         ln = torch.zeros(Q, cls_bf16.shape[1], dtype=adt(), device=dev)
         hip.l2norm_rows(lang, ln[:, :lang.shape[1]], 1e-7)
-        logits = empty(Q, cls_bf16.shape[0], torch.float32, dev)
+        # the GEMM wants N % 4 == 0: class counts like 133 (COCO panoptic) or 101 (100 classes + the softmax mode's "no object" row) run with up to three zero
+        # rows behind the real ones - already there in the storage of the matrices this module hands out (class_rows / normalized_bf16), else appended here
+        n = cls_bf16.shape[0]
+        n4 = ceil_to(n, 4)
+        w = cls_bf16
+        if n4 != n:
+            room = cls_bf16.untyped_storage().nbytes() // cls_bf16.element_size() - cls_bf16.storage_offset()
+            if cls_bf16.stride(1) == 1 and room >= (n4 - 1) * cls_bf16.stride(0) + cls_bf16.shape[1] and getattr(cls_bf16, '_pst_zero_tail', False):
+                w = cls_bf16.as_strided((n4, cls_bf16.shape[1]), cls_bf16.stride())
+            else:
+                w = torch.zeros(n4, cls_bf16.shape[1], dtype=cls_bf16.dtype, device=dev)
+                w[:n].copy_(cls_bf16)
+        logits = empty(Q, n4, torch.float32, dev)
         gams = pk.setdefault('gam', {})            # keyed by class count, entries never replaced (graph-captured addresses)
-        if cls_bf16.shape[0] not in gams:
-            gams[cls_bf16.shape[0]] = torch.full((cls_bf16.shape[0],), pk['scale'], dtype=torch.float32, device=dev)
-        gam = gams[cls_bf16.shape[0]]
-        hip.gemm(ln, cls_bf16, logits, gamma=gam)
-        return logits
+        if n4 not in gams:
+            gams[n4] = torch.full((n4,), pk['scale'], dtype=torch.float32, device=dev)
+        hip.gemm(ln, w, logits, gamma=gams[n4])
+        return logits if n4 == n else logits[:, :n].contiguous()
 
     def _select_queries(self, pk, fpn, grids, portrait, cls_bf16):
         """two_stage (mask_transformer.py:85-104): decoder_norm -> lang_embed -> unit norm -> class logits of EVERY keyframe token; the num_queries tokens
@@ -698,7 +709,9 @@ class TextEncoder(nn.Module):
             cache = self.__dict__['_cls_cache'] = {}
         if key not in cache:
             raw = torch.stack([self.class_embeddings[c] for c in classes]).float().to(device).contiguous()
-            out = torch.zeros(raw.shape[0], ceil_to(raw.shape[1], 64), dtype=adt(), device=device)
+            full = torch.zeros(ceil_to(raw.shape[0], 4), ceil_to(raw.shape[1], 64), dtype=adt(), device=device)
+            out = full[:raw.shape[0]]                # up to three zero rows stay behind the classes (MaskTransformer._class_logits: N % 4 == 0)
+            out._pst_zero_tail = True
             hip.l2norm_rows(raw, out[:, :raw.shape[1]], 0.0)
             cache[key] = out
         return cache[key]
@@ -730,7 +743,9 @@ class PanopticDecoder(HipModule):
         cache = self.__dict__.setdefault('_rows_cache', {})
         key = (rows.data_ptr(), rows.shape, rows.dtype, self.nocls_token.data_ptr(), self.nocls_token._version)
         if key not in cache:
-            out = torch.zeros(rows.shape[0] + 1, rows.shape[1], dtype=rows.dtype, device=device)
+            full = torch.zeros(ceil_to(rows.shape[0] + 1, 4), rows.shape[1], dtype=rows.dtype, device=device)
+            out = full[:rows.shape[0] + 1]
+            out._pst_zero_tail = True
             out[:-1].copy_(rows)
             out[-1, :self.nocls_token.numel()].copy_(self.nocls_token.detach().to(device))
             cache[key] = (out, rows)               # `rows` kept alive: its address is part of the key

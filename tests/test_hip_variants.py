@@ -77,3 +77,19 @@ def test_query_selection_16_bit(pair, amp):
     assert torch.equal(out.cpu(), (fpn16.float() + mo.level_embed.weight[0])[idx])
     picked = score[idx]
     assert bool((picked[:-1] >= picked[1:] - 2 * tol).all())       # descending up to the tolerance
+
+
+@pytest.mark.parametrize('ncls', [7, 5, 1])
+def test_class_count_not_a_multiple_of_4(ncls):
+    """vocabularies like COCO panoptic's 133 classes: the class-logit GEMM runs on zero-padded rows, the result has exactly `ncls` columns"""
+    o = tiny.build(tiny.OracleNS, 'v1')
+    h = tiny.build(tiny.hip_ns(), 'v1').to(DEV)
+    V, K, H, W = 3, 2, 64, 96
+    imgs = tiny.images(V, H, W)
+    ts = torch.tensor([[H, W]] * V)
+    names = tiny.NAMES[:ncls]
+    _, pan_o = o.forward_inference_multi_ar(imgs, ts, names, num_keyframes=K)
+    _, pan_h = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, names, num_keyframes=K, amp='fp16')
+    assert pan_h['pred_logits'].shape == pan_o['pred_logits'].shape == (1, 24, ncls)
+    assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 6e-3
+    assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 1.2e-2

@@ -342,7 +342,9 @@ class PanSt3R(nn.Module):
                                              "operands); run with panoptic_precision='amp' (bf16 there too) or 'reference' (fp32 there)")
                 raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16' (or amp=False)")
             if outdevice is not None:
-                res = {i: (res[i][0].to(outdevice), res[i][1].to(outdevice)) for i in range(V)}
+                from .scene import to_outdevice
+                moved = to_outdevice([res[i][0] for i in range(V)] + [res[i][1] for i in range(V)], outdevice)      # pinned staging, one DMA per block, one sync
+                res = {i: (moved[i], moved[V + i]) for i in range(V)}
                 scene = {'pred_logits': scene['pred_logits'], 'out_queries': scene['out_queries'].clone()}
         panout = {'pred_logits': scene['pred_logits'] if outdevice is None else scene['pred_logits'].to(outdevice),
                   'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}

@@ -139,3 +139,26 @@ def test_reference_stage_methods(variant):
         xe2, pe2 = h.forward_must3r_encoder(extra.to(DEV), ts2)
         pm2, mk2 = h._forward_decoder_render(extra.to(DEV), xe2, pe2, ts2, mem, pan['out_queries'][:, :1], tiny.NAMES)
         assert pm2.shape == (2, H, W, 7) and mk2.shape == (2, 24, H // 2, W // 2) and bool(torch.isfinite(mk2).all())
+
+
+@pytest.mark.parametrize('check_finite', [True, False])
+@pytest.mark.parametrize('cache_graphs', [False, True])
+def test_outdevice_cpu_goes_through_pinned_blocks(check_finite, cache_graphs):
+    """`outdevice='cpu'` (the demo's call, tools/demo_panst3r.py:232-233): the host outputs equal the device outputs bit for bit, for a scene with two shape
+    groups (the per-view tensors are views of one block per group: scene.to_outdevice copies blocks, not views), and they sit in pinned memory."""
+    h = tiny.build(tiny.hip_ns(), 'v2').to(DEV)
+    shapes = [(64, 96), (96, 64), (64, 96), (64, 96), (96, 64)]
+    imgs = [tiny.synth_image(i, a, b, 3) for i, (a, b) in enumerate(shapes)]
+    ts = torch.tensor(shapes)
+    kw = dict(num_keyframes=3, amp='fp16', check_finite=check_finite, cache_graphs=cache_graphs)
+    for _ in range(3 if cache_graphs else 1):                  # with cache_graphs: eager, capture, replay
+        pm_d, pan_d = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, **kw)
+        pm_d = [p.clone() for p in pm_d]
+        mk_d = [m.clone() for m in pan_d['pred_masks']]
+        pm_c, pan_c = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, outdevice='cpu', **kw)
+        for i, (a, b) in enumerate(shapes):
+            assert pm_c[i].device.type == 'cpu' and pm_c[i].is_pinned() and pm_c[i].shape == (1, a, b, 7)
+            assert pan_c['pred_masks'][i].device.type == 'cpu' and pan_c['pred_masks'][i].shape == (1, 24, a // 2, b // 2)
+            assert torch.equal(pm_c[i], pm_d[i].cpu()) and torch.equal(pan_c['pred_masks'][i], mk_d[i].cpu())
+        assert pan_c['pred_logits'].device.type == 'cpu' and torch.equal(pan_c['pred_logits'], pan_d['pred_logits'].cpu())
+    h.clear_runners()

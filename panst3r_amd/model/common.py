@@ -303,10 +303,16 @@ def self_attention_parts(s, lay, H, hd, w_qk, w_v, pos=None, rope=None, vt=None)
                 k_op = hip.Planes(q_op.hi[:, D:], q_op.lo[:, D:])
             else:
                 hip.rope2d_(qk, pos, rope, 2 * H, hd)
-        o = attn_out(lay.rows, D, dev)
-        ldo = o.stride(0)
         if lay.Tp != lay.N:
-            o.view(lay.V, lay.Tp, ldo)[:, lay.N:].zero_()    # only the Tp - N pad rows of each view (attention writes the N real ones): they stay finite
+            # pad rows (DINOv2: 769 tokens in 776 rows): the attention writes the N real rows of each view, the Tp - N pad rows must stay finite - ONE buffer
+            # per pass over the stream, its pad rows zeroed once (layer l's projection has consumed it before layer l + 1's attention rewrites it)
+            o = s.scratch.get(('attn_o', lay.rows, D, x3()))
+            if o is None:
+                o = s.scratch[('attn_o', lay.rows, D, x3())] = attn_out(lay.rows, D, dev)
+                o.view(lay.V, lay.Tp, o.stride(0))[:, lay.N:].zero_()
+        else:
+            o = attn_out(lay.rows, D, dev)
+        ldo = o.stride(0)
         vts = hip.Planes(*hip.split2(v32, transpose=True)) if x3() else vt
         ldq, ldv = (q_op.hi if isinstance(q_op, hip.Planes) else qk).stride(0), (vts.hi if x3() else vt).stride(0)
         st = dict(q_strides=(lay.Tp * ldq, hd, ldq), k_strides=(lay.Tp * ldq, hd, ldq), v_strides=(lay.Tp, hd * ldv, ldv), o_strides=(lay.Tp * ldo, hd, ldo), prescaled=True)
@@ -383,12 +389,13 @@ class Stream:
          `refresh()` does it for a stream no GEMM produced, and consumers pass ln=(st, colsum, eps).
     bf16: xb = LN(x) with the consumer's gamma / beta, one LayerNorm pass per version of x and per LayerNorm (`operand()` runs it lazily);
           consumers are plain GEMMs with the unfolded weights (the round-1 arithmetic)."""
-    __slots__ = ('x', 'xb', 'st', 'fold', 'dirty', 'eps')
+    __slots__ = ('x', 'xb', 'st', 'fold', 'dirty', 'eps', 'scratch')
 
     def __init__(self, x, xb=None, st=None):
         rows, D = x.shape
         assert D % 64 == 0, 'LayerNorm fold needs D %% 64 == 0 (got %d)' % D
         self.x, self.fold, self.dirty, self.eps = x, fold_in_epilogue(), True, None
+        self.scratch = {}                             # buffers the layers of ONE pass over this stream share (self_attention_parts)
         if x.dtype != torch.float32 and self.fold:
             self.xb = x                               # a 16-bit stream is its own raw operand
         elif x3():

@@ -60,6 +60,16 @@ class MemoryBank:
         self.K = [self.K_all[l] for l in range(self.L)]
         self.Vt = [self.Vt_all[l] for l in range(self.L)]
 
+    def vt_scratch(self, D, rows, dtype, device, tag='self'):
+        """zero-initialised V^T scratch [D, rows + 8] of the decoder calls that work on this bank (update and render chunks of `rows` rows): one buffer per
+        shape for the life of the bank instead of a zero fill per call - the transposed GEMM store writes columns [0, rows) only, the 8 pad columns the
+        attention kernel may touch stay 0.  Calls on one bank are ordered on one stream (the sequential build, then the render)."""
+        sc = self.__dict__.setdefault('_vt_scratch', {})
+        key = (tag, D, rows, dtype, str(device))
+        if key not in sc:
+            sc[key] = torch.zeros(D, rows + 8, dtype=dtype, device=device)
+        return sc[key]
+
     def reserve(self, n_tokens):
         if n_tokens <= self.cap:
             return
@@ -138,7 +148,10 @@ class MUSt3R(HipModule):
     # ------------------------------------------------------------------ core
     def _embed(self, pk, x_enc, lay, first_is_ref, out=None):
         dev = x_enc.device
-        x = torch.zeros(lay.rows, self.embed_dim, dtype=torch.float32, device=dev) if out is None else out.zero_()
+        if lay.grp is None:        # no pad rows: the GEMM writes every row
+            x = empty(lay.rows, self.embed_dim, torch.float32, dev) if out is None else out
+        else:
+            x = torch.zeros(lay.rows, self.embed_dim, dtype=torch.float32, device=dev) if out is None else out.zero_()
         hip.gemm(x_enc, pk['e2d'].w, x, bias=pk['bias_other'], grp=lay.grp)
         if first_is_ref:       # scene image 0 carries no image2_embed
             hip.gemm(x_enc[:lay.T], pk['e2d'].w, x[:lay.Tp], bias=pk['bias_ref'])
@@ -220,7 +233,8 @@ class MUSt3R(HipModule):
         # hs[l] = tokens entering block l (the candidate memory entries).  No copies: block l reads its residual from
         # hs[l] and the attention-projection GEMM writes the updated stream to a fresh buffer that becomes hs[l+1].
         hs = [hs_all[0]]
-        vt_self = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)      # V^T scratch shared by all layers (pad columns stay 0)
+        vt_self = bank.vt_scratch(D, lay.rows, adt(), dev)                   # V^T scratch shared by all layers AND by the calls on this bank (pad columns stay 0)
+        vt_pair = bank.vt_scratch(D, lay.rows, adt(), dev, 'pair') if n == 2 else None
         for l, bw in enumerate(pk['blocks']):
             s_in, s = S[l], S[l + 1]
             if lay.Tp != lay.T:
@@ -234,7 +248,7 @@ class MUSt3R(HipModule):
                 # each image attends to the other image's layer input (norm_y folded into projk / projv, on the fly)
                 kk = empty(lay.rows, D, adt(), dev)
                 a, ln = s_in.operand(c['k_f'])
-                vt = torch.zeros(D, lay.rows + 8, dtype=adt(), device=dev)
+                vt = vt_pair
                 hip.gemm_pair((a, c['k_f'].w, kk, dict(bias=c['k_f'].b, ln=ln)),
                               (a, c['v_f'].w, vt, dict(bias=c['v_f'].b, trans_out=True, ln=ln if ln is None else ln_of(c['v_f'], s_in.st))))
                 q = self._cross_q(s, bw)

@@ -279,6 +279,7 @@ class LoftUpUpscaler(HipModule):
         hip.gemm(lr, pk['lr_proj'].w, kv, bias=pk['lr_proj'].b, grp=lay.grp)
         kvn = empty(lay.rows, C, torch.float32, dev)
         hip.layernorm(kv, pk['lr_norm'][0], pk['lr_norm'][1], kvn, pk['lr_norm'][2])
+        vts = {}            # V^T scratch per chunk size, zeroed once (the transposed store writes the real columns; the 8 pad columns stay 0)
         for v0, n in view_chunks(V):
             # ---- 2 x cross-only blocks: 49k queries per view attend to the view's T low-res tokens (hd 96).
             # The residual stream of these two blocks is kept in bf16: they are HBM-bound over P x C elements per view
@@ -295,7 +296,9 @@ class LoftUpUpscaler(HipModule):
                 hip.layernorm(kvn[rows0:rows1], bw['norm_y'][0], bw['norm_y'][1], y, bw['norm_y'][2])
                 kk = empty(rows1 - rows0, C, adt(), dev)
                 hip.gemm(y, bw['k'].w, kk, bias=bw['k'].b)
-                vt = torch.zeros(C, rows1 - rows0 + 8, dtype=adt(), device=dev)
+                if rows1 - rows0 not in vts:
+                    vts[rows1 - rows0] = torch.zeros(C, rows1 - rows0 + 8, dtype=adt(), device=dev)
+                vt = vts[rows1 - rows0]
                 hip.gemm(y, bw['v'].w, vt, bias=bw['v'].b, trans_out=True)
                 a, ln = s.operand(bw['q'])
                 hip.gemm(a, bw['q'].w, q, bias=bw['q'].b, gamma=qscale(C, C, hd, dev), ln=ln)
@@ -621,12 +624,13 @@ class MaskTransformer(HipModule):
         next_mask(out)
         qin, ob = empty(Q, d, adt(), dev), empty(Q, d, adt(), dev)
         t32 = empty(Q, d, torch.float32, dev)
+        vt = torch.zeros(d, ceil_to(NK, 8) + 8, dtype=adt(), device=dev)        # V^T scratch of the cross- / self-attention, shared by the layers (pad columns stay 0)
+        vts = torch.zeros(d, ceil_to(Q, 8) + 8, dtype=adt(), device=dev)
         dn = emb = None
         for i, L in enumerate(pk['layers']):
             # masked cross-attention (post-LN): K from src+pos, V from src
             kc = empty(NK, d, adt(), dev)
             hip.gemm(srcpos, L['ca']['k'].w, kc, bias=L['ca']['k'].b)
-            vt = torch.zeros(d, ceil_to(NK, 8) + 8, dtype=adt(), device=dev)
             hip.gemm(src, L['ca']['v'].w, vt, bias=L['ca']['v'].b, trans_out=True)
             hip.add_cast(out, qin, b=qpos)
             q = empty(Q, d, adt(), dev)
@@ -641,7 +645,6 @@ class MaskTransformer(HipModule):
             qk = empty(Q, 2 * d, adt(), dev)
             hip.gemm(qin, L['sa']['qk'].w, qk, bias=L['sa']['qk'].b, gamma=qscale(d, 2 * d, hd, dev))
             hip.add_cast(out, ob)
-            vts = torch.zeros(d, ceil_to(Q, 8) + 8, dtype=adt(), device=dev)
             hip.gemm(ob, L['sa']['v'].w, vts, bias=L['sa']['v'].b, trans_out=True)
             o2 = empty(Q, d, adt(), dev)
             lds = vts.stride(0)

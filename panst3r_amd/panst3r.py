@@ -332,8 +332,13 @@ class PanSt3R(nn.Module):
             # check_finite=False skips it (SceneRunner.run, which bench.py times, never pays it).  The per-view mask tensors are VIEWS of one
             # [n, Q, H/2, W/2] allocation per shape group (one mask-head launch writes them all): holding one keeps its group's block alive.
             ok = torch.isfinite(scene['out_queries']).all() & torch.isfinite(scene['pred_logits']).all()
+            blocks = {}                     # the per-view tensors are views of one block per shape group and kind: check each block once, not 2 V views
             for i in range(V):
-                ok = ok & torch.isfinite(res[i][0]).all() & torch.isfinite(res[i][1]).all()
+                for t in res[i]:
+                    base = t._base if t._base is not None else t
+                    blocks.setdefault((base.data_ptr(), tuple(base.shape)), base)
+            for base in blocks.values():
+                ok = ok & torch.isfinite(base).all()
             if not bool(ok):
                 if not cache_graphs:
                     runner.release()

@@ -183,6 +183,15 @@ def to_outdevice(tensors, outdevice):
     dev = torch.device(outdevice)
     if dev.type != 'cpu' or not tensors or not tensors[0].is_cuda:
         return [t.to(dev) for t in tensors]
+    try:
+        return _to_host_pinned(tensors)
+    except RuntimeError as e:                  # the host cannot pin that much memory (hipHostMalloc failed): pageable copies, as the reference does
+        if 'out of memory' not in str(e).lower() and 'hipHostMalloc' not in str(e) and 'pin' not in str(e).lower():
+            raise
+        return [t.to(dev) for t in tensors]
+
+
+def _to_host_pinned(tensors):
     by_store = {}
     for k, t in enumerate(tensors):
         by_store.setdefault((t.untyped_storage().data_ptr(), t.dtype), []).append(k)

@@ -162,7 +162,7 @@ class PanSt3R(nn.Module):
         """CroCo encoder of `imgs_enc` and DINOv2 of `imgs_dino` (two independent ViT-L towers, panst3r.py:174-175 and :229-230) layer by layer in
         LOCK-STEP: the GEMMs of layer l of both towers go through hip.gemm_pair and share one persistent launch where the two tile lists fill the chip
         better side by side (model/common.py vit_block_pair).  Results are bit-identical to encode_views(enc only) + encode_views(dino only).
-        Falls back to the two sequential passes when a tower needs more than one chunk of views."""
+        Scenes with more views than one pass takes (ENC_CHUNK) run as several lock-step passes over equal shares of both towers' views (paired_begin)."""
         Ve, Vd = imgs_enc.shape[0], imgs_dino.shape[0]
         if not self.paired_ok(imgs_enc, imgs_dino):
             if Ve:
@@ -175,18 +175,34 @@ class PanSt3R(nn.Module):
         self.paired_finish(st, cat_enc, cat_dino, enc_copy)
 
     def paired_ok(self, imgs_enc, imgs_dino):
-        """the two towers can run in lock-step (one chunk of views each, same image shape)"""
+        """the two towers can run in lock-step (views for both, same image shape)"""
         Ve, Vd = imgs_enc.shape[0], imgs_dino.shape[0]
-        return not (Ve == 0 or Vd == 0 or Ve > ENC_CHUNK or Vd > ENC_CHUNK or tuple(imgs_enc.shape[1:]) != tuple(imgs_dino.shape[1:]))
+        return not (Ve == 0 or Vd == 0 or tuple(imgs_enc.shape[1:]) != tuple(imgs_dino.shape[1:]))
+
+    @staticmethod
+    def paired_shares(Ve, Vd):
+        """[((e0, e1), (d0, d1))]: the views of the two towers in P = ceil(max(Ve, Vd) / ENC_CHUNK) lock-step passes, pass i taking the i-th of P near-equal
+        shares of each tower's views (200 + 168 views: four passes of 50 + 42) - every pass pairs the towers, none is left with one tower alone"""
+        P = max(1, -(-max(Ve, Vd) // ENC_CHUNK))
+        cut = lambda V, i: (V * i) // P
+        return [((cut(Ve, i), cut(Ve, i + 1)), (cut(Vd, i), cut(Vd, i + 1))) for i in range(P)]
 
     # the lock-step pass in three parts, so that a scene runner can put the first layers beside the memory build and the rest behind it (scene.py, masked overlap)
     @torch.no_grad()
     def paired_begin(self, imgs_enc, imgs_dino):
+        """state of the FIRST lock-step pass (paired_layers works on it) plus the image shares of the passes behind it (paired_finish runs those)"""
+        shares = self.paired_shares(imgs_enc.shape[0], imgs_dino.shape[0])
+        (e0, e1), (d0, d1) = shares[0]
+        st = self._pass_begin(imgs_enc[e0:e1], imgs_dino[d0:d1])
+        st.update(shares=shares, imgs_enc=imgs_enc, imgs_dino=imgs_dino, views=(e1 - e0) + (d1 - d0))
+        return st
+
+    def _pass_begin(self, imgs_enc, imgs_dino):
         H, W = imgs_dino.shape[-2:]
         tr = bool(H > W and self.dino_encoder.landscape_only)
-        se = self.must3r_encoder.begin_tokens(imgs_enc.contiguous())
+        se = self.must3r_encoder.begin_tokens(imgs_enc.contiguous()) if imgs_enc.shape[0] else None
         sd = self.dino_encoder.begin_tokens(imgs_dino.contiguous(), transposed=tr)
-        be, bd = self.must3r_encoder.blocks(se), self.dino_encoder.blocks(sd)
+        be, bd = (self.must3r_encoder.blocks(se) if se is not None else []), self.dino_encoder.blocks(sd)
         return dict(se=se, sd=sd, be=be, bd=bd, n=max(len(be), len(bd)))
 
     @torch.no_grad()
@@ -201,8 +217,22 @@ class PanSt3R(nn.Module):
 
     @torch.no_grad()
     def paired_finish(self, st, cat_enc, cat_dino, enc_copy=None):
+        """final norms of the first pass into its rows of the feature concat, then the remaining passes (begin, all layers, norms) into theirs"""
+        T_e = cat_enc.shape[0] // max(st['imgs_enc'].shape[0], 1)
+        T_d = cat_dino.shape[0] // st['imgs_dino'].shape[0]
+        cur = st
+        for i, ((e0, e1), (d0, d1)) in enumerate(st['shares']):
+            if i:
+                cur = self._pass_begin(st['imgs_enc'][e0:e1], st['imgs_dino'][d0:d1])
+                self.paired_layers(cur, 0, cur['n'])
+            self._pass_finish(cur, cat_enc[e0 * T_e:e1 * T_e], cat_dino[d0 * T_d:d1 * T_d], None if enc_copy is None else enc_copy[e0 * T_e:e1 * T_e])
+            cur['se'] = cur['sd'] = None         # the pass's residual streams are not kept while the next one runs
+            cur['be'] = cur['bd'] = []
+
+    def _pass_finish(self, st, cat_enc, cat_dino, enc_copy=None):
         De, Dd = self.must3r_encoder.embed_dim, self.must3r_decoder.embed_dim
-        self.must3r_encoder.finish_tokens(st['se'], cat_enc, enc_copy)
+        if st['se'] is not None:
+            self.must3r_encoder.finish_tokens(st['se'], cat_enc, enc_copy)
         self.dino_encoder.finish_tokens(st['sd'], cat_dino, col0=De + Dd)
 
     # ------------------------------------------------------------------ scene stages (token level)

@@ -142,7 +142,18 @@ OVERLAP_DEFAULT = False
 # queues come up in a slow state on this platform (every kernel 3 - 6 x slower; HipBackend.masked_streams calibrates and re-creates them), so `pick_overlap`
 # below still keeps the masked form only where it is measured faster on the box at hand.
 MASK_BUILD_CUS = int(os.environ.get('PST_MASK_BUILD_CUS', '112'))
-MASK_LAYERS = int(os.environ.get('PST_MASK_LAYERS', '11'))
+MASK_LAYERS = int(os.environ.get('PST_MASK_LAYERS', '0'))      # 0 = from the balance rule below (11 at 50 views / 16 keyframes); tools/overlap_bench.py sets it
+
+
+def mask_layers(K, views_in_pass, n_layers):
+    """how many layers of the first lock-step tower pass run beside the memory build: as many as take the build's time.  Measured at 384 x 512 (768 tokens per
+    view): the build takes 23.2 ms at K = 16 and 53.7 ms at K = 32 (profiles/r5_build_bench.txt; 1.22 K + 0.0143 K^2), x 1.15 on its masked stream; one tower
+    layer of one view takes 0.0286 ms on the other 144 CUs (11 layers of 84 views beside the K = 16 build).  Both sides scale with the token count alike.
+    A mis-estimate costs idle time on one of the two streams, never a bit; `--overlap auto` keeps the masked form only where it is measured faster."""
+    if MASK_LAYERS > 0:
+        return min(MASK_LAYERS, n_layers)
+    build_ms = 1.15 * (1.222 * K + 0.01426 * K * K)
+    return max(1, min(n_layers, int(round(build_ms / (0.0286 * max(views_in_pass, 1))))))
 DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a callable run on the main stream beside the side branch
 
 
@@ -580,13 +591,15 @@ class SceneRunner:
     def stage2_head(self):
         b = self.b
         self._rest = [b.rest_begin(g.imgs[g.k:], g.imgs) for g in self.groups]
+        # the same number of layers for every shape group's first pass, together as long as the build
+        self._head_layers = mask_layers(self.K, sum(st.get('views', 0) for st in self._rest), max(st['n'] for st in self._rest))
         for st in self._rest:
-            b.rest_layers(st, 0, min(MASK_LAYERS, st['n']))
+            b.rest_layers(st, 0, min(self._head_layers, st['n']))
 
     def stage2_tail(self):
         b = self.b
         for g, st in zip(self.groups, self._rest):
-            b.rest_layers(st, min(MASK_LAYERS, st['n']), st['n'])
+            b.rest_layers(st, min(self._head_layers, st['n']), st['n'])
             b.rest_finish(st, g.cat[g.k * g.T:], g.cat, None if g.enc is None else g.enc[g.k * g.T:])
         self._rest = None
         self._guidance()

@@ -93,3 +93,27 @@ def test_class_count_not_a_multiple_of_4(ncls):
     assert pan_h['pred_logits'].shape == pan_o['pred_logits'].shape == (1, 24, ncls)
     assert float((pan_h['pred_logits'].cpu() - pan_o['pred_logits']).abs().max()) < 6e-3
     assert rel_l2(pan_h['out_queries'].cpu(), pan_o['out_queries']) < 1.2e-2
+
+
+@pytest.mark.parametrize('overlap', [False, 'masked'])
+def test_scenes_longer_than_one_tower_pass(monkeypatch, overlap):
+    """more views than one lock-step pass of the two ViT towers takes (ENC_CHUNK, 64 in the product; 2 here): the towers run as several PAIRED passes over equal
+    shares of their views (PanSt3R.paired_shares) - serial and with the first pass beside the memory build - and nothing changes a bit against one pass"""
+    import panst3r_amd.panst3r as P
+    assert P.PanSt3R.paired_shares(168, 200) == [((0, 42), (0, 50)), ((42, 84), (50, 100)), ((84, 126), (100, 150)), ((126, 168), (150, 200))]
+    assert P.PanSt3R.paired_shares(1, 5)[0] == ((0, 0), (0, 1)) or P.ENC_CHUNK >= 5
+    h = tiny.build(tiny.hip_ns(), 'v2').to(DEV)
+    V, K, H, W = 7, 3, 64, 96
+    imgs = {i: tiny.synth_image(i, H, W, 3).to(DEV) for i in range(V)}
+    ref_r = h.scene_runner(imgs, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=False, amp='fp16', overlap=False)
+    ref, sref = ref_r.run()
+    monkeypatch.setattr(P, 'ENC_CHUNK', 2)
+    assert len(P.PanSt3R.paired_shares(V - K, V)) == 4
+    r = h.scene_runner(imgs, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=True, amp='fp16', overlap=overlap)
+    if overlap == 'masked':
+        assert r.masked
+    for _ in range(3):                    # eager warm-up + capture, replay, replay
+        res, sc = r.run()
+        assert torch.equal(sc['out_queries'], sref['out_queries']) and torch.equal(sc['pred_logits'], sref['pred_logits'])
+        for i in range(V):
+            assert torch.equal(res[i][0], ref[i][0]) and torch.equal(res[i][1], ref[i][1])

@@ -351,6 +351,21 @@ class PanSt3R(nn.Module):
         runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs, panoptic_precision, _mm_tables)
         pan_fmt = fmt if runner.pan_amp is None else amp_dtype(runner.pan_amp, quiet=True)
         checked = check_finite and torch.float16 in (fmt, pan_fmt)
+        def nonfinite():
+            if not cache_graphs:
+                runner.release()
+            if fmt != torch.float16:
+                raise FloatingPointError("non-finite outputs: an activation of the panoptic decoder left the f16 range (amp='bf16' runs that stage on f16 "
+                                         "operands); run with panoptic_precision='amp' (bf16 there too) or 'reference' (fp32 there)")
+            raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16' (or amp=False)")
+
+        if outdevice is not None and torch.device(outdevice).type == 'cpu' and not cache_graphs and runner.streamable():
+            # the demo's call (outdevice='cpu', one eager pass): the outputs leave for pinned host memory while the scene still computes (SceneRunner.run_streamed)
+            res, scene, flag = runner.run_streamed(check_finite=checked)
+            if flag is False:
+                nonfinite()
+            runner.release()
+            return [res[i][0] for i in range(V)], {'pred_logits': scene['pred_logits'], 'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
         # (with a finite check AND an output device, the check runs on the GPU first - on the runner's own buffers, no clones - and the copy follows)
         res, scene = runner.run(None if checked else outdevice, copy=not (checked and outdevice is not None))
         if checked:
@@ -370,12 +385,7 @@ class PanSt3R(nn.Module):
             for base in blocks.values():
                 ok = ok & torch.isfinite(base).all()
             if not bool(ok):
-                if not cache_graphs:
-                    runner.release()
-                if fmt != torch.float16:
-                    raise FloatingPointError("non-finite outputs: an activation of the panoptic decoder left the f16 range (amp='bf16' runs that stage on f16 "
-                                             "operands); run with panoptic_precision='amp' (bf16 there too) or 'reference' (fp32 there)")
-                raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16' (or amp=False)")
+                nonfinite()
             if outdevice is not None:
                 from .scene import to_outdevice
                 moved = to_outdevice([res[i][0] for i in range(V)] + [res[i][1] for i in range(V)], outdevice)      # pinned staging, one DMA per block, one sync

@@ -185,6 +185,10 @@ def pick_overlap(make_runner, steps=3):
     return runners[best], res
 
 
+def adt_of(rows):
+    return next(r.dtype for r in rows if r is not None)
+
+
 def to_outdevice(tensors, outdevice):
     """Copies of `tensors` (device tensors, typically per-view VIEWS of a few large blocks) on `outdevice`, same shapes.  Towards the host the copies go
     through PINNED memory: one staging allocation and one DMA per distinct device storage that the tensors cover (almost) completely - the per-view mask
@@ -739,6 +743,109 @@ class SceneRunner:
                 self._eager()
         return self.results(outdevice, copy=copy)
 
+    def streamable(self):
+        """run_streamed applies: one rank, one eager pass, one precision placement for the render (not the reference's split placement)"""
+        return self.world == 1 and not self.split and not self.ref_split and not self.use_graphs and hasattr(self.b, 'copy_stream')
+
+    @torch.no_grad()
+    def run_streamed(self, check_finite=True):
+        """The eager scene with its outputs LEAVING FOR THE HOST WHILE IT STILL COMPUTES (`outdevice='cpu'`, the demo's call): 2.2 GB of pointmaps and mask
+        logits at 50 views cost 40 ms behind the scene when copied at the end (to_outdevice).  Here stage 2b / 3 run keyframes first: pointmaps are on their
+        way once the render is done; the keyframes' features feed the query decoder; then the mask head runs per pass of the upscaler (keyframes, then the
+        other views in `view_chunks` passes) and every pass's block of mask logits is copied to pinned memory on a copy stream while the next pass computes -
+        only the last block's copy is exposed.  Every per-view result is independent of the pass it is computed in: same bits as run().
+        Returns (results, scene dict, finite flag | None) like results(): host tensors (views of pinned blocks), class logits on the host, queries on the device."""
+        assert self.streamable()
+        from .model.panoptic import view_chunks
+        b = self.b
+        dev = self.groups[0].imgs.device
+        cur, cp = torch.cuda.current_stream(), b.copy_stream(dev)
+        keep, ok = [], None
+
+        def finite(t):
+            nonlocal ok
+            if check_finite:
+                f = torch.isfinite(t).all()
+                ok = f if ok is None else ok & f
+
+        def send(t):
+            """device block -> pinned host block, asynchronously behind everything enqueued so far"""
+            finite(t)
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(cp):
+                cp.wait_event(ev)
+                host.copy_(t, non_blocking=True)
+            keep.append(t)                       # the device block stays allocated until the copy stream is drained below
+            return host
+
+        with b.precision(self.amp):
+            self.stage1()
+            self.gather1()
+            self.stage2a()
+            bank = self.bank
+            pm_host, mask_host = {}, {}
+            rows, kf_feats = [], []
+            for gi, g in enumerate(self.groups):
+                n = len(g.idx)
+                g.pointmaps = b.render(g.cat, n, g.h, g.w, bank) if not self.mixed else b.render(g.cat, n, g.h, g.w, bank, g.enc)
+                pm_host[gi] = send(g.pointmaps)
+                P = g.guid.shape[0] // n if g.guid is not None else 0
+                with b.precision(self.pan_amp):
+                    if g.k:
+                        fpn, mf = b.features(g.cat[:g.k * g.T], g.imgs[:g.k], g.k, g.h, g.w, None if g.guid is None else g.guid[:g.k * P],
+                                             None if g.mm is None else g.mm[:g.k])
+                        fm = b.attn_feats(mf, g.k, b.fpn_grid(g.h, g.w)[0])
+                        self.d = fpn.shape[1]
+                        rows.append(torch.cat([fpn, fm], dim=1))
+                        kf_feats.append(mf)
+                    else:
+                        rows.append(None)
+                        kf_feats.append(None)
+            if any(r is None for r in rows):
+                width = next(r.shape[1] for r in rows if r is not None)
+                rows = [r if r is not None else torch.zeros(0, width, dtype=adt_of(rows), device=dev) for r in rows]
+            self.both_send = self._kf_rows(rows)
+            self.gather2()
+            with b.precision(self.pan_amp):
+                outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.kf_fpn_grids,
+                                      self.classes, self.kf_portrait)
+                finite(outq)
+                logits = b.logits(head)
+                finite(logits)
+                for gi, g in enumerate(self.groups):
+                    n = len(g.idx)
+                    P = g.guid.shape[0] // n if g.guid is not None else 0
+                    blocks = []
+                    if g.k:
+                        blocks.append(send(b.masks_group(head, kf_feats[gi])))
+                        kf_feats[gi] = None
+                    for v0, c in view_chunks(n - g.k):
+                        a, e = g.k + v0, g.k + v0 + c
+                        _, mf = b.features(g.cat[a * g.T:e * g.T], g.imgs[a:e], c, g.h, g.w, None if g.guid is None else g.guid[a * P:e * P],
+                                           None if g.mm is None else g.mm[a:e])
+                        blocks.append(send(b.masks_group(head, mf)))
+                        del mf
+                    mask_host[gi] = blocks
+                    g.guid = g.mm = None
+            logits_host = send(logits)
+        cp.synchronize()
+        keep.clear()
+        flag = None if ok is None else bool(ok)
+        res = {}
+        for j, i in enumerate(self.mine):
+            g, r = self.where[j]
+            gi = self.groups.index(g)
+            rr = r
+            for blk in mask_host[gi]:
+                if rr < blk.shape[0]:
+                    m = blk[rr]
+                    break
+                rr -= blk.shape[0]
+            res[self.order[i]] = (pm_host[gi][r][None], m[None])
+        return res, {'pred_logits': logits_host[None], 'out_queries': outq[:, None]}, flag
+
     def results(self, outdevice=None, copy=True):
         """({view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} of this rank's views, scene dict) after stage 3.
         With captured graphs the outputs live in buffers the next run() overwrites in place: copy=True clones them (moving them to
@@ -818,6 +925,12 @@ class HipBackend:
 
     def encode_dino(self, imgs, cat_rows):
         self.m.encode_views(imgs, cat_rows, enc=False)
+
+    def copy_stream(self, device):
+        """a stream that only ever carries device -> host copies of finished blocks (SceneRunner.run_streamed): DMA engines, no kernels beside the scene's"""
+        if getattr(self, '_copy', None) is None:
+            self._copy = torch.cuda.Stream(device=device)
+        return self._copy
 
     def side_stream(self, device):
         if getattr(self, '_side', None) is None:

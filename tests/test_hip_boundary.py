@@ -145,13 +145,14 @@ def test_reference_stage_methods(variant):
 @pytest.mark.parametrize('cache_graphs', [False, True])
 def test_outdevice_cpu_goes_through_pinned_blocks(check_finite, cache_graphs):
     """`outdevice='cpu'` (the demo's call, tools/demo_panst3r.py:232-233): the host outputs equal the device outputs bit for bit, for a scene with two shape
-    groups (the per-view tensors are views of one block per group: scene.to_outdevice copies blocks, not views), and they sit in pinned memory."""
+    groups (the per-view tensors are views of one block per group: scene.to_outdevice copies blocks, not views), and they sit in pinned memory.  The one-off eager
+    call (cache_graphs=False) sends every block on a copy stream as soon as it exists (SceneRunner.run_streamed: keyframes first, mask head per upscaler pass)."""
     h = tiny.build(tiny.hip_ns(), 'v2').to(DEV)
     shapes = [(64, 96), (96, 64), (64, 96), (64, 96), (96, 64)]
     imgs = [tiny.synth_image(i, a, b, 3) for i, (a, b) in enumerate(shapes)]
     ts = torch.tensor(shapes)
     kw = dict(num_keyframes=3, amp='fp16', check_finite=check_finite, cache_graphs=cache_graphs)
-    for _ in range(3 if cache_graphs else 1):                  # with cache_graphs: eager, capture, replay
+    for _ in range(3):                  # with cache_graphs: eager, capture, replay; without: three eager passes whose outputs leave while the scene computes
         pm_d, pan_d = h.forward_inference_multi_ar([i.to(DEV) for i in imgs], ts, tiny.NAMES, **kw)
         pm_d = [p.clone() for p in pm_d]
         mk_d = [m.clone() for m in pan_d['pred_masks']]

@@ -294,3 +294,32 @@ def test_two_stream_stage2_is_opt_in():
     assert S.OVERLAP_DEFAULT is False
     assert S.SceneRunner(Dummy(), imgs, 4, 64, 64, 2, tiny.NAMES).serial is True
     assert S.SceneRunner(Dummy(), imgs, 4, 64, 64, 2, tiny.NAMES, overlap=True).serial is False
+
+
+def test_tower_pass_shares_and_masked_layer_rule(monkeypatch):
+    """host logic of scenes longer than one tower pass (PanSt3R.paired_shares) and of the masked stage 2 (scene.mask_layers): every view in exactly one
+    pass, no pass above the pass size, near-equal shares; the layer count beside the build grows with the build (K) and shrinks with the views of the pass"""
+    import panst3r_amd.panst3r as P
+    import panst3r_amd.scene as S
+    for Ve, Vd in [(34, 50), (168, 200), (1, 200), (64, 64), (65, 64), (0, 3), (200, 1), (129, 130)]:
+        sh = P.PanSt3R.paired_shares(Ve, Vd)
+        assert len(sh) == max(1, -(-max(Ve, Vd) // P.ENC_CHUNK))
+        for tower, V in ((0, Ve), (1, Vd)):
+            spans = [s[tower] for s in sh]
+            assert spans[0][0] == 0 and spans[-1][1] == V and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) <= P.ENC_CHUNK and max(sizes) - min(sizes) <= 1
+    monkeypatch.setattr(S, 'MASK_LAYERS', 0)
+    assert S.mask_layers(16, 84, 24) == 11                    # the bench scene: the measured optimum (profiles/r5_overlap_bench.txt)
+    assert S.mask_layers(32, 92, 24) == 23                    # C5: first of four passes of 42 + 50 views beside the 54 ms build
+    assert S.mask_layers(2, 200, 24) == 1 and S.mask_layers(32, 4, 24) == 24
+    assert [S.mask_layers(K, 84, 24) for K in (4, 8, 16, 32)] == sorted(S.mask_layers(K, 84, 24) for K in (4, 8, 16, 32))
+    monkeypatch.setattr(S, 'MASK_LAYERS', 7)
+    assert S.mask_layers(16, 84, 24) == 7 and S.mask_layers(16, 84, 5) == 5
+
+
+def test_to_outdevice_off_gpu_is_a_plain_move():
+    import panst3r_amd.scene as S
+    a = torch.arange(12.).reshape(3, 4)
+    out = S.to_outdevice([a[0], a[1:]], 'cpu')
+    assert torch.equal(out[0], a[0]) and torch.equal(out[1], a[1:])

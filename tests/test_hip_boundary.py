@@ -163,3 +163,27 @@ def test_outdevice_cpu_goes_through_pinned_blocks(check_finite, cache_graphs):
             assert torch.equal(pm_c[i], pm_d[i].cpu()) and torch.equal(pan_c['pred_masks'][i], mk_d[i].cpu())
         assert pan_c['pred_logits'].device.type == 'cpu' and torch.equal(pan_c['pred_logits'], pan_d['pred_logits'].cpu())
     h.clear_runners()
+
+
+@pytest.mark.parametrize('variant,amp,shapes,K', [
+    ('v1', 'fp16', [(64, 96)] * 4, 2),                                   # pixel-shuffle upscaler: no guidance branch, no scaler tables
+    ('v2', 'bf16', [(64, 96)] * 5, 3),                                   # two formats in one scene (bf16 backbone, f16 panoptic decoder)
+    ('v2', 'fp16', [(64, 96)] * 3, 3),                                   # every view a keyframe: no upscaler pass behind the query decoder
+    ('v2', 'fp16', [(64, 96), (64, 96), (96, 64), (64, 96)], 2),         # keyframes 0 and 3: the portrait group has none
+    ('v2', False, [(64, 96)] * 4, 2),                                    # fp32 mode (no finite check)
+])
+def test_streamed_outputs_equal_the_plain_call(variant, amp, shapes, K):
+    """SceneRunner.run_streamed (the one-off call with outdevice='cpu') against the same call without an output device, bit for bit, over the scene shapes
+    that take different branches in it"""
+    import warnings
+    h = tiny.build(tiny.hip_ns(), variant).to(DEV)
+    imgs = [tiny.synth_image(i, a, b, 5).to(DEV) for i, (a, b) in enumerate(shapes)]
+    ts = torch.tensor(shapes)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        pm_d, pan_d = h.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K, amp=amp)
+        pm_c, pan_c = h.forward_inference_multi_ar(imgs, ts, tiny.NAMES, num_keyframes=K, amp=amp, outdevice='cpu')
+    for i in range(len(shapes)):
+        assert pm_c[i].device.type == 'cpu' and torch.equal(pm_c[i], pm_d[i].cpu()), i
+        assert torch.equal(pan_c['pred_masks'][i], pan_d['pred_masks'][i].cpu()), i
+    assert torch.equal(pan_c['pred_logits'], pan_d['pred_logits'].cpu()) and torch.equal(pan_c['out_queries'].cpu(), pan_d['out_queries'].cpu())

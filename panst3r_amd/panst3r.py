@@ -359,12 +359,13 @@ class PanSt3R(nn.Module):
                                          "operands); run with panoptic_precision='amp' (bf16 there too) or 'reference' (fp32 there)")
             raise FloatingPointError("non-finite outputs in f16 mode: an activation left the f16 range; run with amp='bf16' (or amp=False)")
 
-        if outdevice is not None and torch.device(outdevice).type == 'cpu' and not cache_graphs and runner.streamable():
-            # the demo's call (outdevice='cpu', one eager pass): the outputs leave for pinned host memory while the scene still computes (SceneRunner.run_streamed)
+        if outdevice is not None and torch.device(outdevice).type == 'cpu' and runner.streamable():
+            # the demo's call (outdevice='cpu'): the outputs leave for pinned host memory while the scene still computes (SceneRunner.run_streamed)
             res, scene, flag = runner.run_streamed(check_finite=checked)
             if flag is False:
                 nonfinite()
-            runner.release()
+            if not cache_graphs:
+                runner.release()
             return [res[i][0] for i in range(V)], {'pred_logits': scene['pred_logits'], 'pred_masks': [res[i][1] for i in range(V)], 'out_queries': scene['out_queries']}
         # (with a finite check AND an output device, the check runs on the GPU first - on the runner's own buffers, no clones - and the copy follows)
         res, scene = runner.run(None if checked else outdevice, copy=not (checked and outdevice is not None))

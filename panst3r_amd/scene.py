@@ -663,6 +663,7 @@ class SceneRunner:
             g.imgs = g.cat = g.pointmaps = g.fpn = g.mf = g.guid = g.mm = g.enc = None
         self.enc_kf = self.both_kf = self.enc_send = self.both_send = self.out = self.graphs = self._refs = self.bank = None
         self.mm_all = self.mm_send = self._rest = None
+        self._sgraphs = self._sx = None
 
     def set_images(self, images):
         """Load a new scene of the SAME shapes / schedule into the static input buffers (the captured graphs read them in place).
@@ -744,29 +745,98 @@ class SceneRunner:
         return self.results(outdevice, copy=copy)
 
     def streamable(self):
-        """run_streamed applies: one rank, one eager pass, one precision placement for the render (not the reference's split placement)"""
-        return self.world == 1 and not self.split and not self.ref_split and not self.use_graphs and hasattr(self.b, 'copy_stream')
+        """run_streamed applies: one rank, one precision placement for the render (not the reference's split placement)"""
+        return self.world == 1 and not self.split and not self.ref_split and not self.masked and hasattr(self.b, 'copy_stream')
+
+    def _stream_plan(self, sx):
+        """[(stage, what runs eagerly behind it)] of the scene with its outputs leaving as they appear (run_streamed).  Stages only enqueue device work and
+        leave their tensors in `sx` / on self (with captured graphs: static addresses); the second element of each pair is host code that runs after the stage
+        in every mode - the trivial one-rank gathers and the `send` of finished blocks."""
+        from .model.panoptic import view_chunks
+        b = self.b
+        send, finite = (lambda t: sx['send'](t)), (lambda t: sx['finite'](t))       # (looked up per call: a replayed plan outlives the call that captured it)
+        sx.update(pm={}, kf_mf={}, blocks={}, host_pm={}, host_blocks={})
+
+        def front():           # stage 2 up to the keyframes' features: the query decoder needs nothing else
+            self.stage2a()
+            rows = []
+            for gi, g in enumerate(self.groups):
+                n = len(g.idx)
+                g.pointmaps = b.render(g.cat, n, g.h, g.w, self.bank) if not self.mixed else b.render(g.cat, n, g.h, g.w, self.bank, g.enc)
+                sx['pm'][gi] = g.pointmaps
+                P = g.guid.shape[0] // n if g.guid is not None else 0
+                with b.precision(self.pan_amp):
+                    if g.k:
+                        fpn, mf = b.features(g.cat[:g.k * g.T], g.imgs[:g.k], g.k, g.h, g.w, None if g.guid is None else g.guid[:g.k * P],
+                                             None if g.mm is None else g.mm[:g.k])
+                        fm = b.attn_feats(mf, g.k, b.fpn_grid(g.h, g.w)[0])
+                        self.d = fpn.shape[1]
+                        rows.append(torch.cat([fpn, fm], dim=1))
+                        sx['kf_mf'][gi] = mf
+                    else:
+                        rows.append(None)
+            width = next(r.shape[1] for r in rows if r is not None)
+            rows = [r if r is not None else torch.zeros(0, width, dtype=adt_of(rows), device=self.groups[0].imgs.device) for r in rows]
+            self.both_send = self._kf_rows(rows)
+
+        def after_front():
+            self.gather2()
+            for gi in range(len(self.groups)):
+                sx['host_pm'][gi] = send(sx['pm'][gi])
+
+        def decode():
+            with b.precision(self.pan_amp):
+                outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.kf_fpn_grids,
+                                      self.classes, self.kf_portrait)
+                sx.update(outq=outq, head=head, logits=b.logits(head))
+                for gi, g in enumerate(self.groups):
+                    sx['blocks'][gi] = [b.masks_group(head, sx['kf_mf'].pop(gi))] if g.k else []
+                sx['nkf'] = {gi: len(v) for gi, v in sx['blocks'].items()}
+
+        def after_decode():
+            finite(sx['outq'])
+            for gi in range(len(self.groups)):
+                sx['host_blocks'][gi] = [send(t) for t in sx['blocks'][gi][:sx['nkf'][gi]]]
+            sx['host_logits'] = send(sx['logits'])
+
+        plan = [(self.stage1, self.gather1), (front, after_front), (decode, after_decode)]
+        work = [(gi, g.k + v0, c) for gi, g in enumerate(self.groups) for v0, c in view_chunks(len(g.idx) - g.k)]
+        for w, (gi, a, c) in enumerate(work):
+            def upscale(gi=gi, a=a, c=c, last=(w == len(work) - 1)):          # one upscaler pass of the views that are not keyframes + its mask logits
+                g = self.groups[gi]
+                P = g.guid.shape[0] // len(g.idx) if g.guid is not None else 0
+                with b.precision(self.pan_amp):
+                    _, mf = b.features(g.cat[a * g.T:(a + c) * g.T], g.imgs[a:a + c], c, g.h, g.w, None if g.guid is None else g.guid[a * P:(a + c) * P],
+                                       None if g.mm is None else g.mm[a:a + c])
+                    sx['blocks'][gi].append(b.masks_group(sx['head'], mf))
+                if last:
+                    for gg in self.groups:
+                        gg.guid = gg.mm = None
+
+            def after_upscale(gi=gi):
+                sx['host_blocks'][gi].append(send(sx['blocks'][gi][len(sx['host_blocks'][gi])]))
+            plan.append((upscale, after_upscale))
+        return plan
 
     @torch.no_grad()
     def run_streamed(self, check_finite=True):
-        """The eager scene with its outputs LEAVING FOR THE HOST WHILE IT STILL COMPUTES (`outdevice='cpu'`, the demo's call): 2.2 GB of pointmaps and mask
-        logits at 50 views cost 40 ms behind the scene when copied at the end (to_outdevice).  Here stage 2b / 3 run keyframes first: pointmaps are on their
-        way once the render is done; the keyframes' features feed the query decoder; then the mask head runs per pass of the upscaler (keyframes, then the
+        """The scene with its outputs LEAVING FOR THE HOST WHILE IT STILL COMPUTES (`outdevice='cpu'`, the demo's call): 2.2 GB of pointmaps and mask logits
+        at 50 views cost 40 ms behind the scene when copied at the end (to_outdevice).  Here stage 2b / 3 run keyframes first: pointmaps are on their way
+        once the render is done; the keyframes' features feed the query decoder; then the mask head runs per pass of the upscaler (keyframes, then the
         other views in `view_chunks` passes) and every pass's block of mask logits is copied to pinned memory on a copy stream while the next pass computes -
-        only the last block's copy is exposed.  Every per-view result is independent of the pass it is computed in: same bits as run().
+        only the last block's copy is exposed.  Every per-view result is independent of the pass it is computed in: same bits as run().  Eager, or
+        (use_graphs) one captured graph per stage of _stream_plan with the copies enqueued between the replays.
         Returns (results, scene dict, finite flag | None) like results(): host tensors (views of pinned blocks), class logits on the host, queries on the device."""
         assert self.streamable()
-        from .model.panoptic import view_chunks
         b = self.b
         dev = self.groups[0].imgs.device
         cur, cp = torch.cuda.current_stream(), b.copy_stream(dev)
-        keep, ok = [], None
+        keep, ok = [], [None]
 
         def finite(t):
-            nonlocal ok
             if check_finite:
                 f = torch.isfinite(t).all()
-                ok = f if ok is None else ok & f
+                ok[0] = f if ok[0] is None else ok[0] & f
 
         def send(t):
             """device block -> pinned host block, asynchronously behind everything enqueued so far"""
@@ -777,74 +847,57 @@ class SceneRunner:
             with torch.cuda.stream(cp):
                 cp.wait_event(ev)
                 host.copy_(t, non_blocking=True)
-            keep.append(t)                       # the device block stays allocated until the copy stream is drained below
+            keep.append(t)                       # an eager pass's device block stays allocated until the copy stream is drained below
             return host
 
         with b.precision(self.amp):
-            self.stage1()
-            self.gather1()
-            self.stage2a()
-            bank = self.bank
-            pm_host, mask_host = {}, {}
-            rows, kf_feats = [], []
-            for gi, g in enumerate(self.groups):
-                n = len(g.idx)
-                g.pointmaps = b.render(g.cat, n, g.h, g.w, bank) if not self.mixed else b.render(g.cat, n, g.h, g.w, bank, g.enc)
-                pm_host[gi] = send(g.pointmaps)
-                P = g.guid.shape[0] // n if g.guid is not None else 0
-                with b.precision(self.pan_amp):
-                    if g.k:
-                        fpn, mf = b.features(g.cat[:g.k * g.T], g.imgs[:g.k], g.k, g.h, g.w, None if g.guid is None else g.guid[:g.k * P],
-                                             None if g.mm is None else g.mm[:g.k])
-                        fm = b.attn_feats(mf, g.k, b.fpn_grid(g.h, g.w)[0])
-                        self.d = fpn.shape[1]
-                        rows.append(torch.cat([fpn, fm], dim=1))
-                        kf_feats.append(mf)
-                    else:
-                        rows.append(None)
-                        kf_feats.append(None)
-            if any(r is None for r in rows):
-                width = next(r.shape[1] for r in rows if r is not None)
-                rows = [r if r is not None else torch.zeros(0, width, dtype=adt_of(rows), device=dev) for r in rows]
-            self.both_send = self._kf_rows(rows)
-            self.gather2()
-            with b.precision(self.pan_amp):
-                outq, head = b.decode(self.both_kf[:, :self.d].contiguous(), self.both_kf[:, self.d:].contiguous(), self.K, self.kf_fpn_grids,
-                                      self.classes, self.kf_portrait)
-                finite(outq)
-                logits = b.logits(head)
-                finite(logits)
-                for gi, g in enumerate(self.groups):
-                    n = len(g.idx)
-                    P = g.guid.shape[0] // n if g.guid is not None else 0
-                    blocks = []
-                    if g.k:
-                        blocks.append(send(b.masks_group(head, kf_feats[gi])))
-                        kf_feats[gi] = None
-                    for v0, c in view_chunks(n - g.k):
-                        a, e = g.k + v0, g.k + v0 + c
-                        _, mf = b.features(g.cat[a * g.T:e * g.T], g.imgs[a:e], c, g.h, g.w, None if g.guid is None else g.guid[a * P:e * P],
-                                           None if g.mm is None else g.mm[a:e])
-                        blocks.append(send(b.masks_group(head, mf)))
-                        del mf
-                    mask_host[gi] = blocks
-                    g.guid = g.mm = None
-            logits_host = send(logits)
+            if not self.use_graphs:
+                sx = dict(send=send, finite=finite)
+                for stage, after in self._stream_plan(sx):
+                    stage()
+                    after()
+            elif getattr(self, '_sgraphs', None) is None:
+                # one eager pass of THIS plan first (its passes have their own shapes: position tables, scale vectors are made on first use), then one graph per stage
+                warm = dict(send=lambda t: t, finite=lambda t: None)
+                for stage, after in self._stream_plan(warm):
+                    stage()
+                    after()
+                del warm
+                torch.cuda.synchronize()
+                sx = self._sx = dict(send=send, finite=finite)
+                pool = torch.cuda.graph_pool_handle()
+                self._sgraphs = []
+                for stage, after in self._stream_plan(sx):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
+                        stage()
+                    g.replay()
+                    after()
+                    self._sgraphs.append((g, after))
+                if hasattr(b, 'pack_refs'):
+                    self._refs = b.pack_refs()
+            else:
+                sx = self._sx
+                sx.update(send=send, finite=finite, host_pm={}, host_blocks={})
+                for g, after in self._sgraphs:
+                    g.replay()
+                    after()
         cp.synchronize()
         keep.clear()
-        flag = None if ok is None else bool(ok)
+        flag = None if ok[0] is None else bool(ok[0])
         res = {}
         for j, i in enumerate(self.mine):
             g, r = self.where[j]
             gi = self.groups.index(g)
             rr = r
-            for blk in mask_host[gi]:
+            for blk in sx['host_blocks'][gi]:
                 if rr < blk.shape[0]:
                     m = blk[rr]
                     break
                 rr -= blk.shape[0]
-            res[self.order[i]] = (pm_host[gi][r][None], m[None])
-        return res, {'pred_logits': logits_host[None], 'out_queries': outq[:, None]}, flag
+            res[self.order[i]] = (sx['host_pm'][gi][r][None], m[None])
+        outq = sx['outq']
+        return res, {'pred_logits': sx['host_logits'][None], 'out_queries': (outq.clone() if self.use_graphs else outq)[:, None]}, flag
 
     def results(self, outdevice=None, copy=True):
         """({view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} of this rank's views, scene dict) after stage 3.

@@ -157,9 +157,21 @@ def mask_layers(K, views_in_pass, n_layers):
 DIAG_CONCURRENT = None     # diagnostics only (tests/diag/dino_taps.py): a callable run on the main stream beside the side branch
 
 
+def output_digest(res, scene):
+    """one int64 over every bit of a scene's outputs (pointmaps, mask logits, queries, class logits): equal digests = equal bits, up to collisions of a sum of
+    the 32-bit words; ~1 ms at 50 views.  What bench.py records so that the timed form of the scene is a CHECKED one."""
+    tot = None
+    for t in [scene['out_queries'], scene['pred_logits']] + [x for i in sorted(res) for x in res[i]]:
+        d = t.contiguous().view(torch.int32).to(torch.int64).sum()
+        tot = d if tot is None else tot * 1000003 + d           # (order-sensitive across tensors; wraps in int64)
+    return int(tot)
+
+
 def pick_overlap(make_runner, steps=3):
     """overlap='auto': build the serial and the masked runner of a scene (make_runner(overlap) -> SceneRunner with captured graphs), time `steps` replays of
-    each and keep the faster one; the other is released.  Returns (runner, {'chosen', 'serial_ms', 'masked_ms'}).  Both produce the same bits."""
+    each and keep the faster one; the other is released.  Returns (runner, {'chosen', 'serial_ms', 'masked_ms', 'serial_digest', 'masked_identical'}).
+    Both produce the same bits - and that is CHECKED here on every replay of the trial: a masked form whose outputs deviate from the serial scene's is
+    never chosen ('masked_identical': false in the record)."""
     import time
     res = {}
     runners = {}
@@ -169,15 +181,20 @@ def pick_overlap(make_runner, steps=3):
             r.release()
             continue
         r.run(copy=False)
-        r.run(copy=False)
+        digests = {output_digest(*r.run(copy=False))}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             r.run(copy=False)
         torch.cuda.synchronize()
         res['masked_ms' if mode else 'serial_ms'] = 1e3 * (time.perf_counter() - t0) / steps
+        digests.add(output_digest(*r.results(copy=False)))
+        if mode:
+            res['masked_identical'] = digests == {res['serial_digest']}
+        else:
+            res['serial_digest'] = digests.pop() if len(digests) == 1 else None       # (None: the serial scene itself is not reproducible - never seen)
         runners[mode] = r
-    best = 'masked' if ('masked_ms' in res and res['masked_ms'] < 0.99 * res['serial_ms']) else False
+    best = 'masked' if (res.get('masked_identical') and res['masked_ms'] < 0.99 * res['serial_ms']) else False
     for mode, r in runners.items():
         if mode != best:
             r.release()

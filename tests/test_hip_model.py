@@ -584,5 +584,9 @@ def test_forward_batch_and_dust3r_storage_convention(pair):
             if back and tuple(mk.shape[-2:]) != (H // 2, W // 2):          # v2 masks of a portrait view are native; v1's come landscape-shaped already
                 mk = mk.transpose(-1, -2)
             assert torch.equal(pan['pred_masks'][s, i], mk), (s, i)
+    # the same batch with the outputs sent to the host (per scene through SceneRunner.run_streamed, with the caller-pooled scaler tables): same bits
+    pan_c, pm_c = h.forward(imgs, ts, tiny.NAMES, amp=h.amp, max_bs=1, outdevice='cpu')
+    assert pm_c.device.type == 'cpu' and torch.equal(pm_c, pm.cpu()) and torch.equal(pan_c['pred_masks'], pan['pred_masks'].cpu())
+    assert torch.equal(pan_c['pred_logits'].cpu(), pan['pred_logits'].cpu())
     with pytest.raises(ValueError):
         h.forward(imgs, torch.tensor([[[H, W]] * n, [[H, W], [W + 16, H], [H, W]]]), tiny.NAMES, amp=h.amp, max_bs=1)

@@ -22,9 +22,12 @@ model.panoptic_decoder.text_encoder.class_embeddings = {n: e for n, e in zip(nam
 model.to(dev)
 imgs = [synth_image(i, H, W).to(dev) for i in range(V)]
 ts = torch.tensor([[H, W]] * V)
+ONLY = os.environ.get('PST_API_ONLY')            # e.g. "fp16,False,cpu": one configuration (profiler runs)
 for amp in ('fp16', False):
     for graphs in (False, True):
         for out in ('cpu', None):
+            if ONLY and ONLY != '%s,%s,%s' % (amp, graphs, out):
+                continue
             model.clear_runners()
             for _ in range(2 if graphs else 1):
                 r = model.forward_inference_multi_ar(imgs, ts, names, num_keyframes=K, max_bs=1, outdevice=out, amp=amp, cache_graphs=graphs)

@@ -1,13 +1,12 @@
 #!/usr/bin/env python
 """Which lines of the package still launch ATen kernels per scene (fills, copies, cats inside the captured graphs):
-one EAGER bench scene under torch.profiler (CPU activity with Python stacks), device-launching aten ops counted per (op, innermost panst3r_amd frame).
+one EAGER bench scene with the tensor-creating / copying torch entry points wrapped, every call that launches a framework kernel counted per (op, innermost panst3r_amd frame).
     python tools/aten_ops.py [amp]"""
 import collections
 import os
 import sys
 
 import torch
-from torch.profiler import profile, ProfilerActivity
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -273,6 +273,8 @@ def main():
     ap.add_argument('--plan', default='auto', choices=['auto', 'replicated', 'broadcast'],
                     help="multi-GPU plan (panst3r_amd/scene.py): every rank repeats the memory build | rank 0 builds and broadcasts the banks; "
                          "auto = broadcast from 4 ranks on (projection: profiles/r3_shard_estimate.txt)")
+    ap.add_argument('--stream-bank', action='store_true', help="plan 'broadcast': send the bank per memory update with asynchronous broadcasts beside the build "
+                                                               "(opt-in; default = one event-ordered broadcast behind the build, panst3r_amd/scene.py)")
     ap.add_argument('--tune', action='append', default=[], metavar='KNOB=VALUE', help='pst_tune knob for A/B measurements (G256_PP, PAIR, PAIR_RES); results never depend on a knob')
     ap.add_argument('--launch-selftest', action='store_true', help='only exercise the rank launch / rendezvous / output plumbing (no model work; CPU + gloo when there is no GPU per rank)')
     args = ap.parse_args()
@@ -334,7 +336,7 @@ def main():
     def measure(amp, steps, warmup, instrument, panoptic_precision=None):
         """W untimed warm-up steps (the first also captures the three HIP graphs), then EXACTLY `steps` timed steps between two fences."""
         mk = lambda ov: model.scene_runner(images, V, H, W, names, num_keyframes=K, use_graphs=not args.eager, overlap=ov, amp=amp, plan=args.plan,
-                                           panoptic_precision=panoptic_precision)
+                                           panoptic_precision=panoptic_precision, stream_bank=args.stream_bank)
         if args.overlap == 'auto' and not args.eager and world == 1:
             from panst3r_amd.scene import pick_overlap
             runner, picked = pick_overlap(mk)
@@ -423,7 +425,9 @@ def main():
                                 'collectives_measured': coll_ms,
                                 'projected_ms_per_scene_one_gpu_estimate': proj.get((args.plan, world)) if (V, K, args.variant) == (50, 16, 'v2') else None,
                                 'measured_ms_per_scene': round(1e3 * elapsed / args.steps, 3),
-                                'bank_bytes': (2 * 12 * K * (H // 16) * (W // 16) * 768 * 2) if args.plan == 'broadcast' else 0}
+                                'bank_bytes': (2 * 12 * K * (H // 16) * (W // 16) * 768 * 2) if args.plan == 'broadcast' else 0,
+                                'bank_transfer': ('per memory update, asynchronous broadcasts beside the build (--stream-bank)' if args.stream_bank else
+                                                  'one event-ordered broadcast behind the build (default: no collective shares a CU with compute)') if args.plan == 'broadcast' else None}
         if timer is not None and os.environ.get('PST_SHAPE_PROFILE') == '1':      # per-shape table of the instrumented step (stderr)
             rows = sorted(timer.by_tag().items(), key=lambda kv: -kv[1]['ms'])
             for (name, tag), d in rows[:48]:

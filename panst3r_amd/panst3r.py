@@ -451,18 +451,19 @@ class PanSt3R(nn.Module):
         return run_scene(HipBackend(self), get_image, V, H, W, num_keyframes, classes, rank, world, group, outdevice, amp=amp, plan=plan)
 
     def scene_runner(self, images, V, H, W, classes, num_keyframes=None, group=None, use_graphs=True, shapes=None, overlap=None, keyframes=None, amp=False,
-                     plan='replicated', max_bs=1, panoptic_precision=None):
+                     plan='replicated', max_bs=1, panoptic_precision=None, stream_bank=False):
         """Static-shape scene runner (panst3r_amd/scene.py): `images` = {view_id: [3,H,W] device tensor} of the views
         this rank owns; `.run()` executes the scene, replaying three captured HIP graphs when use_graphs=True.
         `overlap=True` runs the memory build beside the bulk encoder work on a second stream (faster, NOT reproducible on this
         platform - scene.OVERLAP_DEFAULT); the default runs them back to back.  `max_bs`: MinMaxScaler scope as in forward_inference_multi_ar,
-        default 1 = per view (the demo's convention, SURVEY 8(d) synthetic inputs; what bench.py times)."""
+        default 1 = per view (the demo's convention, SURVEY 8(d) synthetic inputs; what bench.py times).  `stream_bank` (plan='broadcast' only): send the
+        bank per memory update with asynchronous broadcasts beside the build instead of one event-ordered broadcast behind it (scene.SceneRunner; opt-in)."""
         import torch.distributed as dist
         from .scene import SceneRunner, HipBackend
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
         pa, ps = pan_amp_of(amp, panoptic_precision)
         return SceneRunner(HipBackend(self), images, V, H, W, num_keyframes, classes, rank, world, group, use_graphs, shapes=shapes, overlap=overlap, keyframes=keyframes, amp=amp,
-                           plan=plan, minmax_bs=max_bs, pan_amp=pa, pan_scope=ps)
+                           plan=plan, minmax_bs=max_bs, pan_amp=pa, pan_scope=ps, stream_bank=stream_bank)
 
     @torch.no_grad()
     def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False):

@@ -267,7 +267,7 @@ class SceneRunner:
     (multi-aspect-ratio scenes); `backend.fpn_grid(h, w)` gives the key grid / orientation flag the query decoder sees."""
 
     def __init__(self, backend, images, V, H, W, K, classes, rank=0, world=1, group=None, use_graphs=False, shapes=None, overlap=None, keyframes=None,
-                 amp=None, plan='replicated', minmax_bs=1, pan_amp=None, mm_override=None, pan_scope='reference', stream_bank=True):
+                 amp=None, plan='replicated', minmax_bs=1, pan_amp=None, mm_override=None, pan_scope='reference', stream_bank=False):
         self.b, self.V, self.classes = backend, V, classes
         # reference AMP placement (panst3r.py:174-175,204-245,268): `amp` names the format of the encoder, the memory build and the keyframes' render +
         # DINOv2; `pan_amp` (None = the same format) that of the panoptic decoder AND of the render + DINOv2 of the views that are not keyframes.
@@ -311,8 +311,11 @@ class SceneRunner:
         self.builder = plan == 'replicated' or rank == 0        # this rank runs the sequential memory build
         # the broadcast plan's split stage 2 also runs on a 1-rank process group (PST_FORCE_DIST=1: the collectives execute on RCCL at world = 1)
         self.split = plan == 'broadcast' and (world > 1 or (dist.is_available() and dist.is_initialized()))
-        # broadcast plan: the bank travels PER MEMORY UPDATE (the entries of update u go out while update u + 1 computes: K - 1 async broadcasts of 13.5 MiB x
-        # keyframes each instead of one of 27 MiB x K after the whole build - off the critical path); stream_bank=False: one broadcast at the end
+        # broadcast plan, stream_bank=True: the bank travels PER MEMORY UPDATE (the entries of update u go out while update u + 1 computes: K - 1 async broadcasts of
+        # 13.5 MiB x keyframes each instead of one of 27 MiB x K after the whole build - off the critical path).  OPT-IN since round 6: the async
+        # broadcasts run on the transport's own queue BESIDE this rank's compute kernels, the co-running-queues situation of DESIGN.md section 4 (two-queue effect),
+        # and no N > 1 RCCL run has shown it bit-identical yet.  The default (False) is EVENT-ORDERED: one synchronous broadcast behind the whole build - the
+        # collective's queue waits for the compute stream and the compute stream for the collective, so the two never share a CU.
         self.stream_bank = bool(stream_bank) and self.split and hasattr(backend, 'bank_update_payload')
         self._works, self._staged = [], []
         self.mine = [i for i in range(V) if owner[i] == rank]       # positions in `order`; keyframe positions first
@@ -523,7 +526,10 @@ class SceneRunner:
 
     def _bank_post_recvs(self):
         b = self.b
-        self.bank = b.bank_alloc(self.K, self.kf_grids, self.groups[0].imgs.device, self.ref_split)
+        # the bank is allocated ONCE per runner (release() drops it): this collective runs eagerly on every run(), while a captured stage2b renders from
+        # the addresses it saw at capture time - a fresh bank per run would leave the graphs on a freed one
+        if self.bank is None:
+            self.bank = b.bank_alloc(self.K, self.kf_grids, self.groups[0].imgs.device, self.ref_split)
         self._works, self._staged = [], []
         for u in range(len(b.update_spans(self.K, self.kf_grids))):
             payload = b.bank_update_buffers(self.bank, self.K, self.kf_grids, u)
@@ -936,7 +942,7 @@ class SceneRunner:
 
 @torch.no_grad()
 def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=None, outdevice=None, shapes=None, keyframes=None, amp=None, plan='replicated',
-              minmax_bs=1, stream_bank=True):
+              minmax_bs=1, stream_bank=False):
     """Run one scene eagerly.  get_image(view_id) -> fp32 [3,H,W] on the rank's device (only called for owned views).
     Returns {view_id: (pointmap [1,H,W,7], masks [1,Q,H/2,W/2])} for the views this rank owns, plus the scene dict
     {'pred_logits' [1,Q,Ncls], 'out_queries' [Q,1,d]} (identical on every rank).  `shapes`: optional per-view (H, W);

@@ -231,6 +231,78 @@ def test_two_rank_gloo_equals_single(variant, V, K, plan, minmax_bs):
         assert torch.equal(merged[i][0], ref[i][0]) and torch.equal(merged[i][1], ref[i][1])
 
 
+def _rerun_worker(rank, world, port, q):
+    """a streamed-bank receiver over two scenes: the bank object must survive set_images() (captured graphs hold its addresses)"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from panst3r_amd.scene import SceneRunner
+        torch.set_num_threads(2)
+        V, K = 5, 3
+        model = tiny.build(tiny.OracleNS, 'v1')
+        first, second = tiny.images(V, H, W), [tiny.synth_image(100 + i, H, W, 7) for i in range(V)]
+        _, order, owner = assign_views(V, K, world, plan='broadcast')
+        mine = lambda imgs: {order[i]: imgs[order[i]] for i in range(V) if owner[i] == rank}
+        with torch.no_grad():
+            rn = SceneRunner(OracleBackend(model), mine(first), V, H, W, K, tiny.NAMES, rank, world, None, plan='broadcast', stream_bank=True)
+            assert rn.stream_bank
+            rn.run()
+            bank_id = id(rn.bank)
+            rn.set_images(mine(second))
+            res, scene = rn.run()
+        q.put((rank, {k: (v[0].numpy().copy(), v[1].numpy().copy()) for k, v in res.items()}, scene['out_queries'].numpy().copy(), id(rn.bank) == bank_id))
+    except Exception as e:
+        q.put((rank, repr(e), None, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_streamed_bank_receiver_keeps_its_bank_across_scenes():
+    """with the bank streamed per memory update, the rank that RECEIVES it re-posted its receives into a freshly allocated bank on every
+    run() - while a captured stage renders from the bank it saw at capture time.  The bank is now allocated once per runner: after set_images() with a
+    different scene the receiver still holds the same bank object, and both ranks' outputs equal the unsharded run of the NEW scene bit for bit."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rerun_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    assert all(not isinstance(g[1], str) for g in got), got
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    V, K = 5, 3
+    torch.set_num_threads(2)          # as the workers: the CPU GEMMs' blocking (and with it the last bit) follows the thread count
+    model = tiny.build(tiny.OracleNS, 'v1')
+    second = [tiny.synth_image(100 + i, H, W, 7) for i in range(V)]
+    with torch.no_grad():
+        ref, ref_scene = run_scene(OracleBackend(model), lambda i: second[i], V, H, W, K, tiny.NAMES)
+    merged = {}
+    for rank, res, outq, same_bank in got:
+        if rank != 0:        # (rank 0 BUILDS its bank inside a stage - eagerly a new one per run, under capture part of the graph)
+            assert same_bank, 'receiving rank %d allocated a new bank for the second scene' % rank
+        assert torch.equal(torch.from_numpy(outq), ref_scene['out_queries'])
+        merged.update({k: (torch.from_numpy(a), torch.from_numpy(b)) for k, (a, b) in res.items()})
+    assert sorted(merged) == list(range(V))
+    for i in range(V):
+        assert torch.equal(merged[i][0], ref[i][0]) and torch.equal(merged[i][1], ref[i][1])
+
+
+def test_bank_streaming_is_opt_in():
+    """The per-update (asynchronous) bank transfer runs the transport's queue beside compute kernels - the co-running-queues situation of DESIGN.md
+    section 4; until an N > 1 RCCL run has shown it bit-identical it is opt-in: the default sends the bank in one event-ordered broadcast."""
+    import inspect
+    import panst3r_amd.scene as S
+    from panst3r_amd.panst3r import PanSt3R
+    assert inspect.signature(S.SceneRunner.__init__).parameters['stream_bank'].default is False
+    assert inspect.signature(S.run_scene).parameters['stream_bank'].default is False
+    assert inspect.signature(PanSt3R.scene_runner).parameters['stream_bank'].default is False
+
+
 def test_single_view_scene_is_refused_clearly():
     """V = 1: the memory build needs a pair (reference quirk 4: get_must3r_mem_batches(n < 2) is broken, the demo duplicates
     the image, tools/demo_panst3r.py:111-112) -> explicit ValueError instead of a failure deep inside; the duplicate works."""

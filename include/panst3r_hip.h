@@ -125,6 +125,7 @@ const char* pst_gemm_pair_variant(const pst_gemm_params* a, const pst_gemm_param
 #define PST_TUNE_ATTN_XCD 9     /* 1 (default): attention blocks in XCD-contiguous order (the query blocks of one head share its K / V tiles through ONE L2), 0: plain order */
 #define PST_TUNE_CUS 10        /* CUs the launches enqueued from now on may assume (grid of the persistent kernels): set around work enqueued on a CU-masked stream (hipExtStreamCreateWithCUMask); 0 (default) = all CUs of the device */
 #define PST_TUNE_PAIR_DELAY 6   /* start delay of the second problem of a shared launch in % of a tile period (default 0 = none; measured slower): de-phases its epilogues from the first's */
+#define PST_TUNE_DEPHASE 11     /* phase groups of the persistent 256x256 kernel's workgroups: G * 1000 + percent of the modelled start offset (epilogue bytes / G at 5.2 TB/s); 0 = off */
 #define PST_TUNE_PAIR_RES 5     /* 1 (default): ... including fp32 residual-stream problems at K >= 1024 that would run on the 128x128 kernel on their own */
 int pst_tune(int knob, int value);
 

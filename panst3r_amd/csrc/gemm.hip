@@ -613,7 +613,7 @@ static int gemm_validate(const pst_gemm_params* pp) {
 }
 
 static int g_deep_ring = 4;          // PST_TUNE_DEEP_RING
-namespace pst { int gemm256_pp(int set); int gemm256p_pair_delay(int set); int attn_pair_enable(int set); int attn_xcd_order(int set); }
+namespace pst { int gemm256_pp(int set); int gemm256p_dephase(int set); int gemm256p_pair_delay(int set); int attn_pair_enable(int set); int attn_xcd_order(int set); }
 
 // the ONE dispatch rule, shared by the launch and by pst_gemm_variant: 0 = 64x64 tiles, 1 = 128x128, 2 = 256x256
 static int gemm_choice(const pst_gemm_params& p) {
@@ -718,6 +718,7 @@ extern "C" int pst_tune(int knob, int value) {
   if (knob == PST_TUNE_G256_PP) return pst::gemm256_pp(value);
   if (knob == PST_TUNE_PAIR_RES) { const int prev = g_pair_res; g_pair_res = value != 0; return prev; }
   if (knob == PST_TUNE_PAIR_DELAY) return pst::gemm256p_pair_delay(value);
+  if (knob == PST_TUNE_DEPHASE) return pst::gemm256p_dephase(value);
   if (knob == PST_TUNE_PAIR_ATTN) return pst::attn_pair_enable(value);
   if (knob == PST_TUNE_ATTN_XCD) return pst::attn_xcd_order(value);
   if (knob == PST_TUNE_DEEP_RING) { const int prev = g_deep_ring; if (value == 4 || value == 6 || value == 8) g_deep_ring = value; return prev; }

@@ -21,6 +21,9 @@ namespace pst {
 #else
 #define PST_ABL_E 0
 #endif
+#ifndef PST_RES_LA
+#define PST_RES_LA 2         // residual row fragments in flight ahead of the one being finished (3: 7-20 spilled registers, 4: 55-66; measurement builds override)
+#endif
 constexpr int HALF_BYTES = 128 * 128;           // 128 rows x 64 bf16
 constexpr int BUF_BYTES = 4 * HALF_BYTES;       // A-lo, A-hi, B-lo, B-hi
 constexpr int G256_GROUP_M = 4;
@@ -367,6 +370,14 @@ __device__ __forceinline__ int perm_row8(int row) {       // LDS row (fragment f
   return (sub << 6) + (f >> 1) * 32 + g * 8 + (f & 1) * 4 + r;
 }
 
+// fp32 residual-stream class (round 6): LDS row (fragment J, fragment row c) -> tile column 4 c + J.  With the MFMA operands swapped (A rows in the first
+// slot) a lane (g, l16) then owns, per row fragment, rows 4 g .. 4 g + 3 and of each the FOUR CONSECUTIVE columns 4 l16 .. 4 l16 + 3 (one from each of the
+// wave's four column fragments): 16 consecutive lanes = 256 contiguous bytes of one fp32 row.
+__device__ __forceinline__ int perm_col4(int row) {
+  const int sub = row >> 6, rho = row & 63;
+  return (sub << 6) + ((rho & 15) << 2) + (rho >> 4);
+}
+
 // sums over the 4 lanes that share a fragment row (lane bits 4 and 5): x + (lane ^ 16), then + (lane ^ 32); VALU row swaps, no LDS
 __device__ __forceinline__ float add_lane16(float v) {
   const unsigned u = __float_as_uint(v);
@@ -430,7 +441,7 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         a_src[h][j] = min(m0 + h * 128 + (TRANS ? perm_row8(lrow) : lrow), p.M - 1) * (int)p.lda + sw;
-        b_src[h][j] = min(n0 + h * 128 + (TRANS ? lrow : perm_row8(lrow)), p.N - 1) * (int)p.ldw + sw;      // N % 64 == 0: a ragged last column tile clamps
+        b_src[h][j] = min(n0 + h * 128 + (TRANS ? lrow : (RES ? perm_col4(lrow) : perm_row8(lrow))), p.N - 1) * (int)p.ldw + sw;      // N % 64 == 0: a ragged last column tile clamps
       }
     }
   };
@@ -484,8 +495,8 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
   auto mma_group = [&](auto mi, auto ni, auto i) {
     static_for<0, 2>([&](auto kk) {
       static_for<0, 2>([&](auto j) {
-        acc[mi * 4 + i][ni * 2 + j] = TRANS ? H16<F16>::mfma(af[i][kk], bfr[ni][j][kk], acc[mi * 4 + i][ni * 2 + j])
-                                            : H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
+        acc[mi * 4 + i][ni * 2 + j] = (TRANS || RES) ? H16<F16>::mfma(af[i][kk], bfr[ni][j][kk], acc[mi * 4 + i][ni * 2 + j])
+                                                     : H16<F16>::mfma(bfr[ni][j][kk], af[i][kk], acc[mi * 4 + i][ni * 2 + j]);
       });
     });
     __builtin_amdgcn_sched_barrier(0);
@@ -721,68 +732,55 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
     tile_tables nt;
     const bool fold = p.ln_stats != nullptr;
     if constexpr (RES) {
-      // The residual tile goes through registers ONE ROW FRAGMENT at a time (16 rows x the wave's 64 columns = 4 x 16 B per lane = 16 registers),
-      // RES_LA fragments ahead of the one being finished: the loads of fragment i + RES_LA are in flight while fragment i is scaled, added, stored.
-      // (Rounds 3-4 loaded four fragments = 64 registers at once, twice per tile: with the 128 accumulators live that is past the 256-register file -
-      // the allocator spilled five of the sixteen loads, each behind its own s_waitcnt vmcnt(0): five serialised HBM round trips per tile and no
-      // store overlap.  vgpr_spill_count 33 -> 0 (1 in the two-problem kernel, outside the tile loop's hot part); proj + residual at K = 1024, both towers in
-      // one launch: 262 -> 251 us, fc2 + residual at K = 4096: 584 -> 568 us, same box (profiles/r4_epi_ab_kernels.txt).)
-      // No LayerNorm-fold consumer and no activation in this class (gemm256_persistent_class): the epilogue is acc + bias, x LayerScale, + residual.
-      constexpr int RES_LA = 2;
+      // fp32 residual stream: C = res + LayerScale x (acc + bias), + 16-bit copy + LayerNorm-fold statistics.  No fold consumer and no activation in this
+      // class (gemm256_persistent_class).
+      // LAYOUT (round 6).  Rounds 2-5 ran this class with the plain class's operand order - lane (g, l16) = row l16, columns 8 g ..: one wave instruction =
+      // 64 pieces of 16 B in 16 different rows, and the vector memory path takes one REQUEST per piece: 36 GB/s per CU for stores and loads alike whatever
+      // the rest of the chip does (tools/probes/store_pattern.py, profiles/r6_store_pattern.txt: 7.1 us per 256 KiB against 2.2 us for whole 256-byte runs),
+      // 640 KiB per tile = 30 us per tile even on 64 CUs (profiles/r6_res_epilogue_probe.txt) - which is why de-phasing the workgroups bought nothing.
+      // Now the MFMA operands are swapped and the W rows staged in perm_col4 order: a lane owns rows 4 g + r and the four consecutive columns 4 l16 ..,
+      // 16 consecutive lanes = 256 contiguous bytes; every load / store instruction = 4 rows x 256 B (the 16-bit copy: 4 x 128 B).  Per element the same
+      // operations in the same order, the statistics through the row phases' own butterfly (row_sum<16>: chunk pairs, quads, octets, halves): same bits.
+      // The residual tile goes through registers ONE ROW FRAGMENT (16 rows = 4 loads of 16 B per lane) at a time, RES_LA fragments ahead.
+      constexpr int RES_LA = PST_RES_LA;
       float* Cf = (float*)p.C;
+      const int ncol = cn0 + wn * 64 + l16 * 4;               // the lane's first column
       const int grp64 = (cn0 + wn * 64) >> 6;
-      const uint32_t ct_a = lds_addr(coltab) + (uint32_t)(wn * 64 + g * 8) * 4u;
-      float4 rv[8][2][2];
+      // column constants of the lane's four columns: read BEFORE the operand request (plain LDS reads; nothing in flight writes LDS at this point)
+      const float4 bias4 = *(const float4*)(coltab + wn * 64 + l16 * 4);
+      const float4 gam4 = *(const float4*)(coltab + 256 + wn * 64 + l16 * 4);
+      float4 rv[8][4];
       auto load_row = [&](auto i) {
-        const int m = min(cm0 + wm * 128 + i * 16 + l16, p.M - 1);
-        const float* rp = p.res + (int64_t)m * p.ldr + cn0 + wn * 64 + g * 8;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int u = 0; u < 2; ++u) rv[i][h][u] = *(const float4*)(rp + h * 32 + 4 * u);
+        for (int r = 0; r < 4; ++r) {
+          const int m = min(cm0 + wm * 128 + i * 16 + g * 4 + r, p.M - 1);
+          rv[i][r] = (PST_ABL_E & 64) ? make_float4(1.f, 2.f, 3.f, 4.f) : *(const float4*)(p.res + (int64_t)m * p.ldr + ncol);
+        }
       };
       auto finish_row = [&](auto i) {
-        const int r = wm * 128 + i * 16 + l16;
-        const int m = cm0 + r;
-        f32x4 bias4[2][2], gam4[2][2];
-        static_for<0, 2>([&](auto h) {
-          static_for<0, 2>([&](auto u) {
-            lds_ldo<(h * 32 + 4 * u) * 4>(bias4[h][u], ct_a);
-            lds_ldo<1024 + (h * 32 + 4 * u) * 4>(gam4[h][u], ct_a);
-          });
-        });
-        if constexpr (i + RES_LA < 8) load_row(std::integral_constant<int, i + RES_LA>{});      // its address arithmetic covers the LDS latency
-        lds_wait();
-        static_for<0, 2>([&](auto h) { static_for<0, 2>([&](auto u) { lds_use(bias4[h][u]); lds_use(gam4[h][u]); }); });
-        float osum[2], osq[2];
+        if constexpr (i + RES_LA < 8) load_row(std::integral_constant<int, i + RES_LA>{});
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int cl = wn * 64 + h * 32 + g * 8;
-          float4 f[2];
-          float cs_[2], cq_[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const f32x4 a = acc[i][2 * h + u], b4 = bias4[h][u], g4 = gam4[h][u];
-            // (the fold consumer's fmaf(acc, rstd, fmaf(-mean rstd, colsum, bias)) with rstd = 1, mean = 0: acc + bias in one rounding, same bits)
-            const float v[4] = {fmaf(a[0], 1.f, b4[0]), fmaf(a[1], 1.f, b4[1]), fmaf(a[2], 1.f, b4[2]), fmaf(a[3], 1.f, b4[3])};
-            // two roundings (scale, then add), as in the row-phase epilogues where an LDS round trip separates them: no fma contraction
-            const float4 q4 = rv[i][h][u];
-            f[u] = make_float4(mul_add_2r(v[0], g4[0], q4.x), mul_add_2r(v[1], g4[1], q4.y), mul_add_2r(v[2], g4[2], q4.z), mul_add_2r(v[3], g4[3], q4.w));
-            ln_acc4(f[u], cs_[u], cq_[u]);
-          }
+        for (int r = 0; r < 4; ++r) {
+          const int m = cm0 + wm * 128 + i * 16 + g * 4 + r;
+          // (the fold consumer's fmaf(acc, rstd, fmaf(-mean rstd, colsum, bias)) with rstd = 1, mean = 0: acc + bias in one rounding, same bits)
+          const float v0 = fmaf(acc[i][0][r], 1.f, bias4.x), v1 = fmaf(acc[i][1][r], 1.f, bias4.y), v2 = fmaf(acc[i][2][r], 1.f, bias4.z),
+                      v3 = fmaf(acc[i][3][r], 1.f, bias4.w);
+          // two roundings (scale, then add), as in the row-phase epilogues where an LDS round trip separates them: no fma contraction
+          const float4 q4 = rv[i][r];
+          const float4 f = make_float4(mul_add_2r(v0, gam4.x, q4.x), mul_add_2r(v1, gam4.y, q4.y), mul_add_2r(v2, gam4.z, q4.z), mul_add_2r(v3, gam4.w, q4.w));
+          float ss, sq;
+          ln_acc4(f, ss, sq);
           if (m < p.M) {
-            float* dst = Cf + (int64_t)m * p.ldc + cn0 + cl;
-            *(float4*)dst = f[0];
-            *(float4*)(dst + 4) = f[1];
-            if (p.xcopy)
-              *(uint4*)((bf16_t*)p.xcopy + (int64_t)m * p.ldxc + cn0 + cl) =
-                  make_uint4(H16<F16>::pack(f[0].x, f[0].y), H16<F16>::pack(f[0].z, f[0].w), H16<F16>::pack(f[1].x, f[1].y), H16<F16>::pack(f[1].z, f[1].w));
+            if (!(PST_ABL_E & 128)) *(float4*)(Cf + (int64_t)m * p.ldc + ncol) = f;      // (measurement builds, tools/pp_ablate.sh: 64 no residual loads, 128 no fp32 stores, 256 no 16-bit copy)
+            if (p.xcopy && !(PST_ABL_E & 256))
+              *(uint2*)((bf16_t*)p.xcopy + (int64_t)m * p.ldxc + ncol) = make_uint2(H16<F16>::pack(f.x, f.y), H16<F16>::pack(f.z, f.w));
           }
-          // chunk pair -> quad (lane ^ 16) -> octet (lane ^ 32): the butterfly of row_sum<16>, same association
-          osum[h] = add_lane32(add_lane16(cs_[0] + cs_[1]));
-          osq[h] = add_lane32(add_lane16(cq_[0] + cq_[1]));
+          if (p.stats_out) {       // (every lane of the 16-lane DPP row takes part; rows past M are computed on clamped residuals and not stored)
+            ss = row_sum<16>(ss);
+            sq = row_sum<16>(sq);
+            if (l16 == 0 && m < p.M) *((float2*)p.stats_out + (int64_t)m * p.stats_ld + grp64) = make_float2(ss, sq);
+          }
         }
-        if (p.stats_out && g == 0 && m < p.M) *((float2*)p.stats_out + (int64_t)m * p.stats_ld + grp64) = make_float2(osum[0] + osum[1], osq[0] + osq[1]);
       };
       static_for<0, RES_LA>(load_row);
       if (more) tables_request(nt, m0, n0);        // three scalars per thread, ahead of the DMA in the in-order queue
@@ -1000,9 +998,28 @@ __device__ __forceinline__ void gemm256p_body(const pst_gemm_params& p, const in
   }
 }
 
+// DE-PHASING (PST_TUNE_DEPHASE, round 6).  Every workgroup of a persistent launch alternates a K loop (matrix pipe, operands from L2 / MALL) with an epilogue
+// (HBM: stores, residual loads), and with equal tile costs the whole chip does so IN STEP: profiles/r6_gemm_k1024.txt - the per-tile fixed part of a launch is
+// exactly its epilogue bytes x 256 CUs at the ~5.2 TB/s the box sustains (plain 16-bit store 6.7 us, fp32 residual class 31.4 us per round), with the matrix
+// cores idle meanwhile.  With the workgroups in G phase groups (group = (index / 8) % G: every XCD holds every phase) that start e / G apart - e = that
+// all-CU epilogue time - only 1 / G of the chip is in its epilogue at any time, each epilogue takes e / G, and the offsets persist (steady state).  Cost: the
+// last group ends (G - 1) e / G late; gain: (rounds - 1) (G - 1) e / G.
+__device__ __forceinline__ void dephase_wait(int bid, int dephase_g, int dephase_ticks) {
+  if (dephase_g > 1) {
+    const int grp = (bid >> 3) % dephase_g;
+    if (grp) {
+      const uint64_t t0 = wall_clock64();
+      const int64_t ticks = (int64_t)grp * dephase_ticks;
+      while ((int64_t)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+
 template <bool F16, bool RES, bool TRANS, bool PP, bool ROPE>
-__global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n) {
+__global__ __launch_bounds__(512, 1) void gemm256p_kernel(const pst_gemm_params p, const int ntiles, const int tiles_m, const int tiles_n, const int dephase_g,
+                                                          const int dephase_ticks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  dephase_wait(blockIdx.x, dephase_g, dephase_ticks);
   gemm256p_body<F16, RES, TRANS, PP, ROPE>(p, ntiles, tiles_m, tiles_n, blockIdx.x, gridDim.x, smem);
 }
 
@@ -1016,6 +1033,7 @@ struct gemm256p2_args {
   int ntiles[2], tiles_m[2], tiles_n[2];
   int g0;
   int delay_ticks;        // start delay of problem 1's workgroups in 100 MHz ticks (0: none), see gemm256p_pair_delay_us
+  int dephase_g, dephase_ticks;      // phase groups within each problem (dephase_wait)
 };
 template <bool F16, bool RES, bool TRANS, bool PP, bool ROPE>
 __global__ __launch_bounds__(512, 1) void gemm256p2_kernel(const gemm256p2_args a) {
@@ -1031,6 +1049,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p2_kernel(const gemm256p2_args 
     const uint64_t t0 = wall_clock64();
     while ((int64_t)(wall_clock64() - t0) < (int64_t)a.delay_ticks) __builtin_amdgcn_s_sleep(32);
   }
+  dephase_wait(bid, a.dephase_g, a.dephase_ticks);
   gemm256p_body<F16, RES, TRANS, PP, ROPE>(a.p[which], a.ntiles[which], a.tiles_m[which], a.tiles_n[which], bid, nblk, smem);
 }
 
@@ -1079,11 +1098,33 @@ int gemm256_pp(int set) {
   return prev;
 }
 
+// PST_TUNE_DEPHASE: G * 1000 + percent (of the modelled step e / G); 0 = off.  e = epilogue bytes of one tile x workgroups of the launch / 5.2 TB/s.
+static int g_dephase = 0;
+int gemm256p_dephase(int set) {
+  const int prev = g_dephase;
+  if (set >= 0 && set < 64000) g_dephase = set;
+  return prev;
+}
+static inline double epilogue_bytes(const pst_gemm_params& p, int cls) {
+  return cls == 2 ? 256.0 * 256.0 * 8.0 + (p.xcopy ? 256.0 * 256.0 * 2.0 : 0.0) : 256.0 * 256.0 * 2.0;
+}
+// (groups, ticks between groups) of a launch whose `wgs` workgroups move `bytes` per round of epilogues; rounds < 2: nothing to gain
+static inline void dephase_plan(double bytes, double rounds, int* g, int* ticks) {
+  *g = 0; *ticks = 0;
+  const int G = g_dephase / 1000, pct = g_dephase % 1000;
+  if (G < 2 || pct <= 0 || rounds < 1.5) return;
+  const double e_us = bytes / 5.2e6;                       // all workgroups in their epilogue at once, at 5.2 TB/s
+  *g = G;
+  *ticks = (int)(e_us / G * pct / 100.0 * 100.0);         // microseconds -> 100 MHz ticks
+}
+
 template <bool F16, bool RES, bool TRANS, bool PP, bool ROPE>
 static void launch_256p_r(const pst_gemm_params& p, hipStream_t s, int grid, int tiles, int tiles_m, int tiles_n) {
   static unsigned long long attr_seen = 0;
   once_per_device(attr_seen, [] { (void)hipFuncSetAttribute((const void*)gemm256p_kernel<F16, RES, TRANS, PP, ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256P); });
-  hipLaunchKernelGGL((gemm256p_kernel<F16, RES, TRANS, PP, ROPE>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n);
+  int dg, dt;
+  dephase_plan(epilogue_bytes(p, RES ? 2 : 1) * grid, (double)tiles / grid, &dg, &dt);
+  hipLaunchKernelGGL((gemm256p_kernel<F16, RES, TRANS, PP, ROPE>), dim3(grid), dim3(512), LDS256P, s, p, tiles, tiles_m, tiles_n, dg, dt);
 }
 template <bool F16, bool RES, bool TRANS, bool PP>
 static void launch_256p_t(const pst_gemm_params& p, hipStream_t s, int grid, int tiles, int tiles_m, int tiles_n) {
@@ -1192,6 +1233,8 @@ int launch_gemm256p_pair(const pst_gemm_params& pa, const pst_gemm_params& pb, h
   }
   a.g0 = g0;
   const int cls = gemm256_persistent_class(pa);
+  dephase_plan(epilogue_bytes(pa, cls) * g0 + epilogue_bytes(pb, cls) * (cus - g0), std::min((double)a.ntiles[0] / g0, (double)a.ntiles[1] / (cus - g0)), &a.dephase_g,
+               &a.dephase_ticks);
   if (cls == 3) launch_256p2_c<false, true>(a, s, cus);
   else if (cls == 2) launch_256p2_c<true, false>(a, s, cus);
   else launch_256p2_c<false, false>(a, s, cus);

@@ -74,7 +74,7 @@ def lib():
     return L
 
 
-TUNE_G256_PP, TUNE_PAIR, TUNE_PAIR_RES, TUNE_PAIR_DELAY, TUNE_PAIR_ATTN, TUNE_DEEP_RING, TUNE_ATTN_XCD, TUNE_CUS = 3, 4, 5, 6, 7, 8, 9, 10
+TUNE_G256_PP, TUNE_PAIR, TUNE_PAIR_RES, TUNE_PAIR_DELAY, TUNE_PAIR_ATTN, TUNE_DEEP_RING, TUNE_ATTN_XCD, TUNE_CUS, TUNE_DEPHASE = 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 
 def tune(knob, value):

@@ -506,19 +506,23 @@ def main():
                 ts_all = _t.tensor([[H, W]] * V)
                 imgs_all = [synth_image(i, H, W).to(dev) for i in range(V)]
 
-                def api(amp, graphs, n):
+                def api(amp, graphs, n, outdevice='cpu'):
                     model.clear_runners()
                     for _ in range(2 if graphs else 1):            # warm-up (weights packed; with graphs: first call eager, second captures)
-                        model.forward_inference_multi_ar(imgs_all, ts_all, names, num_keyframes=K, max_bs=1, outdevice='cpu', amp=amp, cache_graphs=graphs)
+                        model.forward_inference_multi_ar(imgs_all, ts_all, names, num_keyframes=K, max_bs=1, outdevice=outdevice, amp=amp, cache_graphs=graphs)
                     _t.cuda.synchronize()
                     t0 = time.perf_counter()
                     for _ in range(n):
-                        model.forward_inference_multi_ar(imgs_all, ts_all, names, num_keyframes=K, max_bs=1, outdevice='cpu', amp=amp, cache_graphs=graphs)
+                        model.forward_inference_multi_ar(imgs_all, ts_all, names, num_keyframes=K, max_bs=1, outdevice=outdevice, amp=amp, cache_graphs=graphs)
                     _t.cuda.synchronize()
                     return round(V * n / (time.perf_counter() - t0), 2)
                 out['api_entry'] = {'call': "forward_inference_multi_ar(imgs, true_shape, classes, num_keyframes=%d, max_bs=1, outdevice='cpu', amp=...) as tools/demo_panst3r.py:232-233; frames/s incl. the device -> host copy of all outputs" % K,
                                     'amp_False_eager': api(False, False, 2), 'amp_False_cache_graphs': api(False, True, 2),
                                     'amp_fp16_eager': api('fp16', False, 3), 'amp_fp16_cache_graphs': api('fp16', True, 3)}
+                # the same entry with the outputs LEFT ON THE DEVICE (outdevice=None) and cached graphs: stage 2 in the form the runner-level selection picks
+                # (PanSt3R.stage2_overlap='auto' -> scene.pick_overlap, what the timed runner of `value` goes through), incl. input stacking + the finite check
+                out['api_entry']['amp_fp16_cache_graphs_on_device'] = api('fp16', True, 5, None)
+                out['api_entry']['stage2_form_on_device'] = (getattr(model, 'stage2_pick', None) or {}).get('chosen')
                 model.clear_runners()
                 del imgs_all
             except Exception as e:

@@ -166,6 +166,61 @@ class KernelTimer:
 
 TIMER = None      # set to a KernelTimer to time launches
 
+# ---- range telemetry (debug): max |x| of every 16-bit tensor the wrapped launches WRITE, per (stage, producer).  One reduction + one
+# host sync per tensor, eager launches only (never inside a graph capture, never on the timed path): `with hip.maxabs_telemetry() as log:` around a call,
+# `hip.stage(name)` labels the launches of a section (scene.SceneRunner labels its stages).  f16 overflows at 65504: a row of the log near that value says
+# WHICH stage of a checkpoint needs bf16 operands - the after-the-fact finite check only says that something did.
+MAXABS = None
+_STAGE = ['']
+F16_MAX = 65504.0
+
+
+class _Ctx:
+    def __init__(self, enter, leave):
+        self._enter, self._leave = enter, leave
+
+    def __enter__(self):
+        return self._enter()
+
+    def __exit__(self, *exc):
+        self._leave()
+        return False
+
+
+def maxabs_telemetry():
+    def enter():
+        global MAXABS
+        MAXABS = {}
+        return MAXABS
+
+    def leave():
+        global MAXABS
+        MAXABS = None
+    return _Ctx(enter, leave)
+
+
+def stage(name):
+    return _Ctx(lambda: _STAGE.append(name), lambda: _STAGE.pop())
+
+
+def note_maxabs(t, what):
+    """record max |t| under (current stage, what) while the telemetry is on; non-finite values are recorded as inf"""
+    if MAXABS is None or t is None or not torch.is_tensor(t) or t.dtype not in H16 or t.numel() == 0:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('hip.maxabs_telemetry() needs eager launches (it synchronises after every producer)')
+    v = float(torch.amax(t.abs()).float())
+    if v != v:
+        v = float('inf')
+    key = (_STAGE[-1], what)
+    MAXABS[key] = max(MAXABS.get(key, 0.0), v)
+
+
+def maxabs_report(log, top=None):
+    """[(stage, producer, max |x|, fraction of the f16 range)] sorted by magnitude"""
+    rows = sorted(((k[0], k[1], v, v / F16_MAX) for k, v in log.items()), key=lambda r: -r[2])
+    return rows[:top] if top else rows
+
 
 def _esz(t):
     return t.element_size()
@@ -424,7 +479,20 @@ def gemm(a, w, out, **kw):
         ev[1].record()
         return out
     _check(lib().pst_gemm(C.byref(p), _stream()), 'pst_gemm')
+    if MAXABS is not None:
+        _note_gemm(out, kw, tag)
     return out
+
+
+def _note_gemm(out, kw, tag):
+    M, N = int(tag[0]), int(tag[1])
+    what = 'gemm N=%d K=%s%s' % (N, tag[2], (' ' + kw['act']) if kw.get('act') else '')
+    if kw.get('ps') or kw.get('grp') or kw.get('batch') or kw.get('conv'):      # remapped / batched stores: the written region is not a corner of `out`
+        return
+    # only the region the launch wrote (pad rows / columns of a larger buffer hold whatever was there)
+    note_maxabs(out[:N, :M] if kw.get('trans_out') else out[:M, :N], what + ' out')
+    xc = kw.get('xcopy')
+    note_maxabs(None if xc is None else xc[:M, :N], what + ' 16-bit copy of the residual stream')
 
 
 def gemm_pair(first, second):
@@ -468,6 +536,9 @@ def gemm_pair(first, second):
         ev[1].record()
         return o1, o2
     _check(lib().pst_gemm_pair(C.byref(p1), C.byref(p2), _stream()), 'pst_gemm_pair')
+    if MAXABS is not None:
+        _note_gemm(o1, k1, t1)
+        _note_gemm(o2, k2, t2)
     return o1, o2
 
 
@@ -560,6 +631,7 @@ def attention(q, k, vt, out, B, H, Nq, Nk, hd, q_strides, k_strides, v_strides, 
         ev[1].record()
         return out
     _check(lib().pst_attn_fwd(C.byref(p), _stream()), 'pst_attn_fwd')
+    note_maxabs(out, 'attention hd=%d out' % hd)
     return out
 
 
@@ -662,6 +734,8 @@ def attention_pair(first, second):
         ev[1].record()
         return
     _check(lib().pst_attn_pair(C.byref(p1), C.byref(p2), _stream()), 'pst_attn_pair')
+    note_maxabs(a1[3], 'attention hd=%d out' % a1[8])
+    note_maxabs(a2[3], 'attention hd=%d out' % a2[8])
 
 
 def attn_workspace_floats(B, H, Nq, Nk, hd, nsplit=None):
@@ -709,6 +783,7 @@ def layernorm(x, gamma, beta, out, eps, rows=None, grp=None, add=None, split=Fal
     _check(lib().pst_layernorm(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(out), i64(_rowmajor(out)),
                                _tc(out), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)),
                                rows, D, f32(eps), g[0], g[1], g[2], _stream()), 'pst_layernorm')
+    note_maxabs(out, 'layernorm D=%d out' % D)
     return out
 
 
@@ -726,6 +801,7 @@ def rowstats(x, xcopy, stats):
         d16 = _tc(_dev(xcopy, *H16))
     _check(lib().pst_rowstats(_ptr(x), i64(_rowmajor(x)), _tc(x), _ptr(xcopy), i64(_rowmajor(xcopy) if xcopy is not None else 0), _ptr(stats),
                               stats.shape[1], rows, D, d16, _stream()), 'pst_rowstats')
+    note_maxabs(xcopy, 'rowstats D=%d 16-bit copy of the residual stream' % D)
     return xcopy, stats
 
 
@@ -808,6 +884,7 @@ def add_cast(a, out, b=None, b_mod=0):
     _check(lib().pst_add_cast(_ptr(a), i64(_rowmajor(a)), fp(a), _ptr(b), i64(_rowmajor(b) if b is not None else 0),
                               fp(b) if b is not None else 0, b_mod, _ptr(out), i64(_rowmajor(out)), fp(out), rows, D, _stream()),
            'pst_add_cast')
+    note_maxabs(out, 'add_cast D=%d out' % D)
     return out
 
 

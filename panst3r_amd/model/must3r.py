@@ -367,8 +367,10 @@ class MUSt3R(HipModule):
         return out
 
     def _append_f32(self, bank, hs, hs_all, fb, lay, rows, n0):
-        """the fp32 twin of the append: norm_y(h_l + feedback) and projk / projv in float32 (fp32 weights, fp32-input MFMA) from the SAME streams the
-        16-bit build produced - what the reference's fp32 render of the other views reads out of the autocast-built memory (panst3r.py:268)."""
+        """the fp32 twin of the append: norm_y(h_l + feedback) and projk / projv in the fp32 mode (fp32 activations, contractions as 3 x f16 MFMA on split
+        operands - what panoptic_precision='reference', the only placement that keeps a twin, runs its fp32 parts in: pan_amp_of returns pan_amp=False, never
+        'fp32_exact') from the SAME streams the 16-bit build produced - what the reference's fp32 render of the other views reads out of the autocast-built
+        memory (panst3r.py:268)."""
         from .common import precision
         b32, dev, D, L = bank.f32, hs[0].device, self.embed_dim, self.depth
         with precision(torch.float32):

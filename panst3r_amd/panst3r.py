@@ -317,10 +317,44 @@ class PanSt3R(nn.Module):
         return torch.cat(pms) if len(pms) > 1 else pms[0]
 
     # ------------------------------------------------------------------ reference API
+    # range ladder of the 16-bit operand formats: what a call falls back to when its outputs come back non-finite - an activation left the
+    # f16 range (65504; the reference warns "fp16 might be unstable", tools/demo_panst3r.py:88-89).  (amp, panoptic_precision) -> the next, range-safer placement.
+    @staticmethod
+    def range_fallback_of(amp, panoptic_precision):
+        fmt = amp_dtype(amp, quiet=True)
+        if fmt == torch.float16:
+            return 'bf16', None                 # bf16 backbone (fp32 exponent range), panoptic decoder still on f16 operands (every operand there is normalised)
+        if fmt == torch.bfloat16 and panoptic_precision in (None, 'auto', 'fp16'):
+            return 'bf16', 'amp'                # ... and the panoptic decoder on bf16 operands too
+        return None
+
     @torch.no_grad()
     def forward_inference_multi_ar(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=None,
                                    outdevice=None, amp=False, sim_matrix=None, keyframes=None, check_finite=True, cache_graphs=False,
-                                   panoptic_precision=None, _mm_tables=None):
+                                   panoptic_precision=None, _mm_tables=None, range_fallback=True):
+        """The reference's entry point (see _forward_inference_once for the arguments).  `range_fallback` (not in the reference; needs check_finite): when
+        the outputs of an f16-operand call are not finite, the call is REPEATED on the next placement of range_fallback_of - 'fp16' -> 'bf16' (f16 only in the
+        panoptic decoder) -> bf16 everywhere - with a RuntimeWarning naming the step, instead of raising; FloatingPointError only when the last placement
+        fails too (bf16 has the fp32 exponent range: that is not an overflow).  `self.last_precision` records the (amp, panoptic_precision) that produced
+        the returned outputs.  hip.maxabs_telemetry() shows which stage of a checkpoint came close to the limit."""
+        import warnings
+        while True:
+            try:
+                out = self._forward_inference_once(imgs, true_shape, classes, num_keyframes, use_retrieval, max_bs, outdevice, amp, sim_matrix, keyframes,
+                                                   check_finite, cache_graphs, panoptic_precision, _mm_tables)
+                self.last_precision = (amp, panoptic_precision)
+                return out
+            except (FloatingPointError, OverflowError) as e:       # non-finite outputs (check_finite) | a weight that does not fit f16 (raised when the weights are packed)
+                nxt = self.range_fallback_of(amp, panoptic_precision) if (range_fallback and (check_finite or isinstance(e, OverflowError))) else None
+                if nxt is None:
+                    raise
+                warnings.warn('%s - repeating the call with amp=%r, panoptic_precision=%r (range_fallback=False raises instead)' % (e, nxt[0], nxt[1]), RuntimeWarning)
+                amp, panoptic_precision = nxt
+
+    @torch.no_grad()
+    def _forward_inference_once(self, imgs, true_shape, classes, num_keyframes=None, use_retrieval=False, max_bs=None,
+                                outdevice=None, amp=False, sim_matrix=None, keyframes=None, check_finite=True, cache_graphs=False,
+                                panoptic_precision=None, _mm_tables=None):
         """imgs: list[V] of [3,H,W] in [-1,1]; true_shape [V,2]; returns (pointmaps list[V] of [1,H,W,7],
         {'pred_logits' [1,Q,Ncls], 'pred_masks' list[V] of [1,Q,H/2,W/2], 'out_queries' [Q,1,768]}).
         Keyframes: linspace over the views (panst3r.py:183-186) by default.  `use_retrieval=True` (panst3r.py:179-180) takes the
@@ -348,7 +382,8 @@ class PanSt3R(nn.Module):
         shapes = [tuple(int(s) for s in im.shape[-2:]) for im in imgs]        # multi-AR: views are batched per shape group
         H, W = shapes[0]
         fmt = amp_dtype(amp)                    # tells (once) that amp=False is the slow fp32 mode
-        runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs, panoptic_precision, _mm_tables)
+        runner = self._runner_for(imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs, panoptic_precision, _mm_tables,
+                                  streamed=outdevice is not None and torch.device(outdevice).type == 'cpu')
         pan_fmt = fmt if runner.pan_amp is None else amp_dtype(runner.pan_amp, quiet=True)
         checked = check_finite and torch.float16 in (fmt, pan_fmt)
         def nonfinite():
@@ -378,13 +413,21 @@ class PanSt3R(nn.Module):
             # check_finite=False skips it (SceneRunner.run, which bench.py times, never pays it).  The per-view mask tensors are VIEWS of one
             # [n, Q, H/2, W/2] allocation per shape group (one mask-head launch writes them all): holding one keeps its group's block alive.
             ok = torch.isfinite(scene['out_queries']).all() & torch.isfinite(scene['pred_logits']).all()
-            blocks = {}                     # the per-view tensors are views of one block per shape group and kind: check each block once, not 2 V views
+            # the per-view tensors are views of one block per shape group and kind: check each block once, not 2 V views - but only a block its views TILE
+            # (a base with pad rows or scratch behind the views holds uninitialised memory: those are checked view by view)
+            blocks, covered = {}, {}
             for i in range(V):
                 for t in res[i]:
                     base = t._base if t._base is not None else t
-                    blocks.setdefault((base.data_ptr(), tuple(base.shape)), base)
-            for base in blocks.values():
-                ok = ok & torch.isfinite(base).all()
+                    key = (base.data_ptr(), tuple(base.shape))
+                    blocks.setdefault(key, (base, []))[1].append(t)
+                    covered[key] = covered.get(key, 0) + t.numel()
+            for key, (base, views) in blocks.items():
+                if covered[key] == base.numel():
+                    ok = ok & torch.isfinite(base).all()
+                else:
+                    for t in views:
+                        ok = ok & torch.isfinite(t).all()
             if not bool(ok):
                 nonfinite()
             if outdevice is not None:
@@ -399,7 +442,7 @@ class PanSt3R(nn.Module):
             runner.release()                    # a one-off scene keeps no intermediates (stacked inputs, features, mask features) alive
         return pms, panout
 
-    def _runner_for(self, imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs=1, panoptic_precision=None, mm_tables=None):
+    def _runner_for(self, imgs, shapes, classes, num_keyframes, keyframes, dev, amp, cache_graphs, max_bs=1, panoptic_precision=None, mm_tables=None, streamed=False):
         """The SceneRunner of a call.  Default: a fresh eager runner, dropped after the call (what the reference's per-call execution
         costs in memory).  cache_graphs=True: runners are kept per scene SIGNATURE - everything a captured graph depends on: shapes,
         keyframe schedule, class list, device, format, and the version of every weight and class embedding (module generations bumped
@@ -421,7 +464,7 @@ class PanSt3R(nn.Module):
         pver = sum(p._version for p in self.parameters())
         cver = tuple((c, te.class_embeddings[c].data_ptr(), te.class_embeddings[c]._version) if c in te.class_embeddings else (c,) for c in classes)
         key = (tuple(shapes), num_keyframes, None if keyframes is None else tuple(int(k) for k in keyframes), str(dev),
-               amp_dtype(amp, quiet=True), str(amp), gens, pver, cver, getattr(te, '_cls_gen', 0), max_bs, panoptic_precision)
+               amp_dtype(amp, quiet=True), str(amp), gens, pver, cver, getattr(te, '_cls_gen', 0), max_bs, panoptic_precision, bool(streamed))
         ent = self._runners.get(key)
         if ent is None:
             while len(self._runners) >= max(1, self.max_cached_runners):
@@ -430,9 +473,24 @@ class PanSt3R(nn.Module):
             runner = SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=False, shapes=shapes,
                                  keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pa, pan_scope=ps)
             ent = self._runners[key] = [0, runner]
+        elif not ent[1].use_graphs:
+            # second call with this signature: the graph runner.  stage2_overlap='auto' (default) captures the serial AND the CU-masked two-queue form of stage 2
+            # (scene.pick_overlap: the memory build on its own CUs beside the first tower layers), replays each three times, checks that they give the same bits
+            # and keeps the faster - the same selection bench.py's timed runner goes through, so the API entry and the benchmark run the same form on a box.
+            from .scene import pick_overlap
+            ent[1].release()
+            pa, ps = pan_amp_of(amp, panoptic_precision)
+            mk = lambda ov: SceneRunner(HipBackend(self), {i: imgs[i] for i in range(V)}, V, H, W, num_keyframes, classes, use_graphs=True, shapes=shapes,
+                                        keyframes=keyframes, amp=amp, minmax_bs=max_bs, pan_amp=pa, pan_scope=ps, overlap=ov)
+            # (a call whose outputs stream to the host while the scene computes - outdevice='cpu', run_streamed - keeps the serial form: its plan interleaves
+            # the copies with the stages of ONE stream)
+            mode = False if streamed else getattr(self, 'stage2_overlap', 'auto')
+            if mode == 'auto':
+                ent[1], self.stage2_pick = pick_overlap(mk)
+            else:
+                ent[1] = mk('masked' if mode == 'masked' else False)
         else:
             ent[1].set_images(imgs)
-            ent[1].use_graphs = True          # captured lazily by run()
         ent[0] += 1
         return ent[1]
 
@@ -466,11 +524,12 @@ class PanSt3R(nn.Module):
                            plan=plan, minmax_bs=max_bs, pan_amp=pa, pan_scope=ps, stream_bank=stream_bank)
 
     @torch.no_grad()
-    def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False):
+    def forward(self, imgs, true_shape, classes, max_bs=None, outdevice=None, amp=False, panoptic_precision=None):
         """Same-shape batch variant (panst3r.py:286-296): imgs [B,n,3,H,W] -> (panout, pointmaps [B,n,H,W,7]); B scenes, each with its own
         memory and queries; every view is a memory view (mem batches [2,1,...]) and every view is rendered.  `amp` as forward_inference_multi_ar (the reference
         runs this entry point under the caller's autocast).  `max_bs` only chunks the backbone work in the reference (:288-290) - nothing here depends on it:
-        the panoptic decoder is called WITHOUT it (:294), so LoftUp's MinMaxScaler always pools over all B * n views of the call (per orientation)."""
+        the panoptic decoder is called WITHOUT it (:294), so LoftUp's MinMaxScaler always pools over all B * n views of the call (per orientation).
+        `panoptic_precision`: as forward_inference_multi_ar (amp='bf16' runs the panoptic decoder on f16 operands unless 'amp' is passed here)."""
         B, n = imgs.shape[:2]
         Ht, Wt = int(imgs.shape[-2]), int(imgs.shape[-1])
         # views in their TRUE orientation.  DUSt3R storage convention (utils.py:8-61 transpose_to_landscape): a same-shape batch may hold PORTRAIT views stored
@@ -510,7 +569,8 @@ class PanSt3R(nn.Module):
         for b in range(B):                      # the scenes of a batch are independent (own memory, own queries)
             views, stored = scenes[b]
             ts = torch.tensor([list(v.shape[-2:]) for v in views])
-            pms, panout = self.forward_inference_multi_ar(views, ts, classes, num_keyframes=n, outdevice=outdevice, amp=amp, max_bs=1, _mm_tables=mm_tables[b])
+            pms, panout = self.forward_inference_multi_ar(views, ts, classes, num_keyframes=n, outdevice=outdevice, amp=amp, max_bs=1, _mm_tables=mm_tables[b],
+                                                          panoptic_precision=panoptic_precision)
             masks = list(panout['pred_masks'])
             for i in stored:
                 pms[i] = pms[i].transpose(1, 2)

@@ -955,6 +955,12 @@ def run_scene(backend, get_image, V, H, W, K, classes, rank=0, world=1, group=No
                        minmax_bs=minmax_bs, stream_bank=stream_bank).run(outdevice)
 
 
+def _stage(name):
+    """label of the launches of a section for hip.maxabs_telemetry() (a no-op list push / pop otherwise)"""
+    from . import hip
+    return hip.stage(name)
+
+
 class HipBackend:
     """Stage backend on the HIP kernels (wraps a panst3r_amd.PanSt3R)."""
 
@@ -991,16 +997,19 @@ class HipBackend:
     def encode_enc(self, imgs, cat_rows, enc_rows=None):
         """enc_rows: additionally the tokens in the format in effect when `cat_rows` is kept in another one (the final LayerNorm's fp32 result rounded once,
         exactly what the LayerNorm kernel stores when it writes that format itself)"""
-        self.m.encode_views(imgs, cat_rows, dino=False, enc_copy=enc_rows)
+        with _stage('CroCo encoder'):
+            self.m.encode_views(imgs, cat_rows, dino=False, enc_copy=enc_rows)
 
     def bank_f32(self, bank):
         return bank.f32
 
     def encode_rest_paired(self, imgs_enc, cat_enc, imgs_dino, cat_dino, enc_rows=None):
-        self.m.encode_views_paired(imgs_enc, cat_enc, imgs_dino, cat_dino, enc_rows)
+        with _stage('CroCo encoder + DINOv2 (paired towers)'):
+            self.m.encode_views_paired(imgs_enc, cat_enc, imgs_dino, cat_dino, enc_rows)
 
     def encode_dino(self, imgs, cat_rows):
-        self.m.encode_views(imgs, cat_rows, enc=False)
+        with _stage('DINOv2'):
+            self.m.encode_views(imgs, cat_rows, enc=False)
 
     def copy_stream(self, device):
         """a stream that only ever carries device -> host copies of finished blocks (SceneRunner.run_streamed): DMA engines, no kernels beside the scene's"""
@@ -1103,7 +1112,8 @@ class HipBackend:
         return self.m.paired_begin(imgs_enc, imgs_dino)
 
     def rest_layers(self, st, lo, hi):
-        self.m.paired_layers(st, lo, hi)
+        with _stage('CroCo encoder + DINOv2 (paired towers)'):
+            self.m.paired_layers(st, lo, hi)
 
     def rest_finish(self, st, cat_enc, cat_dino, enc_rows=None):
         self.m.paired_finish(st, cat_enc, cat_dino, enc_rows)
@@ -1112,7 +1122,8 @@ class HipBackend:
         return cat[:rows, :self.De].contiguous()
 
     def build_memory(self, enc_kf, K, grids, f32_bank=False):
-        return self.m.build_memory(enc_kf, K, grids=grids, f32_bank=f32_bank)
+        with _stage('memory build'):
+            return self.m.build_memory(enc_kf, K, grids=grids, f32_bank=f32_bank)
 
     def bank_payload(self, bank):
         return [bank.K_all, bank.Vt_all] + ([bank.f32.K_all, bank.f32.Vt_all] if bank.f32 is not None else [])
@@ -1125,7 +1136,8 @@ class HipBackend:
         return self.m.must3r_decoder.new_bank(device, sum(a * c for a, c in grids), f32=f32_bank)
 
     def build_step(self, bank, enc_kf, K, grids, u):
-        self.m.build_memory_step(bank, enc_kf, K, grids, u)
+        with _stage('memory build'):
+            self.m.build_memory_step(bank, enc_kf, K, grids, u)
 
     def bank_final(self, bank):
         return bank
@@ -1156,7 +1168,8 @@ class HipBackend:
         return bank
 
     def render(self, cat, n, h, w, bank, enc=None):
-        return self.m.render_views(cat, n, h, w, bank, enc=enc)
+        with _stage('render (MUSt3R decoder vs. memory)'):
+            return self.m.render_views(cat, n, h, w, bank, enc=enc)
 
     def minmax_scaled(self):
         return self.m.panoptic_decoder.minmax_scaled()
@@ -1194,10 +1207,12 @@ class HipBackend:
         return table.index_select(0, self._index(pos, table.device)).contiguous()
 
     def guidance(self, imgs, h, w, mm=None):
-        return self.m.panoptic_decoder.guidance_tokens(imgs, h, w, mm=mm)
+        with _stage('LoftUp guidance'):
+            return self.m.panoptic_decoder.guidance_tokens(imgs, h, w, mm=mm)
 
     def features(self, cat, imgs, n, h, w, guidance=None, mm=None):
-        return self.m.panoptic_decoder.features_tokens(cat, imgs, n, h, w, guidance=guidance, mm=mm)
+        with _stage('InputMixer + upscaler'):
+            return self.m.panoptic_decoder.features_tokens(cat, imgs, n, h, w, guidance=guidance, mm=mm)
 
     def fpn_grid(self, h, w):
         return self.m.panoptic_decoder.fpn_grid(h, w)
@@ -1211,7 +1226,8 @@ class HipBackend:
     def decode(self, fpn_kf, fm_kf, K, grids, classes, portrait):
         pd = self.m.panoptic_decoder
         cls = pd.class_rows(classes, fpn_kf.device)
-        return pd.mask_transformer.decode_tokens(fpn_kf, fm_kf, list(grids), cls, list(portrait))
+        with _stage('query decoder'):
+            return pd.mask_transformer.decode_tokens(fpn_kf, fm_kf, list(grids), cls, list(portrait))
 
     def masks(self, head, mf, j):
         return self.m.panoptic_decoder.mask_transformer.masks_for(head.embed, mf[j])

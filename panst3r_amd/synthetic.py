@@ -20,8 +20,32 @@ def _gen(key, seed):
     return np.random.Generator(np.random.PCG64((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF))
 
 
-def fill_value(key, shape, seed=0, sharp=1.0):
+# "outlier" weight set: trained ViT-L / DINOv2 checkpoints carry a handful of residual-stream channels 10^2 - 10^3 x larger than the
+# rest, fed by a few rows of the residual-writing projections (attention output, fc2).  `outlier=S` scales those rows (and their bias entries) of every
+# such projection of the three backbones by S for OUTLIER_CHANNELS (taken modulo the layer's width): what an f16 operand path must survive.
+OUTLIER_CHANNELS = (7, 133, 402, 911)
+_RESIDUAL_WRITERS = ('attn.proj.', 'mlp.fc2.', 'cross_attn.proj.', 'attention.output.dense.')
+_OUTLIER_SCOPE = ('must3r_encoder.blocks_enc.', 'must3r_decoder.blocks_dec.', 'dino_encoder.dinov2.encoder.layer.')
+
+
+def _outlier_rows(key, n_out):
+    if not any(s in key for s in _OUTLIER_SCOPE) or not any(s in key for s in _RESIDUAL_WRITERS):
+        return None
+    return sorted({c % n_out for c in OUTLIER_CHANNELS})
+
+
+def fill_value(key, shape, seed=0, sharp=1.0, outlier=None):
     """fp32 numpy array for state-dict entry `key`."""
+    v = _fill_value(key, shape, seed, sharp)
+    if outlier and len(tuple(shape)) in (1, 2) and (key.endswith('weight') or key.endswith('bias')):
+        rows = _outlier_rows(key, tuple(shape)[0])
+        if rows is not None:
+            v = np.array(v, copy=True)
+            v[rows] *= np.float32(outlier)
+    return v
+
+
+def _fill_value(key, shape, seed=0, sharp=1.0):
     g = _gen(key, seed)
     shape = tuple(shape)
     if len(shape) == 0:
@@ -44,12 +68,13 @@ def fill_value(key, shape, seed=0, sharp=1.0):
 
 
 @torch.no_grad()
-def fill_module_(module, seed=0, sharp=1.0, prefix=''):
-    """In-place deterministic fill of every parameter/buffer in module.state_dict()."""
+def fill_module_(module, seed=0, sharp=1.0, prefix='', outlier=None):
+    """In-place deterministic fill of every parameter/buffer in module.state_dict().  `outlier`: see OUTLIER_CHANNELS (keys are matched on
+    prefix + key: pass the prefix the module has in the full model)."""
     for key, t in module.state_dict().items():
         if not t.dtype.is_floating_point:
             continue
-        v = torch.from_numpy(fill_value(prefix + key, t.shape, seed, sharp))
+        v = torch.from_numpy(fill_value(prefix + key, t.shape, seed, sharp, outlier))
         t.copy_(v.to(t.dtype))
     return module
 

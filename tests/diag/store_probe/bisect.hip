@@ -47,6 +47,55 @@ __global__ void churn_kernel(float* buf, int ticks) {
   if (acc == 12345.678f) p[0] = acc;
 }
 
+// co-runners with ONE property of a library GEMM kernel each (~10 us per launch at 48 workgroups of 256 threads, as a 768 x 1024 x 1024 torch.mm):
+// lds_kernel: 64 KiB of LDS per workgroup, ds_write / ds_read loop | mfma_kernel: a chain of MFMAs, no memory | vgpr_kernel: 256 live VGPRs per lane (VALU loop)
+__global__ __launch_bounds__(256) void lds_kernel(float* out, int iters) {
+  extern __shared__ float sm[];
+  float a = threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    for (int j = threadIdx.x; j < 16384; j += 256) sm[j] = a + j;
+    __syncthreads();
+    for (int j = threadIdx.x; j < 16384; j += 256) a += sm[(j * 33) & 16383];
+    __syncthreads();
+  }
+  if (a == 1234.5f) out[0] = a;
+}
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+__global__ __launch_bounds__(256) void mfma_kernel(float* out, int iters) {
+  bf16x8_t a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x & 7); b[i] = (__bf16)1.0f; }
+  f32x4_t c[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int it = 0; it < iters; ++it)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c[k], 0, 0, 0);
+  if (c[0][0] + c[1][1] + c[2][2] + c[3][3] == 1234.5f) out[0] = c[0][0];
+}
+__global__ __launch_bounds__(256) void vgpr_kernel(float* out, int iters) {
+  float r[200];
+#pragma unroll
+  for (int i = 0; i < 200; ++i) r[i] = threadIdx.x + i;
+  for (int it = 0; it < iters; ++it)
+#pragma unroll
+    for (int i = 0; i < 200; ++i) r[i] = fmaf(r[i], 1.0001f, r[(i + 1) % 200]);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 200; ++i) s += r[i];
+  if (s == 1234.5f) out[0] = s;
+}
+// kind: 3 lds | 4 mfma | 5 vgpr ; `count` launches of `grid` workgroups
+extern "C" int bisect_corunner2(int kind, int count, int grid, int iters, float* buf, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); }
+  for (int i = 0; i < count; ++i) {
+    if (kind == 3) hipLaunchKernelGGL(lds_kernel, dim3(grid), dim3(256), 65536, s, buf, iters);
+    else if (kind == 4) hipLaunchKernelGGL(mfma_kernel, dim3(grid), dim3(256), 0, s, buf, iters);
+    else hipLaunchKernelGGL(vgpr_kernel, dim3(grid), dim3(256), 0, s, buf, iters);
+  }
+  return (int)hipGetLastError();
+}
+
 template <int LD, int ST>
 static int launch_victim(const float* img, float* out, int nimg, int H, int W, int Ho, int Wo, hipStream_t s) {
   int64_t g = ((int64_t)nimg * 3 * Ho * Wo + 255) / 256;

@@ -35,6 +35,9 @@ img = torch.rand(13, 3, 384, 512, device=dev) * 2 - 1
 a = torch.randn(768, 1024, device=dev).bfloat16(); b = torch.randn(1024, 1024, device=dev).bfloat16(); c = torch.empty(768, 1024, device=dev, dtype=torch.bfloat16)
 A = torch.randn(6912, 1024, device=dev).bfloat16(); W1 = torch.randn(1024, 4096, device=dev).bfloat16(); W2 = torch.randn(4096, 1024, device=dev).bfloat16()
 churn = torch.zeros(1024 * 16384, device=dev)
+a16, b16, c16 = torch.randn(768, 1024, device=dev).half(), torch.randn(1024, 1024, device=dev).half(), torch.empty(768, 1024, device=dev, dtype=torch.float16)
+bigA = torch.randn(8192, 8192, device=dev).bfloat16(); bigB = torch.randn(8192, 8192, device=dev).bfloat16(); bigC = torch.empty(8192, 8192, device=dev, dtype=torch.bfloat16)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 _so = os.path.join(tempfile.gettempdir(), 'libbisect.so')
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', _so,
@@ -42,6 +45,7 @@ subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-
 lib = ctypes.CDLL(_so)
 lib.bisect_victim.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
 lib.bisect_corunner.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
+lib.bisect_corunner2.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
 
 # 'orig7' / 'orig6': variants 7 / 6 of store_probe/variants.hip from ITS library (the known 25 / 25 and 0 / 25 cases: the same source as 'plain' at another code address)
 _so0 = os.path.join(tempfile.gettempdir(), 'libstoreprobe.so')
@@ -71,6 +75,19 @@ def corun(kind):
         lib.bisect_corunner(2, 1, 1024, RUN_TICKS, churn.data_ptr(), s)
     elif kind == 'churnw':
         lib.bisect_corunner(2, 300, 1024, 10000, churn.data_ptr(), s)
+    elif kind == 'ldsk':              # 3000 x (48 workgroups, 64 KiB LDS each, ds_write / ds_read)
+        lib.bisect_corunner2(3, 3000, 48, 2, churn.data_ptr(), s)
+    elif kind == 'mfmak':             # 3000 x (48 workgroups, a chain of MFMAs)
+        lib.bisect_corunner2(4, 3000, 48, 400, churn.data_ptr(), s)
+    elif kind == 'vgprk':             # 3000 x (48 workgroups, 200+ live VGPRs)
+        lib.bisect_corunner2(5, 3000, 48, 20, churn.data_ptr(), s)
+    elif kind == 'hipgemm':           # 3000 x this library's own GEMM on the torch.mm's shape (hand-written MFMA + LDS-DMA kernel, no rocBLAS)
+        from panst3r_amd import hip
+        for _ in range(3000):
+            hip.gemm(a16, b16, c16)
+    elif kind == 'mm_big':            # 40 x torch.mm of 8192^3 (~1 ms each): a library GEMM with few kernel boundaries
+        for _ in range(40):
+            torch.mm(bigA, bigB, out=bigC)
     else:
         raise ValueError(kind)
 

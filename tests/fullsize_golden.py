@@ -38,6 +38,10 @@ def scene_errors(pm_h, pan_h, g):
     mk_idx = torch.from_numpy(g['mk_idx']).to(dev)
     pm_o = torch.from_numpy(g['pm']).to(dev).double()
     mk_o = torch.from_numpy(g['mk']).to(dev)
+    sg_idx = sg_o = None
+    if 'sg_bits' in g:                                   # sign bits at further pixels: the sample the sign-agreement criterion is evaluated on
+        sg_idx = torch.from_numpy(g['sg_idx']).to(dev)
+        sg_o = torch.from_numpy(np.unpackbits(g['sg_bits'], axis=-1)[..., :sg_idx.numel()]).to(dev).bool()
     pm_rel, pm_ratio, mk_rel, mk_sign, mk_ratio, mk_pos = [], [], [], [], [], []
     num = den = agree = cnt = 0.0
     for v in range(V):
@@ -49,10 +53,13 @@ def scene_errors(pm_h, pan_h, g):
         a = m.reshape(Q, -1)[:, mk_idx]
         b = mk_o[v]
         d2, b2 = float((a.double() - b.double()).pow(2).sum()), float(b.double().pow(2).sum())
-        ag = float(((a > 0) == (b > 0)).sum())
-        num, den, agree, cnt = num + d2, den + b2, agree + ag, cnt + b.numel()
+        if sg_o is not None:
+            ag, n_sg = float(((m.reshape(Q, -1)[:, sg_idx] > 0) == sg_o[v]).sum()), sg_o[v].numel()
+        else:
+            ag, n_sg = float(((a > 0) == (b > 0)).sum()), b.numel()
+        num, den, agree, cnt = num + d2, den + b2, agree + ag, cnt + n_sg
         mk_rel.append((d2 / max(b2, 1e-300)) ** 0.5)
-        mk_sign.append(ag / b.numel())
+        mk_sign.append(ag / n_sg)
         mk_ratio.append(float(m.double().norm()) / float(g['mk_norm'][v]))
         mk_pos.append((float((m > 0).sum()) - float(g['mk_pos'][v])) / m.numel())
     rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
@@ -66,4 +73,5 @@ def scene_errors(pm_h, pan_h, g):
             # whole tensors, not samples: L2 norm of every view's pointmap / mask block against the oracle's, and the change of its share of positive logits
             'full_coverage': {'pointmap_norm_ratio_max_dev': sig(max(abs(r - 1.0) for r in pm_ratio)), 'mask_norm_ratio_max_dev': sig(max(abs(r - 1.0) for r in mk_ratio)),
                               'mask_positive_share_max_dev': sig(max(abs(x) for x in mk_pos))},
-            'samples': {'pointmap_pixels_per_view': int(pm_idx.numel()), 'mask_pixels_per_view': int(mk_idx.numel()), 'views': V}}
+            'samples': {'pointmap_pixels_per_view': int(pm_idx.numel()), 'mask_pixels_per_view': int(mk_idx.numel()),
+                        'sign_pixels_per_view': int(sg_idx.numel()) if sg_idx is not None else int(mk_idx.numel()), 'views': V}}

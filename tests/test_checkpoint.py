@@ -109,7 +109,8 @@ def test_reference_class_surface():
     assert sig(PanSt3R.forward_must3r_decoder) == ['self', 'x_must3r', 'pos_must3r', 'true_shape', 'max_bs', 'amp']
     assert sig(PanSt3R._forward_decoder_render) == ['self', 'imgs', 'x_must3r', 'pos_must3r', 'true_shape', 'mem_must3r', 'mem_panst3r', 'classes',
                                                     'max_bs', 'multi_ar', 'outdevice', 'amp']
-    assert sig(PanSt3R.forward) == ['self', 'imgs', 'true_shape', 'classes', 'max_bs', 'outdevice', 'amp']
+    # (forward: + panoptic_precision, the placement knob forward_inference_multi_ar has - ADVICE r5: the batch entry could not pass it on)
+    assert sig(PanSt3R.forward) == ['self', 'imgs', 'true_shape', 'classes', 'max_bs', 'outdevice', 'amp', 'panoptic_precision']
     assert sig(PanSt3R.forward_inference_multi_ar)[:9] == ['self', 'imgs', 'true_shape', 'classes', 'num_keyframes', 'use_retrieval', 'max_bs',
                                                            'outdevice', 'amp']
     assert sig(PanSt3R.set_vocab)[:3] == ['self', 'class_names', 'device']

@@ -12,6 +12,8 @@ hip.tune(hip.TUNE_G256_PP, int(sys.argv[5]) if len(sys.argv) > 5 else 1)
 if len(sys.argv) > 6:
     hip.tune(hip.TUNE_CUS, int(sys.argv[6]))          # grid of the persistent kernel (as on a CU-masked stream)
 a, w, out, kw = case(M, N, K, kind)
+if os.environ.get('PST_OPERANDS') == 'zeros':      # the same launch on all-zero operands: what the data-dependent power draw of the matrix cores costs (clocks)
+    a.zero_(); w.zero_()
 t = compare([lambda: hip.gemm(a, w, out, kernel=256, **kw)])[0]
 tiles = ((M + 255) // 256) * ((N + 255) // 256)
 wgs = int(sys.argv[6]) if len(sys.argv) > 6 else torch.cuda.get_device_properties(0).multi_processor_count

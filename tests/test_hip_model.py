@@ -590,3 +590,72 @@ def test_forward_batch_and_dust3r_storage_convention(pair):
     assert torch.equal(pan_c['pred_logits'].cpu(), pan['pred_logits'].cpu())
     with pytest.raises(ValueError):
         h.forward(imgs, torch.tensor([[[H, W]] * n, [[H, W], [W + 16, H], [H, W]]]), tiny.NAMES, amp=h.amp, max_bs=1)
+
+
+def _two_rank_graph_worker(rank, world, port, q, stream_bank):
+    """one of two PROCESSES on the same GPU: the 'broadcast' plan with captured HIP graphs over a gloo group (its collectives move device tensors through the
+    host - the transport is not the subject), two scenes through ONE runner"""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from panst3r_amd.scene import SceneRunner, HipBackend, assign_views
+        from panst3r_amd.panst3r import pan_amp_of
+        H, W, V, K = 64, 96, 5, 3
+        dev = torch.device(DEV)
+        h = tiny.build(tiny.hip_ns(), 'v2').to(dev)
+        first = [im.to(dev) for im in tiny.images(V, H, W)]
+        second = [tiny.synth_image(100 + i, H, W, 7).to(dev) for i in range(V)]
+        _, order, owner = assign_views(V, K, world, plan='broadcast')
+        mine = lambda imgs: {order[i]: imgs[order[i]] for i in range(V) if owner[i] == rank}
+        pa, ps = pan_amp_of('fp16', None)
+        with torch.no_grad():
+            rn = SceneRunner(HipBackend(h), mine(first), V, H, W, K, tiny.NAMES, rank, world, None, use_graphs=True, amp='fp16', plan='broadcast', pan_amp=pa,
+                             pan_scope=ps, stream_bank=stream_bank)
+            rn.run()                               # eager warm-up + capture
+            rn.run()                               # replay, first scene
+            rn.set_images(mine(second))
+            res, scene = rn.run()                  # replay, second scene
+            torch.cuda.synchronize()
+        q.put((rank, {k: (v[0].cpu().numpy().copy(), v[1].cpu().numpy().copy()) for k, v in res.items()}, scene['out_queries'].cpu().numpy().copy()))
+    except Exception as e:
+        import traceback
+        q.put((rank, 'rank %d: %s\n%s' % (rank, repr(e), traceback.format_exc()), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('stream_bank', [False, True])
+def test_two_process_broadcast_plan_with_graphs_survives_a_new_scene(stream_bank):
+    """graphs + the bank received from rank 0, then set_images() with a DIFFERENT scene, on the real HIP backend - two processes share
+    the GPU, the collectives run over gloo on device tensors.  The receiving rank's captured stage 2b renders from the bank it saw at capture time: with
+    the bank streamed per memory update it used to allocate a fresh bank on every run() and render the new scene against the old (freed) one.  Both
+    ranks' outputs for the second scene must equal the one-process eager scene bit for bit, for both forms of the bank transfer."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_graph_worker, args=(r, 2, port, q, stream_bank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(not isinstance(g[1], str) for g in got), [g[1] for g in got if isinstance(g[1], str)]
+    H, W, V, K = 64, 96, 5, 3
+    h = tiny.build(tiny.hip_ns(), 'v2').to(DEV)
+    second = {i: tiny.synth_image(100 + i, H, W, 7).to(DEV) for i in range(V)}
+    with torch.no_grad():
+        ref, sref = h.scene_runner(second, V, H, W, tiny.NAMES, num_keyframes=K, use_graphs=False, amp='fp16').run()
+    merged = {}
+    for rank, res, outq in got:
+        assert torch.equal(torch.from_numpy(outq), sref['out_queries'].cpu()), rank
+        merged.update(res)
+    assert sorted(merged) == list(range(V))
+    for i in range(V):
+        assert torch.equal(torch.from_numpy(merged[i][0]), ref[i][0].cpu()) and torch.equal(torch.from_numpy(merged[i][1]), ref[i][1].cpu()), i

@@ -96,3 +96,35 @@ def test_mem_batches_and_encoder_positions():
     with torch.no_grad():
         x, pos = enc(torch.randn(2, 3, 32, 48), None)
     assert x.shape == (2, 6, 32) and pos[0].tolist() == [[0, 0], [0, 1], [0, 2], [1, 0], [1, 1], [1, 2]]
+
+
+def test_block_equals_an_independent_vit_layer():
+    """The restated croco `Block` (pre-LN: x += attn(norm1 x); x += mlp(norm2 x); fused qkv in (q, k, v) order, head-major channel split, exact-erf GELU) has
+    no upstream source here to be pinned against - but without RoPE it IS the standard ViT encoder layer, and the installed `transformers` carries an
+    independent implementation of that (ViTLayer: separate q / k / v projections, its own attention and MLP code).  Same weights mapped across -> same outputs.
+    This pins the block's structure (norm placement, residual order, qkv row order, head split, softmax scale, activation) to a second implementation; the
+    RoPE-2D rotation itself stays on test_rope_identities' naive complex form."""
+    from transformers import ViTConfig
+    from transformers.models.vit.modeling_vit import ViTLayer
+    torch.manual_seed(0)
+    D, H = 64, 4
+    blk = Block(D, H, mlp_ratio=4.0, qkv_bias=True, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6)).eval()
+    fill_module_(blk, seed=5)
+    cfg = ViTConfig(hidden_size=D, num_attention_heads=H, intermediate_size=4 * D, hidden_act='gelu', layer_norm_eps=1e-6, attention_probs_dropout_prob=0.0,
+                    hidden_dropout_prob=0.0, qkv_bias=True)
+    cfg._attn_implementation = 'eager'
+    ref = ViTLayer(cfg).eval()
+    sd = blk.state_dict()
+    qw, kw, vw = sd['attn.qkv.weight'].chunk(3, 0)
+    qb, kb, vb = sd['attn.qkv.bias'].chunk(3, 0)
+    ref.load_state_dict({'attention.q_proj.weight': qw, 'attention.q_proj.bias': qb, 'attention.k_proj.weight': kw, 'attention.k_proj.bias': kb,
+                         'attention.v_proj.weight': vw, 'attention.v_proj.bias': vb, 'attention.o_proj.weight': sd['attn.proj.weight'],
+                         'attention.o_proj.bias': sd['attn.proj.bias'], 'layernorm_before.weight': sd['norm1.weight'], 'layernorm_before.bias': sd['norm1.bias'],
+                         'layernorm_after.weight': sd['norm2.weight'], 'layernorm_after.bias': sd['norm2.bias'], 'mlp.fc1.weight': sd['mlp.fc1.weight'],
+                         'mlp.fc1.bias': sd['mlp.fc1.bias'], 'mlp.fc2.weight': sd['mlp.fc2.weight'], 'mlp.fc2.bias': sd['mlp.fc2.bias']}, strict=True)
+    x = torch.randn(2, 11, D) * 1.5
+    with torch.no_grad():
+        got = blk(x, None)
+        want = ref(x)
+        want = want[0] if isinstance(want, (tuple, list)) else want
+    assert torch.allclose(got, want, atol=2e-6, rtol=1e-5), float((got - want).abs().max())

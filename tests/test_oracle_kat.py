@@ -128,3 +128,20 @@ def test_block_equals_an_independent_vit_layer():
         want = ref(x)
         want = want[0] if isinstance(want, (tuple, list)) else want
     assert torch.allclose(got, want, atol=2e-6, rtol=1e-5), float((got - want).abs().max())
+
+
+def test_cross_attention_equals_torch_multi_head_attention():
+    """The restated croco `CrossAttention` (separate projq / projk / projv, head-major channel split, output projection) against torch's own multi-head attention
+    with separate projection weights (F.multi_head_attention_forward, use_separate_proj_weight=True): an independent implementation of the same operator."""
+    torch.manual_seed(1)
+    D, H, B, Nq, Nk = 48, 4, 2, 7, 11
+    ca = CrossAttention(D, rope=None, num_heads=H, qkv_bias=True).eval()
+    fill_module_(ca, seed=9)
+    x, y = torch.randn(B, Nq, D), torch.randn(B, Nk, D)
+    with torch.no_grad():
+        got = ca(x, y, y, None, None)
+        want, _ = F.multi_head_attention_forward(
+            x.transpose(0, 1), y.transpose(0, 1), y.transpose(0, 1), D, H, None, torch.cat([ca.projq.bias, ca.projk.bias, ca.projv.bias]), None, None, False, 0.0,
+            ca.proj.weight, ca.proj.bias, training=False, need_weights=False, use_separate_proj_weight=True, q_proj_weight=ca.projq.weight,
+            k_proj_weight=ca.projk.weight, v_proj_weight=ca.projv.weight)
+    assert torch.allclose(got, want.transpose(0, 1), atol=2e-6, rtol=1e-5), float((got - want.transpose(0, 1)).abs().max())
